@@ -1,0 +1,771 @@
+"""CPU oracle for the StreamMind streaming hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module, and only as the
+checker.  Nothing under `streammind_amd/` imports it; the product path fails
+loudly when the HIP library is missing.
+
+What it is: a plain-torch (CPU tensor ops only: matmul / exp / sum ...; no
+`transformers`, no `mamba_ssm`, no reference imports) restatement of the
+arithmetic the reference executes for one streamed frame and one reply.  Most of
+that arithmetic lives in third-party wheels the reference pins but does not
+vendor -- `transformers==4.44.2` (CLIP-ViT, Mistral, greedy generate;
+requirements.txt:355) and `mamba-ssm==2.2.2` (requirements.txt:156; a dead copy
+sits at streammind/model/mamba_ssm/) -- so each function cites the reference
+call site that reaches it plus the published algorithm it restates.
+
+Pinning: the reference has no tests / golden vectors for this path.
+The oracle is pinned against the reference ITSELF, imported in the build
+container through `oracle/ref_shims.py` and run on seeded weights by
+`oracle/make_golden.py`; the resulting input/output vectors are committed under
+`tests/golden/` and re-checked by the CPU test-suite on every run.
+
+Precision policy (`Prec`): weights are whatever the caller passes (the tests pass
+bf16-representable fp32 tensors, i.e. exactly the numbers the GPU holds).
+`Prec("fp32")` does every op in fp32 -- this is the mode pinned against the
+reference.  `Prec("mixed")` additionally rounds activations to bf16 at exactly
+the points where the HIP path stores bf16 (operands of the MFMA GEMMs), so that
+GPU-vs-oracle differences reduce to fp32 summation order.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+F32 = torch.float32
+
+# ----------------------------------------------------------------------------------------------
+# configs
+# ----------------------------------------------------------------------------------------------
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # processor config of openai/clip-vit-large-patch14-336
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+VIDEO_TOKEN_INDEX = -201                            # constants.py:29
+LEAKY_SLOPE = 0.01                                  # F.leaky_relu default, builder.py:168,178
+
+
+@dataclass
+class VitCfg:                       # CLIP-ViT-L/14-336 (finetune_stage1.sh:36); read from config.json at load
+    image_size: int = 336
+    patch: int = 14
+    hidden: int = 1024
+    heads: int = 16
+    mlp: int = 4096
+    layers: int = 24
+    eps: float = 1e-5
+    select_layer: int = -2          # finetune_stage1.sh:41
+
+    @property
+    def grid(self): return self.image_size // self.patch
+    @property
+    def n_patches(self): return self.grid * self.grid
+    @property
+    def seq(self): return self.n_patches + 1
+    @property
+    def layers_run(self):           # hidden_states has layers+1 entries; [-2] is the output of layer index layers-2
+        return self.layers + 1 + self.select_layer if self.select_layer < 0 else self.select_layer
+    @property
+    def head_dim(self): return self.hidden // self.heads
+
+
+@dataclass
+class ConnCfg:                      # Video_Mamba_seq, builder.py:390-399 ; Mamba defaults mamba_simple.py:31-58
+    mm_hidden: int = 1024
+    d_model: int = 4096
+    d_state: int = 16
+    d_conv: int = 4
+    expand: int = 2
+    ln_eps: float = 1e-5
+
+    @property
+    def d_inner(self): return self.expand * self.d_model
+    @property
+    def dt_rank(self): return math.ceil(self.d_model / 16)
+
+
+@dataclass
+class LmCfg:                        # Mistral decoder (gate: MistralConfig() defaults, builder.py:373-378)
+    hidden: int = 4096
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 8
+    mlp: int = 14336
+    vocab: int = 32000
+    eps: float = 1e-5
+    rope_theta: float = 1e6
+
+    @property
+    def head_dim(self): return self.hidden // self.heads
+
+    @staticmethod
+    def gate(hidden=4096, heads=32, kv_heads=8, mlp=14336, layers=4):
+        # MistralConfig() defaults: rms_norm_eps 1e-6, rope_theta 1e4; vocab 2, 4 layers (builder.py:376-377)
+        return LmCfg(hidden=hidden, layers=layers, heads=heads, kv_heads=kv_heads, mlp=mlp,
+                     vocab=2, eps=1e-6, rope_theta=1e4)
+
+
+class Prec:
+    def __init__(self, mode: str = "fp32"):
+        assert mode in ("fp32", "mixed")
+        self.mode = mode
+
+    def act(self, x: Tensor) -> Tensor:
+        """activation that the HIP path stores as ONE bf16 (operand of a bf16 MFMA GEMM)."""
+        if self.mode == "mixed":
+            return x.to(torch.bfloat16).to(F32)
+        return x
+
+
+FP32 = Prec("fp32")
+MIXED = Prec("mixed")
+
+
+def bf16_round(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(F32)
+
+
+# ----------------------------------------------------------------------------------------------
+# elementary ops (restated; no nn.Module)
+# ----------------------------------------------------------------------------------------------
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def rms_norm(x: Tensor, w: Tensor, eps: float) -> Tensor:
+    # HF MistralRMSNorm: fp32 variance, x * rsqrt(var + eps), then weight *
+    var = (x * x).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+def quick_gelu(x: Tensor) -> Tensor:       # HF CLIP "quick_gelu": x * sigmoid(1.702 x)
+    return x * torch.sigmoid(1.702 * x)
+
+
+def silu(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+def leaky_relu(x: Tensor) -> Tensor:
+    return torch.where(x >= 0, x, x * LEAKY_SLOPE)
+
+
+def softplus(x: Tensor) -> Tensor:         # F.softplus default beta=1, threshold=20
+    return torch.where(x > 20, x, torch.log1p(torch.exp(torch.clamp(x, max=20))))
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  preprocess  (mm_utils.py:449-451,462-464 -> HF CLIPImageProcessor.preprocess)
+# ----------------------------------------------------------------------------------------------
+
+def preprocess_frames(frames_u8: Tensor, image_size: int = 336) -> Tensor:
+    """u8 HWC [B,H,W,3] -> fp32 CHW [B,3,H,W]: x/255 then (x-mean)/std.
+
+    For H == W == image_size the processor's bicubic shortest-edge resize and centre crop are
+    identities, which is the only case the streaming benchmark uses; other sizes are
+    the ingest front-end and rejected here.
+    """
+    assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
+    if frames_u8.shape[1] != image_size or frames_u8.shape[2] != image_size:
+        raise NotImplementedError("resize/crop front-end is out of scope (SURVEY 8f f2)")
+    x = frames_u8.to(F32) * (1.0 / 255.0)
+    mean = torch.tensor(CLIP_MEAN, dtype=F32)
+    std = torch.tensor(CLIP_STD, dtype=F32)
+    x = (x - mean) / std
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# a2  CLIP vision tower  (clip_encoder.py:31-53 -> HF CLIPVisionModel, hidden_states[-2], drop CLS)
+# ----------------------------------------------------------------------------------------------
+
+def vit_weight_names(cfg: VitCfg, prefix: str = "") -> List[str]:
+    n = [prefix + "embeddings.class_embedding", prefix + "embeddings.patch_embedding.weight",
+         prefix + "embeddings.position_embedding.weight",
+         prefix + "pre_layrnorm.weight", prefix + "pre_layrnorm.bias"]
+    for i in range(cfg.layers):
+        p = f"{prefix}encoder.layers.{i}."
+        for lin in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj",
+                    "mlp.fc1", "mlp.fc2", "layer_norm1", "layer_norm2"):
+            n += [p + lin + ".weight", p + lin + ".bias"]
+    n += [prefix + "post_layernorm.weight", prefix + "post_layernorm.bias"]
+    return n
+
+
+def vit_patchify(pix: Tensor, cfg: VitCfg) -> Tensor:
+    """[B,3,H,W] -> [B, n_patches, 3*p*p] in conv-weight order (c, i, j)."""
+    B = pix.shape[0]
+    g, p = cfg.grid, cfg.patch
+    x = pix.reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5)      # B, gy, gx, c, i, j
+    return x.reshape(B, g * g, 3 * p * p)
+
+
+def vit_embed(pix: Tensor, W: Dict[str, Tensor], cfg: VitCfg, prec: Prec = FP32, prefix: str = "") -> Tensor:
+    """hidden_states[0] of HF CLIPVisionTransformer = pre_layrnorm(patch_embed ++ CLS + pos)."""
+    B = pix.shape[0]
+    patches = prec.act(vit_patchify(pix, cfg))
+    wpe = W[prefix + "embeddings.patch_embedding.weight"].reshape(cfg.hidden, -1)
+    x = patches @ wpe.t()                                               # conv k=s=14, no bias
+    cls = W[prefix + "embeddings.class_embedding"].reshape(1, 1, -1).expand(B, 1, cfg.hidden)
+    x = torch.cat([cls, x], dim=1) + W[prefix + "embeddings.position_embedding.weight"][None]
+    return layer_norm(x, W[prefix + "pre_layrnorm.weight"], W[prefix + "pre_layrnorm.bias"], cfg.eps)
+
+
+def vit_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg: VitCfg, prec: Prec = FP32, prefix: str = "") -> Tensor:
+    p = f"{prefix}encoder.layers.{i}."
+    B, S, D = x.shape
+    H, dh = cfg.heads, cfg.head_dim
+    h = prec.act(layer_norm(x, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.eps))
+    q = prec.act(linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]))
+    k = prec.act(linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"]))
+    v = prec.act(linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]))
+    q = q.reshape(B, S, H, dh).transpose(1, 2)
+    k = k.reshape(B, S, H, dh).transpose(1, 2)
+    v = v.reshape(B, S, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (dh ** -0.5)                        # non-causal
+    if prec.mode == "mixed":
+        # HIP attention: P = exp(s - rowmax) rounded to bf16 feeds the PV MFMA; the normaliser is
+        # the fp32 sum of the UNROUNDED exponentials
+        m = s.max(-1, keepdim=True).values
+        e = torch.exp(s - m)
+        ctx = (prec.act(e) @ v) / e.sum(-1, keepdim=True)
+    else:
+        ctx = torch.softmax(s, dim=-1) @ v
+    ctx = prec.act(ctx.transpose(1, 2).reshape(B, S, D))
+    x = x + linear(ctx, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
+    h = prec.act(layer_norm(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.eps))
+    h = prec.act(quick_gelu(linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])))
+    return x + linear(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
+
+
+def vit_features(pix: Tensor, W: Dict[str, Tensor], cfg: VitCfg, prec: Prec = FP32, prefix: str = "") -> Tensor:
+    """CLIPVisionTower.forward: [B,3,H,W] -> [B, n_patches, hidden] = hidden_states[select_layer][:, 1:].
+
+    Layers after `layers_run` (and post_layernorm) are computed by HF but unused; skipped here."""
+    x = vit_embed(pix, W, cfg, prec, prefix)
+    for i in range(cfg.layers_run):
+        x = vit_layer(x, W, i, cfg, prec, prefix)
+    return x[:, 1:]
+
+
+# ----------------------------------------------------------------------------------------------
+# a5-a7  connector: patch-mean -> PreNet -> Block(LN -> Mamba) -> LN_f(h + r) -> PostNet
+#        builder.py:403-414 ; ssm.py:69-100 ; block.py:42-67 ; mamba_simple.py:119-253
+# ----------------------------------------------------------------------------------------------
+
+CONN = "mamba_model.ssms.0."
+
+
+def conn_weight_shapes(cfg: ConnCfg) -> Dict[str, Tuple[int, ...]]:
+    d, di = cfg.d_model, cfg.d_inner
+    return {
+        "pre_net.fc3.weight": (d, cfg.mm_hidden), "pre_net.fc3.bias": (d,),
+        CONN + "norm.weight": (d,), CONN + "norm.bias": (d,),
+        CONN + "mixer.in_proj.weight": (2 * di, d),
+        CONN + "mixer.conv1d.weight": (di, 1, cfg.d_conv), CONN + "mixer.conv1d.bias": (di,),
+        CONN + "mixer.x_proj.weight": (cfg.dt_rank + 2 * cfg.d_state, di),
+        CONN + "mixer.dt_proj.weight": (di, cfg.dt_rank), CONN + "mixer.dt_proj.bias": (di,),
+        CONN + "mixer.A_log": (di, cfg.d_state), CONN + "mixer.D": (di,),
+        CONN + "mixer.out_proj.weight": (d, di),
+        "mamba_model.norm_fn.weight": (d,), "mamba_model.norm_fn.bias": (d,),
+        "post_net.fc3.weight": (d, d), "post_net.fc3.bias": (d,),
+    }
+
+
+def pool_patches(feats: Tensor) -> Tensor:
+    """builder.py:405  x.mean(dim=2) over the 576 patch tokens: [.., P, C] -> [.., C]."""
+    return feats.mean(dim=-2)
+
+
+def mamba_scan(u: Tensor, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
+    """Mamba.forward non-fused branch (mamba_simple.py:168-205) + selective_scan_ref
+    (selective_scan_interface.py:91-157), batch 1: u [T, d_model] -> [T, d_model]."""
+    T = u.shape[0]
+    di, ds, R = cfg.d_inner, cfg.d_state, cfg.dt_rank
+    xz = u @ W[CONN + "mixer.in_proj.weight"].t()                      # [T, 2*di]
+    x, z = xz[:, :di], xz[:, di:]
+    cw = W[CONN + "mixer.conv1d.weight"].reshape(di, cfg.d_conv)
+    xp = torch.cat([torch.zeros(cfg.d_conv - 1, di), x], dim=0)         # causal depthwise conv, padding d_conv-1
+    xc = sum(xp[j:j + T] * cw[:, j] for j in range(cfg.d_conv)) + W[CONN + "mixer.conv1d.bias"]
+    xc = silu(xc)
+    x_dbl = xc @ W[CONN + "mixer.x_proj.weight"].t()
+    dt_r, Bm, Cm = x_dbl[:, :R], x_dbl[:, R:R + ds], x_dbl[:, R + ds:]
+    delta = softplus(dt_r @ W[CONN + "mixer.dt_proj.weight"].t() + W[CONN + "mixer.dt_proj.bias"])
+    A = -torch.exp(W[CONN + "mixer.A_log"])
+    h = torch.zeros(di, ds)
+    ys = []
+    for t in range(T):
+        dA = torch.exp(delta[t][:, None] * A)
+        h = dA * h + (delta[t] * xc[t])[:, None] * Bm[t][None, :]
+        ys.append(h @ Cm[t])
+    y = torch.stack(ys) + xc * W[CONN + "mixer.D"]
+    y = y * silu(z)
+    return y @ W[CONN + "mixer.out_proj.weight"].t()
+
+
+def connector_scan(pooled: Tensor, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
+    """Reference form: all T frames at once. pooled [T, mm_hidden] -> tokens [T, d_model]."""
+    t0 = leaky_relu(linear(pooled, W["pre_net.fc3.weight"], W["pre_net.fc3.bias"]))
+    u = layer_norm(t0, W[CONN + "norm.weight"], W[CONN + "norm.bias"], cfg.ln_eps)
+    r = mamba_scan(u, W, cfg) + t0                                       # ssm.py:83
+    lnf = layer_norm(r, W["mamba_model.norm_fn.weight"], W["mamba_model.norm_fn.bias"], cfg.ln_eps)
+    return linear(leaky_relu(lnf), W["post_net.fc3.weight"], W["post_net.fc3.bias"])
+
+
+@dataclass
+class ConnState:
+    conv: Tensor      # [d_inner, d_conv]  last d_conv inputs (oldest first)
+    ssm: Tensor       # [d_inner, d_state]
+
+    @staticmethod
+    def zeros(cfg: ConnCfg) -> "ConnState":
+        return ConnState(torch.zeros(cfg.d_inner, cfg.d_conv), torch.zeros(cfg.d_inner, cfg.d_state))
+
+
+def connector_step(pooled_t: Tensor, st: ConnState, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
+    """Recurrent form (Mamba.step, mamba_simple.py:208-253): one frame, O(1) state. pooled_t [mm_hidden]."""
+    di, ds, R = cfg.d_inner, cfg.d_state, cfg.dt_rank
+    t0 = leaky_relu(linear(pooled_t, W["pre_net.fc3.weight"], W["pre_net.fc3.bias"]))
+    u = layer_norm(t0, W[CONN + "norm.weight"], W[CONN + "norm.bias"], cfg.ln_eps)
+    xz = W[CONN + "mixer.in_proj.weight"] @ u
+    x, z = xz[:di], xz[di:]
+    st.conv = torch.roll(st.conv, shifts=-1, dims=-1)
+    st.conv[:, -1] = x
+    cw = W[CONN + "mixer.conv1d.weight"].reshape(di, cfg.d_conv)
+    xc = silu((st.conv * cw).sum(-1) + W[CONN + "mixer.conv1d.bias"])
+    x_dbl = W[CONN + "mixer.x_proj.weight"] @ xc
+    dt_r, Bm, Cm = x_dbl[:R], x_dbl[R:R + ds], x_dbl[R + ds:]
+    delta = softplus(W[CONN + "mixer.dt_proj.weight"] @ dt_r + W[CONN + "mixer.dt_proj.bias"])
+    A = -torch.exp(W[CONN + "mixer.A_log"])
+    st.ssm = torch.exp(delta[:, None] * A) * st.ssm + (delta * xc)[:, None] * Bm[None, :]
+    y = st.ssm @ Cm + W[CONN + "mixer.D"] * xc
+    y = y * silu(z)
+    r = W[CONN + "mixer.out_proj.weight"] @ y + t0
+    lnf = layer_norm(r, W["mamba_model.norm_fn.weight"], W["mamba_model.norm_fn.bias"], cfg.ln_eps)
+    return linear(leaky_relu(lnf), W["post_net.fc3.weight"], W["post_net.fc3.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# Mistral decoder (HF MistralForCausalLM, transformers 4.44.2): a8 gate, a12 LLM
+# ----------------------------------------------------------------------------------------------
+
+def lm_weight_shapes(cfg: LmCfg, prefix: str = "", with_embed: bool = True) -> Dict[str, Tuple[int, ...]]:
+    d, dh = cfg.hidden, cfg.head_dim
+    s: Dict[str, Tuple[int, ...]] = {}
+    if with_embed:
+        s[prefix + "model.embed_tokens.weight"] = (cfg.vocab, d)
+    for i in range(cfg.layers):
+        p = f"{prefix}model.layers.{i}."
+        s[p + "self_attn.q_proj.weight"] = (cfg.heads * dh, d)
+        s[p + "self_attn.k_proj.weight"] = (cfg.kv_heads * dh, d)
+        s[p + "self_attn.v_proj.weight"] = (cfg.kv_heads * dh, d)
+        s[p + "self_attn.o_proj.weight"] = (d, cfg.heads * dh)
+        s[p + "mlp.gate_proj.weight"] = (cfg.mlp, d)
+        s[p + "mlp.up_proj.weight"] = (cfg.mlp, d)
+        s[p + "mlp.down_proj.weight"] = (d, cfg.mlp)
+        s[p + "input_layernorm.weight"] = (d,)
+        s[p + "post_attention_layernorm.weight"] = (d,)
+    s[prefix + "model.norm.weight"] = (d,)
+    s[prefix + "lm_head.weight"] = (cfg.vocab, d)
+    return s
+
+
+def rope_cos_sin(pos: Tensor, cfg: LmCfg) -> Tuple[Tensor, Tensor]:
+    dh = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dh, 2, dtype=F32) / dh))
+    fr = pos.to(F32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    """x [S, H, dh]; HF rotate_half convention: (x1, x2) halves -> (-x2, x1)."""
+    h = x.shape[-1] // 2
+    rot = torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+    return x * cos[:, None, :] + rot * sin[:, None, :]
+
+
+@dataclass
+class KVCache:
+    k: List[Tensor] = field(default_factory=list)    # per layer [S, kv_heads, dh]
+    v: List[Tensor] = field(default_factory=list)
+
+    @property
+    def length(self) -> int:
+        return 0 if not self.k else self.k[0].shape[0]
+
+    def truncate(self, n: int) -> None:
+        self.k = [t[:n] for t in self.k]
+        self.v = [t[:n] for t in self.v]
+
+
+def lm_forward(embeds: Tensor, W: Dict[str, Tensor], cfg: LmCfg, cache: Optional[KVCache] = None,
+               prec: Prec = FP32, prefix: str = "", last_only: bool = True) -> Tensor:
+    """MistralModel + lm_head on inputs_embeds [S_new, hidden]; causal; appends to `cache`.
+    Returns fp32 logits [vocab] of the last position (or [S_new, vocab])."""
+    S_new, d = embeds.shape
+    H, KV, dh = cfg.heads, cfg.kv_heads, cfg.head_dim
+    past = cache.length if cache is not None else 0
+    pos = torch.arange(past, past + S_new)
+    cos, sin = rope_cos_sin(pos, cfg)
+    x = embeds
+    for i in range(cfg.layers):
+        p = f"{prefix}model.layers.{i}."
+        h = prec.act(rms_norm(x, W[p + "input_layernorm.weight"], cfg.eps))
+        q = linear(h, W[p + "self_attn.q_proj.weight"]).reshape(S_new, H, dh)
+        k = linear(h, W[p + "self_attn.k_proj.weight"]).reshape(S_new, KV, dh)
+        v = linear(h, W[p + "self_attn.v_proj.weight"]).reshape(S_new, KV, dh)
+        q = prec.act(apply_rope(q, cos, sin))
+        k = prec.act(apply_rope(k, cos, sin))
+        v = prec.act(v)
+        if cache is not None:
+            if len(cache.k) <= i:
+                cache.k.append(k); cache.v.append(v)
+            else:
+                cache.k[i] = torch.cat([cache.k[i], k]); cache.v[i] = torch.cat([cache.v[i], v])
+            kk, vv = cache.k[i], cache.v[i]
+        else:
+            kk, vv = k, v
+        S = kk.shape[0]
+        rep = H // KV
+        kk = kk.repeat_interleave(rep, dim=1)                            # repeat_kv: q head h -> kv head h // rep
+        vv = vv.repeat_interleave(rep, dim=1)
+        s = torch.einsum("qhd,khd->hqk", q, kk) * (dh ** -0.5)
+        mask = torch.arange(S)[None, :] > pos[:, None]
+        s = s.masked_fill(mask[None], float("-inf"))
+        if prec.mode == "mixed":
+            m = s.max(-1, keepdim=True).values
+            e = torch.exp(s - m)
+            ctx = torch.einsum("hqk,khd->qhd", prec.act(e), vv) / e.sum(-1).transpose(0, 1)[..., None]
+        else:
+            ctx = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), vv)
+        ctx = prec.act(ctx.reshape(S_new, H * dh))
+        x = x + linear(ctx, W[p + "self_attn.o_proj.weight"])
+        h = prec.act(rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.eps))
+        a = prec.act(silu(linear(h, W[p + "mlp.gate_proj.weight"])) * linear(h, W[p + "mlp.up_proj.weight"]))
+        x = x + linear(a, W[p + "mlp.down_proj.weight"])
+    x = rms_norm(x[-1:] if last_only else x, W[prefix + "model.norm.weight"], cfg.eps)
+    logits = linear(prec.act(x), W[prefix + "lm_head.weight"])
+    return logits[0] if last_only else logits
+
+
+def gate_logits(token: Tensor, W: Dict[str, Tensor], cfg: LmCfg, prefix: str = "cls_net.cls_model.") -> Tensor:
+    """a8: ClsNet on ONE token at seq-len 1 (builder.py:547-562) -> fp32 logits [2].  Full HF arithmetic
+    (Q/K/RoPE/softmax included)."""
+    return lm_forward(token[None, :], W, cfg, None, FP32, prefix)
+
+
+def gate_logits_shortcut(tokens: Tensor, W: Dict[str, Tensor], cfg: LmCfg,
+                         prefix: str = "cls_net.cls_model.") -> Tensor:
+    """The algebraic shortcut the HIP gate step takes: at seq-len 1 softmax over one key is 1,
+    so attention == W_o . repeat_kv(W_v . RMSNorm(h)).  tokens [M, hidden] -> [M, 2]."""
+    x = tokens
+    rep = cfg.heads // cfg.kv_heads
+    for i in range(cfg.layers):
+        p = f"{prefix}model.layers.{i}."
+        h = rms_norm(x, W[p + "input_layernorm.weight"], cfg.eps)
+        v = linear(h, W[p + "self_attn.v_proj.weight"]).reshape(-1, cfg.kv_heads, cfg.head_dim)
+        v = v.repeat_interleave(rep, dim=1).reshape(-1, cfg.heads * cfg.head_dim)
+        x = x + linear(v, W[p + "self_attn.o_proj.weight"])
+        h = rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.eps)
+        x = x + linear(silu(linear(h, W[p + "mlp.gate_proj.weight"])) * linear(h, W[p + "mlp.up_proj.weight"]),
+                       W[p + "mlp.down_proj.weight"])
+    return linear(rms_norm(x, W[prefix + "model.norm.weight"], cfg.eps), W[prefix + "lm_head.weight"])
+
+
+def gate_decision(logits: Tensor) -> int:
+    """a9 (videollama2_arch.py:938-941): softmax over the 2 logits, argmax; ties -> 0 (silent)."""
+    return int(torch.softmax(logits.to(F32), dim=0).argmax(dim=0).item())
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  greedy generate from inputs_embeds (videollama2_mistral.py:426-431 -> HF GenerationMixin)
+# ----------------------------------------------------------------------------------------------
+
+def greedy_generate(embeds: Tensor, W: Dict[str, Tensor], cfg: LmCfg, max_new_tokens: int,
+                    eos_token_id: Optional[int], stop_fn: Optional[Callable[[List[int]], bool]] = None,
+                    prec: Prec = FP32, prefix: str = "", cache: Optional[KVCache] = None,
+                    return_logits: bool = False):
+    """Prefill `embeds` [S, hidden] (appending to `cache` if given), then greedy decode.
+    HF semantics: the token that triggers EOS / the stopping criterion IS included in the output;
+    at most `max_new_tokens` new ids are returned (inputs were embeds, so only new ids)."""
+    cache = cache if cache is not None else KVCache()
+    out: List[int] = []
+    trace: List[Tensor] = []
+    logits = lm_forward(embeds, W, cfg, cache, prec, prefix)
+    for _ in range(max_new_tokens):
+        nxt = int(torch.argmax(logits).item())
+        out.append(nxt)
+        if return_logits:
+            trace.append(logits.clone())
+        if eos_token_id is not None and nxt == eos_token_id:
+            break
+        if stop_fn is not None and stop_fn(out):
+            break
+        if len(out) == max_new_tokens:
+            break
+        e = W[prefix + "model.embed_tokens.weight"][nxt][None, :]
+        logits = lm_forward(e, W, cfg, cache, prec, prefix)
+    return (out, trace) if return_logits else out
+
+
+# ----------------------------------------------------------------------------------------------
+# a13  prompt template, <video>-aware tokenisation, keyword stopping
+# ----------------------------------------------------------------------------------------------
+
+SYSTEM_PROMPT = ("A chat between a curious user and an artificial intelligence assistant. "
+                 "The assistant gives helpful, detailed, and polite answers to the user's questions.")   # conversation.py:384-385
+HARDWIRED = "Please describe the video content in detail based on the provided information."              # conversation.py:90
+GROWTH_SUFFIX = " </s>[INST] <video>\n [/INST]"                                                           # video_score_stream_demo.py:124
+
+
+def initial_prompt() -> str:
+    """conv_mistral_instruct (LLAMA_2 style, sep='', sep2='</s>') with messages
+    [(USER, '<video>\\n'), (ASSISTANT, None)]  (video_score_stream_demo.py:88-95, conversation.py:78-98)."""
+    msg = f"<<SYS>>\n{SYSTEM_PROMPT}\n<</SYS>>\n\n" + HARDWIRED + "<video>\n"
+    return f"[INST] {msg} [/INST]"
+
+
+def grow_prompt(prompt: str, reply: str) -> str:
+    return prompt + " " + reply + GROWTH_SUFFIX
+
+
+def tokenize_with_video(prompt: str, tokenizer, video_index: int = VIDEO_TOKEN_INDEX) -> List[int]:
+    """tokenizer_MMODAL_token (mm_utils.py:567-604): split on '<video>', tokenise chunks, re-join with the
+    sentinel, keeping one BOS at the front and dropping each later chunk's BOS."""
+    chunks = [tokenizer(c).input_ids for c in prompt.split("<video>")]
+    ids: List[int] = []
+    offset = 0
+    if len(chunks) > 0 and len(chunks[0]) > 0 and chunks[0][0] == tokenizer.bos_token_id:
+        offset = 1
+        ids.append(chunks[0][0])
+    sep = [video_index] * (offset + 1)
+    inter: List[List[int]] = []
+    for c in chunks:
+        inter += [c, sep]
+    inter = inter[:-1]
+    for x in inter:
+        ids.extend(x[offset:])
+    return ids
+
+
+class KeywordStop:
+    """KeywordsStoppingCriteria (mm_utils.py:616-647) for batch 1.  `start_len` is the length of the
+    `input_ids` the criterion was built with (the reference passes the sentinel-bearing prompt ids although
+    generate() only ever sees NEW ids, because inputs were embeds -- reproduced as is)."""
+
+    def __init__(self, keywords: Sequence[str], tokenizer, start_len: int):
+        self.keywords = list(keywords)
+        self.tokenizer = tokenizer
+        self.start_len = start_len
+        self.keyword_ids: List[List[int]] = []
+        self.max_keyword_len = 0
+        for kw in keywords:
+            ids = tokenizer(kw).input_ids
+            if len(ids) > 1 and ids[0] == tokenizer.bos_token_id:
+                ids = ids[1:]
+            self.max_keyword_len = max(self.max_keyword_len, len(ids))
+            self.keyword_ids.append(list(ids))
+
+    def __call__(self, output_ids: List[int]) -> bool:
+        offset = min(len(output_ids) - self.start_len, self.max_keyword_len)
+        for kid in self.keyword_ids:
+            if output_ids[-len(kid):] == kid:
+                return True
+        # python slicing semantics of output_ids[:, -offset:] reproduced, including offset <= 0
+        tail = output_ids[-offset:] if offset != 0 else output_ids[0:]
+        text = self.tokenizer.decode(tail, skip_special_tokens=True)
+        return any(kw in text for kw in self.keywords)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10  splice visual tokens at the sentinels (videollama2_arch.py:951-987)
+# ----------------------------------------------------------------------------------------------
+
+def splice_embeds(input_ids: Sequence[int], tokens: Tensor, interval_ids: Sequence[int],
+                  embed_table: Tensor, video_index: int = VIDEO_TOKEN_INDEX) -> Tensor:
+    """k-th sentinel <- tokens[start_k:end_k], start = [0] + interval_ids[:-1], end = interval_ids."""
+    starts = [0] + list(interval_ids[:-1])
+    parts: List[Tensor] = []
+    cur: List[int] = []
+    k = 0
+    for t in input_ids:
+        if t == video_index:
+            parts.append(embed_table[torch.tensor(cur, dtype=torch.long)] if cur else embed_table[:0])
+            parts.append(tokens[starts[k]:interval_ids[k]])
+            k += 1
+            cur = []
+        else:
+            cur.append(int(t))
+    if cur:
+        parts.append(embed_table[torch.tensor(cur, dtype=torch.long)])
+    return torch.cat(parts, dim=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# a3/a11/a14  the streaming loop, reference form (O(T) recompute, full re-prefill on every fire)
+# ----------------------------------------------------------------------------------------------
+
+@dataclass
+class StreamOracleState:
+    feats: Optional[Tensor] = None                 # [T, P, C] raw patch history (model.frame_feature)
+    interval_ids: List[int] = field(default_factory=list)
+    prompt: Optional[str] = None
+
+
+@dataclass
+class FrameResult:
+    gate_logits: Tensor
+    cls_pred: int
+    new_ids: Optional[List[int]] = None
+    text: Optional[str] = None
+
+
+def stream_frame(frame_u8: Tensor, st: StreamOracleState, Wv, Wc, Wl, vcfg: VitCfg, ccfg: ConnCfg, gcfg: LmCfg,
+                 lcfg: LmCfg, tokenizer, max_new_tokens: int = 1024, vit_prec: Prec = FP32,
+                 lm_prec: Prec = FP32) -> FrameResult:
+    """One call of eval/video_score_stream_demo.py:infer -> stream_generate_demo for one new frame
+    (frame_u8 [H,W,3] u8).  Wv / Wc / Wl: vision-tower, mm_projector (incl. cls_net) and LM weight dicts."""
+    if st.prompt is None:
+        st.prompt = initial_prompt()
+    pix = preprocess_frames(frame_u8[None], vcfg.image_size)
+    f = vit_features(pix, Wv, vcfg, vit_prec)                             # [1, P, C]
+    st.feats = f if st.feats is None else torch.cat([st.feats, f], dim=0)  # arch.py:190-191
+    T = st.feats.shape[0]
+    tokens = connector_scan(pool_patches(st.feats), Wc, ccfg)            # all T frames again (reference form)
+    logits = gate_logits(tokens[-1], Wc, gcfg)
+    pred = gate_decision(logits)
+    if pred == 0:
+        return FrameResult(logits, 0)
+    st.interval_ids.append(T)
+    ids = tokenize_with_video(st.prompt, tokenizer)
+    embeds = splice_embeds(ids, tokens, st.interval_ids, Wl["model.embed_tokens.weight"])
+    stop = KeywordStop(["</s>"], tokenizer, start_len=len(ids))
+    new_ids = greedy_generate(embeds, Wl, lcfg, max_new_tokens, tokenizer.eos_token_id, stop, lm_prec)
+    text = tokenizer.decode(new_ids, skip_special_tokens=True).strip()
+    st.prompt = grow_prompt(st.prompt, text)
+    return FrameResult(logits, 1, new_ids, text)
+
+
+# ----------------------------------------------------------------------------------------------
+# a15  config-1 plumbing: temporal stride of cached feature files (process_clip_encoder.py:55-57,69-84)
+# ----------------------------------------------------------------------------------------------
+
+def feature_stride(feats: Tensor, fps: int = 25, target: int = 2) -> Tensor:
+    """torch.load(p)[:, ::segment] with segment = fps // target = 12."""
+    return feats[:, :: (fps // target)]
+
+
+def stride_output_path(path: str) -> str:
+    return path.replace("features_video_encode_ddp", "features_video_encode_ddp_fps")
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded synthetic weights / frames (shared by tests, smoke and bench -- plain torch CPU generator)
+# ----------------------------------------------------------------------------------------------
+
+def _randn(gen: torch.Generator, shape, std: float) -> Tensor:
+    return bf16_round(torch.randn(*shape, generator=gen, dtype=F32) * std)
+
+
+def make_vit_weights(cfg: VitCfg, seed: int, prefix: str = "") -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+    for n in vit_weight_names(cfg, prefix):
+        short = n[len(prefix):]
+        if short == "embeddings.class_embedding":
+            W[n] = _randn(g, (cfg.hidden,), 0.02)
+        elif short == "embeddings.patch_embedding.weight":
+            W[n] = _randn(g, (cfg.hidden, 3, cfg.patch, cfg.patch), 0.02)
+        elif short == "embeddings.position_embedding.weight":
+            W[n] = _randn(g, (cfg.seq, cfg.hidden), 0.02)
+        elif "layer_norm" in short or "layrnorm" in short or "layernorm" in short:
+            W[n] = bf16_round(1.0 + 0.1 * torch.randn(cfg.hidden, generator=g)) if short.endswith("weight") \
+                else _randn(g, (cfg.hidden,), 0.02)
+        elif short.endswith("bias"):
+            W[n] = _randn(g, (cfg.mlp if "fc1" in short else cfg.hidden,), 0.02)
+        else:
+            o, i = (cfg.mlp, cfg.hidden) if "fc1" in short else (cfg.hidden, cfg.mlp) if "fc2" in short \
+                else (cfg.hidden, cfg.hidden)
+            W[n] = _randn(g, (o, i), 0.03)
+    return W
+
+
+def make_conn_weights(cfg: ConnCfg, seed: int) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+    for n, shp in conn_weight_shapes(cfg).items():
+        if n.endswith("A_log"):
+            W[n] = torch.log(torch.arange(1, cfg.d_state + 1, dtype=F32)).repeat(cfg.d_inner, 1)   # S4D-real init
+            W[n] = bf16_round(W[n] + 0.05 * torch.randn(*shp, generator=g))
+        elif n.endswith(".D"):
+            W[n] = bf16_round(1.0 + 0.1 * torch.randn(*shp, generator=g))
+        elif n.endswith("dt_proj.bias"):
+            dt = torch.exp(torch.rand(*shp, generator=g) * (math.log(0.1) - math.log(0.001)) + math.log(0.001))
+            W[n] = bf16_round(dt + torch.log(-torch.expm1(-dt)))                                       # mamba_simple.py:92-99
+        elif n.endswith("dt_proj.weight"):
+            W[n] = bf16_round((torch.rand(*shp, generator=g) * 2 - 1) * cfg.dt_rank ** -0.5)
+        elif "norm" in n and n.endswith("weight"):
+            W[n] = bf16_round(1.0 + 0.1 * torch.randn(*shp, generator=g))
+        elif n.endswith("bias"):
+            W[n] = _randn(g, shp, 0.02)
+        elif n.endswith("conv1d.weight"):
+            W[n] = _randn(g, shp, 0.3)
+        else:
+            W[n] = _randn(g, shp, 1.0 / math.sqrt(shp[-1]))
+    return W
+
+
+def make_lm_weights(cfg: LmCfg, seed: int, prefix: str = "", with_embed: bool = True) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+    for n, shp in lm_weight_shapes(cfg, prefix, with_embed).items():
+        if "layernorm" in n or n.endswith("model.norm.weight"):
+            W[n] = bf16_round(1.0 + 0.1 * torch.randn(*shp, generator=g))
+        elif "embed_tokens" in n:
+            W[n] = _randn(g, shp, 1.0)
+        else:
+            W[n] = _randn(g, shp, 1.0 / math.sqrt(shp[-1]))
+    return W
+
+
+def splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def synthetic_frames(n: int, size: int = 336, seed: int = 1234, stream_id: int = 0, start: int = 0,
+                     scene_len: int = 4) -> Tensor:
+    """Seeded u8 HWC frames [n, size, size, 3]: a low-pass 'scene' that drifts slowly and cuts to a new random
+    palette / spatial frequency every `scene_len` frames, plus per-pixel noise (cost-neutral; consecutive frames
+    correlate, cuts give the gate something to react to).  Same generator on the CPU and GPU sides."""
+    out = torch.empty(n, size, size, 3, dtype=torch.uint8)
+    yy, xx = torch.meshgrid(torch.arange(size, dtype=F32), torch.arange(size, dtype=F32), indexing="ij")
+    for i in range(n):
+        t = start + i
+        base = seed * 1000003 + stream_id * 7919
+        g = torch.Generator().manual_seed(splitmix64(base + t) & 0x7FFFFFFFFFFFFFFF)
+        gs = torch.Generator().manual_seed(splitmix64(base ^ (0x5CE7E << 20) ^ (t // scene_len)) & 0x7FFFFFFFFFFFFFFF)
+        pal = torch.rand(3, 4, generator=gs)                 # per channel: offset, amplitude, fx, fy
+        ph = 0.02 * t
+        scene = torch.stack([
+            (40.0 + 175.0 * pal[c, 0]) + (20.0 + 60.0 * pal[c, 1])
+            * torch.sin(xx * (0.005 + 0.03 * pal[c, 2]) + ph * (c + 1)) * torch.cos(yy * (0.005 + 0.03 * pal[c, 3]) - ph)
+            for c in range(3)], dim=-1)
+        noise = torch.randint(-24, 25, (size, size, 3), generator=g).to(F32)
+        out[i] = (scene + noise).clamp(0, 255).to(torch.uint8)
+    return out

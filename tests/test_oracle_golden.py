@@ -1,0 +1,143 @@
+"""The oracle against the golden vectors minted from the reference itself (oracle/make_golden.py).
+CPU only; this is what pins the oracle on every run, here and on the GPU box."""
+import json
+
+import numpy as np
+import torch
+
+from oracle import streammind_oracle as O
+
+torch.set_grad_enabled(False)
+
+
+def close(a, b, tol):
+    a = torch.as_tensor(np.asarray(a)).float()
+    b = torch.as_tensor(np.asarray(b)).float()
+    d = (a - b).abs().max().item()
+    assert d <= tol * max(1.0, a.abs().max().item()), d
+
+
+def test_g1_preprocess(gold):
+    g = gold("g1_preprocess")
+    frames = O.synthetic_frames(int(g["n_frames"]), 336, seed=int(g["seed"]))
+    assert np.array_equal(frames[0, :4, :4].numpy(), g["frame0_corner"])     # the frame generator itself is pinned
+    pix = O.preprocess_frames(frames)
+    close(g["pixel_values_sample"], pix.flatten()[torch.as_tensor(g["idx"])], 2e-6)
+    close(g["channel_sum"], pix.double().sum(dim=(0, 2, 3)), 1e-6)
+
+
+def test_g2_vit_tiny(gold):
+    g = gold("g2_vit_tiny")
+    im, p, h, nh, mlp, L = [int(v) for v in g["cfg"]]
+    cfg = O.VitCfg(image_size=im, patch=p, hidden=h, heads=nh, mlp=mlp, layers=L)
+    W = O.make_vit_weights(cfg, int(g["seed_w"]))
+    pix = torch.randn(3, 3, im, im, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    close(g["out"], O.vit_features(pix, W, cfg), 2e-5)
+    # the bf16-rounding-point mode stays near the fp32 reference (sanity bound, not a parity claim)
+    close(g["out"], O.vit_features(pix, W, cfg, O.MIXED), 3e-2)
+
+
+def test_g2_vit_fullwidth(gold):
+    g = gold("g2_vit_fullwidth")
+    cfg = O.VitCfg(layers=int(g["layers"]))
+    W = O.make_vit_weights(cfg, int(g["seed_w"]))
+    pix = O.preprocess_frames(O.synthetic_frames(1, 336, seed=int(g["seed_frames"])))
+    out = O.vit_features(pix, W, cfg)
+    close(g["out_sample"], out.flatten()[torch.as_tensor(g["idx"])], 5e-5)
+    close(g["pooled"], O.pool_patches(out)[0], 5e-5)
+
+
+def _conn_gate(seed, ccfg, gcfg):
+    Wc = O.make_conn_weights(ccfg, seed)
+    Wc.update(O.make_lm_weights(gcfg, seed + 1, prefix="cls_net.cls_model."))
+    return Wc
+
+
+def test_g3_connector_gate_small(gold):
+    g = gold("g3_conn_gate_small")
+    ccfg = O.ConnCfg(mm_hidden=64, d_model=128)
+    gcfg = O.LmCfg.gate(hidden=128, heads=4, kv_heads=2, mlp=256)
+    seed, T, P = int(g["seed"]), int(g["T"]), int(g["P"])
+    Wc = _conn_gate(seed, ccfg, gcfg)
+    feats = torch.randn(1, T, P, ccfg.mm_hidden, generator=torch.Generator().manual_seed(seed + 7))
+    pooled = O.pool_patches(feats[0])
+    tok = O.connector_scan(pooled, Wc, ccfg)
+    close(g["tokens"], tok, 2e-5)
+    st = O.ConnState.zeros(ccfg)
+    step = torch.stack([O.connector_step(pooled[t], st, Wc, ccfg) for t in range(T)])
+    close(g["tokens"], step, 2e-5)                                   # O(1) recurrent form == reference full re-scan
+    close(g["conv_state"], st.conv, 2e-5)
+    close(g["ssm_state"], st.ssm, 2e-5)
+    lg = torch.stack([O.gate_logits(tok[t], Wc, gcfg) for t in range(T)])
+    close(g["gate_logits"], lg, 2e-5)
+    close(g["gate_logits"], O.gate_logits_shortcut(tok, Wc, gcfg), 2e-5)   # V/O-only shortcut is exact
+    assert [O.gate_decision(l) for l in lg] == g["decisions"].tolist()
+
+
+def test_gate_tie_is_silent():
+    assert O.gate_decision(torch.tensor([0.3, 0.3])) == 0
+
+
+def test_g5_prompt_tokenise_stop(gold, tiny_tokenizer):
+    g = gold("g5_prompt")
+    assert str(g["prompt0"]) == O.initial_prompt()
+    prompts = [O.initial_prompt()]
+    for reply in ["the person picks up a knife", "someone washes a plate", "a player kicks the ball"]:
+        prompts.append(O.grow_prompt(prompts[-1], reply))
+    for i, p in enumerate(prompts):
+        ids = O.tokenize_with_video(p, tiny_tokenizer)
+        assert ids == g[f"ids{i}"].tolist()
+        assert ids.count(O.VIDEO_TOKEN_INDEX) == i + 1 and ids[0] == tiny_tokenizer.bos_token_id
+    stop = O.KeywordStop(["</s>"], tiny_tokenizer, start_len=len(g["ids1"]))
+    for cs, want in zip(g["stop_cases"], g["stop_results"]):
+        assert stop(json.loads(str(cs))) == bool(want)
+
+
+def test_splice_segments():
+    table = torch.arange(40, dtype=torch.float32).reshape(10, 4)
+    toks = 100 + torch.arange(28, dtype=torch.float32).reshape(7, 4)
+    ids = [1, 5, -201, 6, -201, 7, 8]
+    out = O.splice_embeds(ids, toks, [3, 7], table)
+    want = torch.cat([table[[1, 5]], toks[0:3], table[[6]], toks[3:7], table[[7, 8]]])
+    assert torch.equal(out, want)
+
+
+def test_g7_decode(gold):
+    g = gold("g7_decode_tiny")
+    from oracle.make_golden import TINY_L
+    Wl = O.make_lm_weights(TINY_L, int(g["seed_w"]))
+    emb = torch.randn(1, int(g["S"]), TINY_L.hidden, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    ids, trace = O.greedy_generate(emb[0], Wl, TINY_L, len(g["ids"]), eos_token_id=2, return_logits=True)
+    assert ids == g["ids"].tolist()
+    close(g["logits0"], trace[0], 5e-5)
+
+
+def test_g6_stream_end_to_end(gold, tiny_tokenizer):
+    """The whole reference streaming loop (stream_generate_demo driven like video_score_stream_demo.py) on a tiny
+    model: per-frame gate logits, decisions, fire positions, generated ids and the final prompt string."""
+    g = gold("g6_stream_tiny")
+    from oracle.make_golden import TINY_V, TINY_C, TINY_G, TINY_L, tiny_weights
+    Wv, Wc, Wl = tiny_weights()
+    n = int(g["n_frames"])
+    frames = O.synthetic_frames(n, TINY_V.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    st = O.StreamOracleState()
+    fires = 0
+    for i in range(n):
+        r = O.stream_frame(frames[i], st, Wv, Wc, Wl, TINY_V, TINY_C, TINY_G, TINY_L, tiny_tokenizer,
+                           max_new_tokens=int(g["max_new"]))
+        close(g["gate_logits"][i], r.gate_logits, 5e-5)
+        assert r.cls_pred == int(g["preds"][i])
+        if r.cls_pred:
+            assert r.new_ids == g[f"new_ids{fires}"].tolist()
+            assert r.text == str(g["texts"][fires])
+            fires += 1
+    assert fires == int(g["n_fires"]) and fires >= 2
+    assert st.interval_ids == g["interval_ids"].tolist()
+    assert st.prompt == str(g["final_prompt"])
+
+
+def test_a15_feature_stride():
+    x = torch.arange(500 * 2 * 3, dtype=torch.float32).reshape(1, 500, 2, 3)
+    y = O.feature_stride(x)
+    assert y.shape == (1, 42, 2, 3) and torch.equal(y[0, 1], x[0, 12])
+    assert O.stride_output_path("/d/features_video_encode_ddp/a.pt") == "/d/features_video_encode_ddp_fps/a.pt"
