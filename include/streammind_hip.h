@@ -1,0 +1,228 @@
+/* libstreammind_hip.so -- C ABI of the MI355X (gfx950) StreamMind streaming hot path.
+ *
+ * The reference (xinding-sys/StreamMind) is a pure-Python nn.Module composition and has NO FFI/plugin
+ * layer; the boundary its callers use is a set of Python call signatures.  This header is
+ * the C ABI a native replacement sits behind; each entry point names the reference interface whose
+ * arithmetic it replaces (file:line relative to /root/reference).  Python mirrors of those signatures
+ * (streammind_amd/) bind it with ctypes -- see INTEGRATION.md for the stub a maintainer would add.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name ends in `_host`; sizes are element
+ * counts; `stream` is a hipStream_t passed as void*; all calls are asynchronous on `stream` and return
+ * 0 on success or a negative SM_E* code (text via sm_last_error()).  No torch types, no hidden host syncs.
+ * bf16 tensors are raw uint16 storage.  Linear weights are consumed in the "packed" fragment-major
+ * layout produced by sm_pack_weight() (see streammind_amd/csrc/common.h).
+ */
+#ifndef STREAMMIND_HIP_H
+#define STREAMMIND_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_OK 0
+#define SM_EINVAL (-1)
+#define SM_EHIP (-2)
+#define SM_ESTATE (-3)
+
+#define SM_ACT_NONE 0
+#define SM_ACT_QUICK_GELU 1 /* HF CLIP MLP activation x*sigmoid(1.702x)                       */
+#define SM_ACT_LEAKY_RELU 2 /* F.leaky_relu slope 0.01: PreNet/PostNet builder.py:168,178      */
+#define SM_ACT_SOFTPLUS 3   /* F.softplus on dt: mamba_simple.py:238                           */
+#define SM_ACT_SILU 4
+
+#define SM_X_BF16 0
+#define SM_X_F32 1
+
+const char* sm_last_error(void);
+int sm_abi_version(void);
+/* number of device-visible GPUs' CUs etc. are not needed by callers; kept minimal on purpose. */
+
+/* ------------------------------------------------------------------------------------------------
+ * Weights.  Replaces: nn.Linear / nn.Conv2d(k=s=14) weight storage loaded by load_pretrained_model
+ * (streammind/model/builder.py:30-210) and load_mm_projector (multimodal_projector/builder.py:66-85).
+ * ---------------------------------------------------------------------------------------------- */
+size_t sm_packed_elems(int N, int K); /* bf16 elements of the packed image (N->x16, K->x32 padded) */
+int sm_pack_weight(const void* w_bf16, int N, int K, int ldw, void* out_packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear:  Y[M,N] = epilogue( X[M,K] . W[N,K]^T ).  Replaces every torch F.linear / cuBLAS GEMM+GEMV on
+ * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 16 takes the weight-streaming "skinny" kernel
+ * (HBM-bound, MFMA 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sm_linear_t {
+    const void* w;        /* packed bf16 [N][K]                                                     */
+    const void* w2;       /* optional second packed weight (same N,K): out = act(X.W^T) * (X.W2^T)  */
+                          /*   (SwiGLU gate/up; skinny path only)                                   */
+    int N, K;
+    const void* x;        /* activations, row-major [M][ldx], bf16 or fp32 (x_dtype)                */
+    int x_dtype;          /* SM_X_BF16 / SM_X_F32 (fp32 only on the skinny path)                    */
+    int precise;          /* fp32 x only: split x into bf16 hi+lo and issue two MFMAs (~fp32 acts)  */
+    int M, ldx;
+    const float* bias;    /* [N] or NULL                                                            */
+    int act;              /* SM_ACT_* applied after bias                                            */
+    const float* residual;/* fp32 [*][ldr] added after act, or NULL (may alias out_f32)             */
+    int ldr;
+    float* out_f32;       /* [M][ldo] or NULL                                                       */
+    void* out_bf16;       /* [M][ldo_bf16] or NULL                                                  */
+    int ldo, ldo_bf16;
+    /* row remap (patch-embed writes patch p of frame b to token row b*(P+1)+1+p and adds pos-embed):
+     * if remap_in > 0: out_row = (m / remap_in) * remap_out + remap_off + m % remap_in and, when
+     * residual != NULL, residual row = remap_off + m % remap_in (broadcast over frames).            */
+    int remap_in, remap_out, remap_off;
+    /* V-transposed side output (ViT QKV): for n >= vt_n0 the value goes to
+     * vt[((m / vt_S) * ((N - vt_n0) / vt_dh) + (n - vt_n0) / vt_dh) * vt_dh + (n - vt_n0) % vt_dh][m % vt_S]
+     * (row length vt_ld) instead of out_bf16.                                                      */
+    void* vt;
+    int vt_n0, vt_S, vt_dh, vt_ld;
+} sm_linear_t;
+int sm_linear(const sm_linear_t* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vector / normalisation ops
+ * ---------------------------------------------------------------------------------------------- */
+/* LayerNorm (beta != NULL) or RMSNorm (beta == NULL) over rows of fp32 x[M][D]; optional leaky_relu on the
+ * result; writes fp32 and/or bf16.  Replaces nn.LayerNorm (CLIP, mamba Block, norm_fn) and MistralRMSNorm. */
+int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
+            int post_act, float* out_f32, void* out_bf16, int ldo, void* stream);
+
+/* a1 (mm_utils.py:449-464 + video_score_stream_demo.py:86): u8 HWC frames [B][H][W][3] -> bf16 patch
+ * matrix [B*(H/p)*(W/p)][ldp], column c*p*p + i*p + j, value (u8/255 - mean[c]) / std[c]; columns
+ * >= 3*p*p zero-filled up to ldp.  Optionally also the CHW fp32 pixel tensor (pixel_values).        */
+int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch, const float* mean3_host,
+                          const float* std3_host, void* patches_bf16, int ldp, float* pixel_values_opt,
+                          void* stream);
+/* CLS row: x[b*S + 0][:] = class_embedding + pos[0]  (HF CLIPVisionEmbeddings) */
+int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, const float* pos0, void* stream);
+/* non-causal MHA over bf16 qkv [B*S][3*H*dh] (Q|K) and V^T vt[B][H][dh][vt_ld]; ctx bf16 [B*S][H*dh].
+ * Replaces HF CLIPAttention (eager / SDPA).                                                          */
+int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
+                     void* stream);
+/* builder.py:405 mean over the P patch tokens (CLS row skipped): x fp32 [B*S][D] -> pooled fp32 [B][D];
+ * optionally the raw patch features as bf16 [B][P][D] (CLIPVisionTower.forward's return value).      */
+int sm_pool_patches(const float* x, int B, int S, int D, float* pooled, void* feats_bf16_opt, void* stream);
+
+/* Mamba recurrent step pieces (mamba_simple.py:208-253), M frames processed in order inside one launch:
+ * conv: xz fp32 [M][2*di] (x = first di) , conv_state fp32 [di][d_conv] (rolled in place), w [di][d_conv],
+ *       b [di] -> xc fp32 [M][di] = silu(conv)                                                        */
+int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, float* conv_state, const float* conv_w,
+                       const float* conv_b, float* xc, void* stream);
+/* ssm:  h = exp(delta*A) h + delta*B*x ; y = h.C + D x ; y *= silu(z).  x_dbl fp32 [M][ldx] holds
+ *       (dt_r | B | C) with B at column dt_rank; A = -exp(A_log).                                     */
+int sm_mamba_ssm_step(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank,
+                      const float* xz, int M, int di, int d_state, const float* A_log, const float* Dp,
+                      float* ssm_state, float* y, void* stream);
+/* repeat_kv for the seq-len-1 gate shortcut: v fp32 [M][KV*dh] -> out fp32 [M][H*dh], head h <- h/(H/KV) */
+int sm_repeat_kv(const float* v, int M, int KV, int H, int dh, float* out, void* stream);
+/* a9 (videollama2_arch.py:938-941): decision[m] = argmax(softmax(logits[m][0:2])), ties -> 0          */
+int sm_gate_decide(const float* logits, int M, int32_t* decision, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LLM pieces (HF MistralForCausalLM.generate, videollama2_mistral.py:426-431)
+ * ---------------------------------------------------------------------------------------------- */
+/* a10 (videollama2_arch.py:951-984): out_f32[i] = table[ids[i]] if ids[i] >= 0 else tokens[-ids[i]-1]
+ * (the host resolves the <video> sentinels into per-position frame indices encoded as negative ids).  */
+int sm_embed_splice(const int32_t* ids, int n, const void* table_bf16, const float* tokens_f32, int D,
+                    float* out_f32, void* stream);
+/* RoPE (rotate_half convention) on q,k of qkv fp32 [n][(H+2KV)*dh] at positions pos0..pos0+n-1 using the
+ * precomputed fp32 tables cos_tab/sin_tab [S_max][dh/2] (cos/sin(pos * theta^(-2j/dh)), built by the host
+ * exactly as HF MistralRotaryEmbedding does); writes q bf16 [n][H*dh], appends k to kcache bf16
+ * [S_max][KV*dh] and v to the transposed cache vtcache bf16 [KV][dh][S_max].                          */
+int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab,
+                      const float* sin_tab, void* q_bf16, void* kcache, void* vtcache, int S_max, void* stream);
+/* causal GQA attention of n new queries (positions pos0..) against the cache [0, pos0+n): ctx bf16 [n][H*dh] */
+int sm_llm_attention(const void* q_bf16, const void* kcache, const void* vtcache, int n, int pos0, int H,
+                     int KV, int dh, int S_max, void* ctx_bf16, void* stream);
+/* out[m] = bf16( silu(gu[m][0:F]) * gu[m][F:2F] ) */
+int sm_swiglu(const float* gu, int M, int F, void* out_bf16, void* stream);
+/* greedy argmax over fp32 logits[V] -> token (int32, device) ; first max wins (torch.argmax)           */
+int sm_argmax(const float* logits, int V, int32_t* out, void* stream);
+
+/* ================================================================================================
+ * Path-level API: model (weights + workspaces) and per-stream state.
+ * Replaces, as one native object each:
+ *   sm_model  <- what load_pretrained_model() returns as `model` (streammind/model/builder.py:30-210):
+ *                CLIPVisionTower + Video_Mamba_seq (+ClsNet) + MistralForCausalLM weights.
+ *   sm_stream <- the per-stream fields the reference keeps ON the model object
+ *                (frame_feature, interval_id_list: language_model/videollama2_mistral.py:159-162) plus what
+ *                the reference recomputes every frame: Mamba conv/ssm state, per-frame tokens, LLM KV cache.
+ * One host thread per stream handle; different streams of one model may be driven concurrently.
+ * ============================================================================================== */
+typedef struct sm_config_t {
+    /* CLIP ViT (config.json of config.mm_vision_tower; clip_encoder.py:18-29) */
+    int vit_image, vit_patch, vit_hidden, vit_heads, vit_mlp, vit_layers_run;
+    float vit_eps;
+    float img_mean[3], img_std[3];
+    /* connector (multimodal_projector/builder.py:390-399, mamba_simple.py:31-58) */
+    int conn_mm_hidden, conn_d_model, conn_d_state, conn_d_conv, conn_expand, conn_dt_rank;
+    float conn_eps;
+    /* gate = ClsNet (builder.py:370-385) */
+    int gate_hidden, gate_layers, gate_heads, gate_kv_heads, gate_mlp;
+    float gate_eps;
+    /* LLM (Mistral-7B config.json); llm_layers == 0 builds a perception-only model */
+    int llm_hidden, llm_layers, llm_heads, llm_kv_heads, llm_mlp, llm_vocab;
+    float llm_eps, llm_rope_theta;
+    /* capacities */
+    int max_frames_per_call; /* frames batched through sm_vit_encode in one call                       */
+    int gate_precise;        /* 1: hi/lo bf16 activation split in the connector+gate GEMVs (~fp32 acts) */
+} sm_config_t;
+
+typedef struct sm_model sm_model;
+typedef struct sm_stream sm_stream;
+
+#define SM_DT_BF16 0
+#define SM_DT_F32 1
+
+int sm_model_create(const sm_config_t* cfg, sm_model** out);
+/* Hand one checkpoint tensor (DEVICE memory, row-major, HF/reference layout and name, e.g.
+ * "model.mm_projector.mamba_model.ssms.0.mixer.in_proj.weight", "model.vision_tower.vision_tower.
+ * vision_model.encoder.layers.3.mlp.fc1.weight", "model.layers.7.self_attn.q_proj.weight").
+ * The library copies/packs it into its own storage; the caller may free `data` after the stream syncs.
+ * Unknown names are rejected with SM_EINVAL unless they belong to a part the path never reads
+ * (post_layernorm, vision layers >= vit_layers_run, gate q/k projections), which return 1 (= ignored). */
+int sm_model_load_tensor(sm_model* m, const char* name, const void* data, int dtype, int ndim, const int64_t* shape,
+                         void* stream);
+/* checks that every tensor the path reads has been loaded; builds derived tables (RoPE) */
+int sm_model_finalize(sm_model* m, void* stream);
+void sm_model_destroy(sm_model* m);
+/* names of tensors still missing, '\n'-separated, into buf (for error messages) */
+int sm_model_missing(sm_model* m, char* buf, size_t buflen);
+
+/* a1+a2(+K4): B frames u8 HWC [B][H][W][3] -> pooled fp32 [B][vit_hidden] (mean over patches of
+ * hidden_states[-2], CLS dropped); optional raw patch features bf16 [B][P][vit_hidden]
+ * (= CLIPVisionTower.forward, clip_encoder.py:41-53) and pixel_values fp32 [B][3][H][W].            */
+int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats_bf16_opt,
+                  float* pixel_values_opt, void* stream);
+/* same from already-normalised pixel_values bf16/fp32 is not offered: the u8 ring buffer IS the boundary */
+
+int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_stream** out);
+int sm_stream_reset(sm_stream* s, void* stream);
+void sm_stream_close(sm_stream* s);
+/* a5-a9 for M new frames given their pooled features: appends M per-frame tokens to the stream's token store,
+ * writes gate logits fp32 [M][2] and decisions int32 [M] (device).  Recurrent form of the connector
+ * (exactly the reference's full re-scan).                                            */
+int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream);
+/* convenience = sm_vit_encode + sm_stream_push_pooled (the per-frame "gate step") */
+int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream);
+int sm_stream_num_frames(sm_stream* s);
+const float* sm_stream_tokens(sm_stream* s);             /* device fp32 [num_frames][d_model]          */
+int sm_stream_kv_len(sm_stream* s);
+int sm_stream_set_kv_len(sm_stream* s, int n);            /* truncate the KV cache (prefix reuse)       */
+/* a10+a12 prefill: n new positions; ids[i] >= 0 text token, ids[i] < 0 -> frame token (-ids[i]-1).
+ * Appends to the KV cache at kv_len, leaves the greedy next token in the stream (device).           */
+int sm_llm_prefill(sm_stream* s, const int32_t* ids_dev, int n, void* stream);
+/* a12 decode: n_steps greedy steps continuing from the last prefill/decode; out_ids_dev[n_steps] int32 device.
+ * Step j emits the token predicted after the previous one, feeds it back, appends its KV.             */
+int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids_dev, void* stream);
+/* last-position logits of the most recent prefill/decode step: device fp32 [vocab] */
+const float* sm_stream_logits(sm_stream* s);
+/* async device-to-device copies out of the stream's own storage (tokens [t0, t0+n) x d_model fp32; vocabulary
+ * logits fp32 [vocab] and the pending greedy token int32) */
+int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, void* stream);
+int sm_stream_read_logits(sm_stream* s, float* out_opt, int32_t* next_token_out_opt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""ctypes binding of libstreammind_hip.so (the C ABI declared in include/streammind_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing any
+compute entry point raises.  Build it with `python -m streammind_amd.build` (or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstreammind_hip.so")
+
+SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
+SM_X_BF16, SM_X_F32 = 0, 1
+SM_DT_BF16, SM_DT_F32 = 0, 1
+
+vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class sm_linear_t(C.Structure):
+    _fields_ = [
+        ("w", vp), ("w2", vp), ("N", i32), ("K", i32),
+        ("x", vp), ("x_dtype", i32), ("precise", i32), ("M", i32), ("ldx", i32),
+        ("bias", vp), ("act", i32), ("residual", vp), ("ldr", i32),
+        ("out_f32", vp), ("out_bf16", vp), ("ldo", i32), ("ldo_bf16", i32),
+        ("remap_in", i32), ("remap_out", i32), ("remap_off", i32),
+        ("vt", vp), ("vt_n0", i32), ("vt_S", i32), ("vt_dh", i32), ("vt_ld", i32),
+    ]
+
+
+class sm_config_t(C.Structure):
+    _fields_ = [
+        ("vit_image", i32), ("vit_patch", i32), ("vit_hidden", i32), ("vit_heads", i32), ("vit_mlp", i32),
+        ("vit_layers_run", i32), ("vit_eps", f32), ("img_mean", f32 * 3), ("img_std", f32 * 3),
+        ("conn_mm_hidden", i32), ("conn_d_model", i32), ("conn_d_state", i32), ("conn_d_conv", i32),
+        ("conn_expand", i32), ("conn_dt_rank", i32), ("conn_eps", f32),
+        ("gate_hidden", i32), ("gate_layers", i32), ("gate_heads", i32), ("gate_kv_heads", i32), ("gate_mlp", i32),
+        ("gate_eps", f32),
+        ("llm_hidden", i32), ("llm_layers", i32), ("llm_heads", i32), ("llm_kv_heads", i32), ("llm_mlp", i32),
+        ("llm_vocab", i32), ("llm_eps", f32), ("llm_rope_theta", f32),
+        ("max_frames_per_call", i32), ("gate_precise", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/streammind_hip.h declares
+SIGNATURES = {
+    "sm_last_error": (C.c_char_p, []),
+    "sm_abi_version": (i32, []),
+    "sm_packed_elems": (sz, [i32, i32]),
+    "sm_pack_weight": (i32, [vp, i32, i32, i32, vp, vp]),
+    "sm_linear": (i32, [C.POINTER(sm_linear_t), vp]),
+    "sm_norm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, vp]),
+    "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
+    "sm_vit_cls_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "sm_vit_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sm_pool_patches": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "sm_mamba_conv_step": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "sm_mamba_ssm_step": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "sm_repeat_kv": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "sm_gate_decide": (i32, [vp, i32, vp, vp]),
+    "sm_embed_splice": (i32, [vp, i32, vp, vp, i32, vp, vp]),
+    "sm_rope_kv_append": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    "sm_llm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sm_swiglu": (i32, [vp, i32, i32, vp, vp]),
+    "sm_argmax": (i32, [vp, i32, vp, vp]),
+    "sm_model_create": (i32, [C.POINTER(sm_config_t), C.POINTER(vp)]),
+    "sm_model_load_tensor": (i32, [vp, C.c_char_p, vp, i32, i32, C.POINTER(C.c_int64), vp]),
+    "sm_model_finalize": (i32, [vp, vp]),
+    "sm_model_destroy": (None, [vp]),
+    "sm_model_missing": (i32, [vp, C.c_char_p, sz]),
+    "sm_vit_encode": (i32, [vp, vp, i32, vp, vp, vp, vp]),
+    "sm_stream_open": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "sm_stream_reset": (i32, [vp, vp]),
+    "sm_stream_close": (None, [vp]),
+    "sm_stream_push_pooled": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_stream_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_stream_num_frames": (i32, [vp]),
+    "sm_stream_tokens": (vp, [vp]),
+    "sm_stream_kv_len": (i32, [vp]),
+    "sm_stream_set_kv_len": (i32, [vp, i32]),
+    "sm_llm_prefill": (i32, [vp, vp, i32, vp]),
+    "sm_llm_decode": (i32, [vp, i32, vp, vp]),
+    "sm_stream_logits": (vp, [vp]),
+    "sm_stream_read_tokens": (i32, [vp, i32, i32, vp, vp]),
+    "sm_stream_read_logits": (i32, [vp, vp, vp, vp]),
+}
+
+_lib = None
+
+
+class StreamMindHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the library and type every entry point.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StreamMindHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m streammind_amd.build`. "
+            "There is no CPU fallback on the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = load().sm_last_error().decode(errors="replace")
+        raise StreamMindHipError(f"{what or 'libstreammind_hip'} failed ({rc}): {msg}")
+    return rc

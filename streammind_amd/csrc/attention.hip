@@ -1,0 +1,218 @@
+// Flash-style attention for gfx950, all softmax state lane-local.
+//
+// Orientation trick (MFMA 16x16x32 bf16, C/D map col = lane & 15, row = (lane >> 4) * 4 + reg):
+//   S^T = K . Q^T   : A operand = K rows (from LDS), B operand = Q rows (registers) -> a lane owns ONE query
+//                     (col = lane & 15) and 4 keys per fragment, so row max / row sum are in-lane reductions
+//                     plus two xor-shuffles (lanes ^16, ^32).
+//   O^T = V^T . P^T : A operand = V^T rows (d-major, keys contiguous), B operand = P for the lane's own query.
+//   The K rows are PERMUTED when they are written to LDS (row rho = f*16 + i holds key (i>>2)*8 + f*4 + (i&3))
+//   so that the S^T accumulators of fragments f = 0,1 are, register for register, the 8 consecutive keys the
+//   PV MFMA wants in its B operand: no transpose, no LDS round trip, no cross-lane traffic for P.
+//   V is consumed as V^T ([d][keys]); the producers (QKV GEMM epilogue / KV-append kernel) write it that way.
+#include "common.h"
+#include "host.h"
+
+struct AttnP {
+    const bf16_t* q; long q_bs, q_rs;       // batch stride, row stride (elements); head h at column h*DH
+    const bf16_t* k; long k_bs, k_rs;       // kv head kvh at column kvh*DH
+    const bf16_t* vt; long vt_bs, vt_hs;    // V^T: [batch][kv head][DH][vt_ld]
+    int vt_ld;
+    bf16_t* o; long o_bs, o_rs;
+    int nq, nk, H, KV, causal, pos0;
+    float c;                                 // softmax scale * log2(e)
+};
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
+    constexpr int KSQ = DH / 32;             // k-steps of the QK^T contraction
+    constexpr int DF = DH / 16;              // d fragments of the output
+    constexpr int KROW = DH * 2;             // bytes per K row in LDS
+    constexpr int KCH = DH / 8;              // 16-byte chunks per K row
+    constexpr int KMASK = KCH - 1 > 15 ? 15 : (KCH - 1);
+    __shared__ __attribute__((aligned(16))) char lds[64 * KROW + DH * 128];
+    char* Kl = lds;
+    char* Vl = lds + 64 * KROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kvh = h / (p.H / p.KV);
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    bf16x8 qf[2][KSQ];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 16 + i;
+        if (qr >= p.nq) qr = p.nq - 1;
+        const bf16_t* src = p.q + b * p.q_bs + (long)qr * p.q_rs + h * DH + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) qf[qb][ks] = *(const bf16x8*)(src + ks * 32);
+    }
+    f32x4 o[2][DF];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    int k_end = p.nk;
+    if (p.causal) {
+        int last = p.pos0 + min(blockIdx.x * 128 + 127, p.nq - 1) + 1;
+        k_end = min(k_end, last);
+    }
+    const bf16_t* kbase = p.k + b * p.k_bs + kvh * DH;
+    const bf16_t* vbase = p.vt + b * p.vt_bs + kvh * p.vt_hs;
+
+    for (int kt0 = 0; kt0 < k_end; kt0 += 64) {
+        __syncthreads();
+        // ---- stage K (64 keys, permuted rows) and V^T (DH rows x 64 keys) tiles
+#pragma unroll
+        for (int j = 0; j < (64 * KCH) / 256; ++j) {
+            int c = tid + 256 * j;
+            int key = c / KCH, cc = c % KCH;
+            int gk = min(kt0 + key, p.nk - 1);
+            u32x4 v = *(const u32x4*)(kbase + (long)gk * p.k_rs + cc * 8);
+            int kk = key & 31;
+            int rho = (key & 32) + (((kk >> 2) & 1) << 4) + (((kk >> 3) << 2) | (kk & 3));
+            *(u32x4*)(Kl + rho * KROW + ((cc ^ (rho & KMASK)) * 16)) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < (DH * 8) / 256; ++j) {
+            int c = tid + 256 * j;
+            int d = c >> 3, cc = c & 7;
+            u32x4 v = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
+            *(u32x4*)(Vl + d * 128 + ((cc ^ (d & 7)) * 16)) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T  (2 key blocks of 32 x 2 fragments x 2 query blocks)
+        f32x4 s[2][2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int rho = kb * 32 + f * 16 + i;
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) {
+                    bf16x8 kf = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & KMASK)) * 16));
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], a1, 0, 0, 0);
+                }
+                s[0][kb][f] = a0;
+                s[1][kb][f] = a1;
+            }
+        // ---- mask + online softmax (lane-local query = lane & 15)
+        const bool need_mask = (kt0 + 64 > p.nk) || p.causal;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qpos = p.pos0 + q0 + qb * 16 + i;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[qb][kb][f][r];
+                        if (need_mask) {
+                            int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
+                            if (key >= p.nk || (p.causal && key > qpos)) v = -INFINITY;
+                        }
+                        s[qb][kb][f][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qb], mx);
+            // a fully masked row (causal, tile ahead of the query) keeps m_new = -inf: guard the subtraction
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = exp2f((m_run[qb] - m_use) * p.c);
+            m_run[qb] = m_new;
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 pv;
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = exp2f((s[qb][kb][f][r] - m_use) * p.c);
+                        sum += e;
+                        pv[f * 4 + r] = (__bf16)e;
+                    }
+                pf[qb][kb] = pv;
+            }
+            l_run[qb] = l_run[qb] * alpha + sum;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) o[qb][df] *= alpha;
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                const int d = df * 16 + i;
+                bf16x8 vf = *(const bf16x8*)(Vl + d * 128 + (((kb * 4 + g) ^ (d & 7)) * 16));
+                o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][kb], o[0][df], 0, 0, 0);
+                o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][kb], o[1][df], 0, 0, 0);
+            }
+    }
+    // ---- normalise and store: lane (g, q = i) holds d = df*16 + g*4 + 0..3
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float l = l_run[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qb * 16 + i;
+        if (qr < p.nq) {
+            bf16_t* dst = p.o + b * p.o_bs + (long)qr * p.o_rs + h * DH + g * 4;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                f32x4 v = o[qb][df] * inv;
+                bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *(bf16x4*)(dst + df * 16) = w;
+            }
+        }
+    }
+}
+
+static int launch_attn(const AttnP& p, int B, int dh, hipStream_t st) {
+    dim3 grid(cdiv(p.nq, 128), p.H, B);
+    if (dh == 64) attn_kernel<64><<<grid, 256, 0, st>>>(p);
+    else if (dh == 128) attn_kernel<128><<<grid, 256, 0, st>>>(p);
+    else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
+                                void* stream) {
+    SM_REQUIRE(qkv && vt && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
+    SM_REQUIRE(vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64, "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
+    AttnP p;
+    const long ld = 3L * H * dh;
+    p.q = (const bf16_t*)qkv; p.q_bs = (long)S * ld; p.q_rs = ld;
+    p.k = (const bf16_t*)qkv + (long)H * dh; p.k_bs = (long)S * ld; p.k_rs = ld;
+    p.vt = (const bf16_t*)vt; p.vt_bs = (long)H * dh * vt_ld; p.vt_hs = (long)dh * vt_ld; p.vt_ld = vt_ld;
+    p.o = (bf16_t*)ctx; p.o_bs = (long)S * H * dh; p.o_rs = (long)H * dh;
+    p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0;
+    p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    return launch_attn(p, B, dh, (hipStream_t)stream);
+}
+
+extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
+                                int dh, int S_max, void* ctx, void* stream) {
+    SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
+    SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
+    AttnP p;
+    p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = (long)H * dh;
+    p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
+    p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
+    p.o = (bf16_t*)ctx; p.o_bs = 0; p.o_rs = (long)H * dh;
+    p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0;
+    p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    return launch_attn(p, 1, dh, (hipStream_t)stream);
+}

@@ -1,0 +1,57 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef uint16_t bf16_t;   // raw storage type in HBM
+
+#define SM_WAVE 64
+
+// round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet); matches torch .to(bfloat16)
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+
+// activations applied in GEMM epilogues (include/streammind_hip.h SM_ACT_*)
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return v * sigmoidf_(1.702f * v);                         // quick_gelu (HF CLIP)
+        case 2: return v >= 0.f ? v : 0.01f * v;                          // leaky_relu, slope 0.01
+        case 3: return v > 20.f ? v : log1pf(__expf(v));                  // softplus (beta 1, threshold 20)
+        case 4: return siluf_(v);
+        default: return v;
+    }
+}
+
+// Packed ("fragment-major") weight layout used by every linear op:
+//   W[N][K] row-major bf16  ->  Wp[N/16][K/32][lane 0..63][8]   (N, K zero-padded to 16 / 32)
+//   lane = g*16 + i holds W[rg*16 + i][ks*32 + g*8 + 0..7]
+// so one wave-wide 16-byte load of (rg, ks) is exactly the A operand of
+// v_mfma_f32_16x16x32_bf16 and is 1 KiB contiguous in HBM and conflict-free in LDS.
+__host__ __device__ __forceinline__ size_t packed_index(int n, int k, int KS) {
+    return ((size_t)(n >> 4) * KS + (k >> 5)) * 512 + (size_t)((((k & 31) >> 3) << 4) + (n & 15)) * 8 + (k & 7);
+}

@@ -1,0 +1,434 @@
+// Linear ops for gfx950: weight packer, weight-streaming "skinny" kernel (M <= 16) and the LDS-tiled MFMA GEMM.
+//
+// Both compute kernels use v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand and the activations as
+// the B operand, i.e. they produce D[i = n][j = m] (the transposed output tile).  In that orientation a lane
+// holds 4 consecutive n for one m (C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg), so bias loads and
+// output stores are 8/16-byte vectors along the contiguous dimension of the row-major output.
+#include "common.h"
+#include "host.h"
+
+// ------------------------------------------------------------------------------------------------ pack
+__global__ void pack_weight_kernel(const bf16_t* __restrict__ w, int N, int K, int ldw, u32x4* __restrict__ out,
+                                   int KS, size_t total_chunks) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total_chunks) return;
+    int lane = (int)(c & 63);
+    size_t rest = c >> 6;
+    int ks = (int)(rest % KS);
+    int rg = (int)(rest / KS);
+    int n = rg * 16 + (lane & 15);
+    int k0 = ks * 32 + (lane >> 4) * 8;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t lo = 0, hi = 0;
+        if (n < N) {
+            if (k0 + 2 * j < K) lo = w[(size_t)n * ldw + k0 + 2 * j];
+            if (k0 + 2 * j + 1 < K) hi = w[(size_t)n * ldw + k0 + 2 * j + 1];
+        }
+        v[j] = lo | (hi << 16);
+    }
+    u32x4 o = {v[0], v[1], v[2], v[3]};
+    out[c] = o;
+}
+
+extern "C" size_t sm_packed_elems(int N, int K) {
+    return (size_t)((N + 15) / 16) * ((K + 31) / 32) * 512;
+}
+
+// KS_out >= ceil(K/32): number of k-steps of the packed image (extra steps are zero-filled)
+int sm_pack_weight_ks(const void* w, int N, int K, int ldw, int KS, void* out, void* stream) {
+    SM_REQUIRE(w && out && N > 0 && K > 0 && ldw >= K && KS * 32 >= K, "sm_pack_weight: bad args N=%d K=%d ldw=%d KS=%d", N, K, ldw, KS);
+    size_t chunks = (size_t)((N + 15) / 16) * KS * 64;
+    int blocks = (int)((chunks + 255) / 256);
+    pack_weight_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const bf16_t*)w, N, K, ldw, (u32x4*)out, KS, chunks);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+extern "C" int sm_pack_weight(const void* w, int N, int K, int ldw, void* out, void* stream) {
+    return sm_pack_weight_ks(w, N, K, ldw, (K + 31) / 32, out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ epilogue
+struct LinArgs {
+    const bf16x8* w;
+    const bf16x8* w2;
+    int N, K, KS, NRG;
+    const void* x;
+    int M, ldx;
+    const float* bias;
+    int act;
+    const float* residual;
+    int ldr;
+    float* out_f32;
+    bf16_t* out_bf16;
+    int ldo, ldo_bf16;
+    int remap_in, remap_out, remap_off;
+    bf16_t* vt;
+    int vt_n0, vt_S, vt_dh, vt_ld;
+};
+
+// one lane's 4 consecutive outputs (n0..n0+3) of row m
+__device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f32x4 v, const f32x4* v2) {
+    if (m >= a.M || n0 >= a.N) return;
+    int orow = m, rrow = m;
+    if (a.remap_in > 0) {
+        int q = m / a.remap_in, r = m - q * a.remap_in;
+        orow = q * a.remap_out + a.remap_off + r;
+        rrow = a.remap_off + r;
+    }
+    const bool full = (n0 + 3 < a.N);
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        if (a.bias && (full || n0 + r < a.N)) t += a.bias[n0 + r];
+        if (v2) t = siluf_(t) * (*v2)[r];
+        else t = apply_act(t, a.act);
+        if (a.residual && (full || n0 + r < a.N)) t += a.residual[(size_t)rrow * a.ldr + n0 + r];
+        o[r] = t;
+    }
+    if (a.out_f32) {
+        float* p = a.out_f32 + (size_t)orow * a.ldo + n0;
+        if (full && ((a.ldo & 3) == 0)) {
+            *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) p[r] = o[r];
+        }
+    }
+    if (a.vt && n0 >= a.vt_n0) {
+        int b = m / a.vt_S, s = m - b * a.vt_S;
+        int nh = (a.N - a.vt_n0) / a.vt_dh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int c = n0 + r - a.vt_n0;
+            if (n0 + r < a.N) {
+                int h = c / a.vt_dh, d = c - h * a.vt_dh;
+                a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + s] = (bf16_t)f2bf(o[r]);
+            }
+        }
+    } else if (a.out_bf16) {
+        bf16_t* p = a.out_bf16 + (size_t)orow * a.ldo_bf16 + n0;
+        if (full && ((a.ldo_bf16 & 3) == 0)) {
+            *(u32x2*)p = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) p[r] = (bf16_t)f2bf(o[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ skinny (M <= 16)
+// One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
+// ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
+// reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
+template <bool XF32, bool SPLIT>
+__device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16x8& hi, bf16x8& lo) {
+    if (XF32) {
+        f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (valid) {
+            a = *(const f32x4*)(xrow + (size_t)k * 4);
+            b = *(const f32x4*)(xrow + (size_t)k * 4 + 16);
+        }
+        float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        union { bf16x8 v; uint16_t u[8]; } H, L;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t h = f2bf(f[j]);
+            H.u[j] = (uint16_t)h;
+            if (SPLIT) L.u[j] = (uint16_t)f2bf(f[j] - bf2f(h));
+        }
+        hi = H.v;
+        if (SPLIT) lo = L.v;
+    } else {
+        union { bf16x8 v; u32x4 u; } H;
+        H.u = u32x4{0, 0, 0, 0};
+        if (valid) H.u = *(const u32x4*)(xrow + (size_t)k * 2);
+        hi = H.v;
+    }
+}
+
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = blockIdx.x;
+    const int KS = a.KS;
+    const int i = lane & 15, g = lane >> 4;
+    const bf16x8* wp = a.w + (size_t)rg * KS * 64 + lane;
+    const bf16x8* wp2 = DUAL ? a.w2 + (size_t)rg * KS * 64 + lane : nullptr;
+    const bool valid = i < a.M;
+    const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
+    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+
+    constexpr int U = 4;
+    int ks = wave;
+    for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
+        bf16x8 wa[U], wb[U], xh[U], xl[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wa[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
+            if (DUAL) wb[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_x<XF32, SPLIT>(xrow, (ks + u * WAVES) * 32 + g * 8, valid, xh[u], xl[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc, 0, 0, 0);
+            if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc, 0, 0, 0);
+            if (DUAL) {
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2, 0, 0, 0);
+                if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2, 0, 0, 0);
+            }
+        }
+    }
+    for (; ks < KS; ks += WAVES) {
+        bf16x8 xh, xl;
+        bf16x8 wa = __builtin_nontemporal_load(wp + (size_t)ks * 64);
+        load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid, xh, xl);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc, 0, 0, 0);
+        if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc, 0, 0, 0);
+        if (DUAL) {
+            bf16x8 wb = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xh, acc2, 0, 0, 0);
+            if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xl, acc2, 0, 0, 0);
+        }
+    }
+    if (WAVES > 1) {
+        // cross-wave K reduction in a FIXED order (deterministic): red[wave][reg][lane]
+        constexpr int PER = DUAL ? 8 : 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(wave * PER + r) * 64 + lane] = acc[r];
+            if (DUAL) red[(wave * PER + 4 + r) * 64 + lane] = acc2[r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f, s2 = 0.f;
+            for (int w = 0; w < WAVES; ++w) {
+                s += red[(w * PER + r) * 64 + lane];
+                if (DUAL) s2 += red[(w * PER + 4 + r) * 64 + lane];
+            }
+            acc[r] = s;
+            if (DUAL) acc2[r] = s2;
+        }
+    }
+    store4(a, i, rg * 16 + g * 4, acc, DUAL ? &acc2 : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ tiled GEMM
+// 128(m) x 128(n) output tile, BK = 64, 4 waves as 2(n) x 2(m), each wave 4x4 fragments of 16x16.
+// Operands reach LDS by global_load_lds (16 B/lane, 1 KiB per wave-instruction):
+//   W tile  : 16 packed (row-group, k-step) chunks of 1 KiB -> LDS image already in fragment order
+//   X tile  : [128][64] bf16, 128-byte rows, 16-byte chunk index XOR-swizzled with (row & 7); the swizzle is
+//             applied on the per-lane SOURCE address (the LDS destination of global_load_lds is lane-linear)
+//             and again on the ds_read_b128 address.
+// Two LDS stages (64 KiB) -> 2 blocks/CU; loads of tile t+1 are in flight while tile t is multiplied.
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_STAGE_BYTES 32768
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous band of tile ids (bijective
+    // for any grid size) and walk n fastest inside it so the X band stays in that XCD's L2.
+    const int nblk = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+
+    const int KT = a.KS >> 1;
+    const char* xbase = (const char*)a.x;
+
+    // per-lane source addresses for the 4 + 4 staging loads of this wave
+    const char* wsrc[4];
+    const char* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int c = wave * 4 + j;                 // W chunk: rg_local = c >> 1, ks_local = c & 1
+        int rgg = tile_n * 8 + (c >> 1);
+        if (rgg >= a.NRG) rgg = a.NRG - 1;
+        wsrc[j] = (const char*)a.w + ((size_t)rgg * a.KS + (c & 1)) * 1024 + lane * 16;
+        int row = c * 8 + (lane >> 3);        // X piece: 8 rows x 128 B
+        int mg = tile_m * GEMM_BM + row;
+        if (mg >= a.M) mg = a.M - 1;
+        int chunk = (lane & 7) ^ (row & 7);
+        xsrc[j] = xbase + ((size_t)mg * a.ldx + chunk * 8) * 2;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
+
+    auto stage = [&](int kt, int buf) {
+        char* sb = smem + buf * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = wave * 4 + j;
+            glds16(wsrc[j] + (size_t)kt * 2048, sb + c * 1024);
+            glds16(xsrc[j] + (size_t)kt * 128, sb + 16384 + c * 1024);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) {
+            stage(kt + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* sw = smem + buf * GEMM_STAGE_BYTES;
+        const char* sx = sw + 16384;
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) {
+            bf16x8 wf[4], xf[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+                wf[nf] = *(const bf16x8*)(sw + (((wn * 4 + nf) * 2 + ksl) * 1024) + lane * 16);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                int ml = wm * 64 + mf * 16 + i;
+                xf[mf] = *(const bf16x8*)(sx + ml * 128 + (((ksl * 4 + g) ^ (ml & 7)) * 16));
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // ---- epilogue: stage the fp32 tile through LDS ([128 m][128 n] fp32 = the whole 64 KiB; 16-byte chunk index
+    // XOR-swizzled with (m & 31) so both the fragment-shaped writes and the row-shaped reads are conflict-free),
+    // then every wave walks whole rows: 512 B contiguous per row to HBM, epilogue code emitted once.
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            int ml = wm * 64 + mf * 16 + i;
+            int chunk = wn * 16 + nf * 4 + g;
+            *(f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16)) = acc[nf][mf];
+        }
+    __syncthreads();
+    if (a.vt && tile_n * GEMM_BN >= a.vt_n0) {
+        // V^T side output: lanes walk m (= s, the contiguous dim of vt), one n per wave per pass
+        const int nh = (a.N - a.vt_n0) / a.vt_dh;
+        for (int pass = 0; pass < 32; ++pass) {
+            const int nl = pass * 4 + wave;
+            const int n = tile_n * GEMM_BN + nl;
+            if (n >= a.N) continue;
+            const int c = n - a.vt_n0;
+            const int h = c / a.vt_dh, d = c - h * a.vt_dh;
+            const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int ml = lane + 64 * h2;
+                const int m = tile_m * GEMM_BM + ml;
+                if (m < a.M) {
+                    float v = *(const float*)(smem + ml * 512 + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
+                    const int b = m / a.vt_S, sidx = m - b * a.vt_S;
+                    a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act(v, a.act));
+                }
+            }
+        }
+    } else {
+        for (int pass = 0; pass < 16; ++pass) {
+            const int ml = pass * 8 + (tid >> 5);
+            const int chunk = tid & 31;
+            f32x4 v = *(const f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16));
+            store4(a, tile_m * GEMM_BM + ml, tile_n * GEMM_BN + chunk * 4, v, nullptr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+template <int WAVES>
+static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
+    dim3 grid(a.NRG), block(WAVES * 64);
+    size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * 64 * sizeof(float) : 0;
+#define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU><<<grid, block, sh, st>>>(a)
+    if (xf32) {
+        if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
+        else       { if (dual) SK(true, false, true); else SK(true, false, false); }
+    } else {
+        if (dual) SK(false, false, true); else SK(false, false, false);
+    }
+#undef SK
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
+    SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
+    SM_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "sm_linear: bad dims M=%d N=%d K=%d", p->M, p->N, p->K);
+    SM_REQUIRE(p->out_f32 || p->out_bf16 || p->vt, "sm_linear: no output");
+    LinArgs a;
+    a.w = (const bf16x8*)p->w;
+    a.w2 = (const bf16x8*)p->w2;
+    a.N = p->N; a.K = p->K;
+    a.KS = (p->K + 31) / 32;
+    a.NRG = (p->N + 15) / 16;
+    a.x = p->x; a.M = p->M; a.ldx = p->ldx;
+    a.bias = p->bias; a.act = p->act;
+    a.residual = p->residual; a.ldr = p->ldr;
+    a.out_f32 = p->out_f32; a.out_bf16 = (bf16_t*)p->out_bf16;
+    a.ldo = p->ldo; a.ldo_bf16 = p->ldo_bf16;
+    a.remap_in = p->remap_in; a.remap_out = p->remap_out; a.remap_off = p->remap_off;
+    a.vt = (bf16_t*)p->vt; a.vt_n0 = p->vt_n0; a.vt_S = p->vt_S; a.vt_dh = p->vt_dh; a.vt_ld = p->vt_ld;
+    SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
+    SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
+    hipStream_t st = (hipStream_t)stream;
+    const bool xf32 = p->x_dtype == SM_X_F32;
+    if (p->M <= 16) {
+        SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
+        SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
+        const bool split = xf32 && p->precise;
+        const bool dual = p->w2 != nullptr;
+        // enough waves per row-group to keep >= ~32 KiB of weight loads in flight per CU
+        if (a.KS >= 64 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
+        if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);
+        if (a.KS >= 8) return launch_skinny<4>(a, xf32, split, dual, st);
+        return launch_skinny<1>(a, xf32, split, dual, st);
+    }
+    SM_REQUIRE(!xf32, "sm_linear: the tiled GEMM takes bf16 activations (M=%d > 16)", p->M);
+    SM_REQUIRE(!p->w2, "sm_linear: dual weights only on the skinny path");
+    SM_REQUIRE((a.KS & 1) == 0, "sm_linear: GEMM path needs K padded to a multiple of 64 (K=%d)", p->K);
+    SM_REQUIRE(p->ldx % 8 == 0, "sm_linear: bf16 x needs ldx %% 8 == 0");
+    SM_REQUIRE(!p->vt || (p->vt_n0 % GEMM_BN == 0 && !p->residual && p->remap_in == 0), "sm_linear: vt_n0 must be a multiple of %d on the GEMM path", GEMM_BN);
+    int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        attr_set = true;
+    }
+    gemm_kernel<<<tiles_m * tiles_n, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}

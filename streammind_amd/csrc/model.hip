@@ -1,0 +1,629 @@
+// Path-level orchestration behind the C ABI: weight registry (HF/reference names -> packed device storage),
+// workspaces, the ViT forward, the per-frame connector+gate step and the Mistral prefill / greedy decode.
+// Everything here is host code issuing the kernels of linear.hip / attention.hip / vecops.hip on one stream;
+// there is no host synchronisation on any hot call.
+#include <math.h>
+#include <stdlib.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "host.h"
+
+int sm_pack_weight_ks(const void* w, int N, int K, int ldw, int KS, void* out, void* stream);   // linear.hip
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ void bf16_to_f32_kernel(const bf16_t* in, float* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf2f(in[i]);
+}
+__global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16_t)f2bf(in[i]);
+}
+__global__ void embed_last_kernel(const int32_t* tok, const bf16_t* table, int D, float* out) {
+    int id = *tok;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[c] = bf2f(table[(size_t)id * D + c]);
+}
+__global__ void copy_i32_kernel(const int32_t* src, int32_t* dst) { *dst = *src; }
+
+// ------------------------------------------------------------------------------------------------ storage
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t b, bool zero = false) {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = b;
+        if (b == 0) return SM_OK;
+        SM_HIP(hipMalloc(&p, b));
+        if (zero) SM_HIP(hipMemset(p, 0, b));
+        return SM_OK;
+    }
+    ~DevBuf() { if (p) hipFree(p); }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct Slot {            // one tensor the path reads
+    DevBuf buf;
+    int kind = 0;        // 0 = fp32 vector/matrix (as is), 1 = packed linear (possibly a fused group), 2 = bf16 row-major
+    int N = 0, K = 0;    // logical dims of the (fused) matrix
+    int parts = 1, loaded = 0;
+};
+
+struct sm_model {
+    sm_config_t c;
+    std::unordered_map<std::string, Slot> slots;           // canonical name -> storage
+    struct Route { std::string slot; int row0; };          // checkpoint name -> (slot, first row inside a fused slot)
+    std::unordered_map<std::string, Route> routes;
+    std::vector<std::string> ignored_prefixes;
+    bool finalized = false;
+    // workspaces (ViT)
+    DevBuf patches, x, xn, qkv, vt, ctx, hmid;
+    int S = 0, P = 0, Spad = 0, Kpe = 0, Bmax = 0;
+    // RoPE tables for the LLM
+    DevBuf rope_cos, rope_sin;
+    int rope_len = 0;
+
+    Slot* get(const std::string& n) {
+        auto it = slots.find(n);
+        return it == slots.end() ? nullptr : &it->second;
+    }
+    template <typename T> T* ptr(const std::string& n) { return slots.at(n).buf.as<T>(); }
+};
+
+static void add_linear(sm_model* m, const std::string& slot, int N, int K, const std::vector<std::string>& names, int rows_each) {
+    Slot& s = m->slots[slot];
+    s.kind = 1; s.N = N; s.K = K; s.parts = (int)names.size();
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each};
+}
+static void add_f32(sm_model* m, const std::string& name, int N, int K = 1) {
+    Slot& s = m->slots[name];
+    s.kind = 0; s.N = N; s.K = K;
+    m->routes[name] = {name, 0};
+}
+static void add_f32_fused(sm_model* m, const std::string& slot, int N, const std::vector<std::string>& names, int rows_each) {
+    Slot& s = m->slots[slot];
+    s.kind = 0; s.N = N; s.K = 1; s.parts = (int)names.size();
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each};
+}
+
+extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
+    SM_REQUIRE(cfg && out, "sm_model_create: null arg");
+    const sm_config_t& c = *cfg;
+    SM_REQUIRE(c.vit_hidden % 64 == 0 && c.vit_mlp % 64 == 0 && c.vit_hidden % c.vit_heads == 0, "vit dims must be multiples of 64");
+    SM_REQUIRE(c.vit_hidden / c.vit_heads == 64 || c.vit_hidden / c.vit_heads == 128, "vit head_dim must be 64 or 128");
+    SM_REQUIRE(c.vit_image % c.vit_patch == 0, "image size must be a multiple of the patch size");
+    SM_REQUIRE(c.conn_mm_hidden == c.vit_hidden, "connector input width must equal the ViT width");
+    SM_REQUIRE(c.conn_d_model % 32 == 0 && c.conn_d_state <= 32 && c.conn_d_conv <= 8, "connector dims");
+    SM_REQUIRE(c.gate_hidden == c.conn_d_model, "gate width must equal the connector width");
+    SM_REQUIRE(c.gate_hidden % 32 == 0 && c.gate_mlp % 32 == 0 && c.gate_heads % c.gate_kv_heads == 0, "gate dims");
+    SM_REQUIRE(c.max_frames_per_call >= 1, "max_frames_per_call >= 1");
+    if (c.llm_layers > 0) {
+        SM_REQUIRE(c.llm_hidden == c.conn_d_model, "LLM width must equal the connector width");
+        SM_REQUIRE(c.llm_hidden % 64 == 0 && c.llm_mlp % 64 == 0, "LLM dims must be multiples of 64");
+        SM_REQUIRE(c.llm_hidden / c.llm_heads == 64 || c.llm_hidden / c.llm_heads == 128, "LLM head_dim must be 64 or 128");
+    }
+    sm_model* m = new sm_model();
+    m->c = c;
+    const int D = c.vit_hidden, g = c.vit_image / c.vit_patch;
+    m->P = g * g; m->S = m->P + 1; m->Spad = cdiv(m->S, 64) * 64;
+    m->Kpe = cdiv(3 * c.vit_patch * c.vit_patch, 64) * 64;
+    m->Bmax = c.max_frames_per_call;
+    // ---- vision tower
+    add_f32(m, "vit.embeddings.class_embedding", D);
+    add_linear(m, "vit.patch_embed", D, m->Kpe, {"vit.embeddings.patch_embedding.weight"}, D);   // K zero-padded to x64
+    add_f32(m, "vit.embeddings.position_embedding.weight", m->S, D);
+    add_f32(m, "vit.pre_layrnorm.weight", D); add_f32(m, "vit.pre_layrnorm.bias", D);
+    for (int l = 0; l < c.vit_layers_run; ++l) {
+        std::string p = "vit.encoder.layers." + std::to_string(l) + ".";
+        add_linear(m, p + "qkv", 3 * D, D, {p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight"}, D);
+        add_f32_fused(m, p + "qkv.bias", 3 * D, {p + "self_attn.q_proj.bias", p + "self_attn.k_proj.bias", p + "self_attn.v_proj.bias"}, D);
+        add_linear(m, p + "out", D, D, {p + "self_attn.out_proj.weight"}, D);
+        add_f32(m, p + "self_attn.out_proj.bias", D);
+        add_linear(m, p + "fc1", c.vit_mlp, D, {p + "mlp.fc1.weight"}, c.vit_mlp);
+        add_f32(m, p + "mlp.fc1.bias", c.vit_mlp);
+        add_linear(m, p + "fc2", D, c.vit_mlp, {p + "mlp.fc2.weight"}, D);
+        add_f32(m, p + "mlp.fc2.bias", D);
+        add_f32(m, p + "layer_norm1.weight", D); add_f32(m, p + "layer_norm1.bias", D);
+        add_f32(m, p + "layer_norm2.weight", D); add_f32(m, p + "layer_norm2.bias", D);
+    }
+    // ---- connector
+    const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
+    add_linear(m, "proj.pre", d, c.conn_mm_hidden, {"proj.pre_net.fc3.weight"}, d);
+    add_f32(m, "proj.pre_net.fc3.bias", d);
+    const std::string sp = "proj.mamba_model.ssms.0.";
+    add_f32(m, sp + "norm.weight", d); add_f32(m, sp + "norm.bias", d);
+    add_linear(m, "proj.in_proj", 2 * di, d, {sp + "mixer.in_proj.weight"}, 2 * di);
+    add_f32(m, sp + "mixer.conv1d.weight", di, c.conn_d_conv); add_f32(m, sp + "mixer.conv1d.bias", di);
+    add_linear(m, "proj.x_proj", R + 2 * ds, di, {sp + "mixer.x_proj.weight"}, R + 2 * ds);
+    add_linear(m, "proj.dt_proj", di, R, {sp + "mixer.dt_proj.weight"}, di);
+    add_f32(m, sp + "mixer.dt_proj.bias", di);
+    add_f32(m, sp + "mixer.A_log", di, ds); add_f32(m, sp + "mixer.D", di);
+    add_linear(m, "proj.out_proj", d, di, {sp + "mixer.out_proj.weight"}, d);
+    add_f32(m, "proj.mamba_model.norm_fn.weight", d); add_f32(m, "proj.mamba_model.norm_fn.bias", d);
+    add_linear(m, "proj.post", d, d, {"proj.post_net.fc3.weight"}, d);
+    add_f32(m, "proj.post_net.fc3.bias", d);
+    // ---- gate (V/O-only: q_proj / k_proj / embed_tokens are dead at seq-len 1 and ignored)
+    const int gdh = c.gate_hidden / c.gate_heads;
+    for (int l = 0; l < c.gate_layers; ++l) {
+        std::string p = "proj.cls_net.cls_model.model.layers." + std::to_string(l) + ".";
+        add_linear(m, p + "v", c.gate_kv_heads * gdh, d, {p + "self_attn.v_proj.weight"}, c.gate_kv_heads * gdh);
+        add_linear(m, p + "o", d, c.gate_heads * gdh, {p + "self_attn.o_proj.weight"}, d);
+        add_linear(m, p + "gu", 2 * c.gate_mlp, d, {p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"}, c.gate_mlp);
+        add_linear(m, p + "down", d, c.gate_mlp, {p + "mlp.down_proj.weight"}, d);
+        add_f32(m, p + "input_layernorm.weight", d); add_f32(m, p + "post_attention_layernorm.weight", d);
+        m->ignored_prefixes.push_back(p + "self_attn.q_proj."); m->ignored_prefixes.push_back(p + "self_attn.k_proj.");
+    }
+    add_f32(m, "proj.cls_net.cls_model.model.norm.weight", d);
+    add_linear(m, "proj.gate_head", 2, d, {"proj.cls_net.cls_model.lm_head.weight"}, 2);
+    m->ignored_prefixes.push_back("proj.cls_net.cls_model.model.embed_tokens.");
+    m->ignored_prefixes.push_back("vit.post_layernorm.");
+    m->ignored_prefixes.push_back("vit.embeddings.position_ids");
+    // ---- LLM
+    if (c.llm_layers > 0) {
+        const int ld = c.llm_hidden, dh = ld / c.llm_heads, qn = c.llm_heads * dh, kn = c.llm_kv_heads * dh;
+        SM_REQUIRE(qn == kn * (c.llm_heads / c.llm_kv_heads), "llm heads");
+        Slot& e = m->slots["llm.embed"]; e.kind = 2; e.N = c.llm_vocab; e.K = ld;
+        m->routes["llm.model.embed_tokens.weight"] = {"llm.embed", 0};
+        for (int l = 0; l < c.llm_layers; ++l) {
+            std::string p = "llm.model.layers." + std::to_string(l) + ".";
+            // q, k, v fused; all three blocks must start on a 16-row boundary of the packed image
+            SM_REQUIRE(qn % 16 == 0 && kn % 16 == 0, "llm q/k widths must be multiples of 16");
+            Slot& s = m->slots[p + "qkv"]; s.kind = 1; s.N = qn + 2 * kn; s.K = ld; s.parts = 3;
+            m->routes[p + "self_attn.q_proj.weight"] = {p + "qkv", 0};
+            m->routes[p + "self_attn.k_proj.weight"] = {p + "qkv", qn};
+            m->routes[p + "self_attn.v_proj.weight"] = {p + "qkv", qn + kn};
+            add_linear(m, p + "o", ld, qn, {p + "self_attn.o_proj.weight"}, ld);
+            add_linear(m, p + "gu", 2 * c.llm_mlp, ld, {p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"}, c.llm_mlp);
+            add_linear(m, p + "down", ld, c.llm_mlp, {p + "mlp.down_proj.weight"}, ld);
+            add_f32(m, p + "input_layernorm.weight", ld); add_f32(m, p + "post_attention_layernorm.weight", ld);
+        }
+        add_f32(m, "llm.model.norm.weight", ld);
+        add_linear(m, "llm.lm_head", c.llm_vocab, ld, {"llm.lm_head.weight"}, c.llm_vocab);
+    }
+    *out = m;
+    return SM_OK;
+}
+
+// checkpoint name -> canonical "vit." / "proj." / "llm." name
+static std::string canon(const std::string& name, const sm_config_t& c) {
+    size_t p;
+    if ((p = name.rfind("vision_tower.")) != std::string::npos) {
+        std::string r = name.substr(p + 13);
+        if (r.rfind("vision_model.", 0) == 0) r = r.substr(13);
+        return "vit." + r;
+    }
+    if ((p = name.find("mm_projector.")) != std::string::npos) return "proj." + name.substr(p + 13);
+    return "llm." + name;
+}
+
+extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void* data, int dtype, int ndim,
+                                    const int64_t* shape, void* stream) {
+    SM_REQUIRE(m && name_c && data && shape && ndim >= 1 && ndim <= 4, "sm_model_load_tensor: bad args");
+    SM_REQUIRE(dtype == SM_DT_BF16 || dtype == SM_DT_F32, "sm_model_load_tensor: dtype must be bf16 or f32");
+    hipStream_t st = (hipStream_t)stream;
+    std::string name = canon(name_c, m->c);
+    auto it = m->routes.find(name);
+    if (it == m->routes.end()) {
+        for (auto& pre : m->ignored_prefixes)
+            if (name.rfind(pre, 0) == 0) return 1;
+        // vision layers beyond the selected hidden state are computed by HF but never read
+        if (name.rfind("vit.encoder.layers.", 0) == 0) {
+            int l = atoi(name.c_str() + 19);
+            if (l >= m->c.vit_layers_run) return 1;
+        }
+        SM_FAIL(SM_EINVAL, "sm_model_load_tensor: unknown tensor '%s' (canonical '%s')", name_c, name.c_str());
+    }
+    Slot& s = m->slots[it->second.slot];
+    const int row0 = it->second.row0;
+    int64_t rows = shape[0], cols = 1;
+    for (int i = 1; i < ndim; ++i) cols *= shape[i];
+    const size_t n = (size_t)rows * cols;
+    if (s.kind == 1 || s.kind == 2) {
+        SM_REQUIRE((cols == s.K || (s.kind == 1 && cols < s.K && s.parts == 1)) && row0 + rows <= s.N, "tensor '%s': shape [%lld x %lld] does not fit slot [%d x %d] at row %d",
+                   name_c, (long long)rows, (long long)cols, s.N, s.K, row0);
+        DevBuf tmp;
+        const bf16_t* src = (const bf16_t*)data;
+        if (dtype == SM_DT_F32) {
+            int rc = tmp.alloc(n * 2);
+            if (rc) return rc;
+            f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
+            src = tmp.as<bf16_t>();
+        }
+        if (s.kind == 1) {
+            if (!s.buf.p) { int rc = s.buf.alloc(sm_packed_elems(s.N, s.K) * 2, true); if (rc) return rc; }
+            SM_REQUIRE(row0 % 16 == 0, "fused part must start on a 16-row boundary");
+            const int KS = (s.K + 31) / 32;
+            bf16_t* dst = s.buf.as<bf16_t>() + (size_t)(row0 / 16) * KS * 512;
+            int rc = sm_pack_weight_ks(src, (int)rows, (int)cols, (int)cols, KS, dst, stream);
+            if (rc) return rc;
+        } else {
+            if (!s.buf.p) { int rc = s.buf.alloc((size_t)s.N * s.K * 2); if (rc) return rc; }
+            SM_HIP(hipMemcpyAsync(s.buf.as<bf16_t>() + (size_t)row0 * s.K, src, n * 2, hipMemcpyDeviceToDevice, st));
+        }
+        if (tmp.p) SM_HIP(hipStreamSynchronize(st));      // tmp is freed on return
+    } else {
+        SM_REQUIRE((size_t)row0 * s.K + n <= (size_t)s.N * s.K, "tensor '%s': %zu elements do not fit slot of %zu", name_c, n, (size_t)s.N * s.K);
+        if (!s.buf.p) { int rc = s.buf.alloc((size_t)s.N * s.K * 4); if (rc) return rc; }
+        float* dst = s.buf.as<float>() + (size_t)row0 * s.K;
+        if (dtype == SM_DT_F32) SM_HIP(hipMemcpyAsync(dst, data, n * 4, hipMemcpyDeviceToDevice, st));
+        else bf16_to_f32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const bf16_t*)data, dst, n);
+    }
+    SM_LAUNCH_CHECK();
+    s.loaded += 1;
+    return SM_OK;
+}
+
+extern "C" int sm_model_missing(sm_model* m, char* buf, size_t buflen) {
+    SM_REQUIRE(m && buf && buflen > 0, "sm_model_missing: bad args");
+    std::string out;
+    int cnt = 0;
+    for (auto& kv : m->slots)
+        if (kv.second.loaded < kv.second.parts) { out += kv.first; out += "\n"; ++cnt; }
+    snprintf(buf, buflen, "%s", out.c_str());
+    return cnt;
+}
+
+extern "C" int sm_model_finalize(sm_model* m, void* stream) {
+    SM_REQUIRE(m, "sm_model_finalize: null model");
+    for (auto& kv : m->slots)
+        SM_REQUIRE(kv.second.loaded >= kv.second.parts, "sm_model_finalize: tensor group '%s' incomplete (%d of %d parts)",
+                   kv.first.c_str(), kv.second.loaded, kv.second.parts);
+    const sm_config_t& c = m->c;
+    const int D = c.vit_hidden, B = m->Bmax, S = m->S;
+    const size_t rows = (size_t)B * S;
+    int rc;
+    if ((rc = m->patches.alloc((size_t)B * m->P * m->Kpe * 2))) return rc;
+    if ((rc = m->x.alloc(rows * D * 4))) return rc;
+    if ((rc = m->xn.alloc(rows * D * 2))) return rc;
+    if ((rc = m->qkv.alloc(rows * 3 * D * 2))) return rc;
+    if ((rc = m->vt.alloc((size_t)B * D * m->Spad * 2, true))) return rc;     // zero pad columns stay zero forever
+    if ((rc = m->ctx.alloc(rows * D * 2))) return rc;
+    if ((rc = m->hmid.alloc(rows * c.vit_mlp * 2))) return rc;
+    m->finalized = true;
+    return SM_OK;
+}
+
+extern "C" void sm_model_destroy(sm_model* m) { delete m; }
+
+// ------------------------------------------------------------------------------------------------ ViT
+static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dtype, int M, int ldx) {
+    sm_linear_t a;
+    memset(&a, 0, sizeof(a));
+    a.w = w.buf.p; a.N = w.N; a.K = w.K; a.x = x; a.x_dtype = x_dtype; a.M = M; a.ldx = ldx;
+    return a;
+}
+
+extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats, float* pix, void* stream) {
+    SM_REQUIRE(m && m->finalized, "sm_vit_encode: model not finalized");
+    SM_REQUIRE(frames && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode: B=%d outside [1, %d]", B, m->Bmax);
+    const sm_config_t& c = m->c;
+    const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P, M = B * S;
+    int rc;
+    float* x = m->x.as<float>();
+    bf16_t* xn = m->xn.as<bf16_t>();
+    // a1: u8 ring buffer -> normalised bf16 patch matrix
+    if ((rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, m->patches.p, m->Kpe, pix, stream))) return rc;
+    // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
+    {
+        sm_linear_t a = lin(m, m->slots.at("vit.patch_embed"), m->patches.p, SM_X_BF16, B * P, m->Kpe);
+        a.out_f32 = x; a.ldo = D;
+        a.residual = m->ptr<float>("vit.embeddings.position_embedding.weight"); a.ldr = D;
+        a.remap_in = P; a.remap_out = S; a.remap_off = 1;
+        if ((rc = sm_linear(&a, stream))) return rc;
+    }
+    if ((rc = sm_vit_cls_rows(x, B, S, D, m->ptr<float>("vit.embeddings.class_embedding"), m->ptr<float>("vit.embeddings.position_embedding.weight"), stream))) return rc;
+    if ((rc = sm_norm(x, M, D, D, m->ptr<float>("vit.pre_layrnorm.weight"), m->ptr<float>("vit.pre_layrnorm.bias"), c.vit_eps, 0, x, nullptr, D, stream))) return rc;
+    for (int l = 0; l < c.vit_layers_run; ++l) {
+        const std::string p = "vit.encoder.layers." + std::to_string(l) + ".";
+        if ((rc = sm_norm(x, M, D, D, m->ptr<float>(p + "layer_norm1.weight"), m->ptr<float>(p + "layer_norm1.bias"), c.vit_eps, 0, nullptr, xn, D, stream))) return rc;
+        {
+            sm_linear_t a = lin(m, m->slots.at(p + "qkv"), xn, SM_X_BF16, M, D);
+            a.bias = m->ptr<float>(p + "qkv.bias");
+            a.out_bf16 = m->qkv.p; a.ldo_bf16 = 3 * D;
+            a.vt = m->vt.p; a.vt_n0 = 2 * D; a.vt_S = S; a.vt_dh = dh; a.vt_ld = m->Spad;
+            if ((rc = sm_linear(&a, stream))) return rc;
+        }
+        if ((rc = sm_vit_attention(m->qkv.p, m->vt.p, m->ctx.p, B, S, H, dh, m->Spad, stream))) return rc;
+        {
+            sm_linear_t a = lin(m, m->slots.at(p + "out"), m->ctx.p, SM_X_BF16, M, D);
+            a.bias = m->ptr<float>(p + "self_attn.out_proj.bias");
+            a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            if ((rc = sm_linear(&a, stream))) return rc;
+        }
+        if ((rc = sm_norm(x, M, D, D, m->ptr<float>(p + "layer_norm2.weight"), m->ptr<float>(p + "layer_norm2.bias"), c.vit_eps, 0, nullptr, xn, D, stream))) return rc;
+        {
+            sm_linear_t a = lin(m, m->slots.at(p + "fc1"), xn, SM_X_BF16, M, D);
+            a.bias = m->ptr<float>(p + "mlp.fc1.bias"); a.act = SM_ACT_QUICK_GELU;
+            a.out_bf16 = m->hmid.p; a.ldo_bf16 = c.vit_mlp;
+            if ((rc = sm_linear(&a, stream))) return rc;
+        }
+        {
+            sm_linear_t a = lin(m, m->slots.at(p + "fc2"), m->hmid.p, SM_X_BF16, M, c.vit_mlp);
+            a.bias = m->ptr<float>(p + "mlp.fc2.bias");
+            a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            if ((rc = sm_linear(&a, stream))) return rc;
+        }
+    }
+    return sm_pool_patches(x, B, S, D, pooled, feats, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ stream
+struct sm_stream {
+    sm_model* m;
+    int max_frames, max_seq;
+    int T = 0, kv_len = 0;
+    DevBuf conv_state, ssm_state, tokens;
+    // connector/gate scratch for up to 16 frames per call
+    DevBuf pooled, t0, u, xz, xc, xdbl, delta, y, r, lnf, h, hn, v, vrep, act, hfin, logits2;
+    // LLM
+    std::vector<DevBuf> kc, vtc;
+    DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok;
+    int chunk = 0;
+};
+
+extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_stream** out) {
+    SM_REQUIRE(m && m->finalized && out && max_frames > 0, "sm_stream_open: bad args / model not finalized");
+    const sm_config_t& c = m->c;
+    sm_stream* s = new sm_stream();
+    s->m = m; s->max_frames = max_frames;
+    const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
+    const int gdh = c.gate_hidden / c.gate_heads;
+    const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
+    int rc = 0;
+#define A(buf, bytes, z) if (!rc) rc = s->buf.alloc((bytes), z)
+    A(conv_state, (size_t)di * c.conn_d_conv * 4, true);
+    A(ssm_state, (size_t)di * ds * 4, true);
+    A(tokens, (size_t)max_frames * d * 4, false);
+    A(pooled, (size_t)16 * c.conn_mm_hidden * 4, false);
+    A(t0, (size_t)16 * d * 4, false); A(u, (size_t)16 * d * 4, false);
+    A(xz, (size_t)16 * 2 * di * 4, false); A(xc, (size_t)16 * di * 4, false);
+    A(xdbl, (size_t)16 * xd * 4, true); A(delta, (size_t)16 * di * 4, false);
+    A(y, (size_t)16 * di * 4, false); A(r, (size_t)16 * d * 4, false); A(lnf, (size_t)16 * d * 4, false);
+    A(h, (size_t)16 * d * 4, false); A(hn, (size_t)16 * d * 4, false);
+    A(v, (size_t)16 * c.gate_kv_heads * gdh * 4, false); A(vrep, (size_t)16 * c.gate_heads * gdh * 4, false);
+    A(act, (size_t)16 * c.gate_mlp * 4, false); A(hfin, (size_t)16 * d * 4, false);
+    A(logits2, (size_t)16 * 2 * 4, false);
+    if (!rc && c.llm_layers > 0) {
+        SM_REQUIRE(max_seq > 0 && max_seq % 64 == 0, "sm_stream_open: max_seq must be a positive multiple of 64");
+        s->max_seq = max_seq;
+        const int ld = c.llm_hidden, dh = ld / c.llm_heads, kn = c.llm_kv_heads * dh, qn = c.llm_heads * dh;
+        s->kc.resize(c.llm_layers); s->vtc.resize(c.llm_layers);
+        for (int l = 0; l < c.llm_layers && !rc; ++l) {
+            rc = s->kc[l].alloc((size_t)max_seq * kn * 2, true);
+            if (!rc) rc = s->vtc[l].alloc((size_t)kn * max_seq * 2, true);
+        }
+        s->chunk = max_seq < 2048 ? max_seq : 2048;            // prefill chunk (rows of the activation workspace)
+        const size_t ch = s->chunk;
+        A(emb, ch * ld * 4, false); A(xnb, ch * ld * 2, false);
+        A(qkvf, ch * (qn + 2 * kn) * 4, false); A(qb, ch * qn * 2, false); A(ctxb, ch * qn * 2, false);
+        A(guf, ch * 2 * c.llm_mlp * 4, false); A(actb, ch * c.llm_mlp * 2, false);
+        A(lmlog, (size_t)c.llm_vocab * 4, false); A(next_tok, 64, true);
+        if (!rc && m->rope_len < max_seq) {
+            // cos/sin(pos * theta^(-2j/dh)) exactly as HF MistralRotaryEmbedding: fp32 inv_freq, fp32 product
+            const int half = dh / 2;
+            std::vector<float> hc((size_t)max_seq * half), hs((size_t)max_seq * half);
+            for (int j = 0; j < half; ++j) {
+                float inv = 1.0f / powf(c.llm_rope_theta, (float)(2 * j) / (float)dh);
+                for (int p = 0; p < max_seq; ++p) {
+                    float ang = (float)p * inv;
+                    hc[(size_t)p * half + j] = (float)cos((double)ang);
+                    hs[(size_t)p * half + j] = (float)sin((double)ang);
+                }
+            }
+            rc = m->rope_cos.alloc(hc.size() * 4);
+            if (!rc) rc = m->rope_sin.alloc(hs.size() * 4);
+            if (!rc) {
+                SM_HIP(hipMemcpy(m->rope_cos.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+                SM_HIP(hipMemcpy(m->rope_sin.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+                m->rope_len = max_seq;
+            }
+        }
+    }
+#undef A
+    if (rc) { delete s; return rc; }
+    *out = s;
+    return SM_OK;
+}
+
+extern "C" int sm_stream_reset(sm_stream* s, void* stream) {
+    SM_REQUIRE(s, "sm_stream_reset: null");
+    hipStream_t st = (hipStream_t)stream;
+    SM_HIP(hipMemsetAsync(s->conv_state.p, 0, s->conv_state.bytes, st));
+    SM_HIP(hipMemsetAsync(s->ssm_state.p, 0, s->ssm_state.bytes, st));
+    s->T = 0; s->kv_len = 0;
+    return SM_OK;
+}
+extern "C" void sm_stream_close(sm_stream* s) { delete s; }
+extern "C" int sm_stream_num_frames(sm_stream* s) { return s ? s->T : -1; }
+extern "C" const float* sm_stream_tokens(sm_stream* s) { return s ? s->tokens.as<float>() : nullptr; }
+extern "C" int sm_stream_kv_len(sm_stream* s) { return s ? s->kv_len : -1; }
+extern "C" int sm_stream_set_kv_len(sm_stream* s, int n) {
+    SM_REQUIRE(s && n >= 0 && n <= s->kv_len, "sm_stream_set_kv_len: %d outside [0, kv_len]", n);
+    s->kv_len = n;
+    return SM_OK;
+}
+extern "C" const float* sm_stream_logits(sm_stream* s) { return s ? s->lmlog.as<float>() : nullptr; }
+extern "C" int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, void* stream) {
+    SM_REQUIRE(s && out && t0 >= 0 && n >= 0 && t0 + n <= s->T, "sm_stream_read_tokens: [%d, %d) outside [0, %d)", t0, t0 + n, s ? s->T : 0);
+    if (n == 0) return SM_OK;
+    const int d = s->m->c.conn_d_model;
+    SM_HIP(hipMemcpyAsync(out, s->tokens.as<float>() + (size_t)t0 * d, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SM_OK;
+}
+extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_token_out, void* stream) {
+    SM_REQUIRE(s && s->m->c.llm_layers > 0, "sm_stream_read_logits: perception-only model");
+    if (out) SM_HIP(hipMemcpyAsync(out, s->lmlog.p, (size_t)s->m->c.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (next_token_out) SM_HIP(hipMemcpyAsync(next_token_out, s->next_tok.p, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SM_OK;
+}
+
+// a5-a9: PreNet -> LN -> Mamba step -> +res -> LN_f -> PostNet -> 4-layer gate (V/O shortcut) -> logits, decisions
+extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(s && pooled && M >= 1 && M <= 16, "sm_stream_push_pooled: M=%d outside [1,16]", M);
+    SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
+    sm_model* m = s->m;
+    const sm_config_t& c = m->c;
+    const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
+    const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
+    const int pr = c.gate_precise;
+    const std::string sp = "proj.mamba_model.ssms.0.";
+    int rc;
+    auto L = [&](const std::string& slot, const float* x, int ldx) {
+        sm_linear_t a = lin(m, m->slots.at(slot), x, SM_X_F32, M, ldx);
+        a.precise = pr;
+        return a;
+    };
+    float* tok = s->tokens.as<float>() + (size_t)s->T * d;
+    {   // PreNet: leaky_relu(W x + b)                                         builder.py:166-170
+        sm_linear_t a = L("proj.pre", pooled, c.conn_mm_hidden);
+        a.bias = m->ptr<float>("proj.pre_net.fc3.bias"); a.act = SM_ACT_LEAKY_RELU; a.out_f32 = s->t0.as<float>(); a.ldo = d;
+        if ((rc = sm_linear(&a, stream))) return rc;
+    }
+    // Block: hidden = Mamba(LN(residual)), residual = t0                      block.py:51-67
+    if ((rc = sm_norm(s->t0.as<float>(), M, d, d, m->ptr<float>(sp + "norm.weight"), m->ptr<float>(sp + "norm.bias"), c.conn_eps, 0, s->u.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L("proj.in_proj", s->u.as<float>(), d); a.out_f32 = s->xz.as<float>(); a.ldo = 2 * di;
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    if ((rc = sm_mamba_conv_step(s->xz.as<float>(), M, di, c.conn_d_conv, s->conv_state.as<float>(), m->ptr<float>(sp + "mixer.conv1d.weight"), m->ptr<float>(sp + "mixer.conv1d.bias"), s->xc.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L("proj.x_proj", s->xc.as<float>(), di); a.out_f32 = s->xdbl.as<float>(); a.ldo = xd;
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    {   // dt = softplus(W_dt dt_r + b): K = dt_rank is padded to 32 inside the packed weight (zeros), x_dbl rows are xd wide
+        sm_linear_t a = L("proj.dt_proj", s->xdbl.as<float>(), xd);
+        a.bias = m->ptr<float>(sp + "mixer.dt_proj.bias"); a.act = SM_ACT_SOFTPLUS; a.out_f32 = s->delta.as<float>(); a.ldo = di;
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    if ((rc = sm_mamba_ssm_step(s->xc.as<float>(), s->delta.as<float>(), s->xdbl.as<float>(), xd, R, s->xz.as<float>(), M, di, ds, m->ptr<float>(sp + "mixer.A_log"), m->ptr<float>(sp + "mixer.D"), s->ssm_state.as<float>(), s->y.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L("proj.out_proj", s->y.as<float>(), di);
+        a.residual = s->t0.as<float>(); a.ldr = d; a.out_f32 = s->r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    if ((rc = sm_norm(s->r.as<float>(), M, d, d, m->ptr<float>("proj.mamba_model.norm_fn.weight"), m->ptr<float>("proj.mamba_model.norm_fn.bias"), c.conn_eps, SM_ACT_LEAKY_RELU, s->lnf.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L("proj.post", s->lnf.as<float>(), d);
+        a.bias = m->ptr<float>("proj.post_net.fc3.bias"); a.out_f32 = tok; a.ldo = d;
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    // ---- gate on each of the M tokens independently (seq-len 1 each; builder.py:553-562)
+    const int gdh = c.gate_hidden / c.gate_heads, kvn = c.gate_kv_heads * gdh, qn = c.gate_heads * gdh;
+    const float* hcur = tok;       // layer 0 reads the token, writes s->h
+    for (int l = 0; l < c.gate_layers; ++l) {
+        const std::string p = "proj.cls_net.cls_model.model.layers." + std::to_string(l) + ".";
+        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.gate_eps, 0, s->hn.as<float>(), nullptr, d, stream))) return rc;
+        {   sm_linear_t a = L(p + "v", s->hn.as<float>(), d); a.out_f32 = s->v.as<float>(); a.ldo = kvn;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        if ((rc = sm_repeat_kv(s->v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, s->vrep.as<float>(), stream))) return rc;
+        {   sm_linear_t a = L(p + "o", s->vrep.as<float>(), qn);
+            a.residual = hcur; a.ldr = d; a.out_f32 = s->h.as<float>(); a.ldo = d;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        hcur = s->h.as<float>();
+        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.gate_eps, 0, s->hn.as<float>(), nullptr, d, stream))) return rc;
+        {   const Slot& gu = m->slots.at(p + "gu");
+            sm_linear_t a = L(p + "gu", s->hn.as<float>(), d);
+            a.N = c.gate_mlp;
+            a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.gate_mlp / 16) * ((d + 31) / 32) * 512;
+            a.out_f32 = s->act.as<float>(); a.ldo = c.gate_mlp;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        {   sm_linear_t a = L(p + "down", s->act.as<float>(), c.gate_mlp);
+            a.residual = hcur; a.ldr = d; a.out_f32 = s->h.as<float>(); a.ldo = d;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+    }
+    if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>("proj.cls_net.cls_model.model.norm.weight"), nullptr, c.gate_eps, 0, s->hfin.as<float>(), nullptr, d, stream))) return rc;
+    float* lg = logits ? logits : s->logits2.as<float>();
+    {   sm_linear_t a = L("proj.gate_head", s->hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
+        if ((rc = sm_linear(&a, stream))) return rc; }
+    if (decisions && (rc = sm_gate_decide(lg, M, decisions, stream))) return rc;
+    s->T += M;
+    return SM_OK;
+}
+
+extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(s && frames && M >= 1 && M <= 16 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, min(16, max_frames_per_call)]", M);
+    int rc = sm_vit_encode(s->m, frames, M, s->pooled.as<float>(), nullptr, nullptr, stream);
+    if (rc) return rc;
+    return sm_stream_push_pooled(s, s->pooled.as<float>(), M, logits, decisions, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ LLM
+// one pass of the decoder over n rows of s->emb (fp32 residual stream) at positions kv_len..kv_len+n-1
+static int llm_layers(sm_stream* s, int n, void* stream) {
+    sm_model* m = s->m;
+    const sm_config_t& c = m->c;
+    const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh;
+    float* x = s->emb.as<float>();
+    int rc;
+    for (int l = 0; l < c.llm_layers; ++l) {
+        const std::string p = "llm.model.layers." + std::to_string(l) + ".";
+        if ((rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        {   sm_linear_t a = lin(m, m->slots.at(p + "qkv"), s->xnb.p, SM_X_BF16, n, ld);
+            a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        if ((rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
+        if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;
+        {   sm_linear_t a = lin(m, m->slots.at(p + "o"), s->ctxb.p, SM_X_BF16, n, qn);
+            a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        if ((rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if (n <= 16) {   // decode: SwiGLU fused into the dual skinny kernel
+            const Slot& gu = m->slots.at(p + "gu");
+            sm_linear_t a = lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
+            a.N = c.llm_mlp;
+            a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
+            a.out_bf16 = s->actb.p; a.ldo_bf16 = c.llm_mlp;
+            if ((rc = sm_linear(&a, stream))) return rc;
+        } else {
+            sm_linear_t a = lin(m, m->slots.at(p + "gu"), s->xnb.p, SM_X_BF16, n, ld);
+            a.out_f32 = s->guf.as<float>(); a.ldo = 2 * c.llm_mlp;
+            if ((rc = sm_linear(&a, stream))) return rc;
+            if ((rc = sm_swiglu(s->guf.as<float>(), n, c.llm_mlp, s->actb.p, stream))) return rc;
+        }
+        {   sm_linear_t a = lin(m, m->slots.at(p + "down"), s->actb.p, SM_X_BF16, n, c.llm_mlp);
+            a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+    }
+    s->kv_len += n;
+    return SM_OK;
+}
+
+// final norm + lm_head on row `row` of the residual stream, greedy argmax into next_tok
+static int llm_head(sm_stream* s, int row, void* stream) {
+    sm_model* m = s->m;
+    const sm_config_t& c = m->c;
+    const int ld = c.llm_hidden;
+    int rc;
+    if ((rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+    sm_linear_t a = lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, 1, ld);
+    a.out_f32 = s->lmlog.as<float>(); a.ldo = c.llm_vocab;
+    if ((rc = sm_linear(&a, stream))) return rc;
+    return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);
+}
+
+extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* stream) {
+    SM_REQUIRE(s && ids && n > 0 && s->m->c.llm_layers > 0, "sm_llm_prefill: bad args / perception-only model");
+    SM_REQUIRE(s->kv_len + n <= s->max_seq, "sm_llm_prefill: context %d + %d exceeds max_seq %d", s->kv_len, n, s->max_seq);
+    sm_model* m = s->m;
+    const int ld = m->c.llm_hidden;
+    int rc, done = 0, last_rows = 0;
+    while (done < n) {
+        int cur = n - done < s->chunk ? n - done : s->chunk;
+        if ((rc = sm_embed_splice(ids + done, cur, m->slots.at("llm.embed").buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = llm_layers(s, cur, stream))) return rc;
+        done += cur; last_rows = cur;
+    }
+    return llm_head(s, last_rows - 1, stream);
+}
+
+extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* stream) {
+    SM_REQUIRE(s && out_ids && n_steps > 0 && s->m->c.llm_layers > 0, "sm_llm_decode: bad args");
+    SM_REQUIRE(s->kv_len + n_steps <= s->max_seq, "sm_llm_decode: context %d + %d exceeds max_seq %d", s->kv_len, n_steps, s->max_seq);
+    sm_model* m = s->m;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    for (int j = 0; j < n_steps; ++j) {
+        // emit the pending greedy token, then feed it back (its KV is appended, the next token becomes pending)
+        copy_i32_kernel<<<1, 1, 0, st>>>(s->next_tok.as<int32_t>(), out_ids + j);
+        embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->slots.at("llm.embed").buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
+        SM_LAUNCH_CHECK();
+        if ((rc = llm_layers(s, 1, stream))) return rc;
+        if ((rc = llm_head(s, 0, stream))) return rc;
+    }
+    return SM_OK;
+}

@@ -1,0 +1,344 @@
+// Small HBM/latency-bound ops of the path: normalisation, preprocessing, pooling, Mamba recurrent step,
+// gate decision, embedding splice, RoPE + KV append, SwiGLU, argmax.
+#include "common.h"
+#include "host.h"
+
+thread_local char g_sm_err[512] = {0};
+extern "C" const char* sm_last_error(void) { return g_sm_err; }
+extern "C" int sm_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------ norm
+// one wave per row; D <= 16384.  LayerNorm: two-pass (mean, then centred variance) from registers/L1.
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int M, int D, int ldx,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float eps, int post_act, float* __restrict__ of, bf16_t* __restrict__ ob,
+                                                   int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    const int nv = D >> 2;     // D % 4 == 0
+    float s = 0.f;
+    for (int v = lane; v < nv; v += 64) {
+        f32x4 t = *(const f32x4*)(xr + v * 4);
+        s += LN ? (t[0] + t[1] + t[2] + t[3]) : (t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);
+    }
+    s = wave_sum(s);
+    float mu = 0.f, rstd;
+    if (LN) {
+        mu = s / D;
+        float q = 0.f;
+        for (int v = lane; v < nv; v += 64) {
+            f32x4 t = *(const f32x4*)(xr + v * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = t[j] - mu; q += d * d; }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / D + eps);
+    } else {
+        rstd = rsqrtf(s / D + eps);
+    }
+    for (int v = lane; v < nv; v += 64) {
+        f32x4 t = *(const f32x4*)(xr + v * 4);
+        f32x4 gm = *(const f32x4*)(gamma + v * 4);
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float y;
+            if (LN) y = (t[j] - mu) * rstd * gm[j] + beta[v * 4 + j];
+            else y = gm[j] * (t[j] * rstd);
+            o[j] = apply_act(y, post_act);
+        }
+        if (of) *(f32x4*)(of + (size_t)row * ldo + v * 4) = f32x4{o[0], o[1], o[2], o[3]};
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + v * 4) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+}
+
+extern "C" int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
+                       int post_act, float* out_f32, void* out_bf16, int ldo, void* stream) {
+    SM_REQUIRE(x && gamma && (out_f32 || out_bf16), "sm_norm: null arg");
+    SM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "sm_norm: D, ldx, ldo must be multiples of 4");
+    hipStream_t st = (hipStream_t)stream;
+    if (beta) norm_kernel<true><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+    else norm_kernel<false><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ preprocess
+struct Norm3 { float mean[3], istd[3]; };
+
+// one thread per (patch row, 8 output columns).  u8 reads hit L2 (a frame is 338 KB); writes are 16 B/lane.
+__global__ void preprocess_kernel(const uint8_t* __restrict__ fr, int B, int H, int W, int p, Norm3 nm,
+                                  bf16_t* __restrict__ out, int ldp, float* __restrict__ pix) {
+    const int gx = W / p, gy = H / p;
+    const int cols8 = ldp >> 3;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * gx * gy * cols8;
+    if (t >= total) return;
+    int c8 = (int)(t % cols8);
+    size_t prow = t / cols8;
+    int b = (int)(prow / (gx * gy));
+    int pi = (int)(prow % (gx * gy));
+    int py = pi / gx, px = pi % gx;
+    const int pp = p * p;
+    uint32_t o[4];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int col = c8 * 8 + j;
+        float val = 0.f;
+        if (col < 3 * pp) {
+            int c = col / pp, r = col % pp;
+            int ii = r / p, jj = r % p;
+            int y = py * p + ii, x = px * p + jj;
+            float u = (float)fr[(((size_t)b * H + y) * W + x) * 3 + c];
+            val = (u * (1.0f / 255.0f) - nm.mean[c]) * nm.istd[c];
+            if (pix) pix[(((size_t)b * 3 + c) * H + y) * W + x] = val;
+        }
+        v[j] = val;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = pack2bf(v[2 * j], v[2 * j + 1]);
+    *(u32x4*)(out + prow * ldp + c8 * 8) = u32x4{o[0], o[1], o[2], o[3]};
+}
+
+extern "C" int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch, const float* mean3,
+                                     const float* std3, void* patches, int ldp, float* pix, void* stream) {
+    SM_REQUIRE(frames && patches && mean3 && std3, "sm_preprocess_patches: null arg");
+    SM_REQUIRE(B > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "sm_preprocess_patches: H, W must be multiples of patch");
+    SM_REQUIRE(ldp % 8 == 0 && ldp >= 3 * patch * patch, "sm_preprocess_patches: ldp must be a multiple of 8 and >= 3*p*p");
+    Norm3 nm;
+    for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.istd[c] = 1.0f / std3[c]; }
+    size_t total = (size_t)B * (H / patch) * (W / patch) * (ldp / 8);
+    preprocess_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(frames, B, H, W, patch, nm,
+                                                                                       (bf16_t*)patches, ldp, pix);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+__global__ void cls_rows_kernel(float* x, int B, int S, int D, const float* cls, const float* pos0) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    int b = t / D, d = t % D;
+    x[(size_t)b * S * D + d] = cls[d] + pos0[d];
+}
+extern "C" int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, const float* pos0, void* stream) {
+    SM_REQUIRE(x && cls && pos0 && B > 0, "sm_vit_cls_rows: bad args");
+    cls_rows_kernel<<<cdiv(B * D, 256), 256, 0, (hipStream_t)stream>>>(x, B, S, D, cls, pos0);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// block = (frame b, 64-column slab); 4 waves split the P patch rows, lanes own one column each -> coalesced 256 B rows
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, int S, int D, float* __restrict__ pooled,
+                                                   bf16_t* __restrict__ feats) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int P = S - 1;
+    float s = 0.f;
+    if (c < D) {
+        const float* xb = x + ((size_t)b * S + 1) * D + c;
+        for (int r = w; r < P; r += 4) {
+            float v = xb[(size_t)r * D];
+            s += v;
+            if (feats) feats[((size_t)b * P + r) * D + c] = (bf16_t)f2bf(v);
+        }
+    }
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < D) pooled[(size_t)b * D + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)P;
+}
+extern "C" int sm_pool_patches(const float* x, int B, int S, int D, float* pooled, void* feats, void* stream) {
+    SM_REQUIRE(x && pooled && B > 0 && S > 1, "sm_pool_patches: bad args");
+    pool_kernel<<<dim3(cdiv(D, 64), B), 256, 0, (hipStream_t)stream>>>(x, S, D, pooled, (bf16_t*)feats);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mamba step
+__global__ void mamba_conv_kernel(const float* __restrict__ xz, int M, int di, int dc, float* __restrict__ cs,
+                                  const float* __restrict__ cw, const float* __restrict__ cb, float* __restrict__ xc) {
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= di) return;
+    float st[8], w[8];
+    for (int j = 0; j < dc; ++j) { st[j] = cs[(size_t)d * dc + j]; w[j] = cw[(size_t)d * dc + j]; }
+    const float bias = cb[d];
+    for (int m = 0; m < M; ++m) {
+        for (int j = 0; j + 1 < dc; ++j) st[j] = st[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
+        st[dc - 1] = xz[(size_t)m * 2 * di + d];
+        float a = 0.f;
+        for (int j = 0; j < dc; ++j) a += st[j] * w[j];
+        xc[(size_t)m * di + d] = siluf_(a + bias);
+    }
+    for (int j = 0; j < dc; ++j) cs[(size_t)d * dc + j] = st[j];
+}
+extern "C" int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, float* conv_state, const float* conv_w,
+                                  const float* conv_b, float* xc, void* stream) {
+    SM_REQUIRE(xz && conv_state && conv_w && conv_b && xc && M > 0 && d_conv <= 8, "sm_mamba_conv_step: bad args");
+    mamba_conv_kernel<<<cdiv(di, 256), 256, 0, (hipStream_t)stream>>>(xz, M, di, d_conv, conv_state, conv_w, conv_b, xc);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// thread per channel d, d_state (<= 32) state elements in registers
+__global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __restrict__ delta,
+                                 const float* __restrict__ xdbl, int ldx, int R, const float* __restrict__ xz, int M, int di,
+                                 int ds, const float* __restrict__ Alog, const float* __restrict__ Dp,
+                                 float* __restrict__ hst, float* __restrict__ y) {
+    int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= di) return;
+    float h[32], A[32];
+    for (int n = 0; n < ds; ++n) { h[n] = hst[(size_t)d * ds + n]; A[n] = -__expf(Alog[(size_t)d * ds + n]); }
+    const float Dd = Dp[d];
+    for (int m = 0; m < M; ++m) {
+        const float dt = delta[(size_t)m * di + d];
+        const float xv = xc[(size_t)m * di + d];
+        const float* Bm = xdbl + (size_t)m * ldx + R;
+        const float* Cm = Bm + ds;
+        float acc = 0.f;
+        for (int n = 0; n < ds; ++n) {
+            h[n] = __expf(dt * A[n]) * h[n] + (dt * xv) * Bm[n];
+            acc += h[n] * Cm[n];
+        }
+        const float z = xz[(size_t)m * 2 * di + di + d];
+        y[(size_t)m * di + d] = (acc + Dd * xv) * siluf_(z);
+    }
+    for (int n = 0; n < ds; ++n) hst[(size_t)d * ds + n] = h[n];
+}
+extern "C" int sm_mamba_ssm_step(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank,
+                                 const float* xz, int M, int di, int d_state, const float* A_log, const float* Dp,
+                                 float* ssm_state, float* y, void* stream) {
+    SM_REQUIRE(xc && delta && x_dbl && xz && A_log && Dp && ssm_state && y, "sm_mamba_ssm_step: null arg");
+    SM_REQUIRE(M > 0 && d_state <= 32, "sm_mamba_ssm_step: d_state <= 32");
+    mamba_ssm_kernel<<<cdiv(di, 128), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, M, di, d_state,
+                                                                     A_log, Dp, ssm_state, y);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+__global__ void repeat_kv_kernel(const float* v, int M, int KV, int H, int dh, float* out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int tot = M * H * dh;
+    if (t >= tot) return;
+    int j = t % dh, h = (t / dh) % H, m = t / (dh * H);
+    out[t] = v[((size_t)m * KV + h / (H / KV)) * dh + j];
+}
+extern "C" int sm_repeat_kv(const float* v, int M, int KV, int H, int dh, float* out, void* stream) {
+    SM_REQUIRE(v && out && M > 0 && H % KV == 0, "sm_repeat_kv: bad args");
+    repeat_kv_kernel<<<cdiv(M * H * dh, 256), 256, 0, (hipStream_t)stream>>>(v, M, KV, H, dh, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+__global__ void gate_decide_kernel(const float* lg, int M, int32_t* dec) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) dec[m] = lg[2 * m + 1] > lg[2 * m] ? 1 : 0;   // softmax is monotone; tie -> index 0
+}
+extern "C" int sm_gate_decide(const float* logits, int M, int32_t* decision, void* stream) {
+    SM_REQUIRE(logits && decision && M > 0, "sm_gate_decide: bad args");
+    gate_decide_kernel<<<cdiv(M, 64), 64, 0, (hipStream_t)stream>>>(logits, M, decision);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LLM glue
+__global__ void embed_splice_kernel(const int32_t* ids, int n, const bf16_t* table, const float* tokens, int D, float* out) {
+    int row = blockIdx.x;
+    int id = ids[row];
+    for (int c = threadIdx.x; c < D; c += blockDim.x)
+        out[(size_t)row * D + c] = id >= 0 ? bf2f(table[(size_t)id * D + c]) : tokens[(size_t)(-id - 1) * D + c];
+}
+extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, void* stream) {
+    SM_REQUIRE(ids && table && out && n > 0, "sm_embed_splice: bad args");
+    embed_splice_kernel<<<n, 256, 0, (hipStream_t)stream>>>(ids, n, (const bf16_t*)table, tokens, D, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// qkv fp32 [n][(H+2KV)*dh]; rotate_half: out[j] = x[j] cos - x[j+h] sin ; out[j+h] = x[j+h] cos + x[j] sin
+__global__ void rope_kv_kernel(const float* __restrict__ qkv, int n, int pos0, int H, int KV, int dh,
+                               const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, bf16_t* __restrict__ q, bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc, int S_max) {
+    const int t = blockIdx.x;                 // token
+    const int pos = pos0 + t;
+    const int half = dh >> 1;
+    const int ld = (H + 2 * KV) * dh;
+    const float* row = qkv + (size_t)t * ld;
+    for (int e = threadIdx.x; e < (H + KV) * half; e += blockDim.x) {
+        int hd = e / half, j = e % half;
+        float c = cos_tab[(size_t)pos * half + j], s = sin_tab[(size_t)pos * half + j];
+        const float* x = row + (size_t)hd * dh;
+        float a = x[j], b = x[j + half];
+        float o0 = a * c - b * s, o1 = b * c + a * s;
+        if (hd < H) {
+            q[(size_t)t * H * dh + hd * dh + j] = (bf16_t)f2bf(o0);
+            q[(size_t)t * H * dh + hd * dh + j + half] = (bf16_t)f2bf(o1);
+        } else {
+            int kh = hd - H;
+            kc[((size_t)pos * KV + kh) * dh + j] = (bf16_t)f2bf(o0);
+            kc[((size_t)pos * KV + kh) * dh + j + half] = (bf16_t)f2bf(o1);
+        }
+    }
+    const float* v = row + (size_t)(H + KV) * dh;
+    for (int e = threadIdx.x; e < KV * dh; e += blockDim.x)
+        vtc[(size_t)e * S_max + pos] = (bf16_t)f2bf(v[e]);
+}
+extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab,
+                                 const float* sin_tab, void* q, void* kcache, void* vtcache, int S_max, void* stream) {
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && kcache && vtcache && n > 0 && pos0 >= 0 && pos0 + n <= S_max, "sm_rope_kv_append: bad args (pos0=%d n=%d S_max=%d)", pos0, n, S_max);
+    rope_kv_kernel<<<n, 256, 0, (hipStream_t)stream>>>(qkv, n, pos0, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, (bf16_t*)kcache,
+                                                       (bf16_t*)vtcache, S_max);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+__global__ void swiglu_kernel(const float* __restrict__ gu, int M, int F, bf16_t* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t tot = (size_t)M * (F >> 2);
+    if (t >= tot) return;
+    int m = (int)(t / (F >> 2)), c = (int)(t % (F >> 2)) * 4;
+    f32x4 g = *(const f32x4*)(gu + (size_t)m * 2 * F + c);
+    f32x4 u = *(const f32x4*)(gu + (size_t)m * 2 * F + F + c);
+    *(u32x2*)(out + (size_t)m * F + c) = u32x2{pack2bf(siluf_(g[0]) * u[0], siluf_(g[1]) * u[1]),
+                                              pack2bf(siluf_(g[2]) * u[2], siluf_(g[3]) * u[3])};
+}
+extern "C" int sm_swiglu(const float* gu, int M, int F, void* out, void* stream) {
+    SM_REQUIRE(gu && out && M > 0 && F % 4 == 0, "sm_swiglu: bad args");
+    size_t tot = (size_t)M * (F / 4);
+    swiglu_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(gu, M, F, (bf16_t*)out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ lg, int V, int32_t* out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float t = lg[v];
+        if (t > best) { best = t; idx = v; }     // strictly greater: lowest index wins within a thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(idx, o, 64);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
+        *out = idx;
+    }
+}
+extern "C" int sm_argmax(const float* logits, int V, int32_t* out, void* stream) {
+    SM_REQUIRE(logits && out && V > 0, "sm_argmax: bad args");
+    argmax_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, V, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}

@@ -1,0 +1,275 @@
+"""Torch-facing wrappers over the C ABI: device memory and streams come from PyTorch-ROCm, every
+computation is a libstreammind_hip.so call.  No numerical work happens in this file."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, sm_config_t, sm_linear_t
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+@dataclass
+class PathConfig:
+    """Dimensions of the hot path; defaults = CLIP-ViT-L/14-336 + Video_Mamba_seq(4096) + 4-layer gate +
+    Mistral-7B.  In a real deployment these come from the checkpoint's config.json files (SURVEY 8 intro)."""
+    vit_image: int = 336
+    vit_patch: int = 14
+    vit_hidden: int = 1024
+    vit_heads: int = 16
+    vit_mlp: int = 4096
+    vit_layers: int = 24
+    vit_select_layer: int = -2
+    vit_eps: float = 1e-5
+    img_mean: Tuple[float, float, float] = CLIP_MEAN
+    img_std: Tuple[float, float, float] = CLIP_STD
+    conn_d_model: int = 4096
+    conn_d_state: int = 16
+    conn_d_conv: int = 4
+    conn_expand: int = 2
+    conn_eps: float = 1e-5
+    gate_layers: int = 4
+    gate_heads: int = 32
+    gate_kv_heads: int = 8
+    gate_mlp: int = 14336
+    gate_eps: float = 1e-6
+    llm_layers: int = 32
+    llm_heads: int = 32
+    llm_kv_heads: int = 8
+    llm_mlp: int = 14336
+    llm_vocab: int = 32000
+    llm_eps: float = 1e-5
+    llm_rope_theta: float = 1e6
+    max_frames_per_call: int = 8
+    gate_precise: bool = True
+
+    @property
+    def vit_layers_run(self) -> int:
+        return self.vit_layers + 1 + self.vit_select_layer if self.vit_select_layer < 0 else self.vit_select_layer
+
+    @property
+    def n_patches(self) -> int:
+        return (self.vit_image // self.vit_patch) ** 2
+
+    @property
+    def conn_dt_rank(self) -> int:
+        return math.ceil(self.conn_d_model / 16)
+
+    def to_c(self) -> sm_config_t:
+        c = sm_config_t()
+        c.vit_image, c.vit_patch, c.vit_hidden, c.vit_heads, c.vit_mlp = (
+            self.vit_image, self.vit_patch, self.vit_hidden, self.vit_heads, self.vit_mlp)
+        c.vit_layers_run, c.vit_eps = self.vit_layers_run, self.vit_eps
+        for i in range(3):
+            c.img_mean[i] = self.img_mean[i]
+            c.img_std[i] = self.img_std[i]
+        c.conn_mm_hidden, c.conn_d_model, c.conn_d_state, c.conn_d_conv = (
+            self.vit_hidden, self.conn_d_model, self.conn_d_state, self.conn_d_conv)
+        c.conn_expand, c.conn_dt_rank, c.conn_eps = self.conn_expand, self.conn_dt_rank, self.conn_eps
+        c.gate_hidden, c.gate_layers, c.gate_heads, c.gate_kv_heads, c.gate_mlp, c.gate_eps = (
+            self.conn_d_model, self.gate_layers, self.gate_heads, self.gate_kv_heads, self.gate_mlp, self.gate_eps)
+        c.llm_hidden, c.llm_layers, c.llm_heads, c.llm_kv_heads, c.llm_mlp, c.llm_vocab = (
+            self.conn_d_model, self.llm_layers, self.llm_heads, self.llm_kv_heads, self.llm_mlp, self.llm_vocab)
+        c.llm_eps, c.llm_rope_theta = self.llm_eps, self.llm_rope_theta
+        c.max_frames_per_call, c.gate_precise = self.max_frames_per_call, int(self.gate_precise)
+        return c
+
+
+class NativeModel:
+    """sm_model: weights + workspaces on one GPU."""
+
+    def __init__(self, cfg: PathConfig, device: str = "cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.StreamMindHipError("no HIP device visible: the StreamMind hot path runs only on a GPU")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        ccfg = cfg.to_c()
+        check(self.lib.sm_model_create(C.byref(ccfg), C.byref(h)), "sm_model_create")
+        self.h = h
+        self.finalized = False
+        self.ignored = []
+
+    def load_tensor(self, name: str, t: torch.Tensor) -> bool:
+        """Hand one checkpoint tensor over (any device; bf16/fp16/fp32).  Returns False if the path ignores it."""
+        if t.dtype == torch.float16:
+            t = t.float()
+        if t.dtype not in (torch.bfloat16, torch.float32):
+            t = t.float()
+        t = t.to(self.device).contiguous()
+        shape = (C.c_int64 * max(1, t.dim()))(*([int(s) for s in t.shape] or [1]))
+        dt = _lib.SM_DT_BF16 if t.dtype == torch.bfloat16 else _lib.SM_DT_F32
+        rc = check(self.lib.sm_model_load_tensor(self.h, name.encode(), t.data_ptr(), dt, max(1, t.dim()), shape, _stream()),
+                   f"sm_model_load_tensor({name})")
+        torch.cuda.current_stream().synchronize()      # `t` may be a temporary
+        if rc == 1:
+            self.ignored.append(name)
+        return rc == 0
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "") -> None:
+        for k, v in sd.items():
+            self.load_tensor(prefix + k, v)
+
+    def missing(self) -> list:
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.sm_model_missing(self.h, buf, len(buf))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    def finalize(self) -> None:
+        check(self.lib.sm_model_finalize(self.h, _stream()), "sm_model_finalize")
+        self.finalized = True
+
+    def vit_encode(self, frames_u8: torch.Tensor, return_feats: bool = False, return_pixels: bool = False):
+        """frames u8 [B,H,W,3] on the GPU -> pooled fp32 [B, vit_hidden] (+ feats bf16 [B,P,D], pixel_values fp32)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        B, H, W, _ = frames_u8.shape
+        assert H == self.cfg.vit_image and W == self.cfg.vit_image, "resize/crop front-end is out of scope (SURVEY 8f f2)"
+        pooled = torch.empty(B, self.cfg.vit_hidden, dtype=torch.float32, device=self.device)
+        feats = torch.empty(B, self.cfg.n_patches, self.cfg.vit_hidden, dtype=torch.bfloat16, device=self.device) if return_feats else None
+        pix = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device) if return_pixels else None
+        check(self.lib.sm_vit_encode(self.h, frames_u8.data_ptr(), B, pooled.data_ptr(), _p(feats), _p(pix), _stream()), "sm_vit_encode")
+        out = (pooled,)
+        if return_feats:
+            out += (feats,)
+        if return_pixels:
+            out += (pix,)
+        return out if len(out) > 1 else pooled
+
+    def open_stream(self, max_frames: int = 4096, max_seq: int = 4096) -> "NativeStream":
+        return NativeStream(self, max_frames, max_seq)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.sm_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeStream:
+    """sm_stream: Mamba state, per-frame token store and KV cache of ONE video stream."""
+
+    def __init__(self, model: NativeModel, max_frames: int, max_seq: int):
+        self.model, self.lib = model, model.lib
+        h = C.c_void_p()
+        check(self.lib.sm_stream_open(model.h, max_frames, max_seq, C.byref(h)), "sm_stream_open")
+        self.h = h
+        self.dev = model.device
+
+    def reset(self) -> None:
+        check(self.lib.sm_stream_reset(self.h, _stream()), "sm_stream_reset")
+
+    @property
+    def num_frames(self) -> int:
+        return self.lib.sm_stream_num_frames(self.h)
+
+    @property
+    def kv_len(self) -> int:
+        return self.lib.sm_stream_kv_len(self.h)
+
+    def set_kv_len(self, n: int) -> None:
+        check(self.lib.sm_stream_set_kv_len(self.h, n), "sm_stream_set_kv_len")
+
+    def push_pooled(self, pooled: torch.Tensor):
+        assert pooled.dtype == torch.float32 and pooled.is_cuda and pooled.is_contiguous()
+        M = pooled.shape[0]
+        logits = torch.empty(M, 2, dtype=torch.float32, device=self.dev)
+        dec = torch.empty(M, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_stream_push_pooled(self.h, pooled.data_ptr(), M, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_stream_push_pooled")
+        return logits, dec
+
+    def push_frames(self, frames_u8: torch.Tensor):
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        M = frames_u8.shape[0]
+        logits = torch.empty(M, 2, dtype=torch.float32, device=self.dev)
+        dec = torch.empty(M, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_stream_push_frames(self.h, frames_u8.data_ptr(), M, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_stream_push_frames")
+        return logits, dec
+
+    def tokens(self, t0: int = 0, n: Optional[int] = None) -> torch.Tensor:
+        n = self.num_frames - t0 if n is None else n
+        out = torch.empty(n, self.model.cfg.conn_d_model, dtype=torch.float32, device=self.dev)
+        check(self.lib.sm_stream_read_tokens(self.h, t0, n, out.data_ptr(), _stream()), "sm_stream_read_tokens")
+        return out
+
+    def prefill(self, ids: torch.Tensor) -> None:
+        """ids int32 [n] on the GPU: >= 0 text token id, < 0 -> frame token index (-id - 1)."""
+        assert ids.dtype == torch.int32 and ids.is_cuda and ids.is_contiguous() and ids.dim() == 1
+        check(self.lib.sm_llm_prefill(self.h, ids.data_ptr(), ids.numel(), _stream()), "sm_llm_prefill")
+
+    def decode(self, n_steps: int) -> torch.Tensor:
+        out = torch.empty(n_steps, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_llm_decode(self.h, n_steps, out.data_ptr(), _stream()), "sm_llm_decode")
+        return out
+
+    def logits(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        lg = torch.empty(self.model.cfg.llm_vocab, dtype=torch.float32, device=self.dev)
+        nt = torch.empty(1, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_stream_read_logits(self.h, lg.data_ptr(), nt.data_ptr(), _stream()), "sm_stream_read_logits")
+        return lg, nt
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.sm_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ operator level
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] bf16 (GPU) -> packed fragment-major image (flat bf16 tensor)."""
+    lib = _lib.load()
+    assert w.dtype == torch.bfloat16 and w.is_cuda and w.dim() == 2 and w.is_contiguous()
+    N, K = w.shape
+    out = torch.empty(lib.sm_packed_elems(N, K), dtype=torch.bfloat16, device=w.device)
+    check(lib.sm_pack_weight(w.data_ptr(), N, K, K, out.data_ptr(), _stream()), "sm_pack_weight")
+    return out
+
+
+def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[torch.Tensor] = None,
+           bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None,
+           out_dtype: torch.dtype = torch.float32, precise: bool = False) -> torch.Tensor:
+    """Operator-level entry used by the parity tests: y = epilogue(x @ W^T)."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)
+    M = x.shape[0]
+    a = sm_linear_t()
+    a.w, a.w2, a.N, a.K = wp.data_ptr(), _p(w2p), N, K
+    a.x, a.x_dtype = x.data_ptr(), (_lib.SM_X_F32 if x.dtype == torch.float32 else _lib.SM_X_BF16)
+    a.precise, a.M, a.ldx = int(precise), M, x.shape[1]
+    a.bias, a.act = _p(bias), act
+    if residual is not None:
+        a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
+    out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    if out_dtype == torch.float32:
+        a.out_f32, a.ldo = out.data_ptr(), N
+    else:
+        a.out_bf16, a.ldo_bf16 = out.data_ptr(), N
+    check(lib.sm_linear(C.byref(a), _stream()), "sm_linear")
+    return out

@@ -1,0 +1,66 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/streammind_hip.h
+declares (no compute without a GPU), and the ctypes structs match the C structs."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "streammind_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from streammind_amd import _lib
+    lib = _lib.load()                       # raises if the .so is missing: no fallback on the product path
+    decl = _declared_symbols()
+    assert len(decl) >= 35
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/streammind_hip.h but not exported"
+    assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
+    assert lib.sm_abi_version() == 1
+    assert lib.sm_packed_elems(40, 70) == 3 * 3 * 512
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """compile the header with gcc and compare sizeof/offsetof with the ctypes mirrors."""
+    import ctypes as C
+    import subprocess
+    from streammind_amd._lib import sm_linear_t, sm_config_t
+    src = tmp_path / "sz.c"
+    fields_l = [f[0] for f in sm_linear_t._fields_]
+    fields_c = [f[0] for f in sm_config_t._fields_]
+    body = "".join(f'printf("%zu\\n", offsetof(sm_linear_t, {f}));' for f in fields_l)
+    body += "".join(f'printf("%zu\\n", offsetof(sm_config_t, {f}));' for f in fields_c)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "streammind_hip.h"\nint main(){'
+                   'printf("%zu\\n%zu\\n", sizeof(sm_linear_t), sizeof(sm_config_t));' + body + 'return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals[0] == C.sizeof(sm_linear_t) and vals[1] == C.sizeof(sm_config_t)
+    want = [getattr(sm_linear_t, f).offset for f in fields_l] + [getattr(sm_config_t, f).offset for f in fields_c]
+    assert vals[2:] == want
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    from streammind_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+        raise AssertionError("expected failure")
+    except _lib.StreamMindHipError as e:
+        assert "no CPU fallback" in str(e)
+    importlib.reload(_lib)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "streammind_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), f"{f} references the oracle"

@@ -1,0 +1,209 @@
+"""Operator-level parity on a real MI355X: every C-ABI kernel against the oracle's plain-torch arithmetic on the
+same seeded inputs.  Integer/index results are exact; floating point tolerances are stated per test."""
+import ctypes as C
+
+import pytest
+import torch
+
+from oracle import streammind_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from streammind_amd import native, _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return native
+
+
+def rnd(shape, seed, std=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * std
+
+
+def relerr(a, b):
+    return ((a.float().cpu() - b.float().cpu()).abs().max() / b.float().abs().max().clamp_min(1e-6)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 256), (8, 4096, 4096), (16, 288, 8192), (1, 4096, 14336),
+                                   (5, 1024, 96), (2, 2, 4096), (1, 8192, 256)])
+@pytest.mark.parametrize("mode", ["f32_precise", "f32_single", "bf16"])
+def test_skinny_linear(nat, M, N, K, mode):
+    """weight-streaming GEMV path vs fp32 matmul on the bf16-representable weights.
+    precise (hi/lo split) : 2e-5 relative (fp32-class);  single bf16 activation rounding : exact vs the oracle that
+    rounds x the same way, 2e-5."""
+    if K % 8:
+        pytest.skip("K")
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = rnd((M, K), 2)
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4)
+    wp = nat.pack_weight(w.cuda().bfloat16())
+    if mode == "bf16":
+        xg, xr = x.cuda().bfloat16(), O.bf16_round(x)
+    elif mode == "f32_single":
+        xg, xr = x.cuda(), O.bf16_round(x)
+    else:
+        xg, xr = x.cuda(), x
+    y = nat.linear(xg, wp, N, K, bias=bias.cuda(), act=2, residual=res.cuda(), precise=(mode == "f32_precise"))
+    ref = O.leaky_relu(xr.double() @ w.double().t() + bias.double()).float() + res
+    assert relerr(y, ref) < 2e-5
+
+
+def test_skinny_dual_swiglu(nat):
+    M, N, K = 4, 14336, 4096
+    wg, wu = O.bf16_round(rnd((N, K), 1, K ** -0.5)), O.bf16_round(rnd((N, K), 2, K ** -0.5))
+    x = rnd((M, K), 3)
+    y = nat.linear(x.cuda(), nat.pack_weight(wg.cuda().bfloat16()), N, K, w2p=nat.pack_weight(wu.cuda().bfloat16()), precise=True)
+    ref = (O.silu(x.double() @ wg.double().t()) * (x.double() @ wu.double().t())).float()
+    assert relerr(y, ref) < 3e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(17, 128, 64), (300, 384, 256), (577, 1024, 1024), (1154, 3072, 1024), (1000, 200, 4096)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_tiled_gemm(nat, M, N, K, out_dtype):
+    """LDS-tiled MFMA GEMM: bf16 operands, fp32 accumulate -> 1e-5 relative against fp64 on the same bf16 inputs
+    (bf16 output: one extra rounding, 2^-8)."""
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = O.bf16_round(rnd((M, K), 2))
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4)
+    y = nat.linear(x.cuda().bfloat16(), nat.pack_weight(w.cuda().bfloat16()), N, K, bias=bias.cuda(), act=1,
+                   residual=res.cuda(), out_dtype=out_dtype)
+    ref = (O.quick_gelu(x.double() @ w.double().t() + bias.double()) + res.double()).float()
+    assert relerr(y, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
+
+
+def test_pack_layout(nat):
+    """the packed image is the documented permutation of W (integer-exact)."""
+    N, K = 40, 70
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251
+    wp = nat.pack_weight(w.cuda().bfloat16()).cpu().float()
+    KS = (K + 31) // 32
+    for n, k in [(0, 0), (17, 33), (39, 69), (15, 31), (16, 32)]:
+        idx = ((n >> 4) * KS + (k >> 5)) * 512 + ((((k & 31) >> 3) << 4) + (n & 15)) * 8 + (k & 7)
+        assert wp[idx].item() == w[n, k].item()
+    assert wp.numel() == 3 * KS * 512 and wp.sum().item() == w.sum().item()
+
+
+@pytest.mark.parametrize("kind", ["ln", "rms"])
+def test_norm(nat, kind):
+    from streammind_amd._lib import load, check
+    lib = load()
+    M, D = 37, 1024
+    x, g, b = rnd((M, D), 1, 2.0) + 0.3, 1 + rnd((D,), 2, 0.1), rnd((D,), 3, 0.1)
+    xg, gg, bg = x.cuda(), g.cuda(), b.cuda()
+    of = torch.empty(M, D, device="cuda")
+    ob = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.sm_norm(xg.data_ptr(), M, D, D, gg.data_ptr(), bg.data_ptr() if kind == "ln" else None, 1e-5, 0,
+                      of.data_ptr(), ob.data_ptr(), D, st))
+    ref = O.layer_norm(x, g, b, 1e-5) if kind == "ln" else O.rms_norm(x, g, 1e-5)
+    assert relerr(of, ref) < 1e-5
+    assert torch.equal(ob.cpu(), of.cpu().bfloat16())
+
+
+@pytest.mark.parametrize("B,S,H,dh", [(2, 17, 2, 64), (1, 577, 16, 64), (3, 130, 4, 64)])
+def test_vit_attention(nat, B, S, H, dh):
+    """non-causal attention vs the oracle's mixed-precision statement (P rounded to bf16 for PV, fp32 normaliser):
+    output bf16, tolerance 1 bf16 ulp-ish (8e-3 relative to max)."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    D = H * dh
+    qkv = O.bf16_round(rnd((B * S, 3 * D), 1))
+    Spad = (S + 63) // 64 * 64
+    v = qkv[:, 2 * D:].reshape(B, S, H, dh)
+    vt = torch.zeros(B, H, dh, Spad)
+    vt[:, :, :, :S] = v.permute(0, 2, 3, 1)
+    qg, vg = qkv.cuda().bfloat16(), vt.cuda().bfloat16()
+    ctx = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
+    check(lib.sm_vit_attention(qg.data_ptr(), vg.data_ptr(), ctx.data_ptr(), B, S, H, dh, Spad, torch.cuda.current_stream().cuda_stream))
+    q = qkv[:, :D].reshape(B, S, H, dh).transpose(1, 2)
+    k = qkv[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
+    vv = v.transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    e = torch.exp(s - s.max(-1, keepdim=True).values)
+    ref = ((O.bf16_round(e) @ vv) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * S, D)
+    assert relerr(ctx, ref) < 8e-3
+
+
+def test_preprocess_matches_oracle_and_golden(nat, gold):
+    """a1: u8 frame -> (x/255 - mean)/std; fp32 pixel_values within 1e-6 of the oracle / the reference golden, and
+    the bf16 patch matrix equal to the bf16 rounding of the oracle's patchified tensor up to 1 bf16 ulp."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    g = gold("g1_preprocess")
+    frames = O.synthetic_frames(2, 336, seed=int(g["seed"]))
+    fg = frames.cuda()
+    P, ldp = 576, 640
+    patches = torch.empty(2 * P, ldp, device="cuda", dtype=torch.bfloat16)
+    pix = torch.empty(2, 3, 336, 336, device="cuda")
+    mean = (C.c_float * 3)(*O.CLIP_MEAN)
+    std = (C.c_float * 3)(*O.CLIP_STD)
+    check(lib.sm_preprocess_patches(fg.data_ptr(), 2, 336, 336, 14, mean, std, patches.data_ptr(), ldp, pix.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream))
+    ref = O.preprocess_frames(frames)
+    assert (pix.cpu() - ref).abs().max().item() < 1e-6
+    assert (pix.cpu().flatten()[torch.as_tensor(g["idx"])] - torch.as_tensor(g["pixel_values_sample"])).abs().max().item() < 2e-6
+    pref = O.vit_patchify(ref, O.VitCfg())
+    got = patches.cpu().float().reshape(2, P, ldp)
+    assert (got[:, :, 588:] == 0).all()
+    assert (got[:, :, :588] - pref).abs().max().item() <= 2 ** -7 * pref.abs().max().item()
+
+
+def test_mamba_step_kernels(nat):
+    from streammind_amd._lib import load, check
+    lib = load()
+    cfg = O.ConnCfg(mm_hidden=64, d_model=128)
+    di, ds, R, M = cfg.d_inner, cfg.d_state, cfg.dt_rank, 5
+    W = O.make_conn_weights(cfg, 3)
+    xz = rnd((M, 2 * di), 1)
+    st = torch.cuda.current_stream().cuda_stream
+    cs = torch.zeros(di, cfg.d_conv, device="cuda")
+    xc = torch.empty(M, di, device="cuda")
+    cw = W[O.CONN + "mixer.conv1d.weight"].reshape(di, -1).cuda().contiguous()
+    cb = W[O.CONN + "mixer.conv1d.bias"].cuda()
+    xzg = xz.cuda()
+    check(lib.sm_mamba_conv_step(xzg.data_ptr(), M, di, cfg.d_conv, cs.data_ptr(), cw.data_ptr(), cb.data_ptr(), xc.data_ptr(), st))
+    # oracle conv
+    conv = torch.zeros(di, cfg.d_conv)
+    ref_xc = []
+    for m in range(M):
+        conv = torch.roll(conv, -1, -1); conv[:, -1] = xz[m, :di]
+        ref_xc.append(O.silu((conv * cw.cpu()).sum(-1) + cb.cpu()))
+    ref_xc = torch.stack(ref_xc)
+    assert relerr(xc, ref_xc) < 1e-5 and relerr(cs, conv) < 1e-6
+    ldx = 64
+    xdbl = torch.zeros(M, ldx); xdbl[:, :R + 2 * ds] = rnd((M, R + 2 * ds), 2)
+    delta = O.softplus(rnd((M, di), 3))
+    h = torch.zeros(di, ds, device="cuda")
+    y = torch.empty(M, di, device="cuda")
+    Al, Dp = W[O.CONN + "mixer.A_log"].cuda(), W[O.CONN + "mixer.D"].cuda()
+    xdg, dg = xdbl.cuda(), delta.cuda()
+    check(lib.sm_mamba_ssm_step(xc.data_ptr(), dg.data_ptr(), xdg.data_ptr(), ldx, R, xzg.data_ptr(), M, di, ds,
+                                Al.data_ptr(), Dp.data_ptr(), h.data_ptr(), y.data_ptr(), st))
+    A = -torch.exp(Al.cpu())
+    hs = torch.zeros(di, ds)
+    ref_y = []
+    xcc = xc.cpu()
+    for m in range(M):
+        Bm, Cm = xdbl[m, R:R + ds], xdbl[m, R + ds:R + 2 * ds]
+        hs = torch.exp(delta[m][:, None] * A) * hs + (delta[m] * xcc[m])[:, None] * Bm[None]
+        ref_y.append((hs @ Cm + Dp.cpu() * xcc[m]) * O.silu(xz[m, di:]))
+    assert relerr(y, torch.stack(ref_y)) < 2e-5 and relerr(h, hs) < 2e-5
+
+
+def test_gate_decide_and_argmax(nat):
+    from streammind_amd._lib import load, check
+    lib = load()
+    st = torch.cuda.current_stream().cuda_stream
+    lg = torch.tensor([[0.3, 0.3], [0.1, 0.2], [0.5, -0.5], [-1.0, -0.9]], device="cuda")
+    dec = torch.empty(4, dtype=torch.int32, device="cuda")
+    check(lib.sm_gate_decide(lg.data_ptr(), 4, dec.data_ptr(), st))
+    assert dec.tolist() == [O.gate_decision(l) for l in lg.cpu()] == [0, 1, 0, 1]
+    v = rnd((32000,), 5); v[123] = v[31999] = v.max() + 1          # tie -> lowest index (torch.argmax)
+    out = torch.empty(1, dtype=torch.int32, device="cuda")
+    vg = v.cuda()
+    check(lib.sm_argmax(vg.data_ptr(), 32000, out.data_ptr(), st))
+    assert out.item() == 123 == int(torch.argmax(v))

