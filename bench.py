@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: streamed frames/s through the MI355X-native perception hot path
+(u8 frame ring buffer -> CLIP-ViT-L/14-336 (23 layers) -> patch-mean -> Mamba connector step -> 4-layer Mistral
+event gate), BASELINE.json configs[1]; one stream per GPU, `--gpus N` ranks are independent replicas
+(the path shards by stream with no data-path collective) -> weak scaling.
+
+A "step" = one batch of `--batch` consecutive frames of the synthetic 336x336 stream pushed through
+sm_stream_push_frames (ViT batch, then the connector scanned in frame order and the gate applied to every frame:
+results identical to frame-at-a-time).  Frames are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the tiled MFMA GEMM; durations from
+HIP events recorded on the launch stream inside the timed region) and `cpu_baseline` (the oracle -- a plain-torch
+CPU port of the reference arithmetic -- timed on this host on a bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def vit_linear_flops_per_frame(cfg) -> float:
+    """algorithmic FLOPs of the tiled-GEMM launches for ONE frame: 23 x (QKV + out + fc1 + fc2) over
+    577 tokens + the patch-embed GEMM over 576 patches (K = 588 real columns)."""
+    D, F, S, P = cfg.vit_hidden, cfg.vit_mlp, cfg.n_patches + 1, cfg.n_patches
+    per_layer = 2.0 * S * D * (3 * D + D + F) + 2.0 * S * F * D
+    return cfg.vit_layers_run * per_layer + 2.0 * P * (3 * cfg.vit_patch ** 2) * D
+
+
+def random_weights_into(model, cfg, seed: int):
+    """random-init weights of the true shapes, generated ON the GPU (7e8+ parameters are not shipped), handed over
+    under the reference's checkpoint names."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    dev = "cuda"
+
+    def rn(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g, device=dev) * std).to(torch.bfloat16)
+
+    def ln(n):
+        return (1.0 + 0.1 * torch.randn(n, generator=g, device=dev)), 0.02 * torch.randn(n, generator=g, device=dev)
+    D, F = cfg.vit_hidden, cfg.vit_mlp
+    vp = "model.vision_tower.vision_tower.vision_model."
+    L = model.load_tensor
+    L(vp + "embeddings.class_embedding", 0.02 * torch.randn(D, generator=g, device=dev))
+    L(vp + "embeddings.patch_embedding.weight", rn(D, 3, cfg.vit_patch, cfg.vit_patch))
+    L(vp + "embeddings.position_embedding.weight", 0.02 * torch.randn(cfg.n_patches + 1, D, generator=g, device=dev))
+    w, b = ln(D); L(vp + "pre_layrnorm.weight", w); L(vp + "pre_layrnorm.bias", b)
+    for i in range(cfg.vit_layers_run):
+        p = f"{vp}encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            L(p + f"self_attn.{n}.weight", rn(D, D, std=0.03)); L(p + f"self_attn.{n}.bias", 0.02 * torch.randn(D, generator=g, device=dev))
+        L(p + "mlp.fc1.weight", rn(F, D, std=0.03)); L(p + "mlp.fc1.bias", 0.02 * torch.randn(F, generator=g, device=dev))
+        L(p + "mlp.fc2.weight", rn(D, F, std=0.03)); L(p + "mlp.fc2.bias", 0.02 * torch.randn(D, generator=g, device=dev))
+        for n in ("layer_norm1", "layer_norm2"):
+            w, b = ln(D); L(p + n + ".weight", w); L(p + n + ".bias", b)
+    d, di, R, ds = cfg.conn_d_model, cfg.conn_expand * cfg.conn_d_model, cfg.conn_dt_rank, cfg.conn_d_state
+    pp = "model.mm_projector."
+    L(pp + "pre_net.fc3.weight", rn(d, D, std=D ** -0.5)); L(pp + "pre_net.fc3.bias", 0.02 * torch.randn(d, generator=g, device=dev))
+    sp = pp + "mamba_model.ssms.0."
+    w, b = ln(d); L(sp + "norm.weight", w); L(sp + "norm.bias", b)
+    L(sp + "mixer.in_proj.weight", rn(2 * di, d, std=d ** -0.5))
+    L(sp + "mixer.conv1d.weight", 0.3 * torch.randn(di, 1, cfg.conn_d_conv, generator=g, device=dev))
+    L(sp + "mixer.conv1d.bias", 0.02 * torch.randn(di, generator=g, device=dev))
+    L(sp + "mixer.x_proj.weight", rn(R + 2 * ds, di, std=di ** -0.5))
+    L(sp + "mixer.dt_proj.weight", ((torch.rand(di, R, generator=g, device=dev) * 2 - 1) * R ** -0.5).to(torch.bfloat16))
+    dt = torch.exp(torch.rand(di, generator=g, device=dev) * (torch.log(torch.tensor(0.1)) - torch.log(torch.tensor(0.001))).item()
+                   + torch.log(torch.tensor(0.001)).item())
+    L(sp + "mixer.dt_proj.bias", dt + torch.log(-torch.expm1(-dt)))
+    L(sp + "mixer.A_log", torch.log(torch.arange(1, ds + 1, device=dev, dtype=torch.float32)).repeat(di, 1))
+    L(sp + "mixer.D", torch.ones(di, device=dev))
+    L(sp + "mixer.out_proj.weight", rn(d, di, std=di ** -0.5))
+    w, b = ln(d); L(pp + "mamba_model.norm_fn.weight", w); L(pp + "mamba_model.norm_fn.bias", b)
+    L(pp + "post_net.fc3.weight", rn(d, d, std=d ** -0.5)); L(pp + "post_net.fc3.bias", 0.02 * torch.randn(d, generator=g, device=dev))
+    gdh = d // cfg.gate_heads
+    gp = pp + "cls_net.cls_model."
+    for i in range(cfg.gate_layers):
+        p = f"{gp}model.layers.{i}."
+        L(p + "self_attn.v_proj.weight", rn(cfg.gate_kv_heads * gdh, d, std=d ** -0.5))
+        L(p + "self_attn.o_proj.weight", rn(d, d, std=d ** -0.5))
+        L(p + "mlp.gate_proj.weight", rn(cfg.gate_mlp, d, std=d ** -0.5))
+        L(p + "mlp.up_proj.weight", rn(cfg.gate_mlp, d, std=d ** -0.5))
+        L(p + "mlp.down_proj.weight", rn(d, cfg.gate_mlp, std=cfg.gate_mlp ** -0.5))
+        L(p + "input_layernorm.weight", ln(d)[0]); L(p + "post_attention_layernorm.weight", ln(d)[0])
+    L(gp + "model.norm.weight", ln(d)[0])
+    L(gp + "lm_head.weight", rn(2, d, std=d ** -0.5))
+
+
+def synthetic_frames_gpu(n: int, size: int, seed: int, rank: int) -> torch.Tensor:
+    """seeded u8 HWC frames generated on the GPU: slowly drifting low-pass scene with cuts + per-pixel noise."""
+    g = torch.Generator(device="cuda").manual_seed(seed * 1000003 + rank)
+    yy, xx = torch.meshgrid(torch.arange(size, device="cuda", dtype=torch.float32),
+                            torch.arange(size, device="cuda", dtype=torch.float32), indexing="ij")
+    out = torch.empty(n, size, size, 3, dtype=torch.uint8, device="cuda")
+    pal = None
+    for t in range(n):
+        if t % 45 == 0:
+            pal = torch.rand(3, 4, generator=g, device="cuda")
+        ph = 0.02 * t
+        chans = [(40.0 + 175.0 * pal[c, 0]) + (20.0 + 60.0 * pal[c, 1]) * torch.sin(xx * (0.005 + 0.03 * pal[c, 2]) + ph * (c + 1))
+                 * torch.cos(yy * (0.005 + 0.03 * pal[c, 3]) - ph) for c in range(3)]
+        noise = torch.randint(-24, 25, (size, size, 3), generator=g, device="cuda").float()
+        out[t] = (torch.stack(chans, dim=-1) + noise).clamp(0, 255).to(torch.uint8)
+    return out
+
+
+def usable_cores() -> int:
+    """threads the process may actually run: min(affinity, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(n_frames: int = 4) -> dict:
+    """the oracle (plain-torch CPU port of the reference arithmetic, fp32) on a bounded sample of the same workload:
+    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate)."""
+    from oracle import streammind_oracle as O
+    torch.set_grad_enabled(False)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
+    Wv = O.make_vit_weights(vcfg, 11)
+    Wc = O.make_conn_weights(ccfg, 12)
+    Wc.update(O.make_lm_weights(gcfg, 13, prefix="cls_net.cls_model.", with_embed=False))
+    frames = O.synthetic_frames(n_frames, 336, seed=1234)
+    st = O.ConnState.zeros(ccfg)
+    pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[:1]), Wv, vcfg))   # warm-up
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[i:i + 1]), Wv, vcfg))[0]
+        tok = O.connector_step(pooled, st, Wc, ccfg)
+        O.gate_decision(O.gate_logits_shortcut(tok[None], Wc, gcfg)[0])
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_frames} frames x (preprocess + CLIP-ViT-L/14-336 23 layers + pool + connector step + 4-layer gate), "
+                      f"oracle/streammind_oracle.py fp32, torch CPU threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (<= 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1:
+        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from streammind_amd import _lib
+    from streammind_amd.native import NativeModel, PathConfig
+    lib = _lib.load()
+    B = a.batch
+    cfg = PathConfig(llm_layers=0, max_frames_per_call=B)
+    model = NativeModel(cfg, f"cuda:{local}")
+    random_weights_into(model, cfg, seed=1234)
+    model.finalize()
+    n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
+    frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
+    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 16, max_seq=64)
+    torch.cuda.synchronize()
+
+    def step(i):
+        off = (i * B) % (n_pool - B + 1)
+        return stream.push_frames(frames[off:off + B])
+
+    for i in range(a.warmup):
+        step(i)
+    prof = not a.no_prof
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if prof:
+        lib.sm_prof_reset(); lib.sm_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        logits, dec = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if prof:
+        lib.sm_prof_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(logits).all()
+
+    roof = None
+    if prof:
+        cnt, ms = C.c_int(), C.c_float()
+        _lib.check(lib.sm_prof_read(0, C.byref(cnt), C.byref(ms)))
+        if cnt.value:
+            flops_per_launch = vit_linear_flops_per_frame(cfg) * B * a.steps / cnt.value
+            avg_s = ms.value * 1e-3 / cnt.value
+            ach = flops_per_launch / avg_s / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            roof = {"kernel": "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64)", "bound": "mfma", "achieved": round(ach, 1),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "launches": cnt.value, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "flops_per_launch": flops_per_launch}
+    if rank == 0:
+        total_frames = world * B * a.steps
+        out = {
+            "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate)", "value": round(total_frames / dt, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
+                                   "4-layer Mistral event gate, synthetic 336x336 30 fps stream (1800-frame pool), "
+                                   f"{B} frames per step, one stream per GPU, random-init weights of the true shapes",
+                       "frames_per_step": B, "streams_per_gpu": 1, "parallelism": f"replicas x{world} (stream-sharded, no collective)"},
+            "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,18 @@ const float* sm_stream_logits(sm_stream* s);
  * logits fp32 [vocab] and the pending greedy token int32) */
 int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, void* stream);
 int sm_stream_read_logits(sm_stream* s, float* out_opt, int32_t* next_token_out_opt, void* stream);
+/* overwrite / append per-frame tokens [t0, t0+n) from caller-computed fp32 features (t0 <= num_frames): lets a
+ * caller that already holds connector outputs (e.g. restored from a cache) seed the stream                 */
+int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py roofline leg; no reference counterpart -- the reference has only commented-out
+ * time.time() pairs, builder.py:741-745).  Class bits: 0 tiled GEMM, 1 skinny linear, 2 attention.
+ * While enabled, each launch of the class is bracketed by HIP events on its own stream.
+ * ---------------------------------------------------------------------------------------------- */
+int sm_prof_enable(int class_mask);
+int sm_prof_reset(void);
+int sm_prof_read(int cls, int* count, float* total_ms);   /* synchronises the recorded events */
 
 #ifdef __cplusplus
 }

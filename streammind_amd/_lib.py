@@ -84,6 +84,10 @@ SIGNATURES = {
     "sm_stream_logits": (vp, [vp]),
     "sm_stream_read_tokens": (i32, [vp, i32, i32, vp, vp]),
     "sm_stream_read_logits": (i32, [vp, vp, vp, vp]),
+    "sm_stream_write_tokens": (i32, [vp, i32, i32, vp, vp]),
+    "sm_prof_enable": (i32, [i32]),
+    "sm_prof_reset": (i32, []),
+    "sm_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f32)]),
 }
 
 _lib = None
@@ -102,6 +106,9 @@ def load() -> C.CDLL:
         raise StreamMindHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m streammind_amd.build`. "
             "There is no CPU fallback on the product path.")
+    # PyTorch-ROCm ships its own HIP runtime (same SONAME libamdhip64.so.7); import it first so that this library
+    # binds to the SAME runtime instance torch allocates device memory and streams from.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 
 static int launch_attn(const AttnP& p, int B, int dh, hipStream_t st) {
     dim3 grid(cdiv(p.nq, 128), p.H, B);
+    SmProfScope prof(SM_PROF_ATTN, st);
     if (dh == 64) attn_kernel<64><<<grid, 256, 0, st>>>(p);
     else if (dh == 128) attn_kernel<128><<<grid, 256, 0, st>>>(p);
     else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);

@@ -27,3 +27,15 @@ extern thread_local char g_sm_err[512];
 #define SM_LAUNCH_CHECK() SM_HIP(hipGetLastError())
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that
+// class is bracketed by HIP events recorded ON THE LAUNCH STREAM; sm_prof_read() synchronises and sums.
+enum { SM_PROF_GEMM = 0, SM_PROF_SKINNY = 1, SM_PROF_ATTN = 2, SM_PROF_NCLS = 3 };
+void sm_prof_begin_(int cls, hipStream_t st);
+void sm_prof_end_(int cls, hipStream_t st);
+extern int g_sm_prof_mask;
+struct SmProfScope {
+    int cls; hipStream_t st; bool on;
+    SmProfScope(int c, hipStream_t s) : cls(c), st(s), on((g_sm_prof_mask >> c) & 1) { if (on) sm_prof_begin_(cls, st); }
+    ~SmProfScope() { if (on) sm_prof_end_(cls, st); }
+};

@@ -4,6 +4,8 @@
 // the B operand, i.e. they produce D[i = n][j = m] (the transposed output tile).  In that orientation a lane
 // holds 4 consecutive n for one m (C/D map: col = lane & 15, row = (lane >> 4) * 4 + reg), so bias loads and
 // output stores are 8/16-byte vectors along the contiguous dimension of the row-major output.
+#include <stdlib.h>
+
 #include "common.h"
 #include "host.h"
 
@@ -69,6 +71,8 @@ struct LinArgs {
     int vt_n0, vt_S, vt_dh, vt_ld;
 };
 
+__device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
+
 // one lane's 4 consecutive outputs (n0..n0+3) of row m
 __device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f32x4 v, const f32x4* v2) {
     if (m >= a.M || n0 >= a.N) return;
@@ -85,7 +89,7 @@ __device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f32x4 v,
         float t = v[r];
         if (a.bias && (full || n0 + r < a.N)) t += a.bias[n0 + r];
         if (v2) t = siluf_(t) * (*v2)[r];
-        else t = apply_act(t, a.act);
+        else t = apply_act_rt(t, a.act);
         if (a.residual && (full || n0 + r < a.N)) t += a.residual[(size_t)rrow * a.ldr + n0 + r];
         o[r] = t;
     }
@@ -242,6 +246,49 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Fast whole-row epilogue of one [128 m][128 n] fp32 tile staged in LDS.  The output / residual / bias pointers are
+// __restrict__ FUNCTION PARAMETERS on purpose: without the no-alias guarantee hipcc orders every pass's (possibly
+// aliasing, in-place) residual load behind the previous pass's store with s_waitcnt vmcnt(0), which serialises the
+// passes on the store round trip (measured: 25 us of a 34 us QKV GEMM).  In-place residual is still safe: the
+// same lane reads an element before it writes it, and different passes touch different rows.  ACT is a
+// compile-time activation so the 64 inlined element epilogues stay small (I-cache).
+template <int ACT>
+__device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
+                                                   const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
+                                                   int ldo, bf16_t* __restrict__ out_bf16, int ldob, int m0, int n0,
+                                                   int M, int tid) {
+    const int chunk = tid & 31;
+    const int n = n0 + chunk * 4;
+    f32x4 b4 = {0, 0, 0, 0};
+    if (bias) b4 = *(const f32x4*)(bias + n);
+#pragma unroll
+    for (int p0 = 0; p0 < 16; p0 += 4) {
+        f32x4 v[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ml = (p0 + u) * 8 + (tid >> 5);
+            v[u] = *(const f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16));
+            r[u] = f32x4{0, 0, 0, 0};
+            if (residual && m0 + ml < M) r[u] = *(const f32x4*)(residual + (size_t)(m0 + ml) * ldr + n);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = m0 + (p0 + u) * 8 + (tid >> 5);
+            if (m >= M) continue;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = v[u][j] + b4[j];
+                if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
+                o[j] = t + r[u][j];
+            }
+            if (out_f32) *(f32x4*)(out_f32 + (size_t)m * ldo + n) = o;
+            if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+    }
+}
+
+template <int ACT>   // compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
 __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -327,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
     }
     // ---- epilogue: stage the fp32 tile through LDS ([128 m][128 n] fp32 = the whole 64 KiB; 16-byte chunk index
     // XOR-swizzled with (m & 31) so both the fragment-shaped writes and the row-shaped reads are conflict-free),
-    // then every wave walks whole rows: 512 B contiguous per row to HBM, epilogue code emitted once.
+    // then every wave walks whole rows: 512 B contiguous per row to HBM.
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
@@ -354,10 +401,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
                 if (m < a.M) {
                     float v = *(const float*)(smem + ml * 512 + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
                     const int b = m / a.vt_S, sidx = m - b * a.vt_S;
-                    a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act(v, a.act));
+                    a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act_rt(v, a.act));
                 }
             }
         }
+    } else if (ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * GEMM_BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
+               (a.ldr & 3) == 0) {
+        tile_rows_epilogue<ACT>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16,
+                                tile_m * GEMM_BM, tile_n * GEMM_BN, a.M, tid);
     } else {
         for (int pass = 0; pass < 16; ++pass) {
             const int ml = pass * 8 + (tid >> 5);
@@ -411,6 +462,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
         const bool split = xf32 && p->precise;
         const bool dual = p->w2 != nullptr;
+        SmProfScope prof(SM_PROF_SKINNY, st);
         // enough waves per row-group to keep >= ~32 KiB of weight loads in flight per CU
         if (a.KS >= 64 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
         if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);
@@ -425,10 +477,16 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);
     static bool attr_set = false;
     if (!attr_set) {
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         attr_set = true;
     }
-    gemm_kernel<<<tiles_m * tiles_n, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
+    SmProfScope prof(SM_PROF_GEMM, st);
+    const dim3 grid(tiles_m * tiles_n);
+    if (p->act == SM_ACT_NONE) gemm_kernel<0><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
+    else if (p->act == SM_ACT_QUICK_GELU) gemm_kernel<1><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
+    else gemm_kernel<-1><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

@@ -454,6 +454,13 @@ extern "C" int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, vo
     SM_HIP(hipMemcpyAsync(out, s->tokens.as<float>() + (size_t)t0 * d, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SM_OK;
 }
+extern "C" int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream) {
+    SM_REQUIRE(s && src && t0 >= 0 && n > 0 && t0 <= s->T && t0 + n <= s->max_frames, "sm_stream_write_tokens: [%d, %d) not appendable (T=%d, cap=%d)", t0, t0 + n, s ? s->T : 0, s ? s->max_frames : 0);
+    const int d = s->m->c.conn_d_model;
+    SM_HIP(hipMemcpyAsync(s->tokens.as<float>() + (size_t)t0 * d, src, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (t0 + n > s->T) s->T = t0 + n;
+    return SM_OK;
+}
 extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_token_out, void* stream) {
     SM_REQUIRE(s && s->m->c.llm_layers > 0, "sm_stream_read_logits: perception-only model");
     if (out) SM_HIP(hipMemcpyAsync(out, s->lmlog.p, (size_t)s->m->c.llm_vocab * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));

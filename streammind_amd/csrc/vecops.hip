@@ -7,6 +7,37 @@ thread_local char g_sm_err[512] = {0};
 extern "C" const char* sm_last_error(void) { return g_sm_err; }
 extern "C" int sm_abi_version(void) { return 1; }
 
+// ------------------------------------------------------------------------------------------------ profiling hooks
+#include <vector>
+int g_sm_prof_mask = 0;
+static std::vector<hipEvent_t> g_prof_ev[SM_PROF_NCLS];      // begin/end pairs in launch order
+static size_t g_prof_used[SM_PROF_NCLS] = {0, 0, 0};
+static hipEvent_t prof_next(int cls) {
+    if (g_prof_used[cls] == g_prof_ev[cls].size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_prof_ev[cls].push_back(e);
+    }
+    return g_prof_ev[cls][g_prof_used[cls]++];
+}
+void sm_prof_begin_(int cls, hipStream_t st) { (void)hipEventRecord(prof_next(cls), st); }
+void sm_prof_end_(int cls, hipStream_t st) { (void)hipEventRecord(prof_next(cls), st); }
+extern "C" int sm_prof_enable(int mask) { g_sm_prof_mask = mask; return SM_OK; }
+extern "C" int sm_prof_reset(void) { for (int c = 0; c < SM_PROF_NCLS; ++c) g_prof_used[c] = 0; return SM_OK; }
+extern "C" int sm_prof_read(int cls, int* count, float* total_ms) {
+    SM_REQUIRE(cls >= 0 && cls < SM_PROF_NCLS && count && total_ms, "sm_prof_read: bad args");
+    float tot = 0.f;
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_prof_used[cls]; i += 2) {
+        SM_HIP(hipEventSynchronize(g_prof_ev[cls][i + 1]));
+        float ms = 0.f;
+        SM_HIP(hipEventElapsedTime(&ms, g_prof_ev[cls][i], g_prof_ev[cls][i + 1]));
+        tot += ms; ++n;
+    }
+    *count = n; *total_ms = tot;
+    return SM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ norm
 // one wave per row; D <= 16384.  LayerNorm: two-pass (mean, then centred variance) from registers/L1.
 template <bool LN>

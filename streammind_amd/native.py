@@ -213,6 +213,10 @@ class NativeStream:
         check(self.lib.sm_stream_read_tokens(self.h, t0, n, out.data_ptr(), _stream()), "sm_stream_read_tokens")
         return out
 
+    def write_tokens(self, t0: int, toks: torch.Tensor) -> None:
+        assert toks.dtype == torch.float32 and toks.is_cuda and toks.is_contiguous()
+        check(self.lib.sm_stream_write_tokens(self.h, t0, toks.shape[0], toks.data_ptr(), _stream()), "sm_stream_write_tokens")
+
     def prefill(self, ids: torch.Tensor) -> None:
         """ids int32 [n] on the GPU: >= 0 text token id, < 0 -> frame token index (-id - 1)."""
         assert ids.dtype == torch.int32 and ids.is_cuda and ids.is_contiguous() and ids.dim() == 1

@@ -44,9 +44,12 @@ def test_vit_tiny_vs_oracle(tiny):
     assert maxdiff(pooled, O.pool_patches(ref)) < 5e-3
     ref32 = O.vit_features(ref_pix, Wv, TV, O.FP32)
     assert maxdiff(pooled, O.pool_patches(ref32)) < 3e-2
-    # batching is exact: frame-by-frame == batched
+    # frame-by-frame == batched (tiny dims only: B=1 sends the 16-row patch-embed through the skinny kernel, whose
+    # K-summation order differs from the tiled GEMM's; at real dims both take the GEMM and are bit-identical)
     one = torch.cat([m.vit_encode(frames[i:i + 1].cuda()) for i in range(5)])
-    assert torch.equal(one.cpu(), pooled.cpu())
+    assert maxdiff(one, pooled) < 1e-3
+    two = torch.cat([m.vit_encode(frames[i:i + 2].cuda().contiguous()) for i in (0, 2)])
+    assert torch.equal(two.cpu(), pooled.cpu()[:4])
 
 
 def test_vit_fullwidth_golden(gold):
@@ -64,7 +67,7 @@ def test_vit_fullwidth_golden(gold):
     assert (got - torch.as_tensor(g["out_sample"])).abs().max().item() < 6e-2
     assert (pooled.cpu()[0] - torch.as_tensor(g["pooled"])).abs().max().item() < 3e-3
     ref = O.vit_features(O.preprocess_frames(frames), Wv, vcfg, O.MIXED)
-    assert maxdiff(feats, ref) < 3e-2
+    assert maxdiff(feats, ref) < 5e-2      # feats are returned as bf16: quantum 0.0625 at |x| ~ 8
 
 
 def _push_all(m, pooled, chunk):
@@ -124,8 +127,6 @@ def test_llm_tiny_prefill_decode(tiny, gold):
     emb = torch.randn(1, int(g["S"]), TL.hidden, generator=torch.Generator().manual_seed(int(g["seed_x"])))[0]
     s = m.open_stream(max_frames=32, max_seq=128)
     # feed the embeddings through the frame-token store: ids < 0 select rows of it (a10 path)
-    from streammind_amd._lib import check
-    # write embeds as "tokens": push via the private copy path = prefill with negative ids after loading the store
     _load_tokens(s, emb)
     ids = (-torch.arange(1, emb.shape[0] + 1, dtype=torch.int32)).cuda()
     s.prefill(ids)
@@ -134,7 +135,6 @@ def test_llm_tiny_prefill_decode(tiny, gold):
     tol = 3e-2
     assert maxdiff(lg, trace[0]) < tol
     assert maxdiff(lg, torch.as_tensor(g["logits0"])) < 6e-2          # vs the fp32 reference
-    out = [int(nt.item())] if False else None
     got = s.decode(len(g["ids"])).cpu().tolist()
     margins = g["margins"]
     for j, (a, b) in enumerate(zip(got, g["ids"].tolist())):
@@ -145,13 +145,4 @@ def test_llm_tiny_prefill_decode(tiny, gold):
 
 
 def _load_tokens(stream, emb):
-    """test-only: place `emb` rows into the stream's token store by pushing through a dummy path is not possible,
-    so write them with a device copy into sm_stream_tokens()."""
-    import ctypes as C
-    lib = stream.lib
-    ptr = lib.sm_stream_tokens(stream.h)
-    e = emb.float().cuda().contiguous()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipMemcpy(ptr, e.data_ptr(), e.numel() * 4, 3) == 0
-    torch.cuda.synchronize()
+    stream.write_tokens(0, emb.float().cuda().contiguous())
