@@ -93,6 +93,12 @@ int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const flo
 int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch, const float* mean3_host,
                           const float* std3_host, void* patches_bf16, int ldp, float* pixel_values_opt,
                           void* stream);
+/* same patch matrix from ALREADY-normalised pixel_values [B][3][H][W] (dtype SM_DT_BF16 / SM_DT_F32 / SM_DT_F16): the
+ * reference-convention input of CLIPVisionTower.forward (clip_encoder.py:41-53; video_score_stream_demo.py:86) */
+int sm_patchify_pixels(const void* pixel_values, int dtype, int B, int H, int W, int patch, void* patches_bf16,
+                       int ldp, void* stream);
+/* builder.py:405 on caller-held features: feats [T][P][C] (bf16/f32/f16) -> pooled fp32 [T][C] = mean over P */
+int sm_pool_rows(const void* feats, int dtype, int T, int P, int C, float* pooled, void* stream);
 /* CLS row: x[b*S + 0][:] = class_embedding + pos[0]  (HF CLIPVisionEmbeddings) */
 int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, const float* pos0, void* stream);
 /* non-causal MHA over bf16 qkv [B*S][3*H*dh] (Q|K) and V^T vt[B][H][dh][vt_ld]; ctx bf16 [B*S][H*dh].
@@ -173,6 +179,7 @@ typedef struct sm_stream sm_stream;
 
 #define SM_DT_BF16 0
 #define SM_DT_F32 1
+#define SM_DT_F16 2
 
 int sm_model_create(const sm_config_t* cfg, sm_model** out);
 /* Hand one checkpoint tensor (DEVICE memory, row-major, HF/reference layout and name, e.g.
@@ -194,7 +201,9 @@ int sm_model_missing(sm_model* m, char* buf, size_t buflen);
  * (= CLIPVisionTower.forward, clip_encoder.py:41-53) and pixel_values fp32 [B][3][H][W].            */
 int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats_bf16_opt,
                   float* pixel_values_opt, void* stream);
-/* same from already-normalised pixel_values bf16/fp32 is not offered: the u8 ring buffer IS the boundary */
+/* the same from normalised pixel_values [B][3][H][W] (what the reference's callers hand to CLIPVisionTower.forward) */
+int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int dtype, int B, float* pooled, void* feats_bf16_opt,
+                         void* stream);
 
 int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_stream** out);
 int sm_stream_reset(sm_stream* s, void* stream);

@@ -1,0 +1,49 @@
+"""streammind_amd -- MI355X-native drop-in for the StreamMind streaming hot path.
+
+Public API mirrors the reference: `model_init` (streammind/__init__.py:14-35, eval/video_score_stream_demo.py:42-63) and the
+streaming `infer` (eval/video_score_stream_demo.py:66-125).  All arithmetic runs in libstreammind_hip.so."""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+
+from .constants import DEFAULT_MMODAL_TOKEN, MMODAL_TOKEN_INDEX, NUM_FRAMES
+from .conversation import SeparatorStyle, conv_templates
+from .mm_utils import KeywordsStoppingCriteria, process_video, tokenizer_MMODAL_token
+
+
+def model_init(model_path=None, model_base=None, model_name="VideoLLaMA2-7B"):
+    from .model import load_pretrained_model
+    tokenizer, model, processor, context_len = load_pretrained_model(model_path, model_base, model_name)
+    if tokenizer.unk_token is not None:
+        tokenizer.pad_token = tokenizer.unk_token
+    num_frames = getattr(model.config, "num_frames", NUM_FRAMES)
+    version = "v1" if "vicuna" in model_name.lower() else "qwen" if "qwen" in model_name.lower() else "llama_2"
+    return model, partial(process_video, aspect_ratio=None, processor=processor, num_frames=num_frames), tokenizer, version
+
+
+def infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_instruct", score_video=None, prompt=None,
+          max_new_tokens=1024):
+    """One streaming tick: the new frame(s) in `video`, the running `prompt` (None on the first call).
+    -> (reply text | None, prompt).  eval/video_score_stream_demo.py:66-125, line for line in control flow."""
+    modal_index = MMODAL_TOKEN_INDEX["VIDEO"]
+    conv = conv_templates["mistral_instruct"].copy()
+    tensor = video if video.dtype == torch.uint8 else video.half()
+    tensor = tensor.to(model.device)
+    if prompt is None:
+        conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n")
+        conv.append_message(conv.roles[1], None)
+        prompt = conv.get_prompt()
+    input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_index, return_tensors="pt").unsqueeze(0)
+    pad = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else -1
+    attention_masks = input_ids.ne(pad).long()
+    stop_str = conv.sep if conv.sep_style in [SeparatorStyle.SINGLE] else conv.sep2
+    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
+    outputs, cls_pred = model.stream_generate_demo(
+        input_ids, attention_mask=attention_masks, images_or_videos=tensor, modal_list=["video"], do_sample=do_sample,
+        temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens, use_cache=True,
+        stopping_criteria=[stopping_criteria], pad_token_id=tokenizer.eos_token_id, score_video=score_video, tokenizer=tokenizer)
+    if cls_pred == 1:
+        prompt += " " + outputs + " </s>[INST] <video>\n [/INST]"
+    return outputs, prompt

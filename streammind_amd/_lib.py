@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstreammind_hip.so")
 
 SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
 SM_X_BF16, SM_X_F32 = 0, 1
-SM_DT_BF16, SM_DT_F32 = 0, 1
+SM_DT_BF16, SM_DT_F32, SM_DT_F16 = 0, 1, 2
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -52,6 +52,8 @@ SIGNATURES = {
     "sm_linear": (i32, [C.POINTER(sm_linear_t), vp]),
     "sm_norm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, vp]),
     "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
+    "sm_patchify_pixels": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "sm_pool_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sm_vit_cls_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sm_vit_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "sm_pool_patches": (i32, [vp, i32, i32, i32, vp, vp, vp]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     "sm_model_destroy": (None, [vp]),
     "sm_model_missing": (i32, [vp, C.c_char_p, sz]),
     "sm_vit_encode": (i32, [vp, vp, i32, vp, vp, vp, vp]),
+    "sm_vit_encode_pixels": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "sm_stream_open": (i32, [vp, i32, i32, C.POINTER(vp)]),
     "sm_stream_reset": (i32, [vp, vp]),
     "sm_stream_close": (None, [vp]),

@@ -297,16 +297,34 @@ static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dt
     return a;
 }
 
+extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, void* stream);
+static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream);
+
 extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats, float* pix, void* stream) {
     SM_REQUIRE(m && m->finalized, "sm_vit_encode: model not finalized");
     SM_REQUIRE(frames && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode: B=%d outside [1, %d]", B, m->Bmax);
+    const sm_config_t& c = m->c;
+    // a1: u8 ring buffer -> normalised bf16 patch matrix
+    int rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, m->patches.p, m->Kpe, pix, stream);
+    if (rc) return rc;
+    return vit_body(m, B, pooled, feats, stream);
+}
+
+extern "C" int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int dtype, int B, float* pooled, void* feats, void* stream) {
+    SM_REQUIRE(m && m->finalized, "sm_vit_encode_pixels: model not finalized");
+    SM_REQUIRE(pixel_values && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode_pixels: B=%d outside [1, %d]", B, m->Bmax);
+    const sm_config_t& c = m->c;
+    int rc = sm_patchify_pixels(pixel_values, dtype, B, c.vit_image, c.vit_image, c.vit_patch, m->patches.p, m->Kpe, stream);
+    if (rc) return rc;
+    return vit_body(m, B, pooled, feats, stream);
+}
+
+static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream) {
     const sm_config_t& c = m->c;
     const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P, M = B * S;
     int rc;
     float* x = m->x.as<float>();
     bf16_t* xn = m->xn.as<bf16_t>();
-    // a1: u8 ring buffer -> normalised bf16 patch matrix
-    if ((rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, m->patches.p, m->Kpe, pix, stream))) return rc;
     // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
     {
         sm_linear_t a = lin(m, m->slots.at("vit.patch_embed"), m->patches.p, SM_X_BF16, B * P, m->Kpe);

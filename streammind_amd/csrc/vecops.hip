@@ -149,6 +149,73 @@ extern "C" int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W,
     return SM_OK;
 }
 
+// pixel_values (already normalised, CHW, fp32 / bf16 / fp16) -> bf16 patch matrix: the reference-convention input of
+// CLIPVisionTower.forward (clip_encoder.py:41-53), for callers that preprocess on the host like the reference does
+template <int DT>
+__device__ __forceinline__ float load_pix(const void* p, size_t i) {
+    if (DT == 1) return ((const float*)p)[i];
+    if (DT == 0) return bf2f(((const bf16_t*)p)[i]);
+    return (float)((const _Float16*)p)[i];
+}
+template <int DT>
+__global__ void patchify_pixels_kernel(const void* __restrict__ pix, int B, int H, int W, int p, bf16_t* __restrict__ out, int ldp) {
+    const int gx = W / p, gy = H / p, cols8 = ldp >> 3, pp = p * p;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * gx * gy * cols8;
+    if (t >= total) return;
+    int c8 = (int)(t % cols8);
+    size_t prow = t / cols8;
+    int b = (int)(prow / (gx * gy)), pi = (int)(prow % (gx * gy));
+    int py = pi / gx, px = pi % gx;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int col = c8 * 8 + j;
+        float val = 0.f;
+        if (col < 3 * pp) {
+            int c = col / pp, r = col % pp;
+            val = load_pix<DT>(pix, (((size_t)b * 3 + c) * H + py * p + r / p) * W + px * p + r % p);
+        }
+        v[j] = val;
+    }
+    *(u32x4*)(out + prow * ldp + c8 * 8) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+}
+extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, void* stream) {
+    SM_REQUIRE(pix && patches && B > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "sm_patchify_pixels: bad args");
+    SM_REQUIRE(ldp % 8 == 0 && ldp >= 3 * patch * patch && dtype >= 0 && dtype <= 2, "sm_patchify_pixels: ldp / dtype");
+    size_t total = (size_t)B * (H / patch) * (W / patch) * (ldp / 8);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 1) patchify_pixels_kernel<1><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
+    else if (dtype == 0) patchify_pixels_kernel<0><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
+    else patchify_pixels_kernel<2><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// mean over the P rows of each of T groups: feats [T][P][C] (bf16 / fp32 / fp16) -> pooled fp32 [T][C]   (builder.py:405)
+template <int DT>
+__global__ __launch_bounds__(256) void pool_rows_kernel(const void* __restrict__ f, int P, int C, float* __restrict__ pooled) {
+    __shared__ float red[4][64];
+    const int t = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = w; r < P; r += 4) s += load_pix<DT>(f, ((size_t)t * P + r) * C + c);
+    red[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) pooled[(size_t)t * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)P;
+}
+extern "C" int sm_pool_rows(const void* feats, int dtype, int T, int P, int C, float* pooled, void* stream) {
+    SM_REQUIRE(feats && pooled && T > 0 && P > 0 && C > 0 && dtype >= 0 && dtype <= 2, "sm_pool_rows: bad args");
+    dim3 grid(cdiv(C, 64), T);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 1) pool_rows_kernel<1><<<grid, 256, 0, st>>>(feats, P, C, pooled);
+    else if (dtype == 0) pool_rows_kernel<0><<<grid, 256, 0, st>>>(feats, P, C, pooled);
+    else pool_rows_kernel<2><<<grid, 256, 0, st>>>(feats, P, C, pooled);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 __global__ void cls_rows_kernel(float* x, int B, int S, int D, const float* cls, const float* pos0) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * D) return;

@@ -1,0 +1,331 @@
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib
+from .._lib import check
+from ..constants import MMODAL_TOKEN_INDEX
+from ..native import NativeModel, NativeStream, PathConfig, _stream
+
+_DT = {torch.bfloat16: _lib.SM_DT_BF16, torch.float32: _lib.SM_DT_F32, torch.float16: _lib.SM_DT_F16}
+
+
+class CLIPVisionTower:
+    """drop-in for clip_encoder.py:7-84: images [N,3,H,W] (normalised pixel_values, any float dtype) or a list of [3,H,W]
+    -> hidden_states[select_layer][:, 1:] as [N, num_patches, hidden] in the input dtype."""
+
+    def __init__(self, native: NativeModel, select_feature: str = "patch"):
+        self.native = native
+        self.select_layer = native.cfg.vit_select_layer
+        self.select_feature = select_feature
+        self.is_loaded = True
+
+    def feature_select(self, feats: torch.Tensor) -> torch.Tensor:
+        if self.select_feature == "patch":
+            return feats
+        raise ValueError(f"Unexpected select feature: {self.select_feature}")   # clip_encoder.py:38 ('cls_patch' needs the CLS row)
+
+    @torch.no_grad()
+    def forward(self, images):
+        if type(images) is list:
+            return [self.forward(im.unsqueeze(0)) for im in images]
+        cfg, nat = self.native.cfg, self.native
+        x = images.to(self.device)
+        if x.dtype not in _DT:
+            x = x.float()
+        x = x.contiguous()
+        N = x.shape[0]
+        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == cfg.vit_image and x.shape[3] == cfg.vit_image
+        out = torch.empty(N, cfg.n_patches, cfg.vit_hidden, dtype=torch.bfloat16, device=self.device)
+        pooled = torch.empty(N, cfg.vit_hidden, dtype=torch.float32, device=self.device)
+        B = cfg.max_frames_per_call
+        for i in range(0, N, B):
+            n = min(B, N - i)
+            check(nat.lib.sm_vit_encode_pixels(nat.h, x[i:i + n].data_ptr(), _DT[x.dtype], n, pooled[i:i + n].data_ptr(),
+                                              out[i:i + n].data_ptr(), _stream()), "sm_vit_encode_pixels")
+        return self.feature_select(out).to(images.dtype)
+
+    __call__ = forward
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    @property
+    def device(self):
+        return self.native.device
+
+    @property
+    def config(self):
+        c = self.native.cfg
+        return SimpleNamespace(hidden_size=c.vit_hidden, image_size=c.vit_image, patch_size=c.vit_patch,
+                               num_hidden_layers=c.vit_layers, num_attention_heads=c.vit_heads, intermediate_size=c.vit_mlp)
+
+    @property
+    def hidden_size(self):
+        return self.native.cfg.vit_hidden
+
+    @property
+    def num_patches(self):
+        return self.native.cfg.n_patches
+
+    @property
+    def num_patches_per_side(self):
+        return self.native.cfg.vit_image // self.native.cfg.vit_patch
+
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
+
+
+class Video_Mamba_seq:
+    """drop-in for the inference branches of builder.py:403-414,547-564: frames_features [1,t,P,C] -> tokens [1,t,d]
+    (and, with cls_demo=True, the gate logits of the LAST frame, fp32 [2]).  Like the reference it recomputes all t
+    frames on every call; the O(1)-per-frame form is StreamingSession / stream_generate_demo."""
+
+    def __init__(self, native: NativeModel):
+        self.native = native
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, cls_inference=False, cls_training=False, cls_demo=False, frames_features_shape=[],
+                 prompt_time_input_ids=None, prompt_time_lable=None):
+        if cls_inference or cls_training:
+            raise NotImplementedError("teacher-forced gate evaluation is SURVEY 8f row f1 (next), not the streaming path")
+        b, t, l, d = x.shape
+        assert b == 1, "only support batch size 1"          # eval/inference_video_score_stream_ddp.py:325
+        nat = self.native
+        x = x.to(nat.device)
+        if x.dtype not in _DT:
+            x = x.float()
+        x = x.contiguous()
+        pooled = torch.empty(t, d, dtype=torch.float32, device=nat.device)
+        check(nat.lib.sm_pool_rows(x.data_ptr(), _DT[x.dtype], t, l, d, pooled.data_ptr(), _stream()), "sm_pool_rows")
+        s = nat.open_stream(max_frames=t, max_seq=64)
+        logits = None
+        for i in range(0, t, 16):
+            logits, _ = s.push_pooled(pooled[i:i + 16].contiguous())
+        tokens = s.tokens().unsqueeze(0)
+        s.close()
+        if cls_demo:
+            return tokens, logits[-1]
+        return tokens
+
+
+class Videollama2MistralForCausalLM:
+    """The streaming surface of language_model/videollama2_mistral.py:146-449.  Per-stream state lives on the object, as in
+    the reference (frame history -> here the native sm_stream, interval_id_list): one stream per instance, not re-entrant."""
+
+    def __init__(self, native: NativeModel, max_frames: int = 4096, max_seq: int = 4096, eos_token_id: Optional[int] = 2):
+        self.native = native
+        self.config = native.cfg
+        self.vision_tower = CLIPVisionTower(native)
+        self.mm_projector = Video_Mamba_seq(native)
+        self.stream: NativeStream = native.open_stream(max_frames=max_frames, max_seq=max_seq)
+        self.max_seq = max_seq
+        self.interval_id_list: List[int] = []          # videollama2_mistral.py:162 (never reset by the demo loop)
+        self.eos_token_id = eos_token_id
+        self._kv_ids: List[int] = []                   # ids whose K/V currently sit in the cache (prefix reuse)
+        self.decode_chunk = 16
+        self.last_gate_logits: Optional[torch.Tensor] = None
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    def get_model(self):
+        return self
+
+    @property
+    def device(self):
+        return self.native.device
+
+    @property
+    def frame_feature(self):          # the reference exposes the raw patch history; here the history is the token store
+        return None if self.stream.num_frames == 0 else self.stream.tokens()
+
+    @frame_feature.setter
+    def frame_feature(self, v):       # `model.frame_feature = None` is how callers reset a stream (inference_..._ddp.py:373)
+        if v is not None:
+            raise ValueError("frame_feature can only be reset to None")
+        self.stream.reset()
+        self._kv_ids = []
+
+    # ---- a3/a5-a9: one call = the new frame(s) of this tick
+    @torch.no_grad()
+    def _perceive(self, images_or_videos: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        x = images_or_videos
+        assert x.dim() == 4, "expected [n,3,H,W] pixel_values or [n,H,W,3] uint8 frames"      # videollama2_arch.py:179 (5-D after unsqueeze)
+        if x.shape[0] > 600:
+            x = x[-600:]                                                                        # videollama2_arch.py:186-187
+        x = x.to(self.device)
+        nat, cfg = self.native, self.native.cfg
+        logits = None
+        step = min(16, cfg.max_frames_per_call)
+        for i in range(0, x.shape[0], step):
+            xi = x[i:i + step].contiguous()
+            if xi.dtype == torch.uint8 and xi.shape[-1] == 3:
+                logits, dec = self.stream.push_frames(xi)
+            else:
+                if xi.dtype not in _DT:
+                    xi = xi.float()
+                n = xi.shape[0]
+                pooled = torch.empty(n, cfg.vit_hidden, dtype=torch.float32, device=self.device)
+                check(nat.lib.sm_vit_encode_pixels(nat.h, xi.data_ptr(), _DT[xi.dtype], n, pooled.data_ptr(), None, _stream()), "sm_vit_encode_pixels")
+                logits, dec = self.stream.push_pooled(pooled)
+        self.last_gate_logits = logits[-1]
+        return logits[-1], int(dec[-1].item())        # the per-tick device->host read (videollama2_arch.py:941 .item())
+
+    # ---- a10: sentinel expansion (videollama2_arch.py:948-984)
+    def _expand(self, input_ids: Sequence[int]) -> List[int]:
+        starts = [0] + self.interval_id_list[:-1]
+        seq: List[int] = []
+        k = 0
+        for t in input_ids:
+            if t == MMODAL_TOKEN_INDEX["VIDEO"]:
+                seq.extend(-(f + 1) for f in range(starts[k], self.interval_id_list[k]))
+                k += 1
+            else:
+                seq.append(int(t))
+        return seq
+
+    # ---- a12: greedy generate from the spliced context with KV prefix reuse
+    @torch.no_grad()
+    def _generate(self, seq: List[int], max_new_tokens: int, stopping_criteria=None) -> List[int]:
+        if len(seq) + max_new_tokens > self.max_seq:
+            max_new_tokens = self.max_seq - len(seq)
+            if max_new_tokens <= 0:
+                raise ValueError(f"context of {len(seq)} tokens exceeds max_seq={self.max_seq}")
+        lcp = 0
+        for a, b in zip(seq, self._kv_ids):
+            if a != b:
+                break
+            lcp += 1
+        lcp = min(lcp, len(seq) - 1, self.stream.kv_len)
+        self.stream.set_kv_len(lcp)
+        self.stream.prefill(torch.tensor(seq[lcp:], dtype=torch.int32, device=self.device))
+        self._kv_ids = list(seq)
+        out: List[int] = []
+        done = False
+        while not done and len(out) < max_new_tokens:
+            n = min(self.decode_chunk, max_new_tokens - len(out))
+            ids = self.stream.decode(n).cpu().tolist()          # n speculative greedy steps, one host sync
+            for j, tok in enumerate(ids):
+                out.append(tok)
+                self._kv_ids.append(tok)
+                if self.eos_token_id is not None and tok == self.eos_token_id:
+                    done = True
+                elif stopping_criteria is not None:
+                    t = torch.tensor([out], dtype=torch.long)
+                    if all(c(t, None) for c in stopping_criteria):
+                        done = True
+                if done:
+                    # tokens after the stop were speculative: their K/V is dropped
+                    self._kv_ids = self._kv_ids[:len(seq) + len(out)]
+                    self.stream.set_kv_len(len(self._kv_ids))
+                    break
+        return out
+
+    @torch.no_grad()
+    def stream_generate_demo(self, inputs: Optional[torch.Tensor] = None, images_or_videos: Optional[torch.Tensor] = None,
+                             modal_list=None, **kwargs):
+        """-> (decoded str | None, cls_pred).  Mirrors videollama2_mistral.py:385-439 incl. its error behaviour."""
+        kwargs.pop("position_ids", None)
+        kwargs.pop("attention_mask", None)
+        kwargs.pop("score_video", None)
+        tokenizer = kwargs.pop("tokenizer", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        _, cls_pred = self._perceive(images_or_videos)
+        if cls_pred == 0:
+            return None, cls_pred
+        self.interval_id_list.append(self.stream.num_frames)
+        if self.native.cfg.llm_layers == 0:
+            raise RuntimeError("perception-only model: no LLM loaded")
+        ids = inputs[0].tolist() if inputs.dim() == 2 else inputs.tolist()
+        seq = self._expand(ids)
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("only greedy decoding (do_sample=False) is on the streaming path")
+        new_ids = self._generate(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"))
+        self.last_new_ids = new_ids
+        output = tokenizer.batch_decode([new_ids], skip_special_tokens=True)[0].strip()
+        return output, cls_pred
+
+
+# ------------------------------------------------------------------------------------------------ loading
+def build_from_state_dicts(cfg: PathConfig, vision_sd: Dict[str, torch.Tensor], projector_sd: Dict[str, torch.Tensor],
+                           lm_sd: Optional[Dict[str, torch.Tensor]] = None, device: str = "cuda:0", **kw) -> Videollama2MistralForCausalLM:
+    """weights given as the reference's state_dict pieces (names relative to vision_model / mm_projector / the LM root)."""
+    nat = NativeModel(cfg, device)
+    for k, v in vision_sd.items():
+        nat.load_tensor("model.vision_tower.vision_tower.vision_model." + k, v)
+    for k, v in projector_sd.items():
+        nat.load_tensor("model.mm_projector." + k, v)
+    if lm_sd is not None:
+        for k, v in lm_sd.items():
+            nat.load_tensor(k, v)
+    miss = nat.missing()
+    if miss:
+        raise ValueError(f"checkpoint is missing tensors for: {miss[:8]}{' ...' if len(miss) > 8 else ''}")
+    nat.finalize()
+    return Videollama2MistralForCausalLM(nat, **kw)
+
+
+def _read_safetensors_dir(path: str):
+    from safetensors import safe_open
+    idx = os.path.join(path, "model.safetensors.index.json")
+    files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else \
+        [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
+    for f in files:
+        with safe_open(os.path.join(path, f), framework="pt") as sf:
+            for k in sf.keys():
+                yield k, sf.get_tensor(k)
+
+
+def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7B", load_8bit=False, load_4bit=False,
+                          device_map="auto", device="cuda", use_flash_attn=False, **kwargs):
+    """-> (tokenizer, model, image_processor, context_len), as streammind/model/builder.py:30-210 for a merged (non-LoRA)
+    Mistral checkpoint directory: config.json (+ mm_* keys, videollama2_arch.py:69-73), *.safetensors, optional
+    mm_projector.bin, and the CLIP tower directory named by config.mm_vision_tower."""
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes quantisation is not part of the MI355X path")
+    if model_base is not None:
+        raise NotImplementedError("LoRA / base-model merging is a training-side feature (out of scope)")
+    from transformers import AutoTokenizer, CLIPImageProcessor
+    cfgj = json.load(open(os.path.join(model_path, "config.json")))
+    if "mamba" not in cfgj.get("mm_projector_type", ""):
+        raise ValueError(f"Unsupported projector type {cfgj.get('mm_projector_type')}!!!")      # videollama2_arch.py:321
+    tower_dir = cfgj["mm_vision_tower"]
+    vj = json.load(open(os.path.join(tower_dir, "config.json")))
+    vj = vj.get("vision_config", vj)
+    cfg = PathConfig(
+        vit_image=vj["image_size"], vit_patch=vj["patch_size"], vit_hidden=vj["hidden_size"], vit_heads=vj["num_attention_heads"],
+        vit_mlp=vj["intermediate_size"], vit_layers=vj["num_hidden_layers"], vit_select_layer=cfgj.get("mm_vision_select_layer", -2),
+        vit_eps=vj.get("layer_norm_eps", 1e-5), conn_d_model=cfgj["hidden_size"],
+        llm_layers=cfgj["num_hidden_layers"], llm_heads=cfgj["num_attention_heads"], llm_kv_heads=cfgj["num_key_value_heads"],
+        llm_mlp=cfgj["intermediate_size"], llm_vocab=cfgj["vocab_size"], llm_eps=cfgj.get("rms_norm_eps", 1e-5),
+        llm_rope_theta=cfgj.get("rope_theta", 1e4), max_frames_per_call=kwargs.pop("max_frames_per_call", 8))
+    dev = "cuda:0" if device == "cuda" else device
+    nat = NativeModel(cfg, dev)
+    for k, v in _read_safetensors_dir(model_path):
+        nat.load_tensor(k, v)
+    pbin = os.path.join(model_path, "mm_projector.bin")
+    if os.path.exists(pbin):
+        for k, v in torch.load(pbin, map_location="cpu").items():
+            nat.load_tensor(k, v)
+    if nat.missing():                                   # the tower is delay-loaded from its own checkpoint (clip_encoder.py:18-29)
+        for k, v in _read_safetensors_dir(tower_dir):
+            if k.startswith("vision_model.") or not k.startswith("text_model."):
+                nat.load_tensor("model.vision_tower.vision_tower." + k, v)
+    if nat.missing():
+        raise ValueError(f"checkpoint incomplete, missing: {nat.missing()[:8]}")
+    nat.finalize()
+    tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+    image_processor = CLIPImageProcessor.from_pretrained(tower_dir)
+    context_len = cfgj.get("max_sequence_length", 2048)                      # builder.py:205-208
+    model = Videollama2MistralForCausalLM(nat, max_seq=kwargs.pop("max_seq", 4096), eos_token_id=tokenizer.eos_token_id)
+    return tokenizer, model, image_processor, context_len

@@ -10,10 +10,7 @@ from tests.util_models import build_native, conn_gate_weights
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-TV = O.VitCfg(image_size=56, patch=14, hidden=128, heads=2, mlp=256, layers=4)
-TC = O.ConnCfg(mm_hidden=128, d_model=256)
-TG = O.LmCfg.gate(hidden=256, heads=2, kv_heads=1, mlp=512)
-TL = O.LmCfg(hidden=256, layers=2, heads=2, kv_heads=1, mlp=512, vocab=384, eps=1e-5, rope_theta=1e6)
+from oracle.make_golden import TINY_V as TV, TINY_C as TC, TINY_G as TG, TINY_L as TL   # the dims golden g6/g7 were minted with
 
 
 def maxdiff(a, b):
@@ -146,3 +143,69 @@ def test_llm_tiny_prefill_decode(tiny, gold):
 
 def _load_tokens(stream, emb):
     stream.write_tokens(0, emb.float().cuda().contiguous())
+
+
+def test_stream_end_to_end_vs_reference_golden(tiny, gold, tiny_tokenizer):
+    """The reference's own streaming loop (golden g6: stream_generate_demo driven like video_score_stream_demo.py) vs
+    the drop-in API: per-frame gate logits (5e-3: bf16 ViT) and decisions, fire positions, and -- with the prompt
+    teacher-forced from the golden after every fire -- the generated ids wherever the oracle's top-2 margin exceeds
+    the bf16 logit tolerance."""
+    import streammind_amd
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    m, Wv, Wc, Wl = tiny
+    g = gold("g6_stream_tiny")
+    n = int(g["n_frames"])
+    frames = O.synthetic_frames(n, TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+    prompt, fires = None, 0
+    st = O.StreamOracleState()
+    for i in range(n):
+        golden_prompt_before = prompt
+        text, prompt = streammind_amd.infer(model, frames[i:i + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=int(g["max_new"]))
+        assert maxdiff(model.last_gate_logits, torch.as_tensor(g["gate_logits"][i])) < 5e-3
+        pred = int(g["preds"][i])
+        assert (text is not None) == bool(pred)
+        # oracle twin on the same frames (mixed-precision LLM) for margins
+        r = O.stream_frame(frames[i], st, Wv, Wc, Wl, TV, TC, TG, TL, tiny_tokenizer, max_new_tokens=int(g["max_new"]))
+        if pred:
+            want = g[f"new_ids{fires}"].tolist()
+            assert r.new_ids == want
+            ids_in = O.tokenize_with_video(golden_prompt_before or O.initial_prompt(), tiny_tokenizer)
+            emb = O.splice_embeds(ids_in, O.connector_scan(O.pool_patches(st.feats), Wc, TC), st.interval_ids, Wl["model.embed_tokens.weight"])
+            _, trace = O.greedy_generate(emb, Wl, TL, len(want), tiny_tokenizer.eos_token_id, return_logits=True)
+            got = model.last_new_ids
+            for j, (a, b) in enumerate(zip(got, want)):
+                margin = float(torch.topk(trace[j], 2).values.diff().abs())
+                if a != b:
+                    assert margin < 0.15, (i, j, got, want, margin)
+                    break
+            fires += 1
+            prompt = st.prompt                       # teacher-force the reference's prompt for the next ticks
+    assert model.interval_id_list == g["interval_ids"].tolist()
+    assert fires == int(g["n_fires"])
+    assert st.prompt == str(g["final_prompt"])
+
+
+def test_clip_tower_and_projector_dropins(tiny):
+    """CLIPVisionTower.forward(pixel_values) and mm_projector(frames_features, cls_demo=True) keep the reference's
+    signatures and agree with the oracle."""
+    from streammind_amd.model import CLIPVisionTower, Video_Mamba_seq
+    m, Wv, Wc, _ = tiny
+    frames = O.synthetic_frames(3, TV.image_size, seed=5, scene_len=2)
+    pix = O.preprocess_frames(frames, TV.image_size)
+    tower = CLIPVisionTower(m)
+    feats = tower(pix.half())
+    assert feats.dtype == torch.float16 and tuple(feats.shape) == (3, tower.num_patches, tower.hidden_size)
+    ref = O.vit_features(O.bf16_round(pix.half().float()), Wv, TV, O.MIXED)
+    assert maxdiff(feats, ref) < 3e-2 * ref.abs().max().item()
+    proj = Video_Mamba_seq(m)
+    x = torch.randn(1, 5, 16, TC.mm_hidden, generator=torch.Generator().manual_seed(3))
+    tok, lg = proj(x, cls_demo=True)
+    rt = O.connector_scan(O.pool_patches(x[0]), Wc, TC)
+    assert tuple(tok.shape) == (1, 5, TC.d_model) and maxdiff(tok[0], rt) < 1e-4
+    assert maxdiff(lg, O.gate_logits(rt[-1], Wc, TG)) < 1e-3
+    try:
+        tower.select_feature = "bogus"; tower(pix)
+        raise AssertionError
+    except ValueError:
+        pass
