@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (<= 16)")
+    ap.add_argument("--batch", type=int, default=8, help="frames per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     a = ap.parse_args()

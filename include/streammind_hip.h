@@ -140,6 +140,10 @@ int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, 
 /* causal GQA attention of n new queries (positions pos0..) against the cache [0, pos0+n): ctx bf16 [n][H*dh] */
 int sm_llm_attention(const void* q_bf16, const void* kcache, const void* vtcache, int n, int pos0, int H,
                      int KV, int dh, int S_max, void* ctx_bf16, void* stream);
+/* single-token decode attention (flash-decoding: keys split over up to splits_max blocks per KV group, then merged);
+ * q bf16 [H*dh] at position pos, cache as above; workspace fp32 [splits_max * H * (dh + 2)]                */
+int sm_llm_decode_attention(const void* q_bf16, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
+                            int S_max, float* workspace, int splits_max, void* ctx_bf16, void* stream);
 /* out[m] = bf16( silu(gu[m][0:F]) * gu[m][F:2F] ) */
 int sm_swiglu(const float* gu, int M, int F, void* out_bf16, void* stream);
 /* greedy argmax over fp32 logits[V] -> token (int32, device) ; first max wins (torch.argmax)           */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sm_embed_splice": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "sm_rope_kv_append": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "sm_llm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sm_llm_decode_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "sm_swiglu": (i32, [vp, i32, i32, vp, vp]),
     "sm_argmax": (i32, [vp, i32, vp, vp]),
     "sm_model_create": (i32, [C.POINTER(sm_config_t), C.POINTER(vp)]),

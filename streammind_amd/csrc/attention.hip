@@ -20,9 +20,13 @@ struct AttnP {
     bf16_t* o; long o_bs, o_rs;
     int nq, nk, H, KV, causal, pos0;
     float c;                                 // softmax scale * log2(e)
+    // flash-decoding (single-token decode): blockIdx.z = key split; partial (unnormalised o, m, l) go to part_*
+    int split_len;                           // keys per split (multiple of 64), 0 = no splitting
+    float* part_o;                           // [splits][H][nq][DH] fp32
+    float* part_ml;                          // [splits][H][nq][2]  (running max in scaled-log2 domain source units, l)
 };
 
-template <int DH>
+template <int DH, bool GROUPQ = false>   // GROUPQ: decode mode, query row r of kv-group h is head h*nq + r (q is [H][DH])
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     constexpr int KSQ = DH / 32;             // k-steps of the QK^T contraction
     constexpr int DF = DH / 16;              // d fragments of the output
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.y, b = p.split_len ? 0 : blockIdx.z;
     const int kvh = h / (p.H / p.KV);
     const int q0 = blockIdx.x * 128 + wave * 32;
 
@@ -44,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     for (int qb = 0; qb < 2; ++qb) {
         int qr = q0 + qb * 16 + i;
         if (qr >= p.nq) qr = p.nq - 1;
-        const bf16_t* src = p.q + b * p.q_bs + (long)qr * p.q_rs + h * DH + g * 8;
+        const bf16_t* src = GROUPQ ? p.q + ((long)h * p.nq + qr) * DH + g * 8
+                                   : p.q + b * p.q_bs + (long)qr * p.q_rs + h * DH + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks) qf[qb][ks] = *(const bf16x8*)(src + ks * 32);
     }
@@ -55,15 +60,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         for (int df = 0; df < DF; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-    int k_end = p.nk;
+    int k_end = p.nk, k_begin = 0;
     if (p.causal) {
         int last = p.pos0 + min(blockIdx.x * 128 + 127, p.nq - 1) + 1;
         k_end = min(k_end, last);
     }
+    if (p.split_len) {
+        k_begin = blockIdx.z * p.split_len;
+        k_end = min(k_end, k_begin + p.split_len);
+    }
     const bf16_t* kbase = p.k + b * p.k_bs + kvh * DH;
     const bf16_t* vbase = p.vt + b * p.vt_bs + kvh * p.vt_hs;
 
-    for (int kt0 = 0; kt0 < k_end; kt0 += 64) {
+    for (int kt0 = k_begin; kt0 < k_end; kt0 += 64) {
         __syncthreads();
         // ---- stage K (64 keys, permuted rows) and V^T (DH rows x 64 keys) tiles
 #pragma unroll
@@ -165,8 +174,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         float l = l_run[qb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
         const int qr = q0 + qb * 16 + i;
+        if (p.split_len) {
+            if (qr < p.nq) {
+                const size_t row = ((size_t)blockIdx.z * p.H + h) * p.nq + qr;
+                float* dst = p.part_o + row * DH + g * 4;
+#pragma unroll
+                for (int df = 0; df < DF; ++df) *(f32x4*)(dst + df * 16) = o[qb][df];
+                if (g == 0) { p.part_ml[row * 2] = m_run[qb]; p.part_ml[row * 2 + 1] = l; }
+            }
+            continue;
+        }
+        const float inv = 1.0f / l;
         if (qr < p.nq) {
             bf16_t* dst = p.o + b * p.o_bs + (long)qr * p.o_rs + h * DH + g * 4;
 #pragma unroll
@@ -179,11 +198,29 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     }
 }
 
+// merge the key splits of flash-decoding: out[h][r][d] = sum_p w_p o_p / sum_p w_p l_p, w_p = exp2((m_p - M) c)
+__global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int splits, int rows,
+                                    int dh, float c, bf16_t* __restrict__ out) {
+    const int row = blockIdx.x;               // (kv head, query-in-group) flattened == output head index
+    const int d = threadIdx.x;
+    float M = -INFINITY;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, part_ml[((size_t)s * rows + row) * 2]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float m = part_ml[((size_t)s * rows + row) * 2];
+        if (m == -INFINITY) continue;
+        const float w = exp2f((m - M) * c);
+        den += w * part_ml[((size_t)s * rows + row) * 2 + 1];
+        if (d < dh) num += w * part_o[((size_t)s * rows + row) * dh + d];
+    }
+    if (d < dh) out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
+}
+
 static int launch_attn(const AttnP& p, int B, int dh, hipStream_t st) {
     dim3 grid(cdiv(p.nq, 128), p.H, B);
     SmProfScope prof(SM_PROF_ATTN, st);
-    if (dh == 64) attn_kernel<64><<<grid, 256, 0, st>>>(p);
-    else if (dh == 128) attn_kernel<128><<<grid, 256, 0, st>>>(p);
+    if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
+    else if (dh == 128) attn_kernel<128, false><<<grid, 256, 0, st>>>(p);
     else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_LAUNCH_CHECK();
     return SM_OK;
@@ -201,6 +238,7 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     p.o = (bf16_t*)ctx; p.o_bs = (long)S * H * dh; p.o_rs = (long)H * dh;
     p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
     return launch_attn(p, B, dh, (hipStream_t)stream);
 }
 
@@ -215,5 +253,44 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
     p.o = (bf16_t*)ctx; p.o_bs = 0; p.o_rs = (long)H * dh;
     p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
     return launch_attn(p, 1, dh, (hipStream_t)stream);
+}
+
+// Single-token decode ("flash-decoding"): the H/KV query heads of one KV group play the role of the query rows of the
+// tile kernel (so K/V of a group are streamed once for all its heads), the keys are split across gridDim.z blocks so
+// that every CU streams part of the cache, and a tiny kernel merges the partial softmaxes.
+// workspace: fp32 [splits_max * H * (dh + 2)]
+extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
+                                       int S_max, float* workspace, int splits_max, void* ctx, void* stream) {
+    SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
+    SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && dh <= 128, "sm_llm_decode_attention: dims");
+    const int rep = H / KV, nk = pos + 1;
+    int splits = cdiv(nk, 128);
+    if (splits > splits_max) splits = splits_max;
+    const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
+    splits = cdiv(nk, split_len);
+    AttnP p;
+    p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
+    p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
+    p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
+    p.o = nullptr; p.o_bs = 0; p.o_rs = 0;
+    p.nq = rep; p.nk = nk; p.H = KV; p.KV = KV; p.causal = 0; p.pos0 = 0;
+    p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    p.split_len = split_len;
+    p.part_o = workspace; p.part_ml = workspace + (size_t)splits_max * H * dh;
+    // head h of the tile kernel reads q columns h*DH: make group h start at head h*rep by scaling the row stride trick:
+    // q pointer for group h = q + h*rep*dh  ->  handled through q_bs = 0 and a per-group base below (grid.y = KV)
+    hipStream_t st = (hipStream_t)stream;
+    {
+        SmProfScope prof(SM_PROF_ATTN, st);
+        dim3 grid(1, KV, splits);
+        if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
+        else if (dh == 128) attn_kernel<128, true><<<grid, 256, 0, st>>>(p);
+        else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
+        SM_LAUNCH_CHECK();
+    }
+    attn_combine_kernel<<<H, 128, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
 }

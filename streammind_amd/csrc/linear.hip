@@ -6,8 +6,7 @@
 // output stores are 8/16-byte vectors along the contiguous dimension of the row-major output.
 #include <stdlib.h>
 
-#include "common.h"
-#include "host.h"
+#include "linear_common.h"
 
 // ------------------------------------------------------------------------------------------------ pack
 __global__ void pack_weight_kernel(const bf16_t* __restrict__ w, int N, int K, int ldw, u32x4* __restrict__ out,
@@ -50,80 +49,6 @@ int sm_pack_weight_ks(const void* w, int N, int K, int ldw, int KS, void* out, v
 
 extern "C" int sm_pack_weight(const void* w, int N, int K, int ldw, void* out, void* stream) {
     return sm_pack_weight_ks(w, N, K, ldw, (K + 31) / 32, out, stream);
-}
-
-// ------------------------------------------------------------------------------------------------ epilogue
-struct LinArgs {
-    const bf16x8* w;
-    const bf16x8* w2;
-    int N, K, KS, NRG;
-    const void* x;
-    int M, ldx;
-    const float* bias;
-    int act;
-    const float* residual;
-    int ldr;
-    float* out_f32;
-    bf16_t* out_bf16;
-    int ldo, ldo_bf16;
-    int remap_in, remap_out, remap_off;
-    bf16_t* vt;
-    int vt_n0, vt_S, vt_dh, vt_ld;
-};
-
-__device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
-
-// one lane's 4 consecutive outputs (n0..n0+3) of row m
-__device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f32x4 v, const f32x4* v2) {
-    if (m >= a.M || n0 >= a.N) return;
-    int orow = m, rrow = m;
-    if (a.remap_in > 0) {
-        int q = m / a.remap_in, r = m - q * a.remap_in;
-        orow = q * a.remap_out + a.remap_off + r;
-        rrow = a.remap_off + r;
-    }
-    const bool full = (n0 + 3 < a.N);
-    float o[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float t = v[r];
-        if (a.bias && (full || n0 + r < a.N)) t += a.bias[n0 + r];
-        if (v2) t = siluf_(t) * (*v2)[r];
-        else t = apply_act_rt(t, a.act);
-        if (a.residual && (full || n0 + r < a.N)) t += a.residual[(size_t)rrow * a.ldr + n0 + r];
-        o[r] = t;
-    }
-    if (a.out_f32) {
-        float* p = a.out_f32 + (size_t)orow * a.ldo + n0;
-        if (full && ((a.ldo & 3) == 0)) {
-            *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + r < a.N) p[r] = o[r];
-        }
-    }
-    if (a.vt && n0 >= a.vt_n0) {
-        int b = m / a.vt_S, s = m - b * a.vt_S;
-        int nh = (a.N - a.vt_n0) / a.vt_dh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int c = n0 + r - a.vt_n0;
-            if (n0 + r < a.N) {
-                int h = c / a.vt_dh, d = c - h * a.vt_dh;
-                a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + s] = (bf16_t)f2bf(o[r]);
-            }
-        }
-    } else if (a.out_bf16) {
-        bf16_t* p = a.out_bf16 + (size_t)orow * a.ldo_bf16 + n0;
-        if (full && ((a.ldo_bf16 & 3) == 0)) {
-            *(u32x2*)p = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n0 + r < a.N) p[r] = (bf16_t)f2bf(o[r]);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ skinny (M <= 16)
@@ -238,13 +163,6 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 #define GEMM_BN 128
 #define GEMM_BK 64
 #define GEMM_STAGE_BYTES 32768
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
-}
 
 // Fast whole-row epilogue of one [128 m][128 n] fp32 tile staged in LDS.  The output / residual / bias pointers are
 // __restrict__ FUNCTION PARAMETERS on purpose: without the no-alias guarantee hipcc orders every pass's (possibly
@@ -474,6 +392,21 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE((a.KS & 1) == 0, "sm_linear: GEMM path needs K padded to a multiple of 64 (K=%d)", p->K);
     SM_REQUIRE(p->ldx % 8 == 0, "sm_linear: bf16 x needs ldx %% 8 == 0");
     SM_REQUIRE(!p->vt || (p->vt_n0 % GEMM_BN == 0 && !p->residual && p->remap_in == 0), "sm_linear: vt_n0 must be a multiple of %d on the GEMM path", GEMM_BN);
+    // tile choice: the 256x256 kernel (1 block/CU, 2x the FLOP per L2 byte) when its grid still fills the chip;
+    // SM_GEMM_TILE=128|256 overrides (tools/gemm_bench.py)
+    {
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("SM_GEMM_TILE"); force = e ? atoi(e) : 0; }
+        const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
+        const bool ok256 = !p->vt || p->vt_n0 % 256 == 0;
+        bool use256 = ok256 && t256 >= 160;
+        if (force == 128) use256 = false;
+        if (force == 256) use256 = ok256;
+        if (use256) {
+            SmProfScope prof(SM_PROF_GEMM, st);
+            return launch_gemm256(a, p->act, st);
+        }
+    }
     int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);
     static bool attr_set = false;
     if (!attr_set) {

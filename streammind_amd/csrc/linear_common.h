@@ -1,0 +1,89 @@
+// Shared device code of the linear kernels: argument block, generic 4-wide epilogue, LDS-DMA helper.
+#pragma once
+#include "common.h"
+#include "host.h"
+
+// ------------------------------------------------------------------------------------------------ epilogue
+struct LinArgs {
+    const bf16x8* w;
+    const bf16x8* w2;
+    int N, K, KS, NRG;
+    const void* x;
+    int M, ldx;
+    const float* bias;
+    int act;
+    const float* residual;
+    int ldr;
+    float* out_f32;
+    bf16_t* out_bf16;
+    int ldo, ldo_bf16;
+    int remap_in, remap_out, remap_off;
+    bf16_t* vt;
+    int vt_n0, vt_S, vt_dh, vt_ld;
+};
+
+static __device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
+
+// one lane's 4 consecutive outputs (n0..n0+3) of row m
+static __device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f32x4 v, const f32x4* v2) {
+    if (m >= a.M || n0 >= a.N) return;
+    int orow = m, rrow = m;
+    if (a.remap_in > 0) {
+        int q = m / a.remap_in, r = m - q * a.remap_in;
+        orow = q * a.remap_out + a.remap_off + r;
+        rrow = a.remap_off + r;
+    }
+    const bool full = (n0 + 3 < a.N);
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = v[r];
+        if (a.bias && (full || n0 + r < a.N)) t += a.bias[n0 + r];
+        if (v2) t = siluf_(t) * (*v2)[r];
+        else t = apply_act_rt(t, a.act);
+        if (a.residual && (full || n0 + r < a.N)) t += a.residual[(size_t)rrow * a.ldr + n0 + r];
+        o[r] = t;
+    }
+    if (a.out_f32) {
+        float* p = a.out_f32 + (size_t)orow * a.ldo + n0;
+        if (full && ((a.ldo & 3) == 0)) {
+            *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) p[r] = o[r];
+        }
+    }
+    if (a.vt && n0 >= a.vt_n0) {
+        int b = m / a.vt_S, s = m - b * a.vt_S;
+        int nh = (a.N - a.vt_n0) / a.vt_dh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int c = n0 + r - a.vt_n0;
+            if (n0 + r < a.N) {
+                int h = c / a.vt_dh, d = c - h * a.vt_dh;
+                a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + s] = (bf16_t)f2bf(o[r]);
+            }
+        }
+    } else if (a.out_bf16) {
+        bf16_t* p = a.out_bf16 + (size_t)orow * a.ldo_bf16 + n0;
+        if (full && ((a.ldo_bf16 & 3) == 0)) {
+            *(u32x2*)p = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) p[r] = (bf16_t)f2bf(o[r]);
+        }
+    }
+}
+
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// 16 B per lane global -> LDS DMA; the LDS destination is wave-uniform base + lane*16 (1 KiB per wave-instruction)
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+int launch_gemm256(const LinArgs& a, int act, hipStream_t st);     // gemm256.hip

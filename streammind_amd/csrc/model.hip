@@ -370,6 +370,7 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
 }
 
 // ------------------------------------------------------------------------------------------------ stream
+#define SM_DECODE_SPLITS 32
 struct sm_stream {
     sm_model* m;
     int max_frames, max_seq;
@@ -379,7 +380,7 @@ struct sm_stream {
     DevBuf pooled, t0, u, xz, xc, xdbl, delta, y, r, lnf, h, hn, v, vrep, act, hfin, logits2;
     // LLM
     std::vector<DevBuf> kc, vtc;
-    DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok;
+    DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok, attn_ws;
     int chunk = 0;
 };
 
@@ -396,7 +397,7 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
     A(conv_state, (size_t)di * c.conn_d_conv * 4, true);
     A(ssm_state, (size_t)di * ds * 4, true);
     A(tokens, (size_t)max_frames * d * 4, false);
-    A(pooled, (size_t)16 * c.conn_mm_hidden * 4, false);
+    A(pooled, (size_t)(m->Bmax > 16 ? m->Bmax : 16) * c.conn_mm_hidden * 4, false);
     A(t0, (size_t)16 * d * 4, false); A(u, (size_t)16 * d * 4, false);
     A(xz, (size_t)16 * 2 * di * 4, false); A(xc, (size_t)16 * di * 4, false);
     A(xdbl, (size_t)16 * xd * 4, true); A(delta, (size_t)16 * di * 4, false);
@@ -420,6 +421,7 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
         A(qkvf, ch * (qn + 2 * kn) * 4, false); A(qb, ch * qn * 2, false); A(ctxb, ch * qn * 2, false);
         A(guf, ch * 2 * c.llm_mlp * 4, false); A(actb, ch * c.llm_mlp * 2, false);
         A(lmlog, (size_t)c.llm_vocab * 4, false); A(next_tok, 64, true);
+        A(attn_ws, (size_t)SM_DECODE_SPLITS * c.llm_heads * (dh + 2) * 4, false);
         if (!rc && m->rope_len < max_seq) {
             // cos/sin(pos * theta^(-2j/dh)) exactly as HF MistralRotaryEmbedding: fp32 inv_freq, fp32 product
             const int half = dh / 2;
@@ -561,10 +563,18 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
 }
 
 extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
-    SM_REQUIRE(s && frames && M >= 1 && M <= 16 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, min(16, max_frames_per_call)]", M);
+    SM_REQUIRE(s && frames && M >= 1 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, max_frames_per_call=%d]", M, s ? s->m->Bmax : 0);
+    // one ViT batch, then the connector+gate in frame order, at most 16 frames per weight pass
     int rc = sm_vit_encode(s->m, frames, M, s->pooled.as<float>(), nullptr, nullptr, stream);
     if (rc) return rc;
-    return sm_stream_push_pooled(s, s->pooled.as<float>(), M, logits, decisions, stream);
+    const int parts = cdiv(M, 16), per = cdiv(M, parts);
+    for (int i = 0; i < M; i += per) {
+        const int n = M - i < per ? M - i : per;
+        rc = sm_stream_push_pooled(s, s->pooled.as<float>() + (size_t)i * s->m->c.conn_mm_hidden, n, logits ? logits + 2 * i : nullptr,
+                                   decisions ? decisions + i : nullptr, stream);
+        if (rc) return rc;
+    }
+    return SM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ LLM
@@ -582,7 +592,9 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
             if ((rc = sm_linear(&a, stream))) return rc; }
         if ((rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
-        if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;
+        if (n == 1) {
+            if ((rc = sm_llm_decode_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, stream))) return rc;
+        } else if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;
         {   sm_linear_t a = lin(m, m->slots.at(p + "o"), s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }

@@ -207,3 +207,28 @@ def test_gate_decide_and_argmax(nat):
     vg = v.cuda()
     check(lib.sm_argmax(vg.data_ptr(), 32000, out.data_ptr(), st))
     assert out.item() == 123 == int(torch.argmax(v))
+
+
+@pytest.mark.parametrize("pos,H,KV,dh", [(0, 32, 8, 128), (37, 32, 8, 128), (1000, 32, 8, 128), (4095, 32, 8, 128), (200, 2, 1, 128), (77, 4, 4, 64)])
+def test_decode_attention_split_keys(nat, pos, H, KV, dh):
+    """flash-decoding (key-split + merge) vs plain softmax attention over the cache: bf16 output, 8e-3 of max."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    S_max = 4096
+    g = torch.Generator().manual_seed(pos + H)
+    q = O.bf16_round(torch.randn(H, dh, generator=g))
+    k = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    v = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    k[pos + 1:] = 0; v[pos + 1:] = 0
+    qg, kg = q.cuda().bfloat16(), k.cuda().bfloat16()
+    vt = v.permute(1, 2, 0).contiguous().cuda().bfloat16()             # [KV][dh][S_max]
+    ws = torch.empty(32 * H * (dh + 2), device="cuda")
+    ctx = torch.empty(H, dh, device="cuda", dtype=torch.bfloat16)
+    check(lib.sm_llm_decode_attention(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), pos, H, KV, dh, S_max, ws.data_ptr(), 32,
+                                      ctx.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    rep = H // KV
+    kk = k[:pos + 1].repeat_interleave(rep, dim=1)
+    vv = v[:pos + 1].repeat_interleave(rep, dim=1)
+    s = torch.einsum("hd,khd->hk", q, kk) * dh ** -0.5
+    ref = torch.einsum("hk,khd->hd", torch.softmax(s, -1), vv)
+    assert relerr(ctx, ref) < 8e-3

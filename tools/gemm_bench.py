@@ -8,6 +8,7 @@ from streammind_amd import native
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4616
 shapes = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096), ("sq4k", 4096, 4096)]
+CHECK = os.environ.get("SM_CHECK", "0") == "1"
 for name, N, K in shapes:
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     x = torch.randn(M, K, device="cuda").bfloat16()
@@ -15,6 +16,12 @@ for name, N, K in shapes:
     for _ in range(3):
         y = native.linear(x, wp, N, K, out_dtype=torch.bfloat16)
     torch.cuda.synchronize()
+    if CHECK:
+        ref = (x[:512].float() @ w.float().t())
+        err = ((y[:512].float() - ref).abs().max() / ref.abs().max()).item()
+        ref2 = (x[-300:].float() @ w.float().t())
+        err2 = ((y[-300:].float() - ref2).abs().max() / ref2.abs().max()).item()
+        print(f"   check rel err {err:.2e} {err2:.2e}")
     import ctypes as C
     from streammind_amd import _lib
     lib = _lib.load()
