@@ -96,6 +96,64 @@ def random_weights_into(model, cfg, seed: int):
     L(gp + "lm_head.weight", rn(2, d, std=d ** -0.5))
 
 
+def random_llm_weights_into(model, cfg, seed: int):
+    """Mistral-7B-shaped random weights (true shapes), generated on the GPU tensor by tensor."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    d, dh = cfg.conn_d_model, cfg.conn_d_model // cfg.llm_heads
+
+    def rn(*shape, std):
+        return (torch.randn(*shape, generator=g, device="cuda") * std).to(torch.bfloat16)
+    L = model.load_tensor
+    L("model.embed_tokens.weight", rn(cfg.llm_vocab, d, std=0.02))
+    for i in range(cfg.llm_layers):
+        p = f"model.layers.{i}."
+        L(p + "self_attn.q_proj.weight", rn(cfg.llm_heads * dh, d, std=d ** -0.5))
+        L(p + "self_attn.k_proj.weight", rn(cfg.llm_kv_heads * dh, d, std=d ** -0.5))
+        L(p + "self_attn.v_proj.weight", rn(cfg.llm_kv_heads * dh, d, std=d ** -0.5))
+        L(p + "self_attn.o_proj.weight", rn(d, cfg.llm_heads * dh, std=d ** -0.5))
+        L(p + "mlp.gate_proj.weight", rn(cfg.llm_mlp, d, std=d ** -0.5))
+        L(p + "mlp.up_proj.weight", rn(cfg.llm_mlp, d, std=d ** -0.5))
+        L(p + "mlp.down_proj.weight", rn(d, cfg.llm_mlp, std=cfg.llm_mlp ** -0.5))
+        L(p + "input_layernorm.weight", torch.ones(d, device="cuda"))
+        L(p + "post_attention_layernorm.weight", torch.ones(d, device="cuda"))
+    L("model.norm.weight", torch.ones(d, device="cuda"))
+    L("lm_head.weight", rn(cfg.llm_vocab, d, std=d ** -0.5))
+
+
+def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
+    """Mistral-7B greedy decode tokens/s at batch 1 (BASELINE configs[2] shape: persistent KV cache, a context of
+    text + per-frame visual tokens, 256-token replies are timed here as n_new tokens after a 16-token warm-up)."""
+    d = cfg.conn_d_model
+    g = torch.Generator(device="cuda").manual_seed(7)
+    stream.write_tokens(stream.num_frames, torch.randn(n_ctx_frames, d, generator=g, device="cuda"))
+    base = stream.num_frames - n_ctx_frames
+    ids = torch.cat([torch.randint(3, cfg.llm_vocab, (n_ctx_text,), generator=g, device="cuda", dtype=torch.int32),
+                     -(torch.arange(base, base + n_ctx_frames, device="cuda", dtype=torch.int32) + 1),
+                     torch.randint(3, cfg.llm_vocab, (8,), generator=g, device="cuda", dtype=torch.int32)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stream.prefill(ids.contiguous())
+    torch.cuda.synchronize()
+    t_prefill = time.perf_counter() - t0
+    stream.decode(16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = stream.decode(n_new)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    weight_bytes = 2.0 * (cfg.llm_layers * (d * d * 2 + 2 * d * (cfg.llm_kv_heads * (d // cfg.llm_heads)) + 3 * d * cfg.llm_mlp)
+                          + cfg.llm_vocab * d)
+    ctx = ids.numel() + 16 + n_new // 2
+    kv_bytes = 2.0 * 2 * cfg.llm_layers * cfg.llm_kv_heads * (d // cfg.llm_heads) * ctx
+    tps = n_new / dt
+    return {"tokens_per_s": round(tps, 2), "ms_per_token": round(dt / n_new * 1e3, 4), "new_tokens": n_new,
+            "context_tokens": int(ids.numel()), "prefill_ms": round(t_prefill * 1e3, 3),
+            "prefill_tokens_per_s": round(ids.numel() / t_prefill, 1),
+            "roofline": {"bound": "hbm", "achieved": round((weight_bytes + kv_bytes) * tps / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round((weight_bytes + kv_bytes) * tps / 1e9 / HBM_PEAK_GBS, 4),
+                         "bytes_per_token": weight_bytes + kv_bytes}}
+
+
 def synthetic_frames_gpu(n: int, size: int, seed: int, rank: int) -> torch.Tensor:
     """seeded u8 HWC frames generated on the GPU: slowly drifting low-pass scene with cuts + per-pixel noise."""
     g = torch.Generator(device="cuda").manual_seed(seed * 1000003 + rank)
@@ -159,6 +217,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--no-decode", action="store_true", help="skip the Mistral-7B decode tokens/s leg")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,13 +237,15 @@ def main():
     from streammind_amd.native import NativeModel, PathConfig
     lib = _lib.load()
     B = a.batch
-    cfg = PathConfig(llm_layers=0, max_frames_per_call=B)
+    cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B)
     model = NativeModel(cfg, f"cuda:{local}")
     random_weights_into(model, cfg, seed=1234)
+    if not a.no_decode:
+        random_llm_weights_into(model, cfg, seed=4321)
     model.finalize()
     n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
     frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
-    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 16, max_seq=64)
+    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 16 + 256, max_seq=1024)
     torch.cuda.synchronize()
 
     def step(i):
@@ -215,6 +276,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(logits).all()
+    dec_leg = None
+    if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
+        dec_leg = decode_leg(model, stream, cfg)
+        if dist is not None:
+            t = torch.tensor([dec_leg["tokens_per_s"]], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
     roof = None
     if prof:
@@ -235,7 +303,7 @@ def main():
     if rank == 0:
         total_frames = world * B * a.steps
         out = {
-            "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate)", "value": round(total_frames / dt, 2),
+            "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate); Mistral-7B decode tokens/sec in `decode`", "value": round(total_frames / dt, 2),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -245,6 +313,7 @@ def main():
                        "frames_per_step": B, "streams_per_gpu": 1, "parallelism": f"replicas x{world} (stream-sharded, no collective)"},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
+            "decode": dec_leg,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

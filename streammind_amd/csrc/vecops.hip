@@ -86,11 +86,75 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     }
 }
 
+// few rows (decode, gate step): one 256-thread block per row, the row lives in registers (D <= 8192), one HBM/L2 pass
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __restrict__ x, int D, int ldx,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int post_act, float* __restrict__ of,
+                                                             bf16_t* __restrict__ ob, int ldo) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* xr = x + (size_t)row * ldx;
+    const int nv = D >> 2;
+    f32x4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = tid + j * 256;
+        v[j] = f32x4{0, 0, 0, 0};
+        if (c < nv) {
+            v[j] = *(const f32x4*)(xr + c * 4);
+            s += LN ? (v[j][0] + v[j][1] + v[j][2] + v[j][3])
+                    : (v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    float mu = 0.f, rstd;
+    if (LN) {
+        mu = s / D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (tid + j * 256 < nv)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q += d * d; }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + w] = q;
+        __syncthreads();
+        rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / D + eps);
+    } else {
+        rstd = rsqrtf(s / D + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = tid + j * 256;
+        if (c >= nv) continue;
+        f32x4 gm = *(const f32x4*)(gamma + c * 4);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = LN ? (v[j][e] - mu) * rstd * gm[e] + beta[c * 4 + e] : gm[e] * (v[j][e] * rstd);
+            o[e] = apply_act(y, post_act);
+        }
+        if (of) *(f32x4*)(of + (size_t)row * ldo + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c * 4) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+}
+
 extern "C" int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
                        int post_act, float* out_f32, void* out_bf16, int ldo, void* stream) {
     SM_REQUIRE(x && gamma && (out_f32 || out_bf16), "sm_norm: null arg");
     SM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "sm_norm: D, ldx, ldo must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
+    if (M <= 64 && D <= 8192) {
+        if (beta) norm_row_block_kernel<true><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+        else norm_row_block_kernel<false><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
     if (beta) norm_kernel<true><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
     else norm_kernel<false><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
     SM_LAUNCH_CHECK();

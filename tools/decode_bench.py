@@ -1,0 +1,14 @@
+"""Mistral-7B decode-only micro-benchmark (for rocprofv3 kernel traces of the decode step)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from streammind_amd.native import NativeModel, PathConfig
+
+cfg = PathConfig(llm_layers=32, max_frames_per_call=1, vit_layers=2)    # 1-layer ViT: perception is not measured here
+model = NativeModel(cfg)
+bench.random_weights_into(model, cfg, 1)
+bench.random_llm_weights_into(model, cfg, 2)
+model.finalize()
+s = model.open_stream(max_frames=512, max_seq=1024)
+print(bench.decode_leg(model, s, cfg, n_new=int(sys.argv[1]) if len(sys.argv) > 1 else 64))
