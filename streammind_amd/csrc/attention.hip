@@ -24,6 +24,7 @@ struct AttnP {
     int split_len;                           // keys per split (multiple of 64), 0 = no splitting
     float* part_o;                           // [splits][H][nq][DH] fp32
     float* part_ml;                          // [splits][H][nq][2]  (running max in scaled-log2 domain source units, l)
+    int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
 };
 
 template <int DH, bool GROUPQ = false>   // GROUPQ: decode mode, query row r of kv-group h is head h*nq + r (q is [H][DH])
@@ -39,9 +40,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, b = p.split_len ? 0 : blockIdx.z;
+    // Block -> (query tile, head, batch).  In the tiled (non-split) mode the grid is 1-D and remapped so that all the
+    // query tiles of one (batch, head) -- which stream the same K/V -- run on the SAME XCD (block L runs on XCD L % 8):
+    // measured without it, each of the 5 q-tiles of a ViT head fetched its K/V through a different L2 (FETCH_SIZE 5x).
+    int h, b, qtile;
+    if (GROUPQ) {
+        h = blockIdx.y; b = 0; qtile = 0;
+    } else {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int grp = (j / p.nqt) * 8 + xcd;
+        qtile = j % p.nqt;
+        if (grp >= p.H * p.nbatch) return;
+        h = grp % p.H; b = grp / p.H;
+    }
     const int kvh = h / (p.H / p.KV);
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qtile * 128 + wave * 32;
 
     bf16x8 qf[2][KSQ];
 #pragma unroll
@@ -62,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 
     int k_end = p.nk, k_begin = 0;
     if (p.causal) {
-        int last = p.pos0 + min(blockIdx.x * 128 + 127, p.nq - 1) + 1;
+        int last = p.pos0 + min(qtile * 128 + 127, p.nq - 1) + 1;
         k_end = min(k_end, last);
     }
     if (p.split_len) {
@@ -216,8 +229,9 @@ __global__ void attn_combine_kernel(const float* __restrict__ part_o, const floa
     if (d < dh) out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
 }
 
-static int launch_attn(const AttnP& p, int B, int dh, hipStream_t st) {
-    dim3 grid(cdiv(p.nq, 128), p.H, B);
+static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
+    p.nqt = cdiv(p.nq, 128); p.nbatch = B;
+    dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
     SmProfScope prof(SM_PROF_ATTN, st);
     if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
     else if (dh == 128) attn_kernel<128, false><<<grid, 256, 0, st>>>(p);
@@ -279,6 +293,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     p.split_len = split_len;
     p.part_o = workspace; p.part_ml = workspace + (size_t)splits_max * H * dh;
+    p.nqt = 1; p.nbatch = 1;
     // head h of the tile kernel reads q columns h*DH: make group h start at head h*rep by scaling the row stride trick:
     // q pointer for group h = q + h*rep*dh  ->  handled through q_bs = 0 and a per-group base below (grid.y = KV)
     hipStream_t st = (hipStream_t)stream;

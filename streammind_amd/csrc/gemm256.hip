@@ -18,31 +18,29 @@
 
 #define G2_BM 256
 #define G2_BN 256
-#define G2_SLOT 32768
-#define G2_LDS (4 * G2_SLOT)
 
-template <int ACT>
+template <int ACT, int CPR, int RPP>     // CPR: 16-byte chunks per staged row; RPP: rows covered by one pass of the block
 __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
                                                    const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
                                                    int ldo, bf16_t* __restrict__ out_bf16, int ldob, int m0, int n0, int M,
                                                    int tid) {
-    const int chunk = tid & 63;
+    const int chunk = tid % CPR;
     const int n = n0 + chunk * 4;
     f32x4 b4 = {0, 0, 0, 0};
     if (bias) b4 = *(const f32x4*)(bias + n);
 #pragma unroll
-    for (int p0 = 0; p0 < 16; p0 += 4) {
+    for (int p0 = 0; p0 < 128 / RPP; p0 += 4) {
         f32x4 v[4], r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int ml = (p0 + u) * 8 + (tid >> 6);
-            v[u] = *(const f32x4*)(smem + ml * 1024 + ((chunk ^ (ml & 31)) * 16));
+            const int ml = (p0 + u) * RPP + tid / CPR;
+            v[u] = *(const f32x4*)(smem + ml * (CPR * 16) + ((chunk ^ (ml & 31)) * 16));
             r[u] = f32x4{0, 0, 0, 0};
             if (residual && m0 + ml < M) r[u] = *(const f32x4*)(residual + (size_t)(m0 + ml) * ldr + n);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int m = m0 + (p0 + u) * 8 + (tid >> 6);
+            const int m = m0 + (p0 + u) * RPP + tid / CPR;
             if (m >= M) continue;
             f32x4 o;
 #pragma unroll
@@ -57,8 +55,10 @@ __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem
     }
 }
 
-template <int ACT, int VAR = 0>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n) {
+template <int ACT, int WN>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves
+__global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n) {
+    constexpr int BN = 128 * WN;
+    constexpr int NW = 4 * WN;                       // waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -72,84 +72,145 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(LinArgs a, int tiles_m,
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int KT = VAR == 1 ? 1 : a.KS;        // k-steps of 32
+    const int g_noload = a.remap_off == -12345;   // ablation hook (tools/gemm_bench.py): compute-only main loop
 
-    // Staging: a ring of 4 LDS slots of 32 KiB, one 32-deep k-step each (W: 16 packed 1-KiB chunks; X: [256][32] bf16,
-    // 64-byte rows, 16-byte chunk index XOR P[(row >> 2) & 3], P = {0,3,2,1}: conflict-free for the ds_read_b128 lane
-    // groups).  Loads run THREE k-steps ahead of the MFMAs and there is ONE barrier per k-step:
-    //   iteration i:  wait(own loads of slot i) -> barrier -> issue loads of step i+3 into the slot step i-1 just
-    //                 vacated -> 12 ds_read_b128 + 32 MFMA on slot i.
-    const char* wsrc[2];
-    const char* xsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = wave * 2 + j;             // 0..15: W row-group / X piece of 16 rows
-        int rgg = tile_n * 16 + c;
-        if (rgg >= a.NRG) rgg = a.NRG - 1;
-        wsrc[j] = (const char*)a.w + (size_t)rgg * a.KS * 1024 + lane * 16;
-        const int row = c * 16 + (lane >> 2);
-        int mg = tile_m * G2_BM + row;
-        if (mg >= a.M) mg = a.M - 1;
-        const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
-        xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
-    }
     f32x4 acc[8][4];
 #pragma unroll
     for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
 
-    auto stage = [&](int ks, int slot) {
-        char* sb = smem + slot * G2_SLOT;
+    if constexpr (WN == 2) {
+        // ---- 256 x 256: two 64-KiB stages of one 64-deep k-tile each, ONE barrier per k-tile:
+        //   iteration t: wait(own loads of tile t) -> barrier (=> every wave also finished multiplying tile t-1, so
+        //   the other stage is free) -> issue the 8 loads of tile t+1 into it -> 2 x (12 ds_read_b128 + 32 MFMA).
+        // X rows are 128 B, 16-byte chunk index XOR (row & 7) applied on the SOURCE address and on the read.
+        constexpr int STAGE = 65536;
+        const int KT = a.KS >> 1;
+        const char* wsrc[4];
+        const char* xsrc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wave * 4 + j;             // 0..31: W chunk (rg_local = c >> 1, ks_local = c & 1) / X piece (8 rows)
+            int rgg = tile_n * 16 + (c >> 1);
+            if (rgg >= a.NRG) rgg = a.NRG - 1;
+            wsrc[j] = (const char*)a.w + ((size_t)rgg * a.KS + (c & 1)) * 1024 + lane * 16;
+            const int row = c * 8 + (lane >> 3);
+            int mg = tile_m * G2_BM + row;
+            if (mg >= a.M) mg = a.M - 1;
+            const int chunk = (lane & 7) ^ (row & 7);
+            xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
+        }
+        auto stage = [&](int kt, int buf) {
+            char* sb = smem + buf * STAGE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = wave * 4 + j;
+                glds16(wsrc[j] + (size_t)kt * 2048, sb + c * 1024);
+                glds16(xsrc[j] + (size_t)kt * 128, sb + 32768 + c * 1024);
+            }
+        };
+        stage(0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < KT && !g_noload) stage(kt + 1, buf ^ 1);
+            const char* sw = smem + buf * STAGE;
+            const char* sx = sw + 32768;
+            // all 24 fragment reads of the tile are issued up front (96 VGPRs), then 2 x 32 MFMAs: the second half's
+            // reads land under the first half's MFMAs (left to itself hipcc waits lgkmcnt(0) before every group of 4
+            // MFMAs, exposing the LDS latency 16 times per tile)
+            bf16x8 xf[2][4], wf[2][8];
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int ml = wm * 64 + mf * 16 + i;
+                    xf[ksl][mf] = *(const bf16x8*)(sx + ml * 128 + (((ksl * 4 + g) ^ (ml & 7)) * 16));
+                }
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf)
+                    wf[ksl][nf] = *(const bf16x8*)(sw + (((wn * 8 + nf) * 2 + ksl) * 1024) + lane * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ksl = 0; ksl < 2; ++ksl) {
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ksl][nf], xf[ksl][mf], acc[nf][mf], 0, 0, 0);
+            }
+        }
+    } else {
+        // ---- 256 x 128 (two blocks per CU): ring of 3 LDS slots, one 32-deep k-step each (W: packed 1-KiB chunks;
+        // X: [256][32] bf16, 64-byte rows, chunk index XOR P[(row >> 2) & 3], P = {0,3,2,1}); loads run two k-steps
+        // ahead, one barrier per k-step.
+        constexpr int WBYTES = BN * 64;
+        constexpr int SLOT = WBYTES + 16384;
+        constexpr int NSLOT = 3;
+        constexpr int XL = 16 / NW;
+        const int KT = a.KS;
+        const char* wsrc[2];
+        const char* xsrc[XL];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int c = wave * 2 + j;
-            glds16(wsrc[j] + (size_t)ks * 1024, sb + c * 1024);
-            glds16(xsrc[j] + (size_t)ks * 64, sb + 16384 + c * 1024);
-        }
-    };
-
-    stage(0, 0);
-    if (KT > 1) stage(1, 1);
-    if (KT > 2) stage(2, 2);
-    for (int ks = 0; ks < KT; ++ks) {
-        const int rem = KT - 1 - ks;            // k-steps whose loads may still be in flight behind this one
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ks + 3 < KT) stage(ks + 3, (ks + 3) & 3);
-        const char* sw = smem + (ks & 3) * G2_SLOT;
-        const char* sx = sw + 16384;
-        bf16x8 xf[4];
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int ml = wm * 64 + mf * 16 + i;
-            xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+            int rgg = tile_n * (BN / 16) + wave * 2 + j;
+            if (rgg >= a.NRG) rgg = a.NRG - 1;
+            wsrc[j] = (const char*)a.w + (size_t)rgg * a.KS * 1024 + lane * 16;
         }
 #pragma unroll
-        for (int nf = 0; nf < 8; ++nf) {
-            const bf16x8 wf = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
+        for (int j = 0; j < XL; ++j) {
+            const int row = (wave * XL + j) * 16 + (lane >> 2);
+            int mg = tile_m * G2_BM + row;
+            if (mg >= a.M) mg = a.M - 1;
+            const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+            xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
+        }
+        auto stage = [&](int ks, int slot) {
+            char* sb = smem + slot * SLOT;
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf)
-                acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mf], acc[nf][mf], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) glds16(wsrc[j] + (size_t)ks * 1024, sb + (wave * 2 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < XL; ++j) glds16(xsrc[j] + (size_t)ks * 64, sb + WBYTES + (wave * XL + j) * 1024);
+        };
+#pragma unroll
+        for (int pre = 0; pre < NSLOT - 1; ++pre)
+            if (pre < KT) stage(pre, pre);
+        int slot = 0;
+        for (int ks = 0; ks < KT; ++ks) {
+            if (KT - 1 - ks >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ks + NSLOT - 1 < KT) stage(ks + NSLOT - 1, slot == 0 ? NSLOT - 1 : slot - 1);
+            const char* sw = smem + slot * SLOT;
+            const char* sx = sw + WBYTES;
+            bf16x8 xf[4];
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int ml = wm * 64 + mf * 16 + i;
+                xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+            }
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) {
+                const bf16x8 wf = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf)
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mf], acc[nf][mf], 0, 0, 0);
+            }
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
     }
-    __syncthreads();       // every wave is done reading the ring before the epilogue reuses it
+    __syncthreads();       // every wave is done reading the staging buffers before the epilogue reuses them
 
-    if (VAR == 2) {
-        float t = 0.f;
-#pragma unroll
-        for (int nf = 0; nf < 8; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < 4; ++mf) t += acc[nf][mf][0] + acc[nf][mf][1] + acc[nf][mf][2] + acc[nf][mf][3];
-        if (t == 123.456f && a.out_f32) a.out_f32[0] = t;
-        return;
-    }
-    // ---- epilogue in two 128-row halves: waves wm = 2h, 2h+1 stage their accumulators ([128 m][256 n] fp32 = 128 KiB,
-    // 16-byte chunk index XOR (m & 31)), then all 8 waves write whole rows.
-    const bool vt_tile = a.vt && tile_n * G2_BN >= a.vt_n0;
-    const bool fast = ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * G2_BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
+    // ---- epilogue in two 128-row halves: waves wm = 2h, 2h+1 stage their accumulators ([128 m][BN n] fp32, 16-byte
+    // chunk index XOR (m & 31)), then all waves write whole rows.
+    constexpr int ROWB = BN * 4;                     // bytes per staged row
+    constexpr int CPR = BN / 4;                      // 16-byte chunks per row
+    constexpr int RPP = (256 * WN) / CPR;            // rows per pass (= 8)
+    const bool vt_tile = a.vt && tile_n * BN >= a.vt_n0;
+    const bool fast = ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
                       (a.ldr & 3) == 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -161,16 +222,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(LinArgs a, int tiles_m,
                 for (int mf = 0; mf < 4; ++mf) {
                     const int ml = (wm & 1) * 64 + mf * 16 + i;
                     const int chunk = wn * 32 + nf * 4 + g;
-                    *(f32x4*)(smem + ml * 1024 + ((chunk ^ (ml & 31)) * 16)) = acc[nf][mf];
+                    *(f32x4*)(smem + ml * ROWB + ((chunk ^ (ml & 31)) * 16)) = acc[nf][mf];
                 }
         }
         __syncthreads();
         const int m0 = tile_m * G2_BM + half * 128;
         if (vt_tile) {
             const int nh = (a.N - a.vt_n0) / a.vt_dh;
-            for (int pass = 0; pass < 32; ++pass) {
-                const int nl = pass * 8 + wave;
-                const int n = tile_n * G2_BN + nl;
+            for (int pass = 0; pass < BN / NW; ++pass) {
+                const int nl = pass * NW + wave;
+                const int n = tile_n * BN + nl;
                 if (n >= a.N) continue;
                 const int c = n - a.vt_n0;
                 const int h = c / a.vt_dh, d = c - h * a.vt_dh;
@@ -180,43 +241,48 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(LinArgs a, int tiles_m,
                     const int ml = lane + 64 * h2;
                     const int m = m0 + ml;
                     if (m < a.M) {
-                        float v = *(const float*)(smem + ml * 1024 + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
+                        float v = *(const float*)(smem + ml * ROWB + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
                         const int b = m / a.vt_S, sidx = m - b * a.vt_S;
                         a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act_rt(v, a.act));
                     }
                 }
             }
         } else if (fast) {
-            half_rows_epilogue<ACT>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, m0,
-                                    tile_n * G2_BN, a.M, tid);
+            half_rows_epilogue<ACT, CPR, RPP>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, m0,
+                                              tile_n * BN, a.M, tid);
         } else {
-            for (int pass = 0; pass < 16; ++pass) {
-                const int ml = pass * 8 + (tid >> 6);
-                const int chunk = tid & 63;
-                f32x4 v = *(const f32x4*)(smem + ml * 1024 + ((chunk ^ (ml & 31)) * 16));
-                store4(a, m0 + ml, tile_n * G2_BN + chunk * 4, v, nullptr);
+            for (int pass = 0; pass < 128 / RPP; ++pass) {
+                const int ml = pass * RPP + tid / CPR;
+                const int chunk = tid % CPR;
+                f32x4 v = *(const f32x4*)(smem + ml * ROWB + ((chunk ^ (ml & 31)) * 16));
+                store4(a, m0 + ml, tile_n * BN + chunk * 4, v, nullptr);
             }
         }
     }
 }
 
-int launch_gemm256(const LinArgs& a, int act, hipStream_t st) {
-    const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, G2_BN);
+template <int WN>
+static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
+    constexpr int BN = 128 * WN;
+    constexpr int LDS = WN == 2 ? 2 * 65536 : 3 * (BN * 64 + 16384);
+    const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const dim3 grid(tiles_m * tiles_n);
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("SM_G256_VAR"); var = e ? atoi(e) : 0; }
-    if (var == 1) { hipFuncSetAttribute((const void*)gemm256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); gemm256_kernel<0, 1><<<grid, 512, G2_LDS, st>>>(a, tiles_m, tiles_n); return SM_OK; }
-    if (var == 2) { hipFuncSetAttribute((const void*)gemm256_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); gemm256_kernel<0, 2><<<grid, 512, G2_LDS, st>>>(a, tiles_m, tiles_n); return SM_OK; }
-    if (act == SM_ACT_NONE) gemm256_kernel<0><<<grid, 512, G2_LDS, st>>>(a, tiles_m, tiles_n);
-    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1><<<grid, 512, G2_LDS, st>>>(a, tiles_m, tiles_n);
-    else gemm256_kernel<-1><<<grid, 512, G2_LDS, st>>>(a, tiles_m, tiles_n);
+    if (act == SM_ACT_NONE) gemm256_kernel<0, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    else gemm256_kernel<-1, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
     SM_LAUNCH_CHECK();
     return SM_OK;
+}
+
+// bn = 256: one 8-wave block per CU; bn = 128: two independent 4-wave blocks per CU (their phases drift apart, so one
+// block's barriers / epilogue overlap the other's MFMAs)
+int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st) {
+    return bn == 128 ? launch_wn<1>(a, act, st) : launch_wn<2>(a, act, st);
 }

@@ -389,24 +389,27 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     }
     SM_REQUIRE(!xf32, "sm_linear: the tiled GEMM takes bf16 activations (M=%d > 16)", p->M);
     SM_REQUIRE(!p->w2, "sm_linear: dual weights only on the skinny path");
-    SM_REQUIRE((a.KS & 1) == 0, "sm_linear: GEMM path needs K padded to a multiple of 64 (K=%d)", p->K);
     SM_REQUIRE(p->ldx % 8 == 0, "sm_linear: bf16 x needs ldx %% 8 == 0");
     SM_REQUIRE(!p->vt || (p->vt_n0 % GEMM_BN == 0 && !p->residual && p->remap_in == 0), "sm_linear: vt_n0 must be a multiple of %d on the GEMM path", GEMM_BN);
-    // tile choice: the 256x256 kernel (1 block/CU, 2x the FLOP per L2 byte) when its grid still fills the chip;
-    // SM_GEMM_TILE=128|256 overrides (tools/gemm_bench.py)
+    // tile choice: 256x256 (one 8-wave block per CU, 128 FLOP per L2 byte) once its grid fills >= 3/4 of the chip,
+    // else 128x128 (two blocks per CU); SM_GEMM_TILE=128|256128|256 overrides (tools/gemm_bench.py).  Measured on the
+    // ViT shapes: B=28 frames (M=16156) 739 vs 706 TFLOP/s, B=14 565 vs 654 -> the threshold.
     {
         static int force = -1;
         if (force < 0) { const char* e = getenv("SM_GEMM_TILE"); force = e ? atoi(e) : 0; }
         const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
-        const bool ok256 = !p->vt || p->vt_n0 % 256 == 0;
-        bool use256 = ok256 && t256 >= 160;
-        if (force == 128) use256 = false;
-        if (force == 256) use256 = ok256;
-        if (use256) {
+        const bool ok = !p->vt || p->vt_n0 % 256 == 0;
+        int bn = (ok && (a.KS & 1) == 0 && t256 >= 192) ? 256 : 0;
+        if (force == 128) bn = 0;
+        if (force == 256128 && ok) bn = 128;
+        if (force == 256 && ok && (a.KS & 1) == 0) bn = 256;
+        if (bn) {
+            if (getenv("SM_G256_NOLOAD")) a.remap_off = -12345;
             SmProfScope prof(SM_PROF_GEMM, st);
-            return launch_gemm256(a, p->act, st);
+            return launch_gemm256(a, p->act, bn, st);
         }
     }
+    SM_REQUIRE((a.KS & 1) == 0, "sm_linear: the 128x128 GEMM needs K padded to a multiple of 64 (K=%d)", p->K);
     int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);
     static bool attr_set = false;
     if (!attr_set) {

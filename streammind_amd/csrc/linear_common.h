@@ -86,4 +86,4 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
-int launch_gemm256(const LinArgs& a, int act, hipStream_t st);     // gemm256.hip
+int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);     // gemm256.hip (256 x bn tile)
