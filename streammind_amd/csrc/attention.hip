@@ -34,9 +34,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     constexpr int KROW = DH * 2;             // bytes per K row in LDS
     constexpr int KCH = DH / 8;              // 16-byte chunks per K row
     constexpr int KMASK = KCH - 1 > 15 ? 15 : (KCH - 1);
-    __shared__ __attribute__((aligned(16))) char lds[64 * KROW + DH * 128];
-    char* Kl = lds;
-    char* Vl = lds + 64 * KROW;
+    constexpr int TILE_BYTES = 64 * KROW + DH * 128;
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -85,27 +84,49 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     const bf16_t* kbase = p.k + b * p.k_bs + kvh * DH;
     const bf16_t* vbase = p.vt + b * p.vt_bs + kvh * p.vt_hs;
 
-    for (int kt0 = k_begin; kt0 < k_end; kt0 += 64) {
-        __syncthreads();
-        // ---- stage K (64 keys, permuted rows) and V^T (DH rows x 64 keys) tiles
+    // K / V^T tiles go HBM/L2 -> registers -> LDS: the loads of tile t+1 are issued before tile t is multiplied (their
+    // latency hides under the MFMAs) and written to the OTHER LDS buffer at the top of the next iteration, so there is
+    // one __syncthreads per tile.
+    constexpr int KJ = (64 * KCH) / 256, VJ = (DH * 8) / 256;
+    u32x4 kreg[KJ], vreg[VJ];
+    auto fetch = [&](int kt0) {
 #pragma unroll
-        for (int j = 0; j < (64 * KCH) / 256; ++j) {
+        for (int j = 0; j < KJ; ++j) {
             int c = tid + 256 * j;
             int key = c / KCH, cc = c % KCH;
             int gk = min(kt0 + key, p.nk - 1);
-            u32x4 v = *(const u32x4*)(kbase + (long)gk * p.k_rs + cc * 8);
-            int kk = key & 31;
-            int rho = (key & 32) + (((kk >> 2) & 1) << 4) + (((kk >> 3) << 2) | (kk & 3));
-            *(u32x4*)(Kl + rho * KROW + ((cc ^ (rho & KMASK)) * 16)) = v;
+            kreg[j] = *(const u32x4*)(kbase + (long)gk * p.k_rs + cc * 8);
         }
 #pragma unroll
-        for (int j = 0; j < (DH * 8) / 256; ++j) {
+        for (int j = 0; j < VJ; ++j) {
             int c = tid + 256 * j;
             int d = c >> 3, cc = c & 7;
-            u32x4 v = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
-            *(u32x4*)(Vl + d * 128 + ((cc ^ (d & 7)) * 16)) = v;
+            vreg[j] = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
+        }
+    };
+    if (k_begin < k_end) fetch(k_begin);
+    int buf = 0;
+    for (int kt0 = k_begin; kt0 < k_end; kt0 += 64) {
+        char* Kl = lds + buf * TILE_BYTES;
+        char* Vl = Kl + 64 * KROW;
+        // ---- stage K (64 keys, permuted rows) and V^T (DH rows x 64 keys) tiles
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            int c = tid + 256 * j;
+            int key = c / KCH, cc = c % KCH;
+            int kk = key & 31;
+            int rho = (key & 32) + (((kk >> 2) & 1) << 4) + (((kk >> 3) << 2) | (kk & 3));
+            *(u32x4*)(Kl + rho * KROW + ((cc ^ (rho & KMASK)) * 16)) = kreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VJ; ++j) {
+            int c = tid + 256 * j;
+            int d = c >> 3, cc = c & 7;
+            *(u32x4*)(Vl + d * 128 + ((cc ^ (d & 7)) * 16)) = vreg[j];
         }
         __syncthreads();
+        if (kt0 + 64 < k_end) fetch(kt0 + 64);
+        buf ^= 1;
 
         // ---- S^T = K . Q^T  (2 key blocks of 32 x 2 fragments x 2 query blocks)
         f32x4 s[2][2][2];
@@ -150,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             const float m_new = fmaxf(m_run[qb], mx);
             // a fully masked row (causal, tile ahead of the query) keeps m_new = -inf: guard the subtraction
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = exp2f((m_run[qb] - m_use) * p.c);
+            const float mc = m_use * p.c;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));   // raw v_exp_f32; -inf -> 0
             m_run[qb] = m_new;
             float sum = 0.f;
 #pragma unroll
@@ -160,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float e = exp2f((s[qb][kb][f][r] - m_use) * p.c);
+                        float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][f][r], p.c, -mc));
                         sum += e;
                         pv[f * 4 + r] = (__bf16)e;
                     }
