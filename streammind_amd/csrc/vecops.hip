@@ -86,6 +86,52 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     }
 }
 
+// many rows, D == 256 * NV: one wave per row, compile-time trip counts so the NV 16-byte loads of a lane are all in
+// flight at once (the generic kernel's runtime-bounded loops serialise them: 88 % of wave cycles parked on loads)
+template <bool LN, int NV>
+__global__ __launch_bounds__(256) void norm_wave_fixed_kernel(const float* __restrict__ x, int M, int ldx,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float eps, float* __restrict__ of, bf16_t* __restrict__ ob, int ldo) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx + lane * 4;
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = *(const f32x4*)(xr + j * 256);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+        s += LN ? (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]) : (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+    s = wave_sum(s);
+    float mu = 0.f, rstd;
+    if (LN) {
+        mu = s * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q += d * d; }
+        q = wave_sum(q);
+        rstd = rsqrtf(q * (1.0f / D) + eps);
+    } else {
+        rstd = rsqrtf(s * (1.0f / D) + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + j * 256;
+        f32x4 gm = *(const f32x4*)(gamma + c);
+        f32x4 bt = {0, 0, 0, 0};
+        if (LN) bt = *(const f32x4*)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = LN ? (v[j][e] - mu) * rstd * gm[e] + bt[e] : gm[e] * (v[j][e] * rstd);
+        if (of) *(f32x4*)(of + (size_t)row * ldo + c) = o;
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    }
+}
+
 // few rows (decode, gate step): one 256-thread block per row, the row lives in registers (D <= 8192), one HBM/L2 pass
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __restrict__ x, int D, int ldx,
@@ -152,6 +198,18 @@ extern "C" int sm_norm(const float* x, int M, int D, int ldx, const float* gamma
     if (M <= 64 && D <= 8192) {
         if (beta) norm_row_block_kernel<true><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
         else norm_row_block_kernel<false><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
+    if (post_act == 0 && (D == 1024 || D == 4096)) {
+        const bf16_t* dummy = nullptr; (void)dummy;
+        if (D == 1024) {
+            if (beta) norm_wave_fixed_kernel<true, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+            else norm_wave_fixed_kernel<false, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+        } else {
+            if (beta) norm_wave_fixed_kernel<true, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+            else norm_wave_fixed_kernel<false, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+        }
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
