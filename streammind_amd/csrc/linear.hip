@@ -404,7 +404,6 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         if (force == 256128 && ok) bn = 128;
         if (force == 256 && ok && (a.KS & 1) == 0) bn = 256;
         if (bn) {
-            if (getenv("SM_G256_NOLOAD")) a.remap_off = -12345;
             SmProfScope prof(SM_PROF_GEMM, st);
             return launch_gemm256(a, p->act, bn, st);
         }
