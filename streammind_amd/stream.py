@@ -1,0 +1,128 @@
+"""Throughput-mode stream runtime: the caller loop of eval/video_score_stream_demo.py:258-302 re-organised around
+O(1)-per-frame device state instead of one blocking call per frame.
+
+    decoded u8 frames (host) --pinned ring--> async H2D on a copy stream --> device ring
+        --> sm_stream_push_frames (ViT batch + connector scan + gate, one launch sequence per batch)
+        --> ONE device->host read of the batch's decisions
+        --> for every fired frame, in order: splice + prefill (KV prefix reuse) + greedy decode, prompt growth
+
+Results are identical to the frame-at-a-time loop (`streammind_amd.infer` per frame): the gate of frame t depends only on
+frames <= t (the Mamba scan is causal and the gate sees one token), never on what the LLM said, so perceiving a batch
+ahead of the replies changes nothing but latency.  The reply for a fire at frame t is generated from exactly the
+tokens [0, t] and the prompt grown by the earlier replies, as in the reference."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Iterable, Iterator, List, Optional, Tuple
+
+import torch
+
+from .constants import MMODAL_TOKEN_INDEX
+from .mm_utils import KeywordsStoppingCriteria, tokenizer_MMODAL_token
+
+
+class FrameRing:
+    """Pinned-host ring of u8 HWC frames + a device ring; `push` stages a batch with an async copy on a dedicated HIP
+    stream and returns the device view plus the event the compute stream must wait on."""
+
+    def __init__(self, slots: int, frames_per_slot: int, height: int, width: int, device: torch.device):
+        self.slots, self.fps = slots, frames_per_slot
+        self.host = torch.empty(slots, frames_per_slot, height, width, 3, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(slots, frames_per_slot, height, width, 3, dtype=torch.uint8, device=device)
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.ready = [torch.cuda.Event() for _ in range(slots)]
+        self.free = [torch.cuda.Event() for _ in range(slots)]
+        self.head = 0
+
+    def push(self, frames: torch.Tensor) -> Tuple[torch.Tensor, torch.cuda.Event, int]:
+        n = frames.shape[0]
+        assert n <= self.fps and frames.dtype == torch.uint8
+        s = self.head
+        self.head = (self.head + 1) % self.slots
+        self.free[s].synchronize()                      # the slot's previous consumer finished (no-op the first time round)
+        self.host[s, :n].copy_(frames)
+        with torch.cuda.stream(self.copy_stream):
+            self.dev[s, :n].copy_(self.host[s, :n], non_blocking=True)
+            self.ready[s].record(self.copy_stream)
+        return self.dev[s, :n], self.ready[s], s
+
+    def release(self, slot: int) -> None:
+        self.free[slot].record(torch.cuda.current_stream())
+
+
+@dataclass
+class StreamEvent:
+    frame_index: int            # 1-based count of frames seen when the gate fired (== interval id)
+    text: str
+    new_ids: List[int]
+
+
+@dataclass
+class StreamStats:
+    frames: int = 0
+    fires: int = 0
+    gate_logits: List[torch.Tensor] = field(default_factory=list)
+
+
+class StreamingSession:
+    """One video stream on one GPU.  `model` is a streammind_amd.model.Videollama2MistralForCausalLM."""
+
+    def __init__(self, model, tokenizer, batch_frames: int = 8, max_new_tokens: int = 1024, ring_slots: int = 3,
+                 keep_logits: bool = False):
+        self.model, self.tok = model, tokenizer
+        cfg = model.native.cfg
+        self.batch = min(batch_frames, cfg.max_frames_per_call)
+        self.max_new = max_new_tokens
+        self.ring = FrameRing(ring_slots, self.batch, cfg.vit_image, cfg.vit_image, model.device)
+        self.prompt: Optional[str] = None
+        self.stats = StreamStats()
+        self.keep_logits = keep_logits
+
+    def _initial_prompt(self) -> str:
+        from .conversation import conv_templates
+        conv = conv_templates["mistral_instruct"].copy()
+        conv.append_message(conv.roles[0], "<video>\n")
+        conv.append_message(conv.roles[1], None)
+        return conv.get_prompt()
+
+    def _reply(self, upto_frame: int) -> StreamEvent:
+        m = self.model
+        m.interval_id_list.append(upto_frame)
+        input_ids = tokenizer_MMODAL_token(self.prompt, self.tok, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
+        crit = KeywordsStoppingCriteria(["</s>"], self.tok, input_ids)
+        seq = m._expand(input_ids[0].tolist())
+        new_ids = m._generate(seq, self.max_new, [crit])
+        text = self.tok.batch_decode([new_ids], skip_special_tokens=True)[0].strip()
+        self.prompt += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
+        return StreamEvent(upto_frame, text, new_ids)
+
+    def feed(self, frames: torch.Tensor) -> List[StreamEvent]:
+        """frames: u8 [n,H,W,3] on the HOST (n <= batch_frames).  Returns the replies fired by these frames, in order."""
+        if self.prompt is None:
+            self.prompt = self._initial_prompt()
+        dev_frames, ready, slot = self.ring.push(frames)
+        torch.cuda.current_stream().wait_event(ready)
+        base = self.model.stream.num_frames
+        logits, dec = self.model.stream.push_frames(dev_frames)
+        self.ring.release(slot)
+        dec_host = dec.cpu().tolist()                   # the one host sync of this batch
+        if self.keep_logits:
+            self.stats.gate_logits.append(logits.cpu())
+        self.stats.frames += len(dec_host)
+        events = []
+        for j, d in enumerate(dec_host):
+            if d == 1:
+                self.stats.fires += 1
+                events.append(self._reply(base + j + 1))
+        return events
+
+    def run(self, frames: Iterable[torch.Tensor]) -> Iterator[StreamEvent]:
+        """frames: iterable of u8 [H,W,3] host tensors (the decoded stream).  Yields replies as they fire."""
+        buf: List[torch.Tensor] = []
+        for f in frames:
+            buf.append(f)
+            if len(buf) == self.batch:
+                yield from self.feed(torch.stack(buf))
+                buf = []
+        if buf:
+            yield from self.feed(torch.stack(buf))

@@ -209,3 +209,28 @@ def test_clip_tower_and_projector_dropins(tiny):
         raise AssertionError
     except ValueError:
         pass
+
+
+def test_streaming_session_equals_frame_at_a_time(tiny, tiny_tokenizer):
+    """throughput-mode runtime (pinned ring -> async H2D -> batched perceive -> replies in order) produces the same
+    fire positions and replies as the reference-shaped one-frame-per-call loop."""
+    import streammind_amd
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd.stream import StreamingSession
+    m, *_ = tiny
+    frames = O.synthetic_frames(12, TV.image_size, seed=99, scene_len=3)
+    a = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
+    prompt, ref_events, ref_logits = None, [], []
+    for i in range(12):
+        text, prompt = streammind_amd.infer(a, frames[i:i + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=5)
+        ref_logits.append(a.last_gate_logits.cpu())
+        if text is not None:
+            ref_events.append((i + 1, text))
+    b = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
+    sess = StreamingSession(b, tiny_tokenizer, batch_frames=5, max_new_tokens=5, keep_logits=True)
+    got = [(e.frame_index, e.text) for e in sess.run(frames[i] for i in range(12))]
+    lg = torch.cat(sess.stats.gate_logits)
+    assert maxdiff(lg, torch.stack(ref_logits)) < 2e-3
+    assert [g[0] for g in got] == [r[0] for r in ref_events] and len(got) >= 2
+    assert got == ref_events
+    assert sess.prompt == prompt and sess.stats.frames == 12
