@@ -101,7 +101,8 @@ int sm_patchify_pixels(const void* pixel_values, int dtype, int B, int H, int W,
 int sm_pool_rows(const void* feats, int dtype, int T, int P, int C, float* pooled, void* stream);
 /* CLS row: x[b*S + 0][:] = class_embedding + pos[0]  (HF CLIPVisionEmbeddings) */
 int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, const float* pos0, void* stream);
-/* non-causal MHA over bf16 qkv [B*S][3*H*dh] (Q|K) and V^T vt[B][H][dh][vt_ld]; ctx bf16 [B*S][H*dh].
+/* non-causal MHA over bf16 qkv [B*S][3*H*dh] (Q|K|V); ctx bf16 [B*S][H*dh].  V is taken row-major from qkv and
+ * transposed while it is staged in LDS (vt == NULL), or read from a pre-transposed vt[B][H][dh][vt_ld].
  * Replaces HF CLIPAttention (eager / SDPA).                                                          */
 int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
                      void* stream);

@@ -15,8 +15,9 @@
 struct AttnP {
     const bf16_t* q; long q_bs, q_rs;       // batch stride, row stride (elements); head h at column h*DH
     const bf16_t* k; long k_bs, k_rs;       // kv head kvh at column kvh*DH
-    const bf16_t* vt; long vt_bs, vt_hs;    // V^T: [batch][kv head][DH][vt_ld]
+    const bf16_t* vt; long vt_bs, vt_hs;    // V^T: [batch][kv head][DH][vt_ld]   (VROW == false)
     int vt_ld;
+    const bf16_t* v; long v_bs, v_rs;       // row-major V: [batch][key][...], kv head kvh at column kvh*DH (VROW == true)
     bf16_t* o; long o_bs, o_rs;
     int nq, nk, H, KV, causal, pos0;
     float c;                                 // softmax scale * log2(e)
@@ -27,7 +28,8 @@ struct AttnP {
     int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
 };
 
-template <int DH, bool GROUPQ = false>   // GROUPQ: decode mode, query row r of kv-group h is head h*nq + r (q is [H][DH])
+template <int DH, bool GROUPQ = false, bool VROW = false>   // GROUPQ: decode mode (query row r of kv-group h is head h*nq + r);
+                                                            // VROW: V is row-major [key][d] and is transposed while it is staged
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     constexpr int KSQ = DH / 32;             // k-steps of the QK^T contraction
     constexpr int DF = DH / 16;              // d fragments of the output
@@ -82,13 +84,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         k_end = min(k_end, k_begin + p.split_len);
     }
     const bf16_t* kbase = p.k + b * p.k_bs + kvh * DH;
-    const bf16_t* vbase = p.vt + b * p.vt_bs + kvh * p.vt_hs;
+    const bf16_t* vbase = VROW ? nullptr : p.vt + b * p.vt_bs + kvh * p.vt_hs;
 
     // K / V^T tiles go HBM/L2 -> registers -> LDS: the loads of tile t+1 are issued before tile t is multiplied (their
     // latency hides under the MFMAs) and written to the OTHER LDS buffer at the top of the next iteration, so there is
     // one __syncthreads per tile.
     constexpr int KJ = (64 * KCH) / 256, VJ = (DH * 8) / 256;
-    u32x4 kreg[KJ], vreg[VJ];
+    constexpr int VPJ = (32 * KCH) / 256;          // VROW: (key pair, 16-byte d-chunk) items per thread
+    u32x4 kreg[KJ], vreg[VROW ? 2 * VPJ : VJ];
+    const bf16_t* vrow_base = VROW ? p.v + b * p.v_bs + kvh * DH : nullptr;
     auto fetch = [&](int kt0) {
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
@@ -97,11 +101,24 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             int gk = min(kt0 + key, p.nk - 1);
             kreg[j] = *(const u32x4*)(kbase + (long)gk * p.k_rs + cc * 8);
         }
+        if (VROW) {
+            // lanes walk KEY PAIRS (kp = item & 31), the d-chunk cc = item >> 5 is wave-uniform-ish: the transposed
+            // ds_write_b32 of 32 consecutive key pairs then covers one whole 128-byte LDS row -> conflict-free
 #pragma unroll
-        for (int j = 0; j < VJ; ++j) {
-            int c = tid + 256 * j;
-            int d = c >> 3, cc = c & 7;
-            vreg[j] = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
+            for (int j = 0; j < VPJ; ++j) {
+                int it = tid + 256 * j;
+                int kp = it & 31, cc = it >> 5;
+                int k0 = min(kt0 + 2 * kp, p.nk - 1), k1 = min(kt0 + 2 * kp + 1, p.nk - 1);
+                vreg[2 * j] = *(const u32x4*)(vrow_base + (long)k0 * p.v_rs + cc * 8);
+                vreg[2 * j + 1] = *(const u32x4*)(vrow_base + (long)k1 * p.v_rs + cc * 8);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                int c = tid + 256 * j;
+                int d = c >> 3, cc = c & 7;
+                vreg[j] = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
+            }
         }
     };
     if (k_begin < k_end) fetch(k_begin);
@@ -118,11 +135,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             int rho = (key & 32) + (((kk >> 2) & 1) << 4) + (((kk >> 3) << 2) | (kk & 3));
             *(u32x4*)(Kl + rho * KROW + ((cc ^ (rho & KMASK)) * 16)) = kreg[j];
         }
+        if (VROW) {
 #pragma unroll
-        for (int j = 0; j < VJ; ++j) {
-            int c = tid + 256 * j;
-            int d = c >> 3, cc = c & 7;
-            *(u32x4*)(Vl + d * 128 + ((cc ^ (d & 7)) * 16)) = vreg[j];
+            for (int j = 0; j < VPJ; ++j) {
+                int it = tid + 256 * j;
+                int kp = it & 31, cc = it >> 5;
+                const u32x4 a = vreg[2 * j], bq = vreg[2 * j + 1];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t lo = (e & 1) ? (a[e >> 1] >> 16) : (a[e >> 1] & 0xffffu);
+                    const uint32_t hi = (e & 1) ? (bq[e >> 1] & 0xffff0000u) : (bq[e >> 1] << 16);
+                    const int d = cc * 8 + e;
+                    *(uint32_t*)(Vl + d * 128 + (((kp >> 2) ^ (d & 7)) * 16) + (kp & 3) * 4) = lo | hi;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VJ; ++j) {
+                int c = tid + 256 * j;
+                int d = c >> 3, cc = c & 7;
+                *(u32x4*)(Vl + d * 128 + ((cc ^ (d & 7)) * 16)) = vreg[j];
+            }
         }
         __syncthreads();
         if (kt0 + 64 < k_end) fetch(kt0 + 64);
@@ -255,6 +288,13 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
     dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
     SmProfScope prof(SM_PROF_ATTN, st);
+    if (p.v) {
+        if (dh == 64) attn_kernel<64, false, true><<<grid, 256, 0, st>>>(p);
+        else if (dh == 128) attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
+        else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
     if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
     else if (dh == 128) attn_kernel<128, false><<<grid, 256, 0, st>>>(p);
     else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
@@ -264,13 +304,14 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
 
 extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
                                 void* stream) {
-    SM_REQUIRE(qkv && vt && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
-    SM_REQUIRE(vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64, "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
+    SM_REQUIRE(qkv && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
+    SM_REQUIRE(!vt || (vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64), "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
     AttnP p;
     const long ld = 3L * H * dh;
     p.q = (const bf16_t*)qkv; p.q_bs = (long)S * ld; p.q_rs = ld;
     p.k = (const bf16_t*)qkv + (long)H * dh; p.k_bs = (long)S * ld; p.k_rs = ld;
     p.vt = (const bf16_t*)vt; p.vt_bs = (long)H * dh * vt_ld; p.vt_hs = (long)dh * vt_ld; p.vt_ld = vt_ld;
+    p.v = vt ? nullptr : (const bf16_t*)qkv + 2L * H * dh; p.v_bs = (long)S * ld; p.v_rs = ld;   // vt == NULL: V straight from qkv
     p.o = (bf16_t*)ctx; p.o_bs = (long)S * H * dh; p.o_rs = (long)H * dh;
     p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
@@ -286,6 +327,7 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = (long)H * dh;
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
+    p.v = nullptr; p.v_bs = 0; p.v_rs = 0;
     p.o = (bf16_t*)ctx; p.o_bs = 0; p.o_rs = (long)H * dh;
     p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
@@ -310,6 +352,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
+    p.v = nullptr; p.v_bs = 0; p.v_rs = 0;
     p.o = nullptr; p.o_bs = 0; p.o_rs = 0;
     p.nq = rep; p.nk = nk; p.H = KV; p.KV = KV; p.causal = 0; p.pos0 = 0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;

@@ -280,7 +280,6 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
     if ((rc = m->x.alloc(rows * D * 4))) return rc;
     if ((rc = m->xn.alloc(rows * D * 2))) return rc;
     if ((rc = m->qkv.alloc(rows * 3 * D * 2))) return rc;
-    if ((rc = m->vt.alloc((size_t)B * D * m->Spad * 2, true))) return rc;     // zero pad columns stay zero forever
     if ((rc = m->ctx.alloc(rows * D * 2))) return rc;
     if ((rc = m->hmid.alloc(rows * c.vit_mlp * 2))) return rc;
     m->finalized = true;
@@ -342,10 +341,11 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
             sm_linear_t a = lin(m, m->slots.at(p + "qkv"), xn, SM_X_BF16, M, D);
             a.bias = m->ptr<float>(p + "qkv.bias");
             a.out_bf16 = m->qkv.p; a.ldo_bf16 = 3 * D;
-            a.vt = m->vt.p; a.vt_n0 = 2 * D; a.vt_S = S; a.vt_dh = dh; a.vt_ld = m->Spad;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
-        if ((rc = sm_vit_attention(m->qkv.p, m->vt.p, m->ctx.p, B, S, H, dh, m->Spad, stream))) return rc;
+        // V is transposed inside the attention kernel's LDS staging (a V^T side output of the QKV GEMM cost ~50 us of
+        // scalar 2-byte stores per layer at 28 frames)
+        if ((rc = sm_vit_attention(m->qkv.p, nullptr, m->ctx.p, B, S, H, dh, 0, stream))) return rc;
         {
             sm_linear_t a = lin(m, m->slots.at(p + "out"), m->ctx.p, SM_X_BF16, M, D);
             a.bias = m->ptr<float>(p + "self_attn.out_proj.bias");

@@ -104,8 +104,9 @@ def test_norm(nat, kind):
     assert torch.equal(ob.cpu(), of.cpu().bfloat16())
 
 
-@pytest.mark.parametrize("B,S,H,dh", [(2, 17, 2, 64), (1, 577, 16, 64), (3, 130, 4, 64)])
-def test_vit_attention(nat, B, S, H, dh):
+@pytest.mark.parametrize("vmode", ["row_major_v", "pre_transposed_vt"])
+@pytest.mark.parametrize("B,S,H,dh", [(2, 17, 2, 64), (1, 577, 16, 64), (3, 130, 4, 64), (2, 70, 2, 128)])
+def test_vit_attention(nat, B, S, H, dh, vmode):
     """non-causal attention vs the oracle's mixed-precision statement (P rounded to bf16 for PV, fp32 normaliser):
     output bf16, tolerance 1 bf16 ulp-ish (8e-3 relative to max)."""
     from streammind_amd._lib import load, check
@@ -118,7 +119,10 @@ def test_vit_attention(nat, B, S, H, dh):
     vt[:, :, :, :S] = v.permute(0, 2, 3, 1)
     qg, vg = qkv.cuda().bfloat16(), vt.cuda().bfloat16()
     ctx = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
-    check(lib.sm_vit_attention(qg.data_ptr(), vg.data_ptr(), ctx.data_ptr(), B, S, H, dh, Spad, torch.cuda.current_stream().cuda_stream))
+    if vmode == "row_major_v":
+        check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, torch.cuda.current_stream().cuda_stream))
+    else:
+        check(lib.sm_vit_attention(qg.data_ptr(), vg.data_ptr(), ctx.data_ptr(), B, S, H, dh, Spad, torch.cuda.current_stream().cuda_stream))
     q = qkv[:, :D].reshape(B, S, H, dh).transpose(1, 2)
     k = qkv[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
     vv = v.transpose(1, 2)
