@@ -154,6 +154,44 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
                          "bytes_per_token": weight_bytes + kv_bytes}}
 
 
+def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None):
+    """BASELINE configs[2] shape: perception of every frame + Mistral-7B replies on SCHEDULED fires (the random-weight
+    gate's own decisions are not a workload), each reply = prefill of the new context (KV prefix reuse) + exactly
+    `reply_tokens` greedy tokens (EOS ignored).  Returns stream frames/s including the replies."""
+    torch.cuda.synchronize()
+    base = stream.num_frames
+    g = torch.Generator(device="cuda").manual_seed(11)
+    text = torch.randint(3, cfg.llm_vocab, (60,), generator=g, device="cuda", dtype=torch.int32)
+    kv_ids = 0
+    t0 = time.perf_counter()
+    n_frames = n_fires = n_tok = 0
+    stream.set_kv_len(0)
+    seg_start = base
+    ctx = [text]
+    for i in range(n_steps):
+        off = (i * B) % (frames.shape[0] - B + 1)
+        stream.push_frames(frames[off:off + B])
+        n_frames += B
+        if (i + 1) % fire_every == 0:
+            T = stream.num_frames
+            if gather is not None:                   # N > 1: the one exchange of the path, only on fire ticks
+                gather(stream.tokens(seg_start, T - seg_start))
+            ctx.append(-(torch.arange(seg_start, T, device="cuda", dtype=torch.int32) + 1))
+            ctx.append(torch.randint(3, cfg.llm_vocab, (6,), generator=g, device="cuda", dtype=torch.int32))
+            new = torch.cat(ctx).contiguous()
+            stream.prefill(new)                      # only the tokens after the cached prefix: kv_len continues
+            out = stream.decode(reply_tokens)
+            ctx = [torch.randint(3, cfg.llm_vocab, (4,), generator=g, device="cuda", dtype=torch.int32)]
+            seg_start = T
+            n_fires += 1
+            n_tok += reply_tokens
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames": n_frames, "fires": n_fires, "reply_tokens": reply_tokens, "seconds": round(dt, 4),
+            "frames_per_s": round(n_frames / dt, 2), "reply_tokens_per_s_overall": round(n_tok / dt, 2),
+            "kv_len_end": stream.kv_len}
+
+
 def synthetic_frames_gpu(n: int, size: int, seed: int, rank: int) -> torch.Tensor:
     """seeded u8 HWC frames generated on the GPU: slowly drifting low-pass scene with cuts + per-pixel noise."""
     g = torch.Generator(device="cuda").manual_seed(seed * 1000003 + rank)
@@ -214,7 +252,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step")
+    ap.add_argument("--batch", type=int, default=28, help="frames per step (28 x 577 tokens = 63.1 tiles of 256 rows: every "
+                                                           "ViT GEMM is a whole number of 256-CU rounds)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (perception + scheduled replies) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-decode", action="store_true", help="skip the Mistral-7B decode tokens/s leg")
@@ -245,7 +285,7 @@ def main():
     model.finalize()
     n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
     frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
-    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 16 + 256, max_seq=1024)
+    stream = model.open_stream(max_frames=B * (a.steps + a.warmup + 8) + 16 + 256, max_seq=2048)
     torch.cuda.synchronize()
 
     def step(i):
@@ -276,7 +316,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(logits).all()
-    dec_leg = None
+    dec_leg = e2e = None
+    if not a.no_decode and not a.no_e2e:
+        gather, gathered = None, {"calls": 0, "ok": True}
+        if dist is not None:
+            from streammind_amd.dist import allgather_gated_tokens
+
+            def gather(tok):
+                try:
+                    out = allgather_gated_tokens(tok, cfg.conn_d_model)
+                    gathered["calls"] += 1
+                    gathered["rows"] = int(sum(t.shape[0] for t in out)) if out is not None else 0
+                except Exception as e:               # never let the optional exchange take the scaling run down
+                    gathered["ok"] = False
+                    gathered["error"] = repr(e)[:200]
+        e2e = e2e_leg(model, stream, cfg, frames, B, gather=gather)
+        if dist is not None:
+            e2e["allgather_gated_tokens"] = gathered
     if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
         dec_leg = decode_leg(model, stream, cfg)
         if dist is not None:
@@ -296,7 +352,9 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            roof = {"kernel": "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64)", "bound": "mfma", "achieved": round(ach, 1),
+            big = B * (cfg.n_patches + 1) >= 192 * 64
+            roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256x64, 8 waves)" if big else
+                              "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 4 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches": cnt.value, "avg_launch_us": round(avg_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch}
@@ -314,6 +372,7 @@ def main():
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,
+            "end_to_end": e2e,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

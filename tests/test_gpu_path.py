@@ -234,3 +234,18 @@ def test_streaming_session_equals_frame_at_a_time(tiny, tiny_tokenizer):
     assert [g[0] for g in got] == [r[0] for r in ref_events] and len(got) >= 2
     assert got == ref_events
     assert sess.prompt == prompt and sess.stats.frames == 12
+
+
+def test_feature_cache_bulk_encode(tiny, tmp_path):
+    """config-1 plumbing: bulk encode -> chunk files of the reference's shape and naming, then the stride."""
+    from streammind_amd import feature_cache as fc
+    m, Wv, _, _ = tiny
+    frames = O.synthetic_frames(7, TV.image_size, seed=3, scene_len=2)
+    paths = fc.encode_video_features(m, frames, str(tmp_path / "features_video_encode_ddp" / "v0"), "v0")
+    assert [p.split("/")[-1] for p in paths] == ["v0_encode_feature_frame_0_7.pt"]
+    f = torch.load(paths[0])
+    assert tuple(f.shape) == (1, 7, TV.n_patches, TV.hidden) and f.dtype == torch.bfloat16
+    ref = O.vit_features(O.preprocess_frames(frames, TV.image_size), Wv, TV, O.MIXED)
+    assert maxdiff(f[0], ref) < 2e-2 * ref.abs().max().item()
+    y = torch.load(fc.process_file(paths[0]))
+    assert tuple(y.shape) == (1, 1, TV.n_patches, TV.hidden)

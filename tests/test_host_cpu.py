@@ -63,3 +63,18 @@ def test_sentinel_expansion_and_errors():
         raise AssertionError
     except NotImplementedError as e:
         assert "inputs_embeds" in str(e)
+
+
+def test_feature_cache_stride_and_names(tmp_path):
+    from streammind_amd import feature_cache as fc
+    from oracle import streammind_oracle as O
+    x = torch.arange(1 * 500 * 2 * 3, dtype=torch.float32).reshape(1, 500, 2, 3).to(torch.bfloat16)
+    d = tmp_path / "features_video_encode_ddp" / "vid"
+    d.mkdir(parents=True)
+    p = d / fc.chunk_name("vid", 0, 500)
+    torch.save(x, p)
+    out = fc.process_file(str(p))
+    assert out == O.stride_output_path(str(p)) and "features_video_encode_ddp_fps" in out
+    y = torch.load(out)
+    assert tuple(y.shape) == (1, 42, 2, 3) and torch.equal(y, O.feature_stride(x))
+    assert fc.chunk_name("v", 500, 1000) == "v_encode_feature_frame_500_1000.pt"
