@@ -266,22 +266,24 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     }
 }
 
-// merge the key splits of flash-decoding: out[h][r][d] = sum_p w_p o_p / sum_p w_p l_p, w_p = exp2((m_p - M) c)
-__global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int splits, int rows,
-                                    int dh, float c, bf16_t* __restrict__ out) {
-    const int row = blockIdx.x;               // (kv head, query-in-group) flattened == output head index
-    const int d = threadIdx.x;
-    float M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, part_ml[((size_t)s * rows + row) * 2]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < splits; ++s) {
-        const float m = part_ml[((size_t)s * rows + row) * 2];
-        if (m == -INFINITY) continue;
-        const float w = exp2f((m - M) * c);
-        den += w * part_ml[((size_t)s * rows + row) * 2 + 1];
-        if (d < dh) num += w * part_o[((size_t)s * rows + row) * dh + d];
+// merge the key splits of flash-decoding: out[h][d] = sum_p w_p o_p / sum_p w_p l_p, w_p = exp2((m_p - M) c).
+// One block per head; the (m, l) pairs of all splits are read with one load per lane, then each lane owns two d's.
+__global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                          int splits, int rows, int dh, float c, bf16_t* __restrict__ out) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float m = -INFINITY, l = 0.f;
+    if (lane < splits) {
+        m = part_ml[((size_t)lane * rows + row) * 2];
+        l = part_ml[((size_t)lane * rows + row) * 2 + 1];
     }
-    if (d < dh) out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
+    const float M = wave_max(m);
+    const float w = (m == -INFINITY) ? 0.f : exp2f((m - M) * c);
+    const float den = wave_sum(w * l);
+    for (int d = lane; d < dh; d += 64) {
+        float num = 0.f;
+        for (int s = 0; s < splits; ++s) num += __shfl(w, s, 64) * part_o[((size_t)s * rows + row) * dh + d];
+        out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
+    }
 }
 
 static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
@@ -342,7 +344,7 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
 extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
                                        int S_max, float* workspace, int splits_max, void* ctx, void* stream) {
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
-    SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && dh <= 128, "sm_llm_decode_attention: dims");
+    SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
     int splits = cdiv(nk, 128);
     if (splits > splits_max) splits = splits_max;
@@ -370,7 +372,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
         else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
         SM_LAUNCH_CHECK();
     }
-    attn_combine_kernel<<<H, 128, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx);
+    attn_combine_kernel<<<H, 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

@@ -478,38 +478,36 @@ extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, con
     return SM_OK;
 }
 
-// qkv fp32 [n][(H+2KV)*dh]; rotate_half: out[j] = x[j] cos - x[j+h] sin ; out[j+h] = x[j+h] cos + x[j] sin
-__global__ void rope_kv_kernel(const float* __restrict__ qkv, int n, int pos0, int H, int KV, int dh,
-                               const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, bf16_t* __restrict__ q, bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc, int S_max) {
-    const int t = blockIdx.x;                 // token
+// qkv fp32 [n][(H+2KV)*dh]; rotate_half: out[j] = x[j] cos - x[j+h] sin ; out[j+h] = x[j+h] cos + x[j] sin.
+// grid (token, head slot): slots 0..H-1 = q heads, H..H+KV-1 = k heads (rotated, appended), H+KV.. = v heads (appended
+// transposed); one 64-thread block each so a single decode token still spreads over H+2KV blocks.
+__global__ __launch_bounds__(64) void rope_kv_kernel(const float* __restrict__ qkv, int pos0, int H, int KV, int dh,
+                                                     const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                     bf16_t* __restrict__ q, bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc,
+                                                     int S_max) {
+    const int t = blockIdx.x, hd = blockIdx.y;
     const int pos = pos0 + t;
     const int half = dh >> 1;
-    const int ld = (H + 2 * KV) * dh;
-    const float* row = qkv + (size_t)t * ld;
-    for (int e = threadIdx.x; e < (H + KV) * half; e += blockDim.x) {
-        int hd = e / half, j = e % half;
-        float c = cos_tab[(size_t)pos * half + j], s = sin_tab[(size_t)pos * half + j];
-        const float* x = row + (size_t)hd * dh;
-        float a = x[j], b = x[j + half];
-        float o0 = a * c - b * s, o1 = b * c + a * s;
-        if (hd < H) {
-            q[(size_t)t * H * dh + hd * dh + j] = (bf16_t)f2bf(o0);
-            q[(size_t)t * H * dh + hd * dh + j + half] = (bf16_t)f2bf(o1);
-        } else {
-            int kh = hd - H;
-            kc[((size_t)pos * KV + kh) * dh + j] = (bf16_t)f2bf(o0);
-            kc[((size_t)pos * KV + kh) * dh + j + half] = (bf16_t)f2bf(o1);
+    const float* x = qkv + (size_t)t * (H + 2 * KV) * dh + (size_t)hd * dh;
+    if (hd < H + KV) {
+        for (int j = threadIdx.x; j < half; j += 64) {
+            const float c = cos_tab[(size_t)pos * half + j], s = sin_tab[(size_t)pos * half + j];
+            const float a = x[j], b = x[j + half];
+            const float o0 = a * c - b * s, o1 = b * c + a * s;
+            bf16_t* dst = hd < H ? q + ((size_t)t * H + hd) * dh : kc + ((size_t)pos * KV + (hd - H)) * dh;
+            dst[j] = (bf16_t)f2bf(o0);
+            dst[j + half] = (bf16_t)f2bf(o1);
         }
+    } else {
+        const int kh = hd - H - KV;
+        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)f2bf(x[e]);
     }
-    const float* v = row + (size_t)(H + KV) * dh;
-    for (int e = threadIdx.x; e < KV * dh; e += blockDim.x)
-        vtc[(size_t)e * S_max + pos] = (bf16_t)f2bf(v[e]);
 }
 extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab,
                                  const float* sin_tab, void* q, void* kcache, void* vtcache, int S_max, void* stream) {
     SM_REQUIRE(qkv && q && cos_tab && sin_tab && kcache && vtcache && n > 0 && pos0 >= 0 && pos0 + n <= S_max, "sm_rope_kv_append: bad args (pos0=%d n=%d S_max=%d)", pos0, n, S_max);
-    rope_kv_kernel<<<n, 256, 0, (hipStream_t)stream>>>(qkv, n, pos0, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, (bf16_t*)kcache,
-                                                       (bf16_t*)vtcache, S_max);
+    rope_kv_kernel<<<dim3(n, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, pos0, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q,
+                                                                        (bf16_t*)kcache, (bf16_t*)vtcache, S_max);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
