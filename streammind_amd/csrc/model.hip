@@ -51,12 +51,13 @@ struct Slot {            // one tensor the path reads
     int kind = 0;        // 0 = fp32 vector/matrix (as is), 1 = packed linear (possibly a fused group), 2 = bf16 row-major
     int N = 0, K = 0;    // logical dims of the (fused) matrix
     int parts = 1, loaded = 0;
+    int Klogical = 0;    // > 0: checkpoint K (the packed image pads it to K); patch embedding only
 };
 
 struct sm_model {
     sm_config_t c;
     std::unordered_map<std::string, Slot> slots;           // canonical name -> storage
-    struct Route { std::string slot; int row0; };          // checkpoint name -> (slot, first row inside a fused slot)
+    struct Route { std::string slot; int row0; int rows; };   // checkpoint name -> (slot, first row, row count of this part)
     std::unordered_map<std::string, Route> routes;
     std::vector<std::string> ignored_prefixes;
     bool finalized = false;
@@ -77,17 +78,17 @@ struct sm_model {
 static void add_linear(sm_model* m, const std::string& slot, int N, int K, const std::vector<std::string>& names, int rows_each) {
     Slot& s = m->slots[slot];
     s.kind = 1; s.N = N; s.K = K; s.parts = (int)names.size();
-    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each};
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each};
 }
 static void add_f32(sm_model* m, const std::string& name, int N, int K = 1) {
     Slot& s = m->slots[name];
     s.kind = 0; s.N = N; s.K = K;
-    m->routes[name] = {name, 0};
+    m->routes[name] = {name, 0, N};
 }
 static void add_f32_fused(sm_model* m, const std::string& slot, int N, const std::vector<std::string>& names, int rows_each) {
     Slot& s = m->slots[slot];
     s.kind = 0; s.N = N; s.K = 1; s.parts = (int)names.size();
-    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each};
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each};
 }
 
 extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
@@ -115,6 +116,7 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     // ---- vision tower
     add_f32(m, "vit.embeddings.class_embedding", D);
     add_linear(m, "vit.patch_embed", D, m->Kpe, {"vit.embeddings.patch_embedding.weight"}, D);   // K zero-padded to x64
+    m->slots["vit.patch_embed"].Klogical = 3 * c.vit_patch * c.vit_patch;
     add_f32(m, "vit.embeddings.position_embedding.weight", m->S, D);
     add_f32(m, "vit.pre_layrnorm.weight", D); add_f32(m, "vit.pre_layrnorm.bias", D);
     for (int l = 0; l < c.vit_layers_run; ++l) {
@@ -167,15 +169,15 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
         const int ld = c.llm_hidden, dh = ld / c.llm_heads, qn = c.llm_heads * dh, kn = c.llm_kv_heads * dh;
         SM_REQUIRE(qn == kn * (c.llm_heads / c.llm_kv_heads), "llm heads");
         Slot& e = m->slots["llm.embed"]; e.kind = 2; e.N = c.llm_vocab; e.K = ld;
-        m->routes["llm.model.embed_tokens.weight"] = {"llm.embed", 0};
+        m->routes["llm.model.embed_tokens.weight"] = {"llm.embed", 0, c.llm_vocab};
         for (int l = 0; l < c.llm_layers; ++l) {
             std::string p = "llm.model.layers." + std::to_string(l) + ".";
             // q, k, v fused; all three blocks must start on a 16-row boundary of the packed image
             SM_REQUIRE(qn % 16 == 0 && kn % 16 == 0, "llm q/k widths must be multiples of 16");
             Slot& s = m->slots[p + "qkv"]; s.kind = 1; s.N = qn + 2 * kn; s.K = ld; s.parts = 3;
-            m->routes[p + "self_attn.q_proj.weight"] = {p + "qkv", 0};
-            m->routes[p + "self_attn.k_proj.weight"] = {p + "qkv", qn};
-            m->routes[p + "self_attn.v_proj.weight"] = {p + "qkv", qn + kn};
+            m->routes[p + "self_attn.q_proj.weight"] = {p + "qkv", 0, qn};
+            m->routes[p + "self_attn.k_proj.weight"] = {p + "qkv", qn, kn};
+            m->routes[p + "self_attn.v_proj.weight"] = {p + "qkv", qn + kn, kn};
             add_linear(m, p + "o", ld, qn, {p + "self_attn.o_proj.weight"}, ld);
             add_linear(m, p + "gu", 2 * c.llm_mlp, ld, {p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"}, c.llm_mlp);
             add_linear(m, p + "down", ld, c.llm_mlp, {p + "mlp.down_proj.weight"}, ld);
@@ -223,8 +225,9 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
     for (int i = 1; i < ndim; ++i) cols *= shape[i];
     const size_t n = (size_t)rows * cols;
     if (s.kind == 1 || s.kind == 2) {
-        SM_REQUIRE((cols == s.K || (s.kind == 1 && cols < s.K && s.parts == 1)) && row0 + rows <= s.N, "tensor '%s': shape [%lld x %lld] does not fit slot [%d x %d] at row %d",
-                   name_c, (long long)rows, (long long)cols, s.N, s.K, row0);
+        SM_REQUIRE(cols == (s.Klogical ? s.Klogical : s.K) && rows == it->second.rows,
+                   "tensor '%s': shape [%lld x %lld] does not fit the expected [%d x %d]",
+                   name_c, (long long)rows, (long long)cols, it->second.rows, s.Klogical ? s.Klogical : s.K);
         DevBuf tmp;
         const bf16_t* src = (const bf16_t*)data;
         if (dtype == SM_DT_F32) {
@@ -246,7 +249,7 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
         }
         if (tmp.p) SM_HIP(hipStreamSynchronize(st));      // tmp is freed on return
     } else {
-        SM_REQUIRE((size_t)row0 * s.K + n <= (size_t)s.N * s.K, "tensor '%s': %zu elements do not fit slot of %zu", name_c, n, (size_t)s.N * s.K);
+        SM_REQUIRE(n == (size_t)it->second.rows * s.K, "tensor '%s': %zu elements do not fit the expected %zu", name_c, n, (size_t)it->second.rows * s.K);
         if (!s.buf.p) { int rc = s.buf.alloc((size_t)s.N * s.K * 4); if (rc) return rc; }
         float* dst = s.buf.as<float>() + (size_t)row0 * s.K;
         if (dtype == SM_DT_F32) SM_HIP(hipMemcpyAsync(dst, data, n * 4, hipMemcpyDeviceToDevice, st));

