@@ -294,3 +294,30 @@ def test_more_than_600_new_frames_keeps_last_600_rule(tiny, tiny_tokenizer):
     assert model.stream.num_frames == 0
     with pytest.raises(ValueError):
         model.frame_feature = torch.zeros(1)
+
+
+def test_full_size_perception_vs_fp32_oracle():
+    """FULL-SIZE silent-frame path (CLIP-ViT-L/14-336, 23 layers, bf16 MFMA) -> connector -> 872 M-parameter gate against
+    the fp32 oracle (the arithmetic pinned to the reference): pooled features and gate logits.  The connector+gate alone
+    are within 1e-3 of the reference (test_conn_gate_full_size_golden).  End to end, with the bf16-operand ViT in front, the
+    measured gate-logit deviation from the fp32 oracle is 4.3e-4 (pooled features 7e-3 on magnitudes up to 27); asserted
+    at 2e-3 / 2e-2, and the decisions must agree wherever the oracle margin exceeds the tolerance."""
+    vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
+    Wv = O.make_vit_weights(vcfg, 101)
+    Wc = conn_gate_weights(ccfg, gcfg, 102)
+    m = build_native(vcfg, ccfg, gcfg, Wv, Wc, max_frames_per_call=2)
+    frames = O.synthetic_frames(2, 336, seed=55, scene_len=1)
+    s = m.open_stream(max_frames=8, max_seq=64)
+    lg, dec = s.push_frames(frames.cuda())
+    torch.set_num_threads(16)
+    feats = O.vit_features(O.preprocess_frames(frames), Wv, vcfg, O.FP32)
+    pooled = O.pool_patches(feats)
+    tok = O.connector_scan(pooled, Wc, ccfg)
+    ref = O.gate_logits_shortcut(tok, Wc, gcfg)
+    dp = maxdiff(m.vit_encode(frames.cuda()), pooled)
+    dl = maxdiff(lg, ref)
+    print(f"full-size: pooled max|diff| {dp:.3e} (|pooled| max {pooled.abs().max():.2f}); gate logits max|diff| {dl:.3e}; ref logits {ref.tolist()}")
+    assert dp < 2e-2 and dl < 2e-3
+    for j in range(2):
+        if abs(float(ref[j, 1] - ref[j, 0])) > 4e-3:
+            assert int(dec[j]) == O.gate_decision(ref[j])
