@@ -321,3 +321,33 @@ def test_full_size_perception_vs_fp32_oracle():
     for j in range(2):
         if abs(float(ref[j, 1] - ref[j, 0])) > 4e-3:
             assert int(dec[j]) == O.gate_decision(ref[j])
+
+
+def test_full_width_llm_two_layers_prefill_and_decode():
+    """Mistral-7B widths (4096 / 32 q heads / 8 kv heads x 128 / MLP 14336), 2 layers, small vocab: prefill logits of a
+    90-token context (text + frame tokens through the splice) and 6 greedy decode steps (flash-decoding path) against
+    the oracle in mixed precision.  Logits tolerance 3e-2 on O(1) values; ids must match where the margin is larger."""
+    lcfg = O.LmCfg(hidden=4096, layers=2, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
+    Wl = O.make_lm_weights(lcfg, 77)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl)
+    g = torch.Generator().manual_seed(9)
+    toks = torch.randn(30, 4096, generator=g)
+    text = torch.randint(3, lcfg.vocab, (60,), generator=g)
+    s = m.open_stream(max_frames=64, max_seq=256)
+    s.write_tokens(0, toks.cuda())
+    ids = torch.cat([text[:20], -(torch.arange(30) + 1), text[20:]]).to(torch.int32)
+    s.prefill(ids.cuda())
+    lg, nt = s.logits()
+    emb = torch.cat([Wl["model.embed_tokens.weight"][text[:20]], toks, Wl["model.embed_tokens.weight"][text[20:]]])
+    ref_ids, trace = O.greedy_generate(emb, Wl, lcfg, 7, eos_token_id=None, prec=O.MIXED, return_logits=True)
+    assert maxdiff(lg, trace[0]) < 3e-2
+    got = s.decode(6).cpu().tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        margin = float(torch.topk(trace[j], 2).values.diff().abs())
+        if a != b:
+            assert margin < 6e-2, (j, got, ref_ids, margin)
+            break
+    lg2, _ = s.logits()
+    assert torch.isfinite(lg2).all() and s.kv_len == 96
