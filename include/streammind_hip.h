@@ -34,6 +34,8 @@ extern "C" {
 
 #define SM_X_BF16 0
 #define SM_X_F32 1
+#define SM_W_BF16 0
+#define SM_W_FP8 1
 
 const char* sm_last_error(void);
 int sm_abi_version(void);
@@ -45,6 +47,10 @@ int sm_abi_version(void);
  * ---------------------------------------------------------------------------------------------- */
 size_t sm_packed_elems(int N, int K); /* bf16 elements of the packed image (N->x16, K->x32 padded) */
 int sm_pack_weight(const void* w_bf16, int N, int K, int ldw, void* out_packed, void* stream);
+/* weight-only fp8 (OCP e4m3) for the weight-streaming path (BASELINE config 5, opt-in): per-row scale max|w|/448 into
+ * scale_out[N], fp8 image of sm_packed_fp8_bytes(N,K) bytes.  No reference counterpart (the reference is fp16/bf16). */
+size_t sm_packed_fp8_bytes(int N, int K);
+int sm_quant_pack_weight_fp8(const void* w_bf16, int N, int K, int ldw, void* out_packed_fp8, float* scale_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Linear:  Y[M,N] = epilogue( X[M,K] . W[N,K]^T ).  Replaces every torch F.linear / cuBLAS GEMM+GEMV on
@@ -76,6 +82,10 @@ typedef struct sm_linear_t {
      * (row length vt_ld) instead of out_bf16.                                                      */
     void* vt;
     int vt_n0, vt_S, vt_dh, vt_ld;
+    /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 (sm_quant_pack_weight_fp8 image + per-row scales; M <= 16) */
+    int w_dtype;
+    const float* w_scale;
+    const float* w2_scale;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 

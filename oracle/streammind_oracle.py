@@ -128,6 +128,17 @@ def bf16_round(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(F32)
 
 
+def fp8_quantize_rows(w: Tensor) -> Tuple[Tensor, Tensor]:
+    """Weight-only fp8 (OCP e4m3fn) emulation of the opt-in BASELINE config-5 mode: per-output-row scale
+    s = max|w| * (1/448), q = fp8(w * (1/s)); returns (q * s as fp32 -- the weights the GPU effectively multiplies by --, s).
+    No reference counterpart (the reference runs fp16/bf16); used only to check the HIP fp8 path against ITS definition."""
+    m = w.abs().amax(dim=1)
+    s = torch.where(m > 0, (m * torch.tensor(1.0 / 448.0, dtype=F32)), torch.ones_like(m))
+    inv = (1.0 / s).to(F32)
+    q = (w.to(F32) * inv[:, None]).to(torch.float8_e4m3fn).to(F32)
+    return q * s[:, None], s
+
+
 # ----------------------------------------------------------------------------------------------
 # elementary ops (restated; no nn.Module)
 # ----------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstreammind_hip.so")
 
 SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
 SM_X_BF16, SM_X_F32 = 0, 1
+SM_W_BF16, SM_W_FP8 = 0, 1
 SM_DT_BF16, SM_DT_F32, SM_DT_F16 = 0, 1, 2
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -26,6 +27,7 @@ class sm_linear_t(C.Structure):
         ("out_f32", vp), ("out_bf16", vp), ("ldo", i32), ("ldo_bf16", i32),
         ("remap_in", i32), ("remap_out", i32), ("remap_off", i32),
         ("vt", vp), ("vt_n0", i32), ("vt_S", i32), ("vt_dh", i32), ("vt_ld", i32),
+        ("w_dtype", i32), ("w_scale", vp), ("w2_scale", vp),
     ]
 
 
@@ -49,6 +51,8 @@ SIGNATURES = {
     "sm_abi_version": (i32, []),
     "sm_packed_elems": (sz, [i32, i32]),
     "sm_pack_weight": (i32, [vp, i32, i32, i32, vp, vp]),
+    "sm_packed_fp8_bytes": (sz, [i32, i32]),
+    "sm_quant_pack_weight_fp8": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sm_linear": (i32, [C.POINTER(sm_linear_t), vp]),
     "sm_norm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, vp]),
     "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),

@@ -51,10 +51,7 @@ extern "C" int sm_pack_weight(const void* w, int N, int K, int ldw, void* out, v
     return sm_pack_weight_ks(w, N, K, ldw, (K + 31) / 32, out, stream);
 }
 
-// ------------------------------------------------------------------------------------------------ skinny (M <= 16)
-// One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
-// ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
-// reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
+// x fragment of the skinny kernels: 8 consecutive k of row m, as bf16 (hi) and optionally the bf16 residual (lo)
 template <bool XF32, bool SPLIT>
 __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16x8& hi, bf16x8& lo) {
     if (XF32) {
@@ -81,6 +78,145 @@ __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fp8 weights
+// Weight-only fp8 (OCP e4m3, gfx950 v_cvt_pk_fp8_f32) for the HBM-bound weight-streaming path: per-output-row scale
+// s[n] = max|W[n,:]| / 448, q = fp8(W / s).  Packed image: [N/16][ceil(KS/2)][lane][16 B], a lane's 16 bytes holding
+// its 8 elements of k-step 2p followed by those of k-step 2p+1, so one 16-byte load feeds two MFMAs after an exact
+// fp8 -> bf16 expansion in registers.  BASELINE config 5; opt-in (numerics differ from the bf16 checkpoint).
+__global__ void rowscale_kernel(const bf16_t* __restrict__ w, int N, int K, int ldw, float* __restrict__ scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float m = 0.f;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(bf2f(w[(size_t)row * ldw + k])));
+    m = wave_max(m);
+    if (lane == 0) scale[row] = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;
+}
+__global__ void pack_fp8_kernel(const bf16_t* __restrict__ w, int N, int K, int ldw, const float* __restrict__ scale,
+                                u32x4* __restrict__ out, int KSP, size_t total_chunks) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total_chunks) return;
+    const int lane = (int)(c & 63);
+    const size_t rest = c >> 6;
+    const int kp = (int)(rest % KSP), rg = (int)(rest / KSP);
+    const int n = rg * 16 + (lane & 15);
+    const float inv = n < N ? 1.0f / scale[n] : 0.f;
+    uint32_t o[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k0 = (2 * kp + h) * 32 + (lane >> 4) * 8;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (n < N && k0 + j < K) ? bf2f(w[(size_t)n * ldw + k0 + j]) * inv : 0.f;
+        int r0 = 0, r1 = 0;
+        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], r0, false);
+        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], r0, true);
+        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], r1, false);
+        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], r1, true);
+        o[2 * h] = (uint32_t)r0; o[2 * h + 1] = (uint32_t)r1;
+    }
+    out[c] = u32x4{o[0], o[1], o[2], o[3]};
+}
+extern "C" size_t sm_packed_fp8_bytes(int N, int K) {
+    const int KS = (K + 31) / 32;
+    return (size_t)((N + 15) / 16) * ((KS + 1) / 2) * 1024;
+}
+extern "C" int sm_quant_pack_weight_fp8(const void* w, int N, int K, int ldw, void* out, float* scale_out, void* stream) {
+    SM_REQUIRE(w && out && scale_out && N > 0 && K > 0 && ldw >= K, "sm_quant_pack_weight_fp8: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int KSP = ((K + 31) / 32 + 1) / 2;
+    rowscale_kernel<<<cdiv(N, 4), 256, 0, st>>>((const bf16_t*)w, N, K, ldw, scale_out);
+    const size_t chunks = (size_t)((N + 15) / 16) * KSP * 64;
+    pack_fp8_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>((const bf16_t*)w, N, K, ldw, scale_out, (u32x4*)out, KSP, chunks);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// 8 fp8 (two dwords) -> 8 bf16: v_cvt_pk_f32_fp8 then keep the high halves (every e4m3 value is exact in bf16)
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    union { bf16x8 v; uint32_t u[4]; } r;
+    r.u[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
+    r.u[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
+    r.u[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
+    r.u[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
+    return r.v;
+}
+
+// same block/wave decomposition as skinny_kernel, weights streamed as fp8 pairs of k-steps
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = blockIdx.x;
+    const int KS = a.KS, KSP = (KS + 1) >> 1;
+    const int i = lane & 15, g = lane >> 4;
+    const u32x4* wp = (const u32x4*)a.w + (size_t)rg * KSP * 64 + lane;
+    const u32x4* wp2 = DUAL ? (const u32x4*)a.w2 + (size_t)rg * KSP * 64 + lane : nullptr;
+    const bool valid = i < a.M;
+    const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
+    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    constexpr int U = 2;
+    int kp = wave;
+    auto body = [&](u32x4 q, u32x4 q2, int kpi) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ks = 2 * kpi + h;
+            bf16x8 xh, xl;
+            load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid && ks < KS, xh, xl);
+            const bf16x8 wf = fp8x8_to_bf16(h ? q[2] : q[0], h ? q[3] : q[1]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xh, acc, 0, 0, 0);
+            if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xl, acc, 0, 0, 0);
+            if (DUAL) {
+                const bf16x8 wf2 = fp8x8_to_bf16(h ? q2[2] : q2[0], h ? q2[3] : q2[1]);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xh, acc2, 0, 0, 0);
+                if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xl, acc2, 0, 0, 0);
+            }
+        }
+    };
+    for (; kp + (U - 1) * WAVES < KSP; kp += U * WAVES) {
+        u32x4 q[U], q2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            q[u] = __builtin_nontemporal_load(wp + (size_t)(kp + u * WAVES) * 64);
+            if (DUAL) q2[u] = __builtin_nontemporal_load(wp2 + (size_t)(kp + u * WAVES) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) body(q[u], DUAL ? q2[u] : q[u], kp + u * WAVES);
+    }
+    for (; kp < KSP; kp += WAVES) {
+        const u32x4 q = __builtin_nontemporal_load(wp + (size_t)kp * 64);
+        const u32x4 q2 = DUAL ? __builtin_nontemporal_load(wp2 + (size_t)kp * 64) : q;
+        body(q, q2, kp);
+    }
+    if (WAVES > 1) {
+        constexpr int PER = DUAL ? 8 : 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(wave * PER + r) * 64 + lane] = acc[r];
+            if (DUAL) red[(wave * PER + 4 + r) * 64 + lane] = acc2[r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f, s2 = 0.f;
+            for (int w = 0; w < WAVES; ++w) {
+                s += red[(w * PER + r) * 64 + lane];
+                if (DUAL) s2 += red[(w * PER + 4 + r) * 64 + lane];
+            }
+            acc[r] = s;
+            if (DUAL) acc2[r] = s2;
+        }
+    }
+    store4(a, i, rg * 16 + g * 4, acc, DUAL ? &acc2 : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ skinny (M <= 16)
+// One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
+// ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
+// reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
 template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];
@@ -339,6 +475,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
 
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int WAVES>
+static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
+    dim3 grid(a.NRG), block(WAVES * 64);
+    size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * 64 * sizeof(float) : 0;
+#define SK(XF, SP, DU) skinny_fp8_kernel<WAVES, XF, SP, DU><<<grid, block, sh, st>>>(a)
+    if (xf32) {
+        if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
+        else       { if (dual) SK(true, false, true); else SK(true, false, false); }
+    } else {
+        if (dual) SK(false, false, true); else SK(false, false, false);
+    }
+#undef SK
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+template <int WAVES>
 static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
     dim3 grid(a.NRG), block(WAVES * 64);
     size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * 64 * sizeof(float) : 0;
@@ -371,6 +523,10 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     a.ldo = p->ldo; a.ldo_bf16 = p->ldo_bf16;
     a.remap_in = p->remap_in; a.remap_out = p->remap_out; a.remap_off = p->remap_off;
     a.vt = (bf16_t*)p->vt; a.vt_n0 = p->vt_n0; a.vt_S = p->vt_S; a.vt_dh = p->vt_dh; a.vt_ld = p->vt_ld;
+    const bool w8 = p->w_dtype == SM_W_FP8;
+    a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
+    SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
+    SM_REQUIRE(!w8 || p->M <= 16, "sm_linear: fp8 weights are supported on the weight-streaming path only (M <= 16, got %d)", p->M);
     SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
@@ -381,6 +537,12 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const bool split = xf32 && p->precise;
         const bool dual = p->w2 != nullptr;
         SmProfScope prof(SM_PROF_SKINNY, st);
+        if (w8) {
+            if (a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);
+            if (a.KS >= 32) return launch_skinny_fp8<8>(a, xf32, split, dual, st);
+            if (a.KS >= 8) return launch_skinny_fp8<4>(a, xf32, split, dual, st);
+            return launch_skinny_fp8<1>(a, xf32, split, dual, st);
+        }
         // enough waves per row-group to keep >= ~32 KiB of weight loads in flight per CU
         if (a.KS >= 64 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
         if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);

@@ -20,6 +20,8 @@ struct LinArgs {
     int remap_in, remap_out, remap_off;
     bf16_t* vt;
     int vt_n0, vt_S, vt_dh, vt_ld;
+    const float* wscale;        // fp8 weights (skinny path): per-output-row dequantisation scale, applied to the accumulator
+    const float* wscale2;       //   ... of the second (dual) weight
 };
 
 static __device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
@@ -38,8 +40,10 @@ static __device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float t = v[r];
-        if (a.bias && (full || n0 + r < a.N)) t += a.bias[n0 + r];
-        if (v2) t = siluf_(t) * (*v2)[r];
+        const bool inb = full || n0 + r < a.N;
+        if (a.wscale && inb) t *= a.wscale[n0 + r];
+        if (a.bias && inb) t += a.bias[n0 + r];
+        if (v2) t = siluf_(t) * ((*v2)[r] * ((a.wscale2 && inb) ? a.wscale2[n0 + r] : 1.0f));
         else t = apply_act_rt(t, a.act);
         if (a.residual && (full || n0 + r < a.N)) t += a.residual[(size_t)rrow * a.ldr + n0 + r];
         o[r] = t;

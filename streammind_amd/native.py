@@ -256,9 +256,21 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[N,K] bf16 (GPU) -> (fp8 packed image as uint8, per-row scales fp32 [N])."""
+    lib = _lib.load()
+    assert w.dtype == torch.bfloat16 and w.is_cuda and w.dim() == 2 and w.is_contiguous()
+    N, K = w.shape
+    out = torch.empty(lib.sm_packed_fp8_bytes(N, K), dtype=torch.uint8, device=w.device)
+    scale = torch.empty(N, dtype=torch.float32, device=w.device)
+    check(lib.sm_quant_pack_weight_fp8(w.data_ptr(), N, K, K, out.data_ptr(), scale.data_ptr(), _stream()), "sm_quant_pack_weight_fp8")
+    return out, scale
+
+
 def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None,
-           out_dtype: torch.dtype = torch.float32, precise: bool = False) -> torch.Tensor:
+           out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
+           w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T)."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)
@@ -268,6 +280,8 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     a.x, a.x_dtype = x.data_ptr(), (_lib.SM_X_F32 if x.dtype == torch.float32 else _lib.SM_X_BF16)
     a.precise, a.M, a.ldx = int(precise), M, x.shape[1]
     a.bias, a.act = _p(bias), act
+    if w_scale is not None:
+        a.w_dtype, a.w_scale, a.w2_scale = _lib.SM_W_FP8, w_scale.data_ptr(), _p(w2_scale)
     if residual is not None:
         a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)

@@ -236,3 +236,36 @@ def test_decode_attention_split_keys(nat, pos, H, KV, dh):
     s = torch.einsum("hd,khd->hk", q, kk) * dh ** -0.5
     ref = torch.einsum("hk,khd->hd", torch.softmax(s, -1), vv)
     assert relerr(ctx, ref) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 96), (8, 4096, 4096), (1, 4096, 14336), (16, 288, 8192), (2, 2, 4096)])
+@pytest.mark.parametrize("mode", ["f32_precise", "bf16"])
+def test_skinny_linear_fp8_weights(nat, M, N, K, mode):
+    """opt-in weight-only fp8 (config 5): the HIP quantiser + fp8 streaming kernel against the oracle's definition
+    (per-row scale max|w|/448, OCP e4m3fn, RNE).  2e-5 relative when activations are carried as hi/lo, 2e-5 with the
+    same single bf16 rounding of x on both sides."""
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = rnd((M, K), 2)
+    bias = rnd((N,), 3, 0.1)
+    wq, sc = nat.pack_weight_fp8(w.cuda().bfloat16())
+    wd, s_ref = O.fp8_quantize_rows(w)
+    assert relerr(sc, s_ref) < 1e-6
+    xg, xr = (x.cuda(), x) if mode == "f32_precise" else (x.cuda().bfloat16(), O.bf16_round(x))
+    y = nat.linear(xg, wq, N, K, bias=bias.cuda(), w_scale=sc, precise=(mode == "f32_precise"))
+    ref = (xr.double() @ wd.double().t() + bias.double()).float()
+    assert relerr(y, ref) < 2e-5
+    # and the quantisation itself is a ~2^-4 relative perturbation per weight, a few % on the outputs: sanity bound vs bf16 weights
+    ref_bf16 = (xr.double() @ w.double().t() + bias.double()).float()
+    assert relerr(y, ref_bf16) < 0.2
+
+
+def test_skinny_dual_fp8(nat):
+    M, N, K = 4, 1024, 512
+    wg, wu = O.bf16_round(rnd((N, K), 1, K ** -0.5)), O.bf16_round(rnd((N, K), 2, K ** -0.5))
+    x = rnd((M, K), 3)
+    qg, sg = nat.pack_weight_fp8(wg.cuda().bfloat16())
+    qu, su = nat.pack_weight_fp8(wu.cuda().bfloat16())
+    y = nat.linear(x.cuda(), qg, N, K, w2p=qu, w_scale=sg, w2_scale=su, precise=True)
+    dg, du = O.fp8_quantize_rows(wg)[0], O.fp8_quantize_rows(wu)[0]
+    ref = (O.silu(x.double() @ dg.double().t()) * (x.double() @ du.double().t())).float()
+    assert relerr(y, ref) < 3e-5
