@@ -187,6 +187,9 @@ typedef struct sm_config_t {
     /* capacities */
     int max_frames_per_call; /* frames batched through sm_vit_encode in one call                       */
     int gate_precise;        /* 1: hi/lo bf16 activation split in the connector+gate GEMVs (~fp32 acts) */
+    int weights_fp8;         /* 1: gate + LLM linear weights are quantised to fp8 (per-row scale) at load time and every  */
+                             /*    LLM/gate product takes the weight-streaming kernel (prefill in 16-token chunks);        */
+                             /*    BASELINE config 5, opt-in: numerics differ from the bf16 checkpoint                     */
 } sm_config_t;
 
 typedef struct sm_model sm_model;

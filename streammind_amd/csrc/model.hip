@@ -13,6 +13,8 @@
 #include "host.h"
 
 int sm_pack_weight_ks(const void* w, int N, int K, int ldw, int KS, void* out, void* stream);   // linear.hip
+extern "C" size_t sm_packed_fp8_bytes(int N, int K);
+extern "C" int sm_quant_pack_weight_fp8(const void* w, int N, int K, int ldw, void* out, float* scale_out, void* stream);
 
 // ------------------------------------------------------------------------------------------------ small kernels
 __global__ void bf16_to_f32_kernel(const bf16_t* in, float* out, size_t n) {
@@ -52,6 +54,8 @@ struct Slot {            // one tensor the path reads
     int N = 0, K = 0;    // logical dims of the (fused) matrix
     int parts = 1, loaded = 0;
     int Klogical = 0;    // > 0: checkpoint K (the packed image pads it to K); patch embedding only
+    bool fp8 = false;    // packed as fp8 + per-row scales (weights_fp8 mode, gate + LLM linears)
+    DevBuf scale;        // fp32 [N]
 };
 
 struct sm_model {
@@ -186,6 +190,10 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
         add_f32(m, "llm.model.norm.weight", ld);
         add_linear(m, "llm.lm_head", c.llm_vocab, ld, {"llm.lm_head.weight"}, c.llm_vocab);
     }
+    if (c.weights_fp8)
+        for (auto& kv : m->slots)
+            if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head"))
+                kv.second.fp8 = true;
     *out = m;
     return SM_OK;
 }
@@ -236,7 +244,17 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
             f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
             src = tmp.as<bf16_t>();
         }
-        if (s.kind == 1) {
+        if (s.kind == 1 && s.fp8) {
+            if (!s.buf.p) {
+                int rc = s.buf.alloc(sm_packed_fp8_bytes(s.N, s.K), true); if (rc) return rc;
+                rc = s.scale.alloc((size_t)s.N * 4, true); if (rc) return rc;
+            }
+            SM_REQUIRE(row0 % 16 == 0, "fused part must start on a 16-row boundary");
+            const int KSP = ((s.K + 31) / 32 + 1) / 2;
+            char* dst = (char*)s.buf.p + (size_t)(row0 / 16) * KSP * 1024;
+            int rc = sm_quant_pack_weight_fp8(src, (int)rows, s.K, (int)cols, dst, s.scale.as<float>() + row0, stream);
+            if (rc) return rc;
+        } else if (s.kind == 1) {
             if (!s.buf.p) { int rc = s.buf.alloc(sm_packed_elems(s.N, s.K) * 2, true); if (rc) return rc; }
             SM_REQUIRE(row0 % 16 == 0, "fused part must start on a 16-row boundary");
             const int KS = (s.K + 31) / 32;
@@ -296,6 +314,7 @@ static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dt
     sm_linear_t a;
     memset(&a, 0, sizeof(a));
     a.w = w.buf.p; a.N = w.N; a.K = w.K; a.x = x; a.x_dtype = x_dtype; a.M = M; a.ldx = ldx;
+    if (w.fp8) { a.w_dtype = SM_W_FP8; a.w_scale = w.scale.as<float>(); }
     return a;
 }
 
@@ -419,6 +438,7 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
             if (!rc) rc = s->vtc[l].alloc((size_t)kn * max_seq * 2, true);
         }
         s->chunk = max_seq < 2048 ? max_seq : 2048;            // prefill chunk (rows of the activation workspace)
+        if (c.weights_fp8) s->chunk = 16;                      // fp8 weights exist only for the weight-streaming kernels
         const size_t ch = s->chunk;
         A(emb, ch * ld * 4, false); A(xnb, ch * ld * 2, false);
         A(qkvf, ch * (qn + 2 * kn) * 4, false); A(qb, ch * qn * 2, false); A(ctxb, ch * qn * 2, false);
@@ -549,7 +569,8 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
         {   const Slot& gu = m->slots.at(p + "gu");
             sm_linear_t a = L(p + "gu", s->hn.as<float>(), d);
             a.N = c.gate_mlp;
-            a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.gate_mlp / 16) * ((d + 31) / 32) * 512;
+            if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.gate_mlp / 16) * ((((d + 31) / 32) + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.gate_mlp; }
+            else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.gate_mlp / 16) * ((d + 31) / 32) * 512;
             a.out_f32 = s->act.as<float>(); a.ldo = c.gate_mlp;
             if ((rc = sm_linear(&a, stream))) return rc; }
         {   sm_linear_t a = L(p + "down", s->act.as<float>(), c.gate_mlp);
@@ -606,7 +627,8 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             const Slot& gu = m->slots.at(p + "gu");
             sm_linear_t a = lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
             a.N = c.llm_mlp;
-            a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
+            if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
+            else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
             a.out_bf16 = s->actb.p; a.ldo_bf16 = c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         } else {

@@ -57,6 +57,7 @@ class PathConfig:
     llm_rope_theta: float = 1e6
     max_frames_per_call: int = 8
     gate_precise: bool = True
+    weights_fp8: bool = False      # opt-in BASELINE config 5: fp8 gate + LLM weights (weight-streaming path only)
 
     @property
     def vit_layers_run(self) -> int:
@@ -87,6 +88,7 @@ class PathConfig:
             self.conn_d_model, self.llm_layers, self.llm_heads, self.llm_kv_heads, self.llm_mlp, self.llm_vocab)
         c.llm_eps, c.llm_rope_theta = self.llm_eps, self.llm_rope_theta
         c.max_frames_per_call, c.gate_precise = self.max_frames_per_call, int(self.gate_precise)
+        c.weights_fp8 = int(self.weights_fp8)
         return c
 
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import streammind_oracle as O
-from tests.util_models import build_native, conn_gate_weights
+from tests.util_models import build_native, conn_gate_weights, fp8_view
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -351,3 +351,34 @@ def test_full_width_llm_two_layers_prefill_and_decode():
             break
     lg2, _ = s.logits()
     assert torch.isfinite(lg2).all() and s.kv_len == 96
+
+
+def test_fp8_weights_mode_gate_and_llm(gold):
+    """opt-in BASELINE config 5: gate + LLM weights quantised to fp8 at load time.  Checked against the oracle run on
+    the dequantised weights (the mode's own definition): gate logits 1e-3, prefill logits 3e-2, greedy ids where the
+    margin allows; the connector and the ViT stay bf16."""
+    Wv = O.make_vit_weights(TV, 41)
+    Wc = conn_gate_weights(TC, TG, 86)
+    Wl = O.make_lm_weights(TL, 44)
+    m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, weights_fp8=True)
+    Wc8 = {k: (O.fp8_quantize_rows(v)[0] if (k.startswith("cls_net.") and v.dim() == 2 and "embed_tokens" not in k) else v) for k, v in Wc.items()}
+    Wl8 = fp8_view(Wl)
+    pooled = torch.randn(6, TC.mm_hidden, generator=torch.Generator().manual_seed(4))
+    s = m.open_stream(max_frames=32, max_seq=128)
+    lg, dec = s.push_pooled(pooled.cuda())
+    tok = O.connector_scan(pooled, Wc8, TC)
+    ref = O.gate_logits_shortcut(tok, Wc8, TG)
+    assert maxdiff(lg, ref) < 1e-3
+    assert maxdiff(lg, O.gate_logits_shortcut(tok, Wc, TG)) > 1e-4          # it really is a different (quantised) model
+    emb_ids = torch.cat([torch.tensor([1, 7, 9]), -(torch.arange(6) + 1), torch.tensor([11, 12] * 9)]).to(torch.int32)   # 27 > 16: chunked
+    s.prefill(emb_ids.cuda())
+    logits, _ = s.logits()
+    table = Wl["model.embed_tokens.weight"]
+    emb = torch.cat([table[[1, 7, 9]], tok, table[[11, 12] * 9]])
+    ref_ids, trace = O.greedy_generate(emb, Wl8, TL, 5, eos_token_id=None, prec=O.MIXED, return_logits=True)
+    assert maxdiff(logits, trace[0]) < 3e-2
+    got = s.decode(4).cpu().tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 6e-2
+            break
