@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--batch", type=int, default=28, help="frames per step (28 x 577 tokens = 63.1 tiles of 256 rows: every "
                                                            "ViT GEMM is a whole number of 256-CU rounds)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (perception + scheduled replies) leg")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the opt-in fp8-weight decode leg (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-decode", action="store_true", help="skip the Mistral-7B decode tokens/s leg")
@@ -358,6 +359,26 @@ def main():
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches": cnt.value, "avg_launch_us": round(avg_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch}
+    fp8_leg = None
+    if not a.no_decode and not a.no_fp8 and world == 1:
+        # BASELINE config 5 (reported separately, never the headline: reduced-precision weights): a second replica whose gate
+        # + LLM weights are quantised to fp8 at load time
+        try:
+            del stream
+            cfg8 = PathConfig(llm_layers=32, max_frames_per_call=1, vit_layers=2, weights_fp8=True)
+            m8 = NativeModel(cfg8, f"cuda:{local}")
+            random_weights_into(m8, cfg8, seed=1234)
+            random_llm_weights_into(m8, cfg8, seed=4321)
+            m8.finalize()
+            s8 = m8.open_stream(max_frames=512, max_seq=1024)
+            fp8_leg = decode_leg(m8, s8, cfg8)
+            fp8_leg["roofline"]["bytes_per_token"] = fp8_leg["roofline"]["bytes_per_token"] / 2 + 0.0
+            fp8_leg["roofline"]["achieved"] = round(fp8_leg["roofline"]["bytes_per_token"] * fp8_leg["tokens_per_s"] / 1e9, 1)
+            fp8_leg["roofline"]["frac"] = round(fp8_leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
+            fp8_leg["note"] = "weight-only fp8 (OCP e4m3, per-row scales) for gate + LLM, bf16 activations and KV; opt-in mode"
+            s8.close(); m8.close()
+        except Exception as e:          # the optional leg must never take the headline down
+            fp8_leg = {"error": repr(e)[:300]}
     if rank == 0:
         total_frames = world * B * a.steps
         out = {
@@ -373,6 +394,7 @@ def main():
             "roofline": roof,
             "decode": dec_leg,
             "end_to_end": e2e,
+            "decode_fp8_weights": fp8_leg,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

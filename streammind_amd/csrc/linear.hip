@@ -137,10 +137,11 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
     const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
     const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
     union { bf16x8 v; uint32_t u[4]; } r;
-    r.u[0] = (__float_as_uint(a[0]) >> 16) | (__float_as_uint(a[1]) & 0xffff0000u);
-    r.u[1] = (__float_as_uint(b[0]) >> 16) | (__float_as_uint(b[1]) & 0xffff0000u);
-    r.u[2] = (__float_as_uint(c[0]) >> 16) | (__float_as_uint(c[1]) & 0xffff0000u);
-    r.u[3] = (__float_as_uint(d[0]) >> 16) | (__float_as_uint(d[1]) & 0xffff0000u);
+    // v_perm_b32: result = {hi16(second), hi16(first)}  (selector bytes 4-7 index the first source, 0-3 the second)
+    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
+    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
+    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
+    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
     return r.v;
 }
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
     const bool valid = i < a.M;
     const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
     f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    constexpr int U = 2;
+    constexpr int U = DUAL ? 2 : 4;
     int kp = wave;
     auto body = [&](u32x4 q, u32x4 q2, int kpi) {
 #pragma unroll
