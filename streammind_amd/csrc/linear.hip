@@ -545,7 +545,13 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
             return launch_skinny_fp8<1>(a, xf32, split, dual, st);
         }
         // enough waves per row-group to keep >= ~32 KiB of weight loads in flight per CU
-        if (a.KS >= 64 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
+        {   static int fw = -1;                       // SM_SKINNY_WAVES=4|8|16: tuning override (tools/decode_bench.py)
+            if (fw < 0) { const char* e = getenv("SM_SKINNY_WAVES"); fw = e ? atoi(e) : 0; }
+            if (fw == 4 && a.KS >= 4) return launch_skinny<4>(a, xf32, split, dual, st);
+            if (fw == 8 && a.KS >= 8) return launch_skinny<8>(a, xf32, split, dual, st);
+            if (fw == 16 && a.KS >= 16 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
+        }
+        // measured on the Mistral-7B decode step: 8 waves per row-group (2 blocks/CU) 297 tok/s, 16 waves 291, 4 waves 265
         if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);
         if (a.KS >= 8) return launch_skinny<4>(a, xf32, split, dual, st);
         return launch_skinny<1>(a, xf32, split, dual, st);
