@@ -54,8 +54,8 @@ int sm_quant_pack_weight_fp8(const void* w_bf16, int N, int K, int ldw, void* ou
 
 /* ------------------------------------------------------------------------------------------------
  * Linear:  Y[M,N] = epilogue( X[M,K] . W[N,K]^T ).  Replaces every torch F.linear / cuBLAS GEMM+GEMV on
- * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 16 takes the weight-streaming "skinny" kernel
- * (HBM-bound, MFMA 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.
+ * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 32 (<= 16 with fp8 weights) takes the weight-streaming
+ * "skinny" kernel (HBM-bound, MFMA 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sm_linear_t {
     const void* w;        /* packed bf16 [N][K]                                                     */
@@ -63,7 +63,7 @@ typedef struct sm_linear_t {
                           /*   (SwiGLU gate/up; skinny path only)                                   */
     int N, K;
     const void* x;        /* activations, row-major [M][ldx], bf16 or fp32 (x_dtype)                */
-    int x_dtype;          /* SM_X_BF16 / SM_X_F32 (fp32 only on the skinny path)                    */
+    int x_dtype;          /* SM_X_BF16 / SM_X_F32 (fp32 only on the skinny path, M <= 32)            */
     int precise;          /* fp32 x only: split x into bf16 hi+lo and issue two MFMAs (~fp32 acts)  */
     int M, ldx;
     const float* bias;    /* [N] or NULL                                                            */

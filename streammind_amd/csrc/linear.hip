@@ -60,16 +60,17 @@ __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16
             a = *(const f32x4*)(xrow + (size_t)k * 4);
             b = *(const f32x4*)(xrow + (size_t)k * 4 + 16);
         }
-        float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        union { bf16x8 v; uint16_t u[8]; } H, L;
+        // hardware RNE conversions (v_cvt_pk_bf16_f32); lo = bf16(x - hi) carries the next 8 mantissa bits
+        const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        bf16x8 H, L;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            uint32_t h = f2bf(f[j]);
-            H.u[j] = (uint16_t)h;
-            if (SPLIT) L.u[j] = (uint16_t)f2bf(f[j] - bf2f(h));
+            const __bf16 h = (__bf16)f[j];
+            H[j] = h;
+            if (SPLIT) L[j] = (__bf16)(f[j] - (float)h);
         }
-        hi = H.v;
-        if (SPLIT) lo = L.v;
+        hi = H;
+        if (SPLIT) lo = L;
     } else {
         union { bf16x8 v; u32x4 u; } H;
         H.u = u32x4{0, 0, 0, 0};
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
 // reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB>   // MB: 16-row activation blocks (M <= 16 * MB)
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -227,65 +228,84 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
     const int i = lane & 15, g = lane >> 4;
     const bf16x8* wp = a.w + (size_t)rg * KS * 64 + lane;
     const bf16x8* wp2 = DUAL ? a.w2 + (size_t)rg * KS * 64 + lane : nullptr;
-    const bool valid = i < a.M;
-    const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
-    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    bool valid[MB];
+    const char* xrow[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        valid[mb] = mb * 16 + i < a.M;
+        xrow[mb] = (const char*)a.x + (size_t)(valid[mb] ? mb * 16 + i : 0) * a.ldx * (XF32 ? 4 : 2);
+    }
+    f32x4 acc[MB], acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { acc[mb] = f32x4{0, 0, 0, 0}; acc2[mb] = f32x4{0, 0, 0, 0}; }
 
-    constexpr int U = 4;
+    constexpr int U = MB == 1 ? 4 : 2;
     int ks = wave;
     for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
-        bf16x8 wa[U], wb[U], xh[U], xl[U];
+        bf16x8 wa[U], wb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             wa[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
             if (DUAL) wb[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) load_x<XF32, SPLIT>(xrow, (ks + u * WAVES) * 32 + g * 8, valid, xh[u], xl[u]);
+        for (int mb = 0; mb < MB; ++mb) {
+            bf16x8 xh[U], xl[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc, 0, 0, 0);
-            if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc, 0, 0, 0);
-            if (DUAL) {
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2, 0, 0, 0);
-                if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2, 0, 0, 0);
+            for (int u = 0; u < U; ++u) load_x<XF32, SPLIT>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc[mb], 0, 0, 0);
+                if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc[mb], 0, 0, 0);
+                if (DUAL) {
+                    acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2[mb], 0, 0, 0);
+                    if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2[mb], 0, 0, 0);
+                }
             }
         }
     }
     for (; ks < KS; ks += WAVES) {
-        bf16x8 xh, xl;
-        bf16x8 wa = __builtin_nontemporal_load(wp + (size_t)ks * 64);
-        load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid, xh, xl);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc, 0, 0, 0);
-        if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc, 0, 0, 0);
-        if (DUAL) {
-            bf16x8 wb = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xh, acc2, 0, 0, 0);
-            if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xl, acc2, 0, 0, 0);
+        bf16x8 wa = __builtin_nontemporal_load(wp + (size_t)ks * 64), wb;
+        if (DUAL) wb = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            bf16x8 xh, xl;
+            load_x<XF32, SPLIT>(xrow[mb], ks * 32 + g * 8, valid[mb], xh, xl);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc[mb], 0, 0, 0);
+            if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc[mb], 0, 0, 0);
+            if (DUAL) {
+                acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xh, acc2[mb], 0, 0, 0);
+                if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xl, acc2[mb], 0, 0, 0);
+            }
         }
     }
     if (WAVES > 1) {
-        // cross-wave K reduction in a FIXED order (deterministic): red[wave][reg][lane]
-        constexpr int PER = DUAL ? 8 : 4;
+        // cross-wave K reduction in a FIXED order (deterministic): red[wave][mb][reg][lane]
+        constexpr int PER = (DUAL ? 8 : 4) * MB;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[(wave * PER + r) * 64 + lane] = acc[r];
-            if (DUAL) red[(wave * PER + 4 + r) * 64 + lane] = acc2[r];
-        }
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(wave * PER + mb * (DUAL ? 8 : 4) + r) * 64 + lane] = acc[mb][r];
+                if (DUAL) red[(wave * PER + mb * 8 + 4 + r) * 64 + lane] = acc2[mb][r];
+            }
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = 0.f, s2 = 0.f;
-            for (int w = 0; w < WAVES; ++w) {
-                s += red[(w * PER + r) * 64 + lane];
-                if (DUAL) s2 += red[(w * PER + 4 + r) * 64 + lane];
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, s2 = 0.f;
+                for (int w = 0; w < WAVES; ++w) {
+                    s += red[(w * PER + mb * (DUAL ? 8 : 4) + r) * 64 + lane];
+                    if (DUAL) s2 += red[(w * PER + mb * 8 + 4 + r) * 64 + lane];
+                }
+                acc[mb][r] = s;
+                if (DUAL) acc2[mb][r] = s2;
             }
-            acc[r] = s;
-            if (DUAL) acc2[r] = s2;
-        }
     }
-    store4(a, i, rg * 16 + g * 4, acc, DUAL ? &acc2 : nullptr);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) store4(a, mb * 16 + i, rg * 16 + g * 4, acc[mb], DUAL ? &acc2[mb] : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------ tiled GEMM
@@ -491,11 +511,11 @@ static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual,
     return SM_OK;
 }
 
-template <int WAVES>
+template <int WAVES, int MB = 1>
 static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
     dim3 grid(a.NRG), block(WAVES * 64);
-    size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * 64 * sizeof(float) : 0;
-#define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU><<<grid, block, sh, st>>>(a)
+    size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * MB * 64 * sizeof(float) : 0;
+#define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB><<<grid, block, sh, st>>>(a)
     if (xf32) {
         if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
         else       { if (dual) SK(true, false, true); else SK(true, false, false); }
@@ -528,11 +548,12 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
     SM_REQUIRE(!w8 || p->M <= 16, "sm_linear: fp8 weights are supported on the weight-streaming path only (M <= 16, got %d)", p->M);
+    SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
     SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
     const bool xf32 = p->x_dtype == SM_X_F32;
-    if (p->M <= 16) {
+    if (p->M <= 16 || (p->M <= 32 && !w8)) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
         const bool split = xf32 && p->precise;
@@ -547,17 +568,22 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         // enough waves per row-group to keep >= ~32 KiB of weight loads in flight per CU
         {   static int fw = -1;                       // SM_SKINNY_WAVES=4|8|16: tuning override (tools/decode_bench.py)
             if (fw < 0) { const char* e = getenv("SM_SKINNY_WAVES"); fw = e ? atoi(e) : 0; }
-            if (fw == 4 && a.KS >= 4) return launch_skinny<4>(a, xf32, split, dual, st);
-            if (fw == 8 && a.KS >= 8) return launch_skinny<8>(a, xf32, split, dual, st);
-            if (fw == 16 && a.KS >= 16 && !dual) return launch_skinny<16>(a, xf32, split, dual, st);
+            if (fw == 4 && a.KS >= 4 && p->M <= 16) return launch_skinny<4>(a, xf32, split, dual, st);
+            if (fw == 8 && a.KS >= 8 && p->M <= 16) return launch_skinny<8>(a, xf32, split, dual, st);
+            if (fw == 16 && a.KS >= 16 && !dual && p->M <= 16) return launch_skinny<16>(a, xf32, split, dual, st);
+        }
+        if (p->M > 16) {                              // 17..32 activation rows: two MFMA column blocks share every weight load
+            if (a.KS >= 32) return launch_skinny<8, 2>(a, xf32, split, dual, st);
+            if (a.KS >= 8) return launch_skinny<4, 2>(a, xf32, split, dual, st);
+            return launch_skinny<1, 2>(a, xf32, split, dual, st);
         }
         // measured on the Mistral-7B decode step: 8 waves per row-group (2 blocks/CU) 297 tok/s, 16 waves 291, 4 waves 265
         if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);
         if (a.KS >= 8) return launch_skinny<4>(a, xf32, split, dual, st);
         return launch_skinny<1>(a, xf32, split, dual, st);
     }
-    SM_REQUIRE(!xf32, "sm_linear: the tiled GEMM takes bf16 activations (M=%d > 16)", p->M);
-    SM_REQUIRE(!p->w2, "sm_linear: dual weights only on the skinny path");
+    SM_REQUIRE(!xf32, "sm_linear: the tiled GEMM takes bf16 activations (M=%d > 32)", p->M);
+
     SM_REQUIRE(p->ldx % 8 == 0, "sm_linear: bf16 x needs ldx %% 8 == 0");
     SM_REQUIRE(!p->vt || (p->vt_n0 % GEMM_BN == 0 && !p->residual && p->remap_in == 0), "sm_linear: vt_n0 must be a multiple of %d on the GEMM path", GEMM_BN);
     // tile choice: 256x256 (one 8-wave block per CU, 128 FLOP per L2 byte) once its grid fills >= 3/4 of the chip,

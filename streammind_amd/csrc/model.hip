@@ -419,15 +419,15 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
     A(conv_state, (size_t)di * c.conn_d_conv * 4, true);
     A(ssm_state, (size_t)di * ds * 4, true);
     A(tokens, (size_t)max_frames * d * 4, false);
-    A(pooled, (size_t)(m->Bmax > 16 ? m->Bmax : 16) * c.conn_mm_hidden * 4, false);
-    A(t0, (size_t)16 * d * 4, false); A(u, (size_t)16 * d * 4, false);
-    A(xz, (size_t)16 * 2 * di * 4, false); A(xc, (size_t)16 * di * 4, false);
-    A(xdbl, (size_t)16 * xd * 4, true); A(delta, (size_t)16 * di * 4, false);
-    A(y, (size_t)16 * di * 4, false); A(r, (size_t)16 * d * 4, false); A(lnf, (size_t)16 * d * 4, false);
-    A(h, (size_t)16 * d * 4, false); A(hn, (size_t)16 * d * 4, false);
-    A(v, (size_t)16 * c.gate_kv_heads * gdh * 4, false); A(vrep, (size_t)16 * c.gate_heads * gdh * 4, false);
-    A(act, (size_t)16 * c.gate_mlp * 4, false); A(hfin, (size_t)16 * d * 4, false);
-    A(logits2, (size_t)16 * 2 * 4, false);
+    A(pooled, (size_t)(m->Bmax > 32 ? m->Bmax : 32) * c.conn_mm_hidden * 4, false);
+    A(t0, (size_t)32 * d * 4, false); A(u, (size_t)32 * d * 4, false);
+    A(xz, (size_t)32 * 2 * di * 4, false); A(xc, (size_t)32 * di * 4, false);
+    A(xdbl, (size_t)32 * xd * 4, true); A(delta, (size_t)32 * di * 4, false);
+    A(y, (size_t)32 * di * 4, false); A(r, (size_t)32 * d * 4, false); A(lnf, (size_t)32 * d * 4, false);
+    A(h, (size_t)32 * d * 4, false); A(hn, (size_t)32 * d * 4, false);
+    A(v, (size_t)32 * c.gate_kv_heads * gdh * 4, false); A(vrep, (size_t)32 * c.gate_heads * gdh * 4, false);
+    A(act, (size_t)32 * c.gate_mlp * 4, false); A(hfin, (size_t)32 * d * 4, false);
+    A(logits2, (size_t)32 * 2 * 4, false);
     if (!rc && c.llm_layers > 0) {
         SM_REQUIRE(max_seq > 0 && max_seq % 64 == 0, "sm_stream_open: max_seq must be a positive multiple of 64");
         s->max_seq = max_seq;
@@ -513,7 +513,7 @@ extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_tok
 
 // a5-a9: PreNet -> LN -> Mamba step -> +res -> LN_f -> PostNet -> 4-layer gate (V/O shortcut) -> logits, decisions
 extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
-    SM_REQUIRE(s && pooled && M >= 1 && M <= 16, "sm_stream_push_pooled: M=%d outside [1,16]", M);
+    SM_REQUIRE(s && pooled && M >= 1 && M <= (s->m->c.weights_fp8 ? 16 : 32), "sm_stream_push_pooled: M=%d outside [1,%d]", M, s->m->c.weights_fp8 ? 16 : 32);
     SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
     sm_model* m = s->m;
     const sm_config_t& c = m->c;
@@ -588,10 +588,11 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
 
 extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
     SM_REQUIRE(s && frames && M >= 1 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, max_frames_per_call=%d]", M, s ? s->m->Bmax : 0);
-    // one ViT batch, then the connector+gate in frame order, at most 16 frames per weight pass
+    // one ViT batch, then the connector+gate in frame order, at most 32 frames (16 with fp8 weights) per weight pass
     int rc = sm_vit_encode(s->m, frames, M, s->pooled.as<float>(), nullptr, nullptr, stream);
     if (rc) return rc;
-    const int parts = cdiv(M, 16), per = cdiv(M, parts);
+    const int cap = s->m->c.weights_fp8 ? 16 : 32;
+    const int parts = cdiv(M, cap), per = cdiv(M, parts);
     for (int i = 0; i < M; i += per) {
         const int n = M - i < per ? M - i : per;
         rc = sm_stream_push_pooled(s, s->pooled.as<float>() + (size_t)i * s->m->c.conn_mm_hidden, n, logits ? logits + 2 * i : nullptr,
@@ -623,7 +624,7 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
         if ((rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-        if (n <= 16) {   // decode: SwiGLU fused into the dual skinny kernel
+        if (n <= 32) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel
             const Slot& gu = m->slots.at(p + "gu");
             sm_linear_t a = lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
             a.N = c.llm_mlp;

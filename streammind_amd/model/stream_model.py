@@ -108,8 +108,9 @@ class Video_Mamba_seq:
         check(nat.lib.sm_pool_rows(x.data_ptr(), _DT[x.dtype], t, l, d, pooled.data_ptr(), _stream()), "sm_pool_rows")
         s = nat.open_stream(max_frames=t, max_seq=64)
         logits = None
-        for i in range(0, t, 16):
-            logits, _ = s.push_pooled(pooled[i:i + 16].contiguous())
+        cap = 16 if nat.cfg.weights_fp8 else 32
+        for i in range(0, t, cap):
+            logits, _ = s.push_pooled(pooled[i:i + cap].contiguous())
         tokens = s.tokens().unsqueeze(0)
         s.close()
         if cls_demo:
@@ -165,7 +166,7 @@ class Videollama2MistralForCausalLM:
         x = x.to(self.device)
         nat, cfg = self.native, self.native.cfg
         logits = None
-        step = min(16, cfg.max_frames_per_call)
+        step = min(16 if cfg.weights_fp8 else 32, cfg.max_frames_per_call)
         for i in range(0, x.shape[0], step):
             xi = x[i:i + step].contiguous()
             if xi.dtype == torch.uint8 and xi.shape[-1] == 3:

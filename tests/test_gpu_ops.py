@@ -27,7 +27,7 @@ def relerr(a, b):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 256), (8, 4096, 4096), (16, 288, 8192), (1, 4096, 14336),
-                                   (5, 1024, 96), (2, 2, 4096), (1, 8192, 256)])
+                                   (5, 1024, 96), (2, 2, 4096), (1, 8192, 256), (17, 64, 128), (28, 4096, 4096), (32, 288, 8192)])
 @pytest.mark.parametrize("mode", ["f32_precise", "f32_single", "bf16"])
 def test_skinny_linear(nat, M, N, K, mode):
     """weight-streaming GEMV path vs fp32 matmul on the bf16-representable weights.
@@ -51,8 +51,9 @@ def test_skinny_linear(nat, M, N, K, mode):
     assert relerr(y, ref) < 2e-5
 
 
-def test_skinny_dual_swiglu(nat):
-    M, N, K = 4, 14336, 4096
+@pytest.mark.parametrize("M", [4, 28])
+def test_skinny_dual_swiglu(nat, M):
+    N, K = 14336, 4096
     wg, wu = O.bf16_round(rnd((N, K), 1, K ** -0.5)), O.bf16_round(rnd((N, K), 2, K ** -0.5))
     x = rnd((M, K), 3)
     y = nat.linear(x.cuda(), nat.pack_weight(wg.cuda().bfloat16()), N, K, w2p=nat.pack_weight(wu.cuda().bfloat16()), precise=True)
@@ -60,7 +61,7 @@ def test_skinny_dual_swiglu(nat):
     assert relerr(y, ref) < 3e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(17, 128, 64), (300, 384, 256), (577, 1024, 1024), (1154, 3072, 1024), (1000, 200, 4096)])
+@pytest.mark.parametrize("M,N,K", [(33, 128, 64), (300, 384, 256), (577, 1024, 1024), (1154, 3072, 1024), (1000, 200, 4096)])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_tiled_gemm(nat, M, N, K, out_dtype):
     """LDS-tiled MFMA GEMM: bf16 operands, fp32 accumulate -> 1e-5 relative against fp64 on the same bf16 inputs

@@ -45,8 +45,8 @@ def test_vit_tiny_vs_oracle(tiny):
     # K-summation order differs from the tiled GEMM's; at real dims both take the GEMM and are bit-identical)
     one = torch.cat([m.vit_encode(frames[i:i + 1].cuda()) for i in range(5)])
     assert maxdiff(one, pooled) < 1e-3
-    two = torch.cat([m.vit_encode(frames[i:i + 2].cuda().contiguous()) for i in (0, 2)])
-    assert torch.equal(two.cpu(), pooled.cpu()[:4])
+    three = m.vit_encode(frames[:3].cuda().contiguous())          # 51 token rows / 48 patch rows: tiled GEMM like the batch of 5
+    assert torch.equal(three.cpu(), pooled.cpu()[:3])
 
 
 def test_vit_fullwidth_golden(gold):
