@@ -12,15 +12,11 @@ typedef uint16_t bf16_t;   // raw storage type in HBM
 
 #define SM_WAVE 64
 
-// round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet); matches torch .to(bfloat16)
-__device__ __forceinline__ uint32_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+// round-to-nearest-even fp32 -> bf16 bits (hardware v_cvt_pk_bf16_f32; NaN stays NaN); matches torch .to(bfloat16)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return __builtin_bit_cast(uint32_t, bf16x2{(__bf16)lo, (__bf16)hi}); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -33,7 +29,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1/(1+e^-x) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~20-instruction IEEE division;
+// x -> -inf gives rcp(inf) = 0, x -> +inf gives rcp(1) = 1
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 
 // activations applied in GEMM epilogues (include/streammind_hip.h SM_ACT_*)

@@ -19,6 +19,14 @@
 #define G2_BM 256
 #define G2_BN 256
 
+// tools/gemm_timeline.hip compiles this file with SM_GEMM_TIMELINE to stamp each block's phases (100 MHz wall clock)
+#ifdef SM_GEMM_TIMELINE
+__device__ long long* g_gemm_timeline;
+#define TL(k) do { if (threadIdx.x == 0) g_gemm_timeline[(size_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TL(k) do {} while (0)
+#endif
+
 template <int ACT, int CPR, int RPP>     // CPR: 16-byte chunks per staged row; RPP: rows covered by one pass of the block
 __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
                                                    const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
@@ -73,6 +81,13 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     }
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
 
+    TL(0);
+#ifdef SM_GEMM_TIMELINE
+    if (threadIdx.x == 0) {
+        g_gemm_timeline[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+        g_gemm_timeline[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    }
+#endif
     f32x4 acc[8][4];
 #pragma unroll
     for (int nf = 0; nf < 8; ++nf)
@@ -115,6 +130,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             const int buf = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef SM_GEMM_TIMELINE
+            if (kt == 0) TL(1);
+#endif
             if (kt + 1 < KT) stage_half(kt + 1, buf ^ 1, 0);
             const char* sw = smem + buf * STAGE;
             const char* sx = sw + 32768;
@@ -209,6 +227,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         }
     }
     __syncthreads();       // every wave is done reading the staging buffers before the epilogue reuses them
+    TL(2);
 
     // ---- epilogue in two 128-row halves: waves wm = 2h, 2h+1 stage their accumulators ([128 m][BN n] fp32, 16-byte
     // chunk index XOR (m & 31)), then all waves write whole rows.
@@ -218,9 +237,54 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     const bool vt_tile = a.vt && tile_n * BN >= a.vt_n0;
     const bool fast = ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
                       (a.ldr & 3) == 0;
+    if constexpr (WN == 2 && ACT >= 0) {
+        // bf16-only outputs (qkv, fc1): bias + activation in registers, the WHOLE tile staged as bf16 ([256 m][256 n], 512-byte
+        // rows, 16-byte chunk index XOR (m & 31)) and written with 16 B per lane (two whole rows per wave-store): half the
+        // store instructions and LDS bytes of the fp32 staging below -- 8-byte stores ran at ~4.7 B/clk/CU, store-issue-bound.
+        if (fast && !vt_tile && a.out_bf16 && !a.out_f32 && !a.residual && (a.ldo_bf16 & 7) == 0 && ((uintptr_t)a.out_bf16 & 15) == 0) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) {
+                const int nl = wn * 128 + nf * 16 + g * 4;
+                f32x4 b4 = {0, 0, 0, 0};
+                if (a.bias) b4 = *(const f32x4*)(a.bias + tile_n * BN + nl);
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int ml = wm * 64 + mf * 16 + i;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = acc[nf][mf][j] + b4[j];
+                        if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
+                        o[j] = t;
+                    }
+                    *(u32x2*)(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) * 16) + (nl & 4) * 2) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                }
+            }
+            __syncthreads();
+            TL(3);
+            bf16_t* const __restrict__ ob = a.out_bf16;
+            const int chunk = tid & 31;
+#pragma unroll
+            for (int p0 = 0; p0 < 16; p0 += 4) {
+                u32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ml = (p0 + u) * 16 + (tid >> 5);
+                    v[u] = *(const u32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int m = tile_m * G2_BM + (p0 + u) * 16 + (tid >> 5);
+                    if (m < a.M) *(u32x4*)(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8) = v[u];
+                }
+            }
+            TL(4);
+            return;
+        }
+    }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+        if (half) { __syncthreads(); TL(3); }
         if ((wm >> 1) == half) {
 #pragma unroll
             for (int nf = 0; nf < 8; ++nf)
@@ -265,6 +329,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             }
         }
     }
+    TL(4);
 }
 
 template <int WN>
