@@ -28,8 +28,10 @@ struct AttnP {
     int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
 };
 
-template <int DH, bool GROUPQ = false, bool VROW = false>   // GROUPQ: decode mode (query row r of kv-group h is head h*nq + r);
-                                                            // VROW: V is row-major [key][d] and is transposed while it is staged
+template <int DH, bool GROUPQ = false, bool VROW = false, bool CAUSAL = false>
+// GROUPQ: decode mode (query row r of kv-group h is head h*nq + r); VROW: V is row-major [key][d] and is transposed while
+// it is staged; CAUSAL is compile-time so that the mask is a handful of v_cmp/v_cndmask under ONE wave-uniform branch (as
+// a runtime flag it compiled to two scalar branches per score: 64 per key tile)
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     constexpr int KSQ = DH / 32;             // k-steps of the QK^T contraction
     constexpr int DF = DH / 16;              // d fragments of the output
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
     int k_end = p.nk, k_begin = 0;
-    if (p.causal) {
+    if (CAUSAL) {
         int last = p.pos0 + min(qtile * 128 + 127, p.nq - 1) + 1;
         k_end = min(k_end, last);
     }
@@ -93,33 +95,61 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     constexpr int VPJ = (32 * KCH) / 256;          // VROW: (key pair, 16-byte d-chunk) items per thread
     u32x4 kreg[KJ], vreg[VROW ? 2 * VPJ : VJ];
     const bf16_t* vrow_base = VROW ? p.v + b * p.v_bs + kvh * DH : nullptr;
-    auto fetch = [&](int kt0) {
+    // per-thread source pointers of tile 0, advanced by one tile per fetch (the per-key clamp is only needed in a tile
+    // that runs past nk: recomputing min(key, nk-1) * row_stride for every item cost ~80 VALU instructions per tile)
+    const bf16_t* kptr[KJ];
+    const bf16_t* vptr[VROW ? 2 * VPJ : VJ];
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            int c = tid + 256 * j;
-            int key = c / KCH, cc = c % KCH;
-            int gk = min(kt0 + key, p.nk - 1);
-            kreg[j] = *(const u32x4*)(kbase + (long)gk * p.k_rs + cc * 8);
+    for (int j = 0; j < KJ; ++j) {
+        const int c = tid + 256 * j;
+        kptr[j] = kbase + (long)(k_begin + c / KCH) * p.k_rs + (c % KCH) * 8;
+    }
+    if (VROW) {
+#pragma unroll
+        for (int j = 0; j < VPJ; ++j) {
+            const int it = tid + 256 * j;
+            vptr[2 * j] = vrow_base + (long)(k_begin + 2 * (it & 31)) * p.v_rs + (it >> 5) * 8;
+            vptr[2 * j + 1] = vptr[2 * j] + p.v_rs;
         }
-        if (VROW) {
-            // lanes walk KEY PAIRS (kp = item & 31), the d-chunk cc = item >> 5 is wave-uniform-ish: the transposed
-            // ds_write_b32 of 32 consecutive key pairs then covers one whole 128-byte LDS row -> conflict-free
+    } else {
 #pragma unroll
-            for (int j = 0; j < VPJ; ++j) {
-                int it = tid + 256 * j;
-                int kp = it & 31, cc = it >> 5;
-                int k0 = min(kt0 + 2 * kp, p.nk - 1), k1 = min(kt0 + 2 * kp + 1, p.nk - 1);
-                vreg[2 * j] = *(const u32x4*)(vrow_base + (long)k0 * p.v_rs + cc * 8);
-                vreg[2 * j + 1] = *(const u32x4*)(vrow_base + (long)k1 * p.v_rs + cc * 8);
+        for (int j = 0; j < VJ; ++j) {
+            const int c = tid + 256 * j;
+            vptr[j] = vbase + (long)(c >> 3) * p.vt_ld + k_begin + (c & 7) * 8;
+        }
+    }
+    const long kstep = 64 * p.k_rs, vstep = VROW ? 64 * p.v_rs : 64;
+    auto fetch = [&](int kt0) {
+        if (kt0 + 64 <= p.nk || !VROW) {
+            if (kt0 + 64 <= p.nk) {
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) kreg[j] = *(const u32x4*)kptr[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    const int key = (tid + 256 * j) / KCH;
+                    kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (p.nk - 1), 0) * p.k_rs);
+                }
             }
+#pragma unroll
+            for (int j = 0; j < (VROW ? 2 * VPJ : VJ); ++j) vreg[j] = *(const u32x4*)vptr[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < VJ; ++j) {
-                int c = tid + 256 * j;
-                int d = c >> 3, cc = c & 7;
-                vreg[j] = *(const u32x4*)(vbase + (long)d * p.vt_ld + kt0 + cc * 8);
+            for (int j = 0; j < KJ; ++j) {
+                const int key = (tid + 256 * j) / KCH;
+                kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (p.nk - 1), 0) * p.k_rs);
+            }
+#pragma unroll
+            for (int j = 0; j < VPJ; ++j) {
+                const int kp = (tid + 256 * j) & 31;
+                vreg[2 * j] = *(const u32x4*)(vptr[2 * j] - (long)max(kt0 + 2 * kp - (p.nk - 1), 0) * p.v_rs);
+                vreg[2 * j + 1] = *(const u32x4*)(vptr[2 * j + 1] - (long)max(kt0 + 2 * kp + 1 - (p.nk - 1), 0) * p.v_rs);
             }
         }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) kptr[j] += kstep;
+#pragma unroll
+        for (int j = 0; j < (VROW ? 2 * VPJ : VJ); ++j) vptr[j] += vstep;
     };
     if (k_begin < k_end) fetch(k_begin);
     int buf = 0;
@@ -179,51 +209,64 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 s[1][kb][f] = a1;
             }
         // ---- mask + online softmax (lane-local query = lane & 15)
-        const bool need_mask = (kt0 + 64 > p.nk) || p.causal;
+        if (CAUSAL || kt0 + 64 > p.nk) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qpos = p.pos0 + q0 + qb * 16 + i;
+                const int lim = CAUSAL ? min(p.nk - 1, qpos) : p.nk - 1;       // last visible key of this lane's query
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
+                            s[qb][kb][f][r] = key > lim ? -INFINITY : s[qb][kb][f][r];
+                        }
+            }
+        }
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const int qpos = p.pos0 + q0 + qb * 16 + i;
             float mx = -INFINITY;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = s[qb][kb][f][r];
-                        if (need_mask) {
-                            int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
-                            if (key >= p.nk || (p.causal && key > qpos)) v = -INFINITY;
-                        }
-                        s[qb][kb][f][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kb][f][r]);
+            mx = xor32_max(xor16_max(mx));            // the 4 lanes (g = 0..3) that share this query
             const float m_new = fmaxf(m_run[qb], mx);
             // a fully masked row (causal, tile ahead of the query) keeps m_new = -inf: guard the subtraction
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float mc = m_use * p.c;
-            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));   // raw v_exp_f32; -inf -> 0
+            const bool moved = m_new != m_run[qb];                                  // the running max rose in this tile
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));   // raw v_exp_f32; -inf -> 0; 1 if !moved
             m_run[qb] = m_new;
-            float sum = 0.f;
+            f32x2 sum2 = {0.f, 0.f};
+            const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 bf16x8 pv;
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float e = __builtin_amdgcn_exp2f(fmaf(s[qb][kb][f][r], p.c, -mc));
-                        sum += e;
-                        pv[f * 4 + r] = (__bf16)e;
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;      // v_pk_fma_f32
+                        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        sum2 += e;                                                                    // v_pk_add_f32
+                        pv[f * 4 + r] = (__bf16)e[0];
+                        pv[f * 4 + r + 1] = (__bf16)e[1];
                     }
                 pf[qb][kb] = pv;
             }
-            l_run[qb] = l_run[qb] * alpha + sum;
+            l_run[qb] = l_run[qb] * alpha + (sum2[0] + sum2[1]);
+            // rescale the accumulators only when some lane's max moved (multiplying by alpha == 1 is exact, so skipping it
+            // is bit-identical); after the first few key tiles the maxima are stable and the 16 multiplies disappear
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
-            for (int df = 0; df < DF; ++df) o[qb][df] *= alpha;
+                for (int df = 0; df < DF; ++df) o[qb][df] *= alpha;
+            }
         }
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -240,8 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         float l = l_run[qb];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor32_sum(xor16_sum(l));
         const int qr = q0 + qb * 16 + i;
         if (p.split_len) {
             if (qr < p.nq) {
@@ -290,16 +332,18 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
     dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
     SmProfScope prof(SM_PROF_ATTN, st);
+    SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
+    SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
     if (p.v) {
         if (dh == 64) attn_kernel<64, false, true><<<grid, 256, 0, st>>>(p);
-        else if (dh == 128) attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
-        else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
-        SM_LAUNCH_CHECK();
-        return SM_OK;
+        else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
+    } else if (p.causal) {
+        if (dh == 64) attn_kernel<64, false, false, true><<<grid, 256, 0, st>>>(p);
+        else attn_kernel<128, false, false, true><<<grid, 256, 0, st>>>(p);
+    } else {
+        if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
+        else attn_kernel<128, false><<<grid, 256, 0, st>>>(p);
     }
-    if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
-    else if (dh == 128) attn_kernel<128, false><<<grid, 256, 0, st>>>(p);
-    else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

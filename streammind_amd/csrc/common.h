@@ -6,17 +6,48 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef uint16_t bf16_t;   // raw storage type in HBM
 
 #define SM_WAVE 64
 
+// 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1): the line leaves the XCD's L2 as it is written instead of
+// staying dirty until the end-of-kernel L2 write-back.  Big outputs that the NEXT kernel reads (GEMM / LayerNorm / attention
+// results) use it: with plain stores every kernel boundary paid dirty-bytes / ~6 TB/s (5.5-7 us behind a ViT-batch GEMM).
+__device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // round-to-nearest-even fp32 -> bf16 bits (hardware v_cvt_pk_bf16_f32; NaN stays NaN); matches torch .to(bfloat16)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return __builtin_bit_cast(uint32_t, bf16x2{(__bf16)lo, (__bf16)hi}); }
+
+// cross-row exchanges on the VALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of ds_bpermute's LDS round trip:
+// swapping x with itself leaves {row0,row0,row2,row2} / {row1,row1,row3,row3} (resp. the two 32-lane halves) in the pair
+__device__ __forceinline__ float xor16_max(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -57,7 +57,7 @@ __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem
                 if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
                 o[j] = t + r[u][j];
             }
-            if (out_f32) *(f32x4*)(out_f32 + (size_t)m * ldo + n) = o;
+            if (out_f32) store16_wt(out_f32 + (size_t)m * ldo + n, __builtin_bit_cast(u32x4, o));
             if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         }
     }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int m = tile_m * G2_BM + (p0 + u) * 16 + (tid >> 5);
-                    if (m < a.M) *(u32x4*)(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8) = v[u];
+                    if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8, v[u]);
                 }
             }
             TL(4);
