@@ -359,7 +359,7 @@ def main():
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
             big = B * (cfg.n_patches + 1) >= 192 * 64
-            roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256x64, 8 waves)" if big else
+            roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups)" if big else
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 4 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),

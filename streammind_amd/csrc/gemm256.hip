@@ -1,17 +1,20 @@
-// 256(m) x 256(n) x 64 bf16 MFMA GEMM for gfx950: the large-M workhorse (ViT batches, LLM prefill).
+// 256(m) x 256(n) bf16 MFMA GEMM for gfx950: the large-M workhorse (ViT batches, LLM prefill).
 //
 // Why a second tile size: the 128x128 kernel moves 32 KiB of operands through L2->LDS per 4.2 MFLOP (64 FLOP/B) and
 // is bound by that traffic (~15 TB/s chip-wide measured) at ~0.5-0.75 PFLOP/s; 256x256 doubles the intensity
 // (128 FLOP/B), so the same L2 bandwidth feeds twice the MFMA rate.
 //
 // Structure: 512 threads = 8 waves as 2(n) x 4(m); a wave owns 128(n) x 64(m) = 8 x 4 fragments (128 accumulator
-// VGPRs).  One block per CU; LDS = ring of 4 slots x (W 16 KiB + X 16 KiB), one 32-deep k-step per slot, loads three
-// k-steps ahead, one barrier per k-step (a 2-stage BK=64 version measured 1.7-2.4 us per 64-deep tile against
-// 0.85 us of MFMA time: with one block per CU a single tile in flight cannot cover the L2 latency).  Both operands
-// arrive by global_load_lds (16 B/lane): W chunks are already fragment-ordered (packed layout), X rows are
-// XOR-swizzled on the SOURCE address.  Epilogue: the fp32 tile is staged through LDS in two 128-row halves and written
-// as whole rows (1 KiB per wave-store), with the activation resolved at compile time and __restrict__ pointers so the
-// passes are not serialised on store round trips (see linear.hip).
+// VGPRs).  One block per CU; LDS = ring of 4 stages x (W 16 KiB + X 16 KiB), one 32-deep k-step per stage, loads three
+// k-steps ahead.  Both operands arrive by global_load_lds (16 B/lane): W chunks are already fragment-ordered (packed
+// layout), X rows are XOR-swizzled on the SOURCE address.  The two wave columns run one barrier apart so that one of the
+// two waves of every SIMD multiplies while the other reads fragments and issues the DMA (see the main loop).
+// Measured per 64-deep k-tile per CU (MI355X, M=16156): lockstep 2-stage BK=64 loop 1.63-1.80 us, this loop 1.45-1.55 us
+// (0.85 us = MFMA issue at 2.4 GHz); 4096^3: 1146 -> 1283 TFLOP/s.
+// Epilogues: bf16-only outputs are converted in registers, staged whole-tile as bf16 and written 16 B per lane; fp32 /
+// residual outputs are staged as fp32 in two 128-row halves and written as whole rows.  All stores are write-through
+// (sc1), the activation is resolved at compile time and the pointers are __restrict__ so the passes are not serialised
+// on store round trips (see linear.hip).  tools/gemm_timeline.hip prints the per-block phase times.
 #include <stdlib.h>
 
 #include "linear_common.h"
@@ -95,78 +98,86 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
 
     if constexpr (WN == 2) {
-        // ---- 256 x 256: two 64-KiB stages of one 64-deep k-tile each, ONE barrier per k-tile:
-        //   iteration t: wait(own loads of tile t) -> barrier (=> every wave also finished multiplying tile t-1, so
-        //   the other stage is free) -> issue the 8 loads of tile t+1 into it -> 2 x (12 ds_read_b128 + 32 MFMA).
-        // X rows are 128 B, 16-byte chunk index XOR (row & 7) applied on the SOURCE address and on the read.
-        constexpr int STAGE = 65536;
-        const int KT = a.KS >> 1;
-        const char* wsrc[4];
-        const char* xsrc[4];
+        // ---- 256 x 256: ring of four 32-KiB stages, one 32-deep k-step each (W: 16 packed 1-KiB fragment chunks; X: [256][32]
+        // bf16, 64-byte rows, 16-byte chunk index XOR P[(row >> 2) & 3], P = {0,3,2,1}, applied on the SOURCE address of the
+        // LDS-DMA and again on the read).  Loads run three k-steps ahead (4 global_load_lds per wave per step).
+        //
+        // Two wave groups (wn = 0 / 1: one wave of each per SIMD) run the SAME code one barrier apart, and every k-step is two
+        // barrier-delimited intervals  R | M  (R = 12 fragment reads + the 4 DMA issues of step t+3, M = 32 MFMAs): while one
+        // group multiplies, the other reads and issues loads, so a SIMD's matrix pipe and its LDS / address path work at
+        // the same time instead of alternately (lockstep BK=64 version: ~3600 clk per 64-deep tile against 2048 clk of MFMA
+        // issue; a staggered BK=64 version still put all 8 DMA issues, ~100 clk each, into one of its four intervals).
+        // Hazards (intervals numbered globally; group 0 does R(t) in 2t and M(t) in 2t+1, group 1 one interval later):
+        //   WAR  step t+3 is DMA'd into the stage of step t-1 during R(t) (interval >= 2t); that stage's last reader, group 1's
+        //        R(t-1) in interval 2t-1, retired its reads (lgkmcnt(0)) before the barrier that opens interval 2t.
+        //   RAW  before the barrier that closes its R(t) a wave has waited for its own loads of step t+1 (counted vmcnt: the
+        //        batches of t+2 and t+3 may stay in flight); group 0 first reads step t+1 in interval 2t+2, which opens with
+        //        the barrier group 1 reaches from its R(t) with that wait behind it.
+        constexpr int STAGE = 32768;
+        const int KS = a.KS;
+        const char* wsrc[2];
+        const char* xsrc[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = wave * 4 + j;             // 0..31: W chunk (rg_local = c >> 1, ks_local = c & 1) / X piece (8 rows)
-            int rgg = tile_n * 16 + (c >> 1);
+        for (int j = 0; j < 2; ++j) {
+            int rgg = tile_n * 16 + wave * 2 + j;
             if (rgg >= a.NRG) rgg = a.NRG - 1;
-            wsrc[j] = (const char*)a.w + ((size_t)rgg * a.KS + (c & 1)) * 1024 + lane * 16;
-            const int row = c * 8 + (lane >> 3);
+            wsrc[j] = (const char*)a.w + (size_t)rgg * KS * 1024 + lane * 16;
+            const int row = (wave * 2 + j) * 16 + (lane >> 2);
             int mg = tile_m * G2_BM + row;
             if (mg >= a.M) mg = a.M - 1;
-            const int chunk = (lane & 7) ^ (row & 7);
+            const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
             xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
         }
-        auto stage_half = [&](int kt, int buf, int half) {   // half 0: W chunks, half 1: X pieces (4 loads each)
-            char* sb = smem + buf * STAGE;
+        auto stage = [&](int ks) {
+            char* sb = smem + (ks & 3) * STAGE;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = wave * 4 + j;
-                if (half == 0) glds16(wsrc[j] + (size_t)kt * 2048, sb + c * 1024);
-                else glds16(xsrc[j] + (size_t)kt * 128, sb + 32768 + c * 1024);
-            }
+            for (int j = 0; j < 2; ++j) glds16(wsrc[j] + (size_t)ks * 1024, sb + (wave * 2 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) glds16(xsrc[j] + (size_t)ks * 64, sb + 16384 + (wave * 2 + j) * 1024);
         };
-        stage_half(0, 0, 0);
-        stage_half(0, 0, 1);
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#ifdef SM_GEMM_TIMELINE
-            if (kt == 0) TL(1);
-#endif
-            if (kt + 1 < KT) stage_half(kt + 1, buf ^ 1, 0);
-            const char* sw = smem + buf * STAGE;
-            const char* sx = sw + 32768;
-            // all 24 fragment reads of the tile are issued up front (96 VGPRs), then 2 x 32 MFMAs: the second half's
-            // reads land under the first half's MFMAs (left to itself hipcc waits lgkmcnt(0) before every group of 4
-            // MFMAs, exposing the LDS latency 16 times per tile).  The other half of the next tile's staging loads is
-            // issued between the two MFMA halves to spread the L2 request burst.
-            bf16x8 xf[2][4], wf[2][8];
+        stage(0);
+        if (KS > 1) stage(1);
+        if (KS > 2) stage(2);
+        if (KS > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (KS > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        TL(1);
+        if (wn == 1) __builtin_amdgcn_s_barrier();
+        for (int ks = 0; ks < KS; ++ks) {
+            const char* sw = smem + (ks & 3) * STAGE;
+            const char* sx = sw + 16384;
+            bf16x8 xf[4], wf[8];
 #pragma unroll
-            for (int ksl = 0; ksl < 2; ++ksl) {
+            for (int mf = 0; mf < 4; ++mf) {
+                const int ml = wm * 64 + mf * 16 + i;
+                xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+            }
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf) {
-                    const int ml = wm * 64 + mf * 16 + i;
-                    xf[ksl][mf] = *(const bf16x8*)(sx + ml * 128 + (((ksl * 4 + g) ^ (ml & 7)) * 16));
-                }
-#pragma unroll
-                for (int nf = 0; nf < 8; ++nf)
-                    wf[ksl][nf] = *(const bf16x8*)(sw + (((wn * 8 + nf) * 2 + ksl) * 1024) + lane * 16);
+            for (int nf = 0; nf < 8; ++nf) wf[nf] = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
+            if (ks + 3 < KS) {
+                stage(ks + 3);
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            } else if (ks + 2 < KS) {
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nf], xf[0][mf], acc[nf][mf], 0, 0, 0);
+                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < KT) stage_half(kt + 1, buf ^ 1, 1);
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
-#pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][nf], xf[1][mf], acc[nf][mf], 0, 0, 0);
         }
+        if (wn == 0) __builtin_amdgcn_s_barrier();
     } else {
         // ---- 256 x 128 (two blocks per CU): ring of 3 LDS slots, one 32-deep k-step each (W: packed 1-KiB chunks;
         // X: [256][32] bf16, 64-byte rows, chunk index XOR P[(row >> 2) & 3], P = {0,3,2,1}); loads run two k-steps
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 template <int WN>
 static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
     constexpr int BN = 128 * WN;
-    constexpr int LDS = WN == 2 ? 2 * 65536 : 3 * (BN * 64 + 16384);
+    constexpr int LDS = WN == 2 ? 4 * 32768 : 3 * (BN * 64 + 16384);
     const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, BN);
     static bool attr_set = false;
     if (!attr_set) {
