@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int df = 0; df < DF; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const bool active = q0 < p.nq;
 
     int k_end = p.nk, k_begin = 0;
     if (CAUSAL) {
@@ -191,12 +192,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         if (kt0 + 64 < k_end) fetch(kt0 + 64);
         buf ^= 1;
 
+        // a wave whose 32 query rows are all past nq (ViT: 577 = 4 x 128 + 65 -> the last wave of the last q-tile) only helps
+        // staging; a tile whose second 32-key block is all past k_end (ViT: key 576 alone in tile 10) skips that block
+        if (!active) continue;
+        const bool half = kt0 + 32 >= k_end;
         // ---- S^T = K . Q^T  (2 key blocks of 32 x 2 fragments x 2 query blocks)
         f32x4 s[2][2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
+                if (kb == 1 && half) {
+                    s[0][1][f] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    s[1][1][f] = s[0][1][f];
+                    continue;
+                }
                 const int rho = kb * 32 + f * 16 + i;
                 f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
@@ -248,6 +258,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 bf16x8 pv;
+                if (kb == 1 && half) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = (__bf16)0.0f;
+                    pf[qb][1] = pv;
+                    continue;
+                }
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -270,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         }
         // ---- O^T += V^T . P^T
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && half) continue;
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 const int d = df * 16 + i;
@@ -278,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][kb], o[0][df], 0, 0, 0);
                 o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][kb], o[1][df], 0, 0, 0);
             }
+        }
     }
     // ---- normalise and store: lane (g, q = i) holds d = df*16 + g*4 + 0..3
 #pragma unroll
