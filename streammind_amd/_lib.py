@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstreammind_hip.so")
+# A/B builds for tools/ (kernel variants compiled side by side): STREAMMIND_HIP_LIB=/path/to/other.so
+LIB_PATH = os.environ.get("STREAMMIND_HIP_LIB", LIB_PATH)
 
 SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
 SM_X_BF16, SM_X_F32 = 0, 1

@@ -16,6 +16,7 @@
 // (sc1), the activation is resolved at compile time and the pointers are __restrict__ so the passes are not serialised
 // on store round trips (see linear.hip).  tools/gemm_timeline.hip prints the per-block phase times.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "linear_common.h"
 
@@ -128,24 +129,27 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
             xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
         }
-        auto stage = [&](int ks) {
-            char* sb = smem + (ks & 3) * STAGE;
+        auto stage = [&](int ks, int slot) {
+            char* sb = smem + slot * STAGE;
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(wsrc[j] + (size_t)ks * 1024, sb + (wave * 2 + j) * 1024);
 #pragma unroll
             for (int j = 0; j < 2; ++j) glds16(xsrc[j] + (size_t)ks * 64, sb + 16384 + (wave * 2 + j) * 1024);
         };
-        stage(0);
-        if (KS > 1) stage(1);
-        if (KS > 2) stage(2);
+        stage(0, 0);
+        if (KS > 1) stage(1, 1);
+        if (KS > 2) stage(2, 2);
         if (KS > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (KS > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         TL(1);
         if (wn == 1) __builtin_amdgcn_s_barrier();
-        for (int ks = 0; ks < KS; ++ks) {
-            const char* sw = smem + (ks & 3) * STAGE;
+        // one k-step; TAIL = 0: steady state (issue step ks+3, leave the batches of ks+2 and ks+3 in flight), 1 / 2: the last
+        // steps (nothing left to issue).  A compile-time switch: runtime branches around the waits cost ~8 % in this loop.
+        auto kstep = [&](int ks, auto tail, int slot) {      // slot = ks & 3
+            constexpr int TAIL = decltype(tail)::value;
+            const char* sw = smem + slot * STAGE;
             const char* sx = sw + 16384;
             bf16x8 xf[4], wf[8];
 #pragma unroll
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             }
 #pragma unroll
             for (int nf = 0; nf < 8; ++nf) wf[nf] = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
-            if (ks + 3 < KS) {
-                stage(ks + 3);
+            if (TAIL == 0) {
+                stage(ks + 3, (slot + 3) & 3);
                 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            } else if (ks + 2 < KS) {
+            } else if (TAIL == 1) {
                 asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -176,7 +180,11 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        int ks = 0;
+        for (; ks + 3 < KS; ++ks) kstep(ks, std::integral_constant<int, 0>{}, ks & 3);
+        if (ks + 2 < KS) { kstep(ks, std::integral_constant<int, 1>{}, ks & 3); ++ks; }
+        for (; ks < KS; ++ks) kstep(ks, std::integral_constant<int, 2>{}, ks & 3);
         if (wn == 0) __builtin_amdgcn_s_barrier();
     } else {
         // ---- 256 x 128 (two blocks per CU): ring of 3 LDS slots, one 32-deep k-step each (W: packed 1-KiB chunks;
