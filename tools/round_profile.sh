@@ -1,0 +1,16 @@
+#!/bin/bash
+# End-of-round measurement set (run on the GPU box via gpurun): full GPU test suite, default bench line, rocprofv3 kernel
+# stats of the same command, PMC traffic passes.  Summaries land in gpurun_out/round/ -- copy what is to be judged to profiles/.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/round; mkdir -p $O
+timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+timeout 900 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log > $O/bench_default.json; cut -c1-400 $O/bench_default.json
+rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_profiled.log 2>&1
+grep '^{"metric"' $O/bench_profiled.log > $O/bench_profiled.json
+cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" $O/kernel_stats.csv
+rm -rf /tmp/pmc_f /tmp/pmc_w
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof > /dev/null 2>&1
+python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
+head -12 $O/kernel_stats.csv | cut -c1-160
