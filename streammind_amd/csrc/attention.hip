@@ -9,8 +9,12 @@
 //   so that the S^T accumulators of fragments f = 0,1 are, register for register, the 8 consecutive keys the
 //   PV MFMA wants in its B operand: no transpose, no LDS round trip, no cross-lane traffic for P.
 //   V is consumed as V^T ([d][keys]); the producers (QKV GEMM epilogue / KV-append kernel) write it that way.
+#include <type_traits>
 #include "common.h"
 #include "host.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_a;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_a;
 
 struct AttnP {
     const bf16_t* q; long q_bs, q_rs;       // batch stride, row stride (elements); head h at column h*DH
@@ -74,7 +78,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int df = 0; df < DF; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    // row sums ride the matrix pipe: one extra PV fragment whose V^T rows are all ones accumulates sum_k P[q][k] (of the SAME
+    // bf16-rounded P the numerator uses) in every row -> no VALU adds per score and no cross-lane reduction at the end
+    f32x4 lsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const bool active = q0 < p.nq;
 
     int k_end = p.nk, k_begin = 0;
@@ -253,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             const bool moved = m_new != m_run[qb];                                  // the running max rose in this tile
             const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));   // raw v_exp_f32; -inf -> 0; 1 if !moved
             m_run[qb] = m_new;
-            f32x2 sum2 = {0.f, 0.f};
             const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -270,24 +279,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                     for (int r = 0; r < 4; r += 2) {
                         const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;      // v_pk_fma_f32
                         const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                        sum2 += e;                                                                    // v_pk_add_f32
                         pv[f * 4 + r] = (__bf16)e[0];
                         pv[f * 4 + r + 1] = (__bf16)e[1];
                     }
                 pf[qb][kb] = pv;
             }
-            l_run[qb] = l_run[qb] * alpha + (sum2[0] + sum2[1]);
             // rescale the accumulators only when some lane's max moved (multiplying by alpha == 1 is exact, so skipping it
             // is bit-identical); after the first few key tiles the maxima are stable and the 16 multiplies disappear
             if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
                 for (int df = 0; df < DF; ++df) o[qb][df] *= alpha;
+                lsum[qb] *= alpha;
             }
         }
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && half) continue;
+            lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][kb], lsum[0], 0, 0, 0);
+            lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][kb], lsum[1], 0, 0, 0);
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 const int d = df * 16 + i;
@@ -300,8 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // ---- normalise and store: lane (g, q = i) holds d = df*16 + g*4 + 0..3
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        float l = l_run[qb];
-        l = xor32_sum(xor16_sum(l));
+        const float l = lsum[qb][0];
         const int qr = q0 + qb * 16 + i;
         if (p.split_len) {
             if (qr < p.nq) {
@@ -318,6 +327,223 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             bf16_t* dst = p.o + b * p.o_bs + (long)qr * p.o_rs + h * DH + g * 4;
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
+                f32x4 v = o[qb][df] * inv;
+                bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                *(bf16x4*)(dst + df * 16) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ViT fast path
+// Non-causal attention with head_dim 64 and V row-major inside the fused qkv buffer (CLIP ViT).  Same math and register
+// layout as attn_kernel, but the tiles never pass through registers:
+//   * K and V tiles are DMA'd global -> LDS (global_load_lds, 16 B/lane); the K row permutation / chunk swizzle and the V
+//     block swizzle are applied on the per-lane SOURCE address (the LDS image of an LDS-DMA is lane-linear);
+//   * V stays row-major [key][d] in LDS and the PV A-operand (V^T fragment: 8 keys of one d per lane) is fetched with two
+//     ds_read_b64_tr_b16 (hardware 4x4 transpose) -- the register-staged version spent ~26 VALU + 8 ds_write_b32 per thread
+//     and tile on the transpose, and measured 26 % of the kernel in staging + its barrier.
+//   V LDS image: byte(key, d) = key*128 + (((d >> 4) ^ h(key)) * 32) + (d & 15)*2, h = ((key >> 1) & 1) | (((key >> 3) & 1) << 1):
+//   the 8 rows x 32 B that one 32-lane phase of the transpose read touches land on 8 different 32-byte bank groups.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
+    constexpr int DH = 64, KROW = 128, TILE_BYTES = 16384;
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    int h, b, qtile;
+    {
+        const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+        const int grp = (j / p.nqt) * 8 + xcd;
+        qtile = j % p.nqt;
+        if (grp >= p.H * p.nbatch) return;
+        h = grp % p.H; b = grp / p.H;
+    }
+    const int q0 = qtile * 128 + wave * 32;
+    bf16x8 qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 16 + i;
+        if (qr >= p.nq) qr = p.nq - 1;
+        const bf16_t* src = p.q + b * p.q_bs + (long)qr * p.q_rs + h * DH + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = *(const bf16x8*)(src + ks * 32);
+    }
+    f32x4 o[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int df = 0; df < 4; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    f32x4 lsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const bool active = q0 < p.nq;
+    const int nk = p.nk;
+
+    // per-lane DMA sources: wave w issues K pieces 2w, 2w+1 and V pieces 2w, 2w+1 (1 KiB = 8 LDS rows each)
+    const bf16_t* ksrc[2];
+    const bf16_t* vsrc[2];
+    int krow[2], vrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int R = (wave * 2 + j) * 8 + (lane >> 3), slot = lane & 7;
+        // K: LDS row R holds key inv(R) (rows permuted so that S^T accumulators are PV B-operands), chunk cc at slot cc ^ (R & 7)
+        const int r5 = R & 31;
+        const int key = (R & 32) | (((r5 >> 2) & 3) << 3) | (((r5 >> 4) & 1) << 2) | (r5 & 3);
+        krow[j] = key;
+        ksrc[j] = p.k + b * p.k_bs + h * DH + (long)key * p.k_rs + ((slot ^ (R & 7)) * 8);
+        // V: LDS row R = key R, 32-byte block (slot >> 1) holds d-block (slot >> 1) ^ h(R)
+        const int hk = ((R >> 1) & 1) | (((R >> 3) & 1) << 1);
+        vrow[j] = R;
+        vsrc[j] = p.v + b * p.v_bs + h * DH + (long)R * p.v_rs + ((((slot >> 1) ^ hk) * 2 + (slot & 1)) * 8);
+    }
+    // DMA of the tile the source pointers currently point at; CLAMP: the tile runs past nk (keys >= nk re-read row nk-1, they
+    // are masked later).  The pointers then advance by one tile -- no per-tile address arithmetic beyond four 64-bit adds.
+    const long kadv = 64 * p.k_rs, vadv = 64 * p.v_rs;
+    auto issue = [&](int kt0, int bufi, auto clamp) {
+        constexpr bool CLAMP = decltype(clamp)::value;
+        char* Kl = lds + bufi * TILE_BYTES;
+        char* Vl = Kl + 8192;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* ks = ksrc[j];
+            const bf16_t* vs = vsrc[j];
+            if (CLAMP) {
+                ks -= (long)max(kt0 + krow[j] - (nk - 1), 0) * p.k_rs;
+                vs -= (long)max(kt0 + vrow[j] - (nk - 1), 0) * p.v_rs;
+            }
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)ks, (lds_ptr_a)(Kl + (wave * 2 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)vs, (lds_ptr_a)(Vl + (wave * 2 + j) * 1024), 16, 0, 0);
+            ksrc[j] += kadv;
+            vsrc[j] += vadv;
+        }
+    };
+    // one key tile; PART: the (last) tile that runs past nk -- only it carries the key mask and the half-tile skip
+    int buf = 0;
+    auto tile = [&](int kt0, auto part) {
+        constexpr bool PART = decltype(part)::value;
+        const char* Kl = lds + buf * TILE_BYTES;
+        const char* Vl = Kl + 8192;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();              // every wave's pieces of this tile have landed; everyone is done with the other buffer
+        if (!PART) {
+            if (kt0 + 128 <= nk) issue(kt0 + 64, buf ^ 1, std::false_type{});
+            else if (kt0 + 64 < nk) issue(kt0 + 64, buf ^ 1, std::true_type{});
+        }
+        buf ^= 1;
+        if (!active) return;
+        const bool half = PART && kt0 + 32 >= nk;
+        // ---- S^T = K . Q^T
+        f32x4 s[2][2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                if (PART && kb == 1 && half) {
+                    s[0][1][f] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    s[1][1][f] = s[0][1][f];
+                    continue;
+                }
+                const int rho = kb * 32 + f * 16 + i;
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 kf = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & 7)) * 16));
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], a1, 0, 0, 0);
+                }
+                s[0][kb][f] = a0;
+                s[1][kb][f] = a1;
+            }
+        if (PART) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
+                            s[qb][kb][f][r] = key >= nk ? -INFINITY : s[qb][kb][f][r];
+                        }
+        }
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            // two independent max chains per query block (a single chain is 32 dependent v_max)
+            float mxa = fmaxf(fmaxf(s[qb][0][0][0], s[qb][0][0][1]), fmaxf(s[qb][0][0][2], s[qb][0][0][3]));
+            float mxb = fmaxf(fmaxf(s[qb][0][1][0], s[qb][0][1][1]), fmaxf(s[qb][0][1][2], s[qb][0][1][3]));
+            float mxc = fmaxf(fmaxf(s[qb][1][0][0], s[qb][1][0][1]), fmaxf(s[qb][1][0][2], s[qb][1][0][3]));
+            float mxd = fmaxf(fmaxf(s[qb][1][1][0], s[qb][1][1][1]), fmaxf(s[qb][1][1][2], s[qb][1][1][3]));
+            float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
+            mx = xor32_max(xor16_max(mx));
+            const float m_new = fmaxf(m_run[qb], mx);         // finite: every tile holds at least one real key
+            const float mc = m_new * p.c;
+            const bool moved = m_new != m_run[qb];
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));
+            m_run[qb] = m_new;
+            const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 pv;
+                if (PART && kb == 1 && half) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = (__bf16)0.0f;
+                    pf[qb][1] = pv;
+                    continue;
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;
+                        pv[f * 4 + r] = (__bf16)__builtin_amdgcn_exp2f(t[0]);
+                        pv[f * 4 + r + 1] = (__bf16)__builtin_amdgcn_exp2f(t[1]);
+                    }
+                pf[qb][kb] = pv;
+            }
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+                for (int df = 0; df < 4; ++df) o[qb][df] *= alpha;
+                lsum[qb] *= alpha;
+            }
+        }
+        // ---- O^T += V^T . P^T, V^T fragments by transpose reads of the row-major V tile
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (PART && kb == 1 && half) continue;
+            lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][kb], lsum[0], 0, 0, 0);
+            lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][kb], lsum[1], 0, 0, 0);
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                union { bf16x8 v; s16x4 hlf[2]; } vf;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int key = kb * 32 + g * 8 + u * 4 + (i >> 2);
+                    const int hk = ((key >> 1) & 1) | (((key >> 3) & 1) << 1);
+                    vf.hlf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(Vl + key * 128 + ((df ^ hk) * 32) + (i & 3) * 8));
+                }
+                o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[0][kb], o[0][df], 0, 0, 0);
+                o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[1][kb], o[1][df], 0, 0, 0);
+            }
+        }
+    };
+    if (nk >= 64) issue(0, 0, std::false_type{}); else issue(0, 0, std::true_type{});
+    int kt0 = 0;
+    for (; kt0 + 64 <= nk; kt0 += 64) tile(kt0, std::false_type{});
+    if (kt0 < nk) tile(kt0, std::true_type{});
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float inv = 1.0f / lsum[qb][0];
+        const int qr = q0 + qb * 16 + i;
+        if (qr < p.nq) {
+            bf16_t* dst = p.o + b * p.o_bs + (long)qr * p.o_rs + h * DH + g * 4;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
                 f32x4 v = o[qb][df] * inv;
                 bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 *(bf16x4*)(dst + df * 16) = w;
@@ -353,7 +579,7 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
     if (p.v) {
-        if (dh == 64) attn_kernel<64, false, true><<<grid, 256, 0, st>>>(p);
+        if (dh == 64) vit_attn_kernel<<<grid, 256, 0, st>>>(p);
         else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
     } else if (p.causal) {
         if (dh == 64) attn_kernel<64, false, false, true><<<grid, 256, 0, st>>>(p);
