@@ -239,6 +239,16 @@ int sm_stream_set_kv_len(sm_stream* s, int n);            /* truncate the KV cac
 /* a10+a12 prefill: n new positions; ids[i] >= 0 text token, ids[i] < 0 -> frame token (-ids[i]-1).
  * Appends to the KV cache at kv_len, leaves the greedy next token in the stream (device).           */
 int sm_llm_prefill(sm_stream* s, const int32_t* ids_dev, int n, void* stream);
+/* f1 teacher-forced forward (videollama2_mistral.py:173-259 with labels / llm_eval: super().forward over the spliced
+ * sequence): the same n new positions as sm_llm_prefill, but the final norm + lm_head run on EVERY position;
+ * logits_dev fp32 [n][vocab].  Appends to the KV cache like a prefill and leaves the greedy token of the last row. */
+int sm_llm_forward_logits(sm_stream* s, const int32_t* ids_dev, int n, float* logits_dev, void* stream);
+/* per-row softmax cross-entropy + argmax over logits fp32 [n][ld] (V valid columns): nll[i] = logsumexp(row i) -
+ * row i[labels[i]], 0 where labels[i] == ignore_index; argmax = first maximal column (torch.argmax).  The caller passes
+ * SHIFTED labels (row t scored against label t+1) and reduces nll as HF's CrossEntropyLoss does (mean over the scored
+ * rows; class-weighted mean for the gate, builder.py:345-349).  Either output may be NULL.                   */
+int sm_cross_entropy(const float* logits, int n, int V, int ld, const int32_t* labels, int ignore_index, float* nll,
+                     int32_t* argmax, void* stream);
 /* a12 decode: n_steps greedy steps continuing from the last prefill/decode; out_ids_dev[n_steps] int32 device.
  * Step j emits the token predicted after the previous one, feeds it back, appends its KV.             */
 int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids_dev, void* stream);

@@ -625,6 +625,143 @@ def splice_embeds(input_ids: Sequence[int], tokens: Tensor, interval_ids: Sequen
 
 
 # ----------------------------------------------------------------------------------------------
+# f1  teacher-forced evaluation: all frames -> ViT -> full scan -> ONE LLM forward with labels, and the
+#     batch gate evaluation.  videollama2_arch.py:135-170,613-753 ; videollama2_mistral.py:173-259 ; builder.py:496-545
+# ----------------------------------------------------------------------------------------------
+
+IGNORE_INDEX = -100                                                                                       # constants.py
+
+
+def exponential_sampling(tokens: Tensor, percentage: float = 0.6) -> Tensor:
+    """videollama2_arch.py:595-601 ("log" sampling; despite the name the live code is LINEAR spacing): int(percentage*n)
+    frames (at least one) at torch.linspace(0, n-1, num).int() positions."""
+    n = tokens.shape[0]
+    num = 1 if int(percentage * n) == 0 else int(percentage * n)
+    return tokens[torch.linspace(0, n - 1, num).int().tolist()]
+
+
+def similarity_sampling(tokens: Tensor, percentage: float = 0.6) -> Tensor:
+    """videollama2_arch.py:603-611: the top `percentage` frames by cosine similarity to the LAST frame, in time order."""
+    sim = torch.nn.functional.cosine_similarity(tokens, tokens[-1].unsqueeze(0), dim=1)
+    order = torch.argsort(sim, descending=True)
+    k = max(int(percentage * len(order)), 1)
+    return tokens[sorted(order[:k].tolist())]
+
+
+def teacher_forced_splice(input_ids: Sequence[int], labels: Optional[Sequence[int]], tokens: Tensor,
+                          feature_idx: Sequence[int], embed_table: Tensor, sample_type: str = "all",
+                          sample_per: float = 0.5, video_index: int = VIDEO_TOKEN_INDEX):
+    """videollama2_arch.py:640-699 for ONE sample: the k-th sentinel <- the (optionally sub-sampled) tokens of clip k
+    (tokens[start_k:end_k], start = [0] + feature_idx[:-1]); labels get IGNORE_INDEX over the inserted positions.
+    -> (embeds [S, hidden], labels list or None)."""
+    starts = [0] + list(feature_idx[:-1])
+    parts: List[Tensor] = []
+    new_labels: List[int] = []
+    cur: List[int] = []
+    cur_lab: List[int] = []
+    k = 0
+    for j, t in enumerate(input_ids):
+        if t == video_index:
+            parts.append(embed_table[torch.tensor(cur, dtype=torch.long)] if cur else embed_table[:0])
+            clip = tokens[starts[k]:feature_idx[k]]
+            if sample_type == "log":
+                clip = exponential_sampling(clip, sample_per)
+            elif sample_type == "similarity":
+                clip = similarity_sampling(clip, sample_per)
+            parts.append(clip)
+            if labels is not None:
+                new_labels += cur_lab + [IGNORE_INDEX] * clip.shape[0]
+            k += 1
+            cur, cur_lab = [], []
+        else:
+            cur.append(int(t))
+            if labels is not None:
+                cur_lab.append(int(labels[j]))
+    if cur:
+        parts.append(embed_table[torch.tensor(cur, dtype=torch.long)])
+        if labels is not None:
+            new_labels += cur_lab
+    return torch.cat(parts, dim=0), (new_labels if labels is not None else None)
+
+
+def causal_lm_loss(logits: Tensor, labels: Sequence[int], class_weight: Optional[Tensor] = None) -> Tensor:
+    """HF causal-LM loss: position t predicts label t+1, IGNORE_INDEX skipped, mean (weighted mean with class weights,
+    as CrossEntropyLoss(weight=...) does for the gate, builder.py:345-349)."""
+    lab = torch.tensor(list(labels), dtype=torch.long)
+    return torch.nn.functional.cross_entropy(logits[:-1].to(F32), lab[1:], weight=class_weight, ignore_index=IGNORE_INDEX)
+
+
+def teacher_forced_tokens(clips_pix: Sequence[Tensor], Wv, Wc, vcfg: VitCfg, ccfg: ConnCfg, prec: Prec = FP32):
+    """videollama2_arch.py:135-170: every clip through the ViT (last 600 frames of a longer clip), features concatenated in
+    time, ONE connector scan over the whole sequence.  -> (tokens [T, d_model], cumulative frame counts per clip)."""
+    pooled, counts = [], []
+    for pix in clips_pix:
+        if pix.shape[0] > 600:
+            pix = pix[-600:]
+        pooled.append(pool_patches(vit_features(pix, Wv, vcfg, prec)))
+        counts.append(pix.shape[0])
+    feature_idx = [sum(counts[:i + 1]) for i in range(len(counts))]
+    return connector_scan(torch.cat(pooled, dim=0), Wc, ccfg), feature_idx
+
+
+def teacher_forced_forward(input_ids: Sequence[int], labels: Optional[Sequence[int]], clips_pix: Sequence[Tensor],
+                           Wv, Wc, Wl, vcfg: VitCfg, ccfg: ConnCfg, lcfg: LmCfg, prec: Prec = FP32,
+                           sample_type: str = "all", sample_per: float = 0.5):
+    """model(input_ids, labels, images=[clips, ["video"]], timestamp=..., llm_eval=True) for batch 1
+    (videollama2_mistral.py:173-259): -> (logits [S, vocab] fp32, loss or None, expanded labels or None)."""
+    tokens, feature_idx = teacher_forced_tokens(clips_pix, Wv, Wc, vcfg, ccfg, prec)
+    embeds, new_labels = teacher_forced_splice(input_ids, labels, tokens, feature_idx, Wl["model.embed_tokens.weight"],
+                                               sample_type, sample_per)
+    logits = lm_forward(embeds, Wl, lcfg, None, prec, "", last_only=False)
+    loss = causal_lm_loss(logits, new_labels) if new_labels is not None else None
+    return logits, loss, new_labels
+
+
+GATE_CLASS_WEIGHT = (0.15, 0.85)                                                                          # builder.py:345-347
+
+
+def gate_eval(tokens: Tensor, feature_idx: Sequence[int], Wc, gcfg: LmCfg, prefix: str = "cls_net.cls_model."):
+    """builder.py:496-545 (the branch without a prompt; the prompt-conditioned one above it is debug-broken in the reference):
+    every frame becomes the 2-token sequence [frame token, embed(target)] with labels [IGNORE, target], target = 1
+    ("respond") for the last frame of a clip and 0 ("silent") otherwise; at most 4000 sequences.
+    -> (logits [T, 2, 2], labels [T, 2], class-weighted loss).  Position 0 is the streaming gate's logit pair."""
+    emb = Wc[prefix + "model.embed_tokens.weight"]
+    starts = [0] + list(feature_idx[:-1])
+    seqs, labs = [], []
+    for k, end in enumerate(feature_idx):
+        for f in range(starts[k], end):
+            tgt = 1 if f == end - 1 else 0
+            seqs.append(torch.stack([tokens[f], emb[tgt]]))
+            labs.append([IGNORE_INDEX, tgt])
+    seqs, labs = seqs[:4000], labs[:4000]
+    logits = torch.stack([lm_forward(sq, Wc, gcfg, None, FP32, prefix, last_only=False) for sq in seqs])
+    lab = torch.tensor(labs, dtype=torch.long)
+    loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, 2), lab[:, 1:].reshape(-1),
+                                             weight=torch.tensor(GATE_CLASS_WEIGHT), ignore_index=IGNORE_INDEX)
+    return logits, lab, loss
+
+
+def llm_turn_metrics(logits: Tensor, labels: Sequence[int], eos_id: int = 2):
+    """eval/inference_video_ego4d_stream_parallel_new.py:190-222 for one video: turns end at label == eos; per turn the
+    perplexity exp(CE), the token accuracy and the counts.  -> dict of per-video means, as the script prints them."""
+    lab = torch.tensor(list(labels), dtype=torch.long)
+    turns = (lab == eos_id).nonzero(as_tuple=True)[0].tolist()
+    prev = [-1] + turns[:-1]
+    ppls, corr, ntok, ncorr, preds = [], [], [], [], []
+    for a, b in zip(prev, turns):
+        tl, tg = logits[a + 1:b + 1][:-1], lab[a + 1:b + 1][1:]
+        keep = tg != IGNORE_INDEX
+        tl, tg = tl[keep], tg[keep]
+        ppls.append(torch.nn.functional.cross_entropy(tl.to(F32), tg).exp())
+        ok = (tl.argmax(dim=-1) == tg).sum()
+        preds.append(tl.argmax(dim=-1).tolist())
+        ntok.append(tg.numel()); ncorr.append(ok); corr.append(ok / tg.numel())
+    n = len(turns)
+    return {"lm_ppl": float(sum(ppls) / n), "lm_correctness": float(sum(corr) / n),
+            "lm_correct_tokens": float(sum(ncorr) / n), "lm_tokens": float(sum(ntok) / n), "pred_ids": preds}
+
+
+# ----------------------------------------------------------------------------------------------
 # a3/a11/a14  the streaming loop, reference form (O(T) recompute, full re-prefill on every fire)
 # ----------------------------------------------------------------------------------------------
 

@@ -90,6 +90,8 @@ SIGNATURES = {
     "sm_stream_kv_len": (i32, [vp]),
     "sm_stream_set_kv_len": (i32, [vp, i32]),
     "sm_llm_prefill": (i32, [vp, vp, i32, vp]),
+    "sm_llm_forward_logits": (i32, [vp, vp, i32, vp, vp]),
+    "sm_cross_entropy": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),
     "sm_llm_decode": (i32, [vp, i32, vp, vp]),
     "sm_stream_logits": (vp, [vp]),
     "sm_stream_read_tokens": (i32, [vp, i32, i32, vp, vp]),

@@ -674,6 +674,29 @@ extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* str
     return llm_head(s, last_rows - 1, stream);
 }
 
+extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, float* logits, void* stream) {
+    SM_REQUIRE(s && ids && logits && n > 0 && s->m->c.llm_layers > 0, "sm_llm_forward_logits: bad args / perception-only model");
+    SM_REQUIRE(s->kv_len + n <= s->max_seq, "sm_llm_forward_logits: context %d + %d exceeds max_seq %d", s->kv_len, n, s->max_seq);
+    sm_model* m = s->m;
+    const sm_config_t& c = m->c;
+    const int ld = c.llm_hidden, V = c.llm_vocab;
+    int rc, done = 0;
+    while (done < n) {
+        const int cur = n - done < s->chunk ? n - done : s->chunk;
+        if ((rc = sm_embed_splice(ids + done, cur, m->slots.at("llm.embed").buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = llm_layers(s, cur, stream))) return rc;
+        // final norm + lm_head on all `cur` rows of this chunk (llm_head does the last row only)
+        if ((rc = sm_norm(s->emb.as<float>(), cur, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        sm_linear_t a = lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, cur, ld);
+        a.out_f32 = logits + (size_t)done * V; a.ldo = V;
+        if ((rc = sm_linear(&a, stream))) return rc;
+        done += cur;
+    }
+    // keep the stream's "pending token / last logits" state what a prefill would have left
+    SM_HIP(hipMemcpyAsync(s->lmlog.p, logits + (size_t)(n - 1) * V, (size_t)V * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return sm_argmax(s->lmlog.as<float>(), V, s->next_tok.as<int32_t>(), stream);
+}
+
 extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* stream) {
     SM_REQUIRE(s && out_ids && n_steps > 0 && s->m->c.llm_layers > 0, "sm_llm_decode: bad args");
     SM_REQUIRE(s->kv_len + n_steps <= s->max_seq, "sm_llm_decode: context %d + %d exceeds max_seq %d", s->kv_len, n_steps, s->max_seq);

@@ -554,6 +554,55 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
         *out = idx;
     }
 }
+// f1: per-row softmax cross-entropy + argmax; one 256-thread block per row, two passes over the (L2-resident) row
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ lg, int V, int ld, const int32_t* __restrict__ labels,
+                                                            int ignore, float* __restrict__ nll, int32_t* __restrict__ amax) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float* row = lg + (size_t)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const float t = row[v];
+        if (t > best) { best = t; idx = v; }          // strictly greater: the lowest index wins inside a thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    if (lane == 0) { sv[w] = best; si[w] = idx; }
+    __syncthreads();
+    best = sv[0]; idx = si[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (sv[k] > best || (sv[k] == best && si[k] < idx)) { best = sv[k]; idx = si[k]; }
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = tid; v < V; v += 256) sum += __expf(row[v] - best);
+    sum = wave_sum(sum);
+    if (lane == 0) sv[w] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        if (amax) amax[blockIdx.x] = idx;
+        if (nll) {
+            const int lab = labels ? labels[blockIdx.x] : ignore;
+            float out = 0.f;
+            if (lab != ignore && lab >= 0 && lab < V) out = __logf((sv[0] + sv[1]) + (sv[2] + sv[3])) + best - row[lab];
+            nll[blockIdx.x] = out;
+        }
+    }
+}
+extern "C" int sm_cross_entropy(const float* logits, int n, int V, int ld, const int32_t* labels, int ignore_index, float* nll,
+                                int32_t* argmax, void* stream) {
+    SM_REQUIRE(logits && n > 0 && V > 0 && ld >= V && (nll || argmax) && (!nll || labels), "sm_cross_entropy: bad args");
+    cross_entropy_kernel<<<n, 256, 0, (hipStream_t)stream>>>(logits, V, ld, labels, ignore_index, nll, argmax);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 extern "C" int sm_argmax(const float* logits, int V, int32_t* out, void* stream) {
     SM_REQUIRE(logits && out && V > 0, "sm_argmax: bad args");
     argmax_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(logits, V, out);

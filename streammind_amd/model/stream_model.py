@@ -10,7 +10,8 @@ import torch
 
 from .. import _lib
 from .._lib import check
-from ..constants import MMODAL_TOKEN_INDEX
+from ..constants import IGNORE_INDEX, MMODAL_TOKEN_INDEX
+from .. import native as _native
 from ..native import NativeModel, NativeStream, PathConfig, _stream
 
 _DT = {torch.bfloat16: _lib.SM_DT_BF16, torch.float32: _lib.SM_DT_F32, torch.float16: _lib.SM_DT_F16}
@@ -95,8 +96,9 @@ class Video_Mamba_seq:
     @torch.no_grad()
     def __call__(self, x: torch.Tensor, cls_inference=False, cls_training=False, cls_demo=False, frames_features_shape=[],
                  prompt_time_input_ids=None, prompt_time_lable=None):
-        if cls_inference or cls_training:
-            raise NotImplementedError("teacher-forced gate evaluation is SURVEY 8f row f1 (next), not the streaming path")
+        if (cls_inference or cls_training) and prompt_time_input_ids is not None and prompt_time_input_ids.numel() > 1:
+            # builder.py:424-494: needs gate token ids 32000/32001 that its own 2-word ClsNet does not have
+            raise NotImplementedError("the prompt-conditioned gate branch is debug-broken in the reference (builder.py:422-494)")
         b, t, l, d = x.shape
         assert b == 1, "only support batch size 1"          # eval/inference_video_score_stream_ddp.py:325
         nat = self.native
@@ -109,13 +111,58 @@ class Video_Mamba_seq:
         s = nat.open_stream(max_frames=t, max_seq=64)
         logits = None
         cap = 16 if nat.cfg.weights_fp8 else 32
+        all_logits = []
         for i in range(0, t, cap):
             logits, _ = s.push_pooled(pooled[i:i + cap].contiguous())
+            all_logits.append(logits)
+        self._all_logits = torch.cat(all_logits)
         tokens = s.tokens().unsqueeze(0)
         s.close()
+        if cls_inference or cls_training:
+            out, lab = gate_eval_outputs(self._all_logits, frames_features_shape)
+            return out if cls_training else (out, lab)
         if cls_demo:
             return tokens, logits[-1]
         return tokens
+
+
+GATE_CLASS_WEIGHT = (0.15, 0.85)                                   # CrossEntropyLoss(weight=...) of builder.py:345-349
+
+
+def gate_eval_outputs(gate_logits: torch.Tensor, frames_features_shape: Sequence[int]):
+    """builder.py:496-545 (prompt-free branch): per frame the 2-token sequence [frame token, embed(target)], labels
+    [IGNORE, target], target 1 for the last frame of a clip else 0, at most 4000 frames; the class-weighted shifted CE.
+    -> (SimpleNamespace(logits [T,2,2], loss), labels [T,2]).  Only position 0 is ever scored (its label sits at
+    position 1); it is the streaming gate's logit pair, computed by the same HIP step.  Position 1 of `logits` would need
+    the 2-token attention the gate path never runs: it is returned as NaN."""
+    T = gate_logits.shape[0]
+    starts = [0] + list(frames_features_shape[:-1])
+    tgt = torch.zeros(T, dtype=torch.int32)
+    for k, end in enumerate(frames_features_shape):
+        if end > starts[k]:
+            tgt[end - 1] = 1
+    n = min(T, 4000)
+    lg, tgt = gate_logits[:n], tgt[:n]
+    nll, _ = _native.cross_entropy(lg.contiguous(), tgt)
+    w = torch.tensor(GATE_CLASS_WEIGHT, device=nll.device)[tgt.to(nll.device).long()]
+    loss = (nll * w).sum() / w.sum()
+    logits = torch.full((n, 2, 2), float("nan"), dtype=torch.float32, device=lg.device)
+    logits[:, 0] = lg
+    labels = torch.stack([torch.full((n,), IGNORE_INDEX, dtype=torch.long), tgt.long()], dim=1)
+    return SimpleNamespace(logits=logits, loss=loss), labels
+
+
+def exponential_sampling_indices(n: int, percentage: float = 0.6) -> List[int]:
+    """videollama2_arch.py:595-601 ("log" sampling; the live code is linear spacing)."""
+    num = 1 if int(percentage * n) == 0 else int(percentage * n)
+    return torch.linspace(0, n - 1, num).int().tolist()
+
+
+def similarity_sampling_indices(tokens: torch.Tensor, percentage: float = 0.6) -> List[int]:
+    """videollama2_arch.py:603-611: the top `percentage` frames by cosine similarity to the last one, in time order."""
+    sim = torch.nn.functional.cosine_similarity(tokens, tokens[-1].unsqueeze(0), dim=1)
+    order = torch.argsort(sim, descending=True)
+    return sorted(order[:max(int(percentage * len(order)), 1)].tolist())
 
 
 class Videollama2MistralForCausalLM:
@@ -166,6 +213,7 @@ class Videollama2MistralForCausalLM:
         x = x.to(self.device)
         nat, cfg = self.native, self.native.cfg
         logits = None
+        tick_logits = []
         step = min(16 if cfg.weights_fp8 else 32, cfg.max_frames_per_call)
         for i in range(0, x.shape[0], step):
             xi = x[i:i + step].contiguous()
@@ -178,7 +226,9 @@ class Videollama2MistralForCausalLM:
                 pooled = torch.empty(n, cfg.vit_hidden, dtype=torch.float32, device=self.device)
                 check(nat.lib.sm_vit_encode_pixels(nat.h, xi.data_ptr(), _DT[xi.dtype], n, pooled.data_ptr(), None, _stream()), "sm_vit_encode_pixels")
                 logits, dec = self.stream.push_pooled(pooled)
+            tick_logits.append(logits)
         self.last_gate_logits = logits[-1]
+        self._tick_logits = torch.cat(tick_logits)
         return logits[-1], int(dec[-1].item())        # the per-tick device->host read (videollama2_arch.py:941 .item())
 
     # ---- a10: sentinel expansion (videollama2_arch.py:948-984)
@@ -230,6 +280,81 @@ class Videollama2MistralForCausalLM:
                     self.stream.set_kv_len(len(self._kv_ids))
                     break
         return out
+
+    # ---- f1: teacher-forced evaluation forward (videollama2_mistral.py:173-259, videollama2_arch.py:613-753), batch 1
+    @torch.no_grad()
+    def forward(self, input_ids: torch.Tensor = None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels: Optional[torch.Tensor] = None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, images=None, return_dict=None, cls_output=None, **kwargs):
+        """model(input_ids, labels=..., images=[clips, ["video"]], timestamp=..., llm_eval=True) -> (output, labels) with
+        output.logits fp32 [1, S, vocab] and output.loss (HF shifted CE); model_type="cls" -> the batch gate evaluation
+        (data_type "train" -> output, else (output, labels)).  The stream state of this object is reset and reused."""
+        if inputs_embeds is not None:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        if "timestamp" not in kwargs:
+            raise NotImplementedError("only the stream path (timestamp=...) of forward() is part of this build")
+        if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+            raise NotImplementedError("teacher-forced forward: batch size 1 (eval/inference_video_ego4d_stream_parallel_new.py:186)")
+        model_type, data_type = kwargs.pop("model_type", None), kwargs.pop("data_type", None)
+        Xs, keys = images
+        # videollama2_arch.py:135-170: every clip through the ViT (last 600 frames), ONE connector pass over all frames
+        self.frame_feature = None
+        counts = []
+        all_logits = []
+        for clip in Xs:
+            if clip.shape[0] > 600:
+                clip = clip[-600:]
+            self._perceive(clip)
+            all_logits.append(self._tick_logits)
+            counts.append(int(clip.shape[0]))
+        feature_idx = [sum(counts[:i + 1]) for i in range(len(counts))]
+        if model_type == "cls":
+            out, lab = gate_eval_outputs(torch.cat(all_logits), feature_idx)
+            return out if data_type == "train" else (out, lab)
+        if self.native.cfg.llm_layers == 0:
+            raise RuntimeError("perception-only model: no LLM loaded")
+        sample_type, sample_per = getattr(self, "sample_type", "all"), getattr(self, "sample_per", 0.5)
+        ids, lab_in = input_ids[0].tolist(), (labels[0].tolist() if labels is not None else None)
+        starts = [0] + feature_idx[:-1]
+        seq: List[int] = []
+        new_labels: List[int] = []
+        k = 0
+        for j, t in enumerate(ids):
+            if t in (MMODAL_TOKEN_INDEX[key.upper()] for key in keys):
+                n_clip = feature_idx[k] - starts[k]
+                if sample_type == "log":
+                    sel = exponential_sampling_indices(n_clip, sample_per)
+                elif sample_type == "similarity":
+                    sel = similarity_sampling_indices(self.stream.tokens(starts[k], n_clip), sample_per)
+                else:
+                    sel = list(range(n_clip))
+                seq.extend(-(starts[k] + f + 1) for f in sel)
+                new_labels.extend([IGNORE_INDEX] * len(sel))
+                k += 1
+            else:
+                seq.append(int(t))
+                if lab_in is not None:
+                    new_labels.append(int(lab_in[j]))
+        if len(seq) > self.max_seq:
+            raise ValueError(f"spliced sequence of {len(seq)} tokens exceeds max_seq={self.max_seq}")
+        self.stream.set_kv_len(0)
+        self._kv_ids = []
+        logits = self.stream.forward_logits(torch.tensor(seq, dtype=torch.int32, device=self.device))
+        self._kv_ids = list(seq)
+        loss = None
+        out_labels = None
+        if lab_in is not None:
+            out_labels = torch.tensor([new_labels], dtype=torch.long)
+            shifted = torch.tensor(new_labels[1:] + [IGNORE_INDEX], dtype=torch.int32)
+            nll, _ = _native.cross_entropy(logits, shifted)
+            n_scored = int((shifted != IGNORE_INDEX).sum())
+            loss = nll.sum() / max(n_scored, 1)
+        output = SimpleNamespace(loss=loss, logits=logits.unsqueeze(0), past_key_values=None, hidden_states=None, attentions=None)
+        if kwargs.pop("llm_eval", None):
+            return output, out_labels
+        return output
+
+    __call__ = forward
 
     @torch.no_grad()
     def stream_generate_demo(self, inputs: Optional[torch.Tensor] = None, images_or_videos: Optional[torch.Tensor] = None,

@@ -224,6 +224,13 @@ class NativeStream:
         assert ids.dtype == torch.int32 and ids.is_cuda and ids.is_contiguous() and ids.dim() == 1
         check(self.lib.sm_llm_prefill(self.h, ids.data_ptr(), ids.numel(), _stream()), "sm_llm_prefill")
 
+    def forward_logits(self, ids: torch.Tensor) -> torch.Tensor:
+        """teacher-forced forward (f1): like prefill, but returns the fp32 logits of EVERY new position [n, vocab]."""
+        assert ids.dtype == torch.int32 and ids.is_cuda and ids.is_contiguous() and ids.dim() == 1
+        out = torch.empty(ids.numel(), self.model.cfg.llm_vocab, dtype=torch.float32, device=self.dev)
+        check(self.lib.sm_llm_forward_logits(self.h, ids.data_ptr(), ids.numel(), out.data_ptr(), _stream()), "sm_llm_forward_logits")
+        return out
+
     def decode(self, n_steps: int) -> torch.Tensor:
         out = torch.empty(n_steps, dtype=torch.int32, device=self.dev)
         check(self.lib.sm_llm_decode(self.h, n_steps, out.data_ptr(), _stream()), "sm_llm_decode")
@@ -267,6 +274,21 @@ def pack_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     scale = torch.empty(N, dtype=torch.float32, device=w.device)
     check(lib.sm_quant_pack_weight_fp8(w.data_ptr(), N, K, K, out.data_ptr(), scale.data_ptr(), _stream()), "sm_quant_pack_weight_fp8")
     return out, scale
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rows of fp32 logits [n, V] scored against int32 labels [n] (already shifted by the caller):
+    -> (nll fp32 [n], 0 where ignored; argmax int32 [n])."""
+    lib = _lib.load()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    labels = labels.to(device=logits.device, dtype=torch.int32).contiguous()
+    n, V = logits.shape
+    assert labels.numel() == n
+    nll = torch.empty(n, dtype=torch.float32, device=logits.device)
+    am = torch.empty(n, dtype=torch.int32, device=logits.device)
+    check(lib.sm_cross_entropy(logits.data_ptr(), n, V, logits.stride(0), labels.data_ptr(), ignore_index, nll.data_ptr(),
+                               am.data_ptr(), _stream()), "sm_cross_entropy")
+    return nll, am
 
 
 def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[torch.Tensor] = None,

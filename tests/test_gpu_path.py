@@ -382,3 +382,111 @@ def test_fp8_weights_mode_gate_and_llm(gold):
         if a != b:
             assert float(torch.topk(trace[j], 2).values.diff().abs()) < 6e-2
             break
+
+
+# ---------------------------------------------------------------------------------------------- f1: teacher-forced evaluation
+def _f1_clips(g):
+    frames = O.synthetic_frames(int(g["clip_lens"].sum()), TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    pix = O.preprocess_frames(frames, TV.image_size)
+    cuts = np.cumsum(g["clip_lens"])
+    return [pix[a:b] for a, b in zip([0] + cuts[:-1].tolist(), cuts.tolist())]
+
+
+@pytest.mark.parametrize("sample_type,sample_per", [("all", 0.5), ("log", 0.5), ("similarity", 0.6)])
+def test_teacher_forced_forward_vs_reference_golden(tiny, gold, tiny_tokenizer, sample_type, sample_per):
+    """model(input_ids, labels=.., images=[clips, ["video"]], timestamp=None, llm_eval=True) of the drop-in against golden g8
+    (the reference's own forward): expanded labels identical, logits of every position within the bf16 tolerance of the tiny
+    model (3e-2 on O(4) logits), HF shifted loss within 2e-2, per-turn perplexity within 3 %."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd import eval_metrics as M
+    m, Wv, Wc, Wl = tiny
+    g = gold("g8_teacher_forced_tiny")
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+    model.sample_type, model.sample_per = sample_type, sample_per
+    ids = torch.from_numpy(g["input_ids"])[None]
+    out, lab = model(input_ids=ids, attention_mask=torch.ones_like(ids), labels=torch.from_numpy(g["labels"])[None],
+                     images=[_f1_clips(g), ["video"]], timestamp=None, llm_eval=True)
+    assert lab[0].tolist() == g[f"labels_{sample_type}"].tolist()
+    assert out.logits.shape == (1, len(lab[0]), TL.vocab)
+    assert maxdiff(out.logits[0], torch.from_numpy(g[f"logits_{sample_type}"])) < 3e-2
+    assert abs(float(out.loss) - float(g[f"loss_{sample_type}"])) < 2e-2
+    if sample_type == "all":
+        r = M.llm_turn_metrics(out.logits[0], lab)
+        assert abs(r["lm_ppl"] - float(g["lm_ppl"])) < 0.03 * float(g["lm_ppl"])
+        # the forward leaves a reusable KV prefix: decoding continues from the teacher-forced context
+        assert model.stream.kv_len == len(lab[0])
+        assert model.stream.decode(2).shape == (2,)
+
+
+def test_gate_batch_eval_vs_reference_golden(tiny, gold):
+    """model(..., model_type="cls", data_type="eval") and mm_projector(feats, cls_inference=True) against golden g9
+    (Video_Mamba_seq.forward(cls_inference=True) of the reference): labels identical, position-0 logits within 5e-3,
+    class-weighted loss within 5e-3; position 1 is documented NaN."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd import eval_metrics as M
+    m, Wv, Wc, Wl = tiny
+    g = gold("g9_gate_eval_tiny")
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=64)
+    clips = _f1_clips(g)
+    ids = torch.tensor([[1, -201, 5, -201, 2]])
+    out, lab = model(input_ids=ids, labels=ids.clone(), images=[clips, ["video"]], timestamp=None, model_type="cls", data_type="eval")
+    assert lab.tolist() == g["labels"].tolist()
+    assert maxdiff(out.logits[:, 0], torch.from_numpy(g["logits"][:, 0])) < 5e-3
+    assert torch.isnan(out.logits[:, 1]).all()
+    assert abs(float(out.loss) - float(g["loss"])) < 5e-3
+    # the projector drop-in, fed with the tower's patch features like the reference does
+    feats = torch.cat([model.get_vision_tower()(c) for c in clips]).unsqueeze(0)
+    out2, lab2 = model.mm_projector(feats, cls_inference=True, frames_features_shape=[3, 5])
+    assert lab2.tolist() == g["labels"].tolist() and maxdiff(out2.logits[:, 0], out.logits[:, 0]) < 5e-3   # bf16 patch features in between
+    assert isinstance(model.mm_projector(feats, cls_training=True, frames_features_shape=[3, 5]).loss, torch.Tensor)
+    r = M.gate_metrics(out.logits, lab)
+    want = M.gate_metrics(torch.from_numpy(g["logits"]), torch.from_numpy(g["labels"]))
+    assert r["time_diffs"] == want["time_diffs"] and abs(r["accuracy"] - want["accuracy"]) < 1e-9
+    with pytest.raises(NotImplementedError):
+        model.mm_projector(feats, cls_inference=True, frames_features_shape=[3, 5], prompt_time_input_ids=ids)
+
+
+def test_cross_entropy_op():
+    """sm_cross_entropy against torch on random rows (ragged vocabulary, ignored rows, ties -> first index)."""
+    from streammind_amd import native
+    g = torch.Generator().manual_seed(3)
+    lg = torch.randn(37, 1000, generator=g) * 4
+    lg[5, 17] = lg[5, 400] = lg[5].max() + 1.0
+    lab = torch.randint(0, 1000, (37,), generator=g)
+    lab[::5] = -100
+    nll, am = native.cross_entropy(lg.cuda(), lab)
+    ref = torch.nn.functional.cross_entropy(lg, lab, ignore_index=-100, reduction="none")
+    assert maxdiff(nll, ref) < 2e-5
+    assert am.cpu().tolist() == lg.argmax(dim=-1).tolist() and int(am[5]) == 17
+
+
+def test_full_width_teacher_forced_logits_match_prefill_and_oracle():
+    """Mistral-7B widths, 2 layers: sm_llm_forward_logits over a 90-token spliced context (chunked like a prefill) -- the
+    last row equals what sm_llm_prefill leaves, every row is within 3e-2 of the mixed-precision oracle, and the loss of
+    random labels agrees with the oracle's to 1e-2."""
+    from streammind_amd import native
+    lcfg = O.LmCfg(hidden=4096, layers=2, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
+    Wl = O.make_lm_weights(lcfg, 77)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl)
+    g = torch.Generator().manual_seed(9)
+    toks = torch.randn(30, 4096, generator=g)
+    text = torch.randint(3, lcfg.vocab, (60,), generator=g)
+    ids = torch.cat([text[:20], -(torch.arange(30) + 1), text[20:]]).to(torch.int32)
+    s = m.open_stream(max_frames=64, max_seq=256)
+    s.write_tokens(0, toks.cuda())
+    lg = s.forward_logits(ids.cuda())
+    last, _ = s.logits()
+    assert torch.equal(last.cpu(), lg[-1].cpu()) and s.kv_len == 90
+    s.set_kv_len(0)
+    s.prefill(ids.cuda())
+    assert maxdiff(s.logits()[0], lg[-1]) < 2e-3          # prefill's head runs the 1-row kernel, forward_logits the tiled GEMM
+    emb = torch.cat([Wl["model.embed_tokens.weight"][text[:20]], toks, Wl["model.embed_tokens.weight"][text[20:]]])
+    ref = O.lm_forward(emb, Wl, lcfg, None, O.MIXED, "", last_only=False)
+    assert maxdiff(lg, ref) < 3e-2
+    labels = torch.randint(0, lcfg.vocab, (90,), generator=g)
+    labels[20:50] = -100
+    nll, _ = native.cross_entropy(lg, torch.cat([labels[1:], torch.tensor([-100])]))
+    loss = float(nll.sum() / int((labels[1:] != -100).sum()))
+    assert abs(loss - float(O.causal_lm_loss(ref, labels.tolist()))) < 1e-2

@@ -3,6 +3,7 @@ CPU only; this is what pins the oracle on every run, here and on the
 import json
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import streammind_oracle as O
@@ -141,3 +142,60 @@ def test_a15_feature_stride():
     y = O.feature_stride(x)
     assert y.shape == (1, 42, 2, 3) and torch.equal(y[0, 1], x[0, 12])
     assert O.stride_output_path("/d/features_video_encode_ddp/a.pt") == "/d/features_video_encode_ddp_fps/a.pt"
+
+
+# ---------------------------------------------------------------------------------------------- f1
+from oracle.make_golden import TINY_V, TINY_C, TINY_G, TINY_L, tiny_weights  # noqa: E402
+
+def _f1_inputs(g):
+    frames = O.synthetic_frames(int(g["clip_lens"].sum()), TINY_V.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    pix = O.preprocess_frames(frames, TINY_V.image_size)
+    cuts = np.cumsum(g["clip_lens"])
+    return [pix[a:b] for a, b in zip([0] + cuts[:-1].tolist(), cuts.tolist())]
+
+
+@pytest.mark.parametrize("sample_type,sample_per", [("all", 0.5), ("log", 0.5), ("similarity", 0.6)])
+def test_g8_teacher_forced_forward(gold, sample_type, sample_per):
+    """model(input_ids, labels, images=[clips, ["video"]], timestamp=.., llm_eval=True) of the reference (golden g8): logits
+    of every position, HF shifted loss and the expanded labels, for the three frame-sampling modes."""
+    g = gold("g8_teacher_forced_tiny")
+    Wv, Wc, Wl = tiny_weights()
+    lg, loss, nl = O.teacher_forced_forward(g["input_ids"].tolist(), g["labels"].tolist(), _f1_inputs(g), Wv, Wc, Wl,
+                                            TINY_V, TINY_C, TINY_L, sample_type=sample_type, sample_per=sample_per)
+    assert nl == g[f"labels_{sample_type}"].tolist()
+    assert (lg - torch.from_numpy(g[f"logits_{sample_type}"])).abs().max() < 5e-5
+    assert abs(float(loss) - float(g[f"loss_{sample_type}"])) < 2e-5
+
+
+def test_g9_gate_batch_eval(gold):
+    """Video_Mamba_seq.forward(cls_inference=True) of the reference (golden g9): 2-token sequences per frame, labels, the
+    class-weighted loss; position 0 equals the streaming gate."""
+    g = gold("g9_gate_eval_tiny")
+    Wv, Wc, Wl = tiny_weights()
+    tokens, fidx = O.teacher_forced_tokens(_f1_inputs(g), Wv, Wc, TINY_V, TINY_C)
+    lg, lab, loss = O.gate_eval(tokens, fidx, Wc, TINY_G)
+    assert lab.tolist() == g["labels"].tolist()
+    assert (lg - torch.from_numpy(g["logits"])).abs().max() < 5e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert (O.gate_logits_shortcut(tokens, Wc, TINY_G) - torch.from_numpy(g["logits"][:, 0])).abs().max() < 5e-5
+
+
+def test_eval_metrics_hand_cases(gold):
+    """the per-video metric arithmetic of the reference's evaluation script on cases small enough to check by hand, and
+    the golden's perplexity"""
+    from streammind_amd import eval_metrics as M
+    g = gold("g8_teacher_forced_tiny")
+    m = M.llm_turn_metrics(torch.from_numpy(g["logits_all"]), torch.from_numpy(g["labels_all"])[None])
+    assert abs(m["lm_ppl"] - float(g["lm_ppl"])) < 1e-3 * float(g["lm_ppl"])
+    assert m["lm_tokens"] == 5.5 and len(m["pred_ids"]) == 2
+    # gate: 2 turns of 3 frames, second turn's respond frame predicted one frame early
+    lab = torch.tensor([[-100, 0], [-100, 0], [-100, 1], [-100, 0], [-100, 0], [-100, 1]])
+    pred = [0, 0, 1, 0, 1, 0]
+    lg = torch.zeros(6, 2, 2)
+    for i, p in enumerate(pred):
+        lg[i, 0, p] = 1.0
+    r = M.gate_metrics(lg, lab)
+    assert abs(r["accuracy"] - 1.0) < 1e-6            # every frame is matched within +-2 frames
+    assert r["time_diffs"] == [0.0, 1.0]              # two wrong frames in turn 2 -> 2 / 2
+    assert r["time_total"] == 3.0 and r["correct_time_total"] == 2.0
+    assert torch.equal(M.relaxed_correct(torch.tensor([0, 1, 0]), torch.tensor([1, 0, 0]), 0), torch.tensor([False, False, True]))
