@@ -154,6 +154,35 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
                          "bytes_per_token": weight_bytes + kv_bytes}}
 
 
+def teacher_forced_leg(model, stream, cfg, n_text=128, n_frames=384):
+    """ONE teacher-forced Mistral-7B forward over a spliced context (text + per-frame tokens) with the
+    logits of every position (sm_llm_forward_logits) and the shifted cross-entropy (sm_cross_entropy) -- the unit of the
+    reference's TimeDiff / Fluency / PPL evaluation.  Scored positions per second."""
+    from streammind_amd import native
+    d = cfg.conn_d_model
+    g = torch.Generator(device="cuda").manual_seed(13)
+    if stream.num_frames < n_frames:
+        stream.write_tokens(stream.num_frames, torch.randn(n_frames - stream.num_frames, d, generator=g, device="cuda"))
+    text = torch.randint(3, cfg.llm_vocab, (n_text,), generator=g, device="cuda", dtype=torch.int32)
+    ids = torch.cat([text[:n_text // 2], -(torch.arange(n_frames, device="cuda", dtype=torch.int32) + 1), text[n_text // 2:]]).contiguous()
+    labels = torch.full((ids.numel(),), -100, dtype=torch.int32)
+    labels[-n_text // 2:-1] = text[n_text // 2 + 1:].cpu()
+    S = ids.numel()
+    for _ in range(2):
+        stream.set_kv_len(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lg = stream.forward_logits(ids)
+        nll, _ = native.cross_entropy(lg, labels)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    flops = 2.0 * S * (cfg.llm_layers * (2 * d * d + 2 * d * cfg.llm_kv_heads * (d // cfg.llm_heads) + 3 * d * cfg.llm_mlp) + cfg.llm_vocab * d)
+    loss = float(nll.sum() / int((labels != -100).sum()))
+    stream.set_kv_len(0)
+    return {"positions": S, "ms": round(dt * 1e3, 3), "positions_per_s": round(S / dt, 1),
+            "linear_tflops": round(flops / dt / 1e12, 1), "loss_random_weights": round(loss, 4)}
+
+
 def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None):
     """BASELINE configs[2] shape: perception of every frame + Mistral-7B replies on SCHEDULED fires (the random-weight
     gate's own decisions are not a workload), each reply = prefill of the new context (KV prefix reuse) + exactly
@@ -346,6 +375,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
+    tf_leg = None
+    if not a.no_decode and world == 1:
+        try:
+            tf_leg = teacher_forced_leg(model, stream, cfg)
+        except Exception as e:                   # an auxiliary leg must never take the headline line down
+            tf_leg = {"error": repr(e)[:200]}
+
     roof = None
     if prof:
         cnt, ms = C.c_int(), C.c_float()
@@ -399,6 +435,7 @@ def main():
             "roofline": roof,
             "decode": dec_leg,
             "end_to_end": e2e,
+            "teacher_forced_eval": tf_leg,
             "decode_fp8_weights": fp8_leg,
         }
         if world == 1 and not a.no_cpu_baseline:
