@@ -183,6 +183,25 @@ def teacher_forced_leg(model, stream, cfg, n_text=128, n_frames=384):
             "linear_tflops": round(flops / dt / 1e12, 1), "loss_random_weights": round(loss, 4)}
 
 
+def ingest_leg(B=28, H=720, W=1280, reps=20):
+    """decoded 720p u8 frames -> expand2square + PIL-exact bicubic resize + centre crop -> 336x336 u8
+    (sm_ingest_frames), device-resident.  Algorithmic bytes per frame = H*W*3 read + 336*336*3 written."""
+    from streammind_amd import native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    src = torch.randint(0, 256, (B, H, W, 3), generator=g, device="cuda", dtype=torch.uint8)
+    native.ingest_frames(src, True, 336)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        native.ingest_frames(src, True, 336)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    byts = B * (H * W * 3 + 336 * 336 * 3)
+    return {"source": f"{H}x{W}", "frames_per_call": B, "frames_per_s": round(B / dt, 1), "ms_per_call": round(dt * 1e3, 3),
+            "roofline": {"bound": "hbm", "achieved": round(byts / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_frame": byts // B}}
+
+
 def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None):
     """BASELINE configs[2] shape: perception of every frame + Mistral-7B replies on SCHEDULED fires (the random-weight
     gate's own decisions are not a workload), each reply = prefill of the new context (KV prefix reuse) + exactly
@@ -382,6 +401,13 @@ def main():
         except Exception as e:                   # an auxiliary leg must never take the headline line down
             tf_leg = {"error": repr(e)[:200]}
 
+    ing_leg = None
+    if world == 1:
+        try:
+            ing_leg = ingest_leg()
+        except Exception as e:
+            ing_leg = {"error": repr(e)[:200]}
+
     roof = None
     if prof:
         cnt, ms = C.c_int(), C.c_float()
@@ -436,6 +462,7 @@ def main():
             "decode": dec_leg,
             "end_to_end": e2e,
             "teacher_forced_eval": tf_leg,
+            "ingest_frontend": ing_leg,
             "decode_fp8_weights": fp8_leg,
         }
         if world == 1 and not a.no_cpu_baseline:

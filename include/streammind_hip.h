@@ -105,6 +105,14 @@ int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch,
                           void* stream);
 /* same patch matrix from ALREADY-normalised pixel_values [B][3][H][W] (dtype SM_DT_BF16 / SM_DT_F32 / SM_DT_F16): the
  * reference-convention input of CLIPVisionTower.forward (clip_encoder.py:41-53; video_score_stream_demo.py:86) */
+/* f2 ingest front-end (mm_utils.py:257-268 expand2square; 452-464 -> HF CLIPImageProcessor bicubic shortest-edge resize +
+ * centre crop, i.e. PIL ImagingResample on 8-bit pixels): u8 frames [B][H][W][3] of ANY size -> u8 [B][out][out][3],
+ * bit-exact with PIL.  pad_square: paste on a square canvas of pad_rgb (host, 3 bytes; the reference uses
+ * int(image_mean * 255)) first.  tmp: caller-provided scratch of sm_ingest_tmp_bytes() bytes (the horizontal pass).
+ * The first call for a new (size -> size) pair builds + uploads its coefficient tables synchronously.             */
+size_t sm_ingest_tmp_bytes(int B, int H, int W, int pad_square, int out_size);
+int sm_ingest_frames(const uint8_t* frames, int B, int H, int W, int pad_square, const uint8_t* pad_rgb_host, int out_size,
+                     uint8_t* out_frames, uint8_t* tmp, void* stream);
 int sm_patchify_pixels(const void* pixel_values, int dtype, int B, int H, int W, int patch, void* patches_bf16,
                        int ldp, void* stream);
 /* builder.py:405 on caller-held features: feats [T][P][C] (bf16/f32/f16) -> pooled fp32 [T][C] = mean over P */

@@ -198,6 +198,125 @@ def preprocess_frames(frames_u8: Tensor, image_size: int = 336) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
+# f2  ingest front-end for sources that are not image_size x image_size: frame sampling, expand2square,
+#     the image processor's bicubic shortest-edge resize + centre crop.  mm_utils.py:257-268,377-467 ; HF
+#     CLIPImageProcessor(resample=BICUBIC, size={"shortest_edge": 336}, crop_size 336) -> PIL ImagingResample (8 bpc).
+#     Byte/integer work: restated in numpy, bit-exact against PIL (tests) and against process_video (golden g10).
+# ----------------------------------------------------------------------------------------------
+import math
+import numpy as np
+
+_PIL_PRECISION_BITS = 32 - 8 - 2          # Resample.c: 8-bit coefficients scaled by 2^22
+
+
+def frame_sample(duration: int, mode: str = "uniform", num_frames: int = 8, local_fps: Optional[float] = None,
+                 frames_per_second: int = 1) -> List[int]:
+    """mm_utils.py:378-397: 'uniform' = the middle of each of num_frames equal segments; 'fps' = every
+    (local_fps // NUM_FRAMES_PER_SECOND)-th frame starting half a segment in."""
+    if mode == "uniform":
+        seg = float(duration - 1) / num_frames
+        return [(int(np.round(seg * i)) + int(np.round(seg * (i + 1)))) // 2 for i in range(num_frames)]
+    if mode == "fps":
+        assert local_fps is not None
+        seg_len = min(local_fps // frames_per_second, duration)
+        return np.arange(seg_len // 2, duration, seg_len, dtype=int).tolist()
+    raise ImportError(f"Unsupported frame sampling mode: {mode}")
+
+
+def _bicubic_filter(x: float, a: float = -0.5) -> float:
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size: int, out_size: int):
+    """precompute_coeffs + normalize_coeffs_8bpc of PIL's Resample.c for the bicubic filter (support 2, widened by the
+    downscale factor = antialiasing).  -> (xmin int[out], count int[out], kk int64[out][ksize])."""
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = 2.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    xmin_a = np.zeros(out_size, dtype=np.int32)
+    cnt_a = np.zeros(out_size, dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        k = np.array([_bicubic_filter((x + xmin - center + 0.5) / fs) for x in range(xmax)], dtype=np.float64)
+        ww = k.sum()
+        if ww != 0.0:
+            k = k / ww
+        kk[xx, :xmax] = np.where(k < 0, np.trunc(-0.5 + k * (1 << _PIL_PRECISION_BITS)), np.trunc(0.5 + k * (1 << _PIL_PRECISION_BITS)))
+        xmin_a[xx], cnt_a[xx] = xmin, xmax
+    return xmin_a, cnt_a, kk
+
+
+def resize_u8_bicubic(img: "np.ndarray", out_h: int, out_w: int) -> "np.ndarray":
+    """PIL Image.resize((out_w, out_h), BICUBIC) on a uint8 HWC image: horizontal pass, then vertical, each rounding to
+    uint8 (clip8 of (sum + 2^21) >> 22)."""
+    H, W, C = img.shape
+    out = img
+    half = 1 << (_PIL_PRECISION_BITS - 1)
+    if out_w != W:
+        xmin, cnt, kk = pil_bicubic_coeffs(W, out_w)
+        tmp = np.empty((H, out_w, C), dtype=np.uint8)
+        for xx in range(out_w):
+            a, n = int(xmin[xx]), int(cnt[xx])
+            acc = (out[:, a:a + n, :].astype(np.int64) * kk[xx, :n][None, :, None]).sum(1) + half
+            tmp[:, xx, :] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255)
+        out = tmp
+    if out_h != H:
+        ymin, cnt, kk = pil_bicubic_coeffs(H, out_h)
+        tmp = np.empty((out_h, out.shape[1], C), dtype=np.uint8)
+        for yy in range(out_h):
+            a, n = int(ymin[yy]), int(cnt[yy])
+            acc = (out[a:a + n].astype(np.int64) * kk[yy, :n][:, None, None]).sum(0) + half
+            tmp[yy] = np.clip(acc >> _PIL_PRECISION_BITS, 0, 255)
+        out = tmp
+    return out
+
+
+def expand2square_u8(img: "np.ndarray", background: Sequence[int]) -> "np.ndarray":
+    """mm_utils.py:257-268: paste centred ((long - short) // 2) on a long x long canvas of the background colour."""
+    H, W, C = img.shape
+    if H == W:
+        return img
+    L = max(H, W)
+    out = np.empty((L, L, C), dtype=np.uint8)
+    out[:] = np.asarray(background, dtype=np.uint8)
+    if W > H:
+        out[(W - H) // 2:(W - H) // 2 + H] = img
+    else:
+        out[:, (H - W) // 2:(H - W) // 2 + W] = img
+    return out
+
+
+def ingest_frames(frames: Sequence["np.ndarray"], aspect_ratio: Optional[str] = "pad", image_size: int = 336) -> Tensor:
+    """process_video's tail (mm_utils.py:452-464) up to the uint8 image the normalisation sees: optional expand2square with
+    the processor mean colour (int(mean * 255)), shortest edge -> image_size (long edge int(image_size * long / short)),
+    centre crop image_size x image_size.  -> uint8 [n, image_size, image_size, 3] (feed to preprocess_frames)."""
+    bg = tuple(int(x * 255) for x in CLIP_MEAN)
+    out = []
+    for f in frames:
+        f = np.asarray(f)
+        if aspect_ratio == "pad":
+            f = expand2square_u8(f, bg)
+        H, W = f.shape[:2]
+        if H <= W:
+            oh, ow = image_size, int(image_size * W / H)
+        else:
+            oh, ow = int(image_size * H / W), image_size
+        f = resize_u8_bicubic(f, oh, ow)
+        top, left = (oh - image_size) // 2, (ow - image_size) // 2
+        out.append(f[top:top + image_size, left:left + image_size])
+    return torch.from_numpy(np.stack(out))
+
+
+# ----------------------------------------------------------------------------------------------
 # a2  CLIP vision tower  (clip_encoder.py:31-53 -> HF CLIPVisionModel, hidden_states[-2], drop CLS)
 # ----------------------------------------------------------------------------------------------
 

@@ -58,6 +58,8 @@ SIGNATURES = {
     "sm_linear": (i32, [C.POINTER(sm_linear_t), vp]),
     "sm_norm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, vp]),
     "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
+    "sm_ingest_tmp_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "sm_ingest_frames": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
     "sm_patchify_pixels": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "sm_pool_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sm_vit_cls_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),

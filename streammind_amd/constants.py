@@ -1,5 +1,6 @@
 """Sentinel ids and defaults of the streaming path (mirror of streammind/constants.py:6-7,13-31)."""
 NUM_FRAMES = 8
+NUM_FRAMES_PER_SECOND = 1
 MAX_FRAMES = 320000
 IGNORE_INDEX = -100
 IMAGE_TOKEN_INDEX = -200

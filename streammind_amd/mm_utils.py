@@ -7,32 +7,51 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-from .constants import IMAGE_TOKEN_INDEX, MMODAL_INDEX_TOKEN, NUM_FRAMES
+from .constants import IMAGE_TOKEN_INDEX, MMODAL_INDEX_TOKEN, NUM_FRAMES, NUM_FRAMES_PER_SECOND
+
+
+def frame_sample(duration: int, mode: str = "uniform", num_frames: int = NUM_FRAMES, local_fps=None) -> List[int]:
+    """mm_utils.py:378-397 (the nested helper of process_video): which decoded frames feed the model."""
+    if mode == "uniform":
+        seg_size = float(duration - 1) / num_frames
+        return [(int(np.round(seg_size * i)) + int(np.round(seg_size * (i + 1)))) // 2 for i in range(num_frames)]
+    if mode == "fps":
+        assert local_fps is not None
+        segment_len = min(local_fps // NUM_FRAMES_PER_SECOND, duration)
+        return np.arange(segment_len // 2, duration, segment_len, dtype=int).tolist()
+    raise ImportError(f"Unsupported frame sampling mode: {mode}")
 
 
 def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NUM_FRAMES, image_grid: bool = False,
                   sample_scheme: str = "uniform") -> torch.Tensor:
-    """list of PIL images / HWC arrays (or an [n,H,W,3] uint8 array) -> uint8 frames tensor [n,H,W,3].
+    """list of PIL images / HWC arrays (or an [n,H,W,3] uint8 array) -> uint8 frames tensor [n,S,S,3], S = the
+    processor's crop size (336).
 
     The reference normalises on the CPU here (HF CLIPImageProcessor) and ships fp32/fp16 pixel_values; this build keeps
     the frames as u8 -- the (x/255 - mean)/std affine is fused into the device-side patchify kernel -- so the
-    host->device copy is 4x smaller.  `processor` is accepted for signature compatibility and only consulted for the
-    expected size.  Sources that are not already image_size x image_size need the resize/crop front-end
-    (SURVEY 8f f2), which is out of scope: they are rejected."""
+    host->device copy is 4x smaller.  Frames that already are S x S pass through on the host (resize and crop are
+    identities); any other size goes through the device ingest front-end (`sm_ingest_frames`:
+    expand2square with int(image_mean * 255) when aspect_ratio == "pad", PIL-exact bicubic shortest-edge resize, centre
+    crop) and comes back as a CUDA tensor.  Decoding a file path (decord / imageio / moviepy) stays outside this build:
+    decode with the tool of your choice, pick frames with `frame_sample`, and pass the arrays."""
     if isinstance(video, str):
-        raise NotImplementedError("video decoding (decord) is the ingest front-end, out of scope (SURVEY 8f f2)")
+        raise NotImplementedError("video decoding (decord) is outside this build: pass decoded frames (see frame_sample)")
+    if image_grid:
+        raise NotImplementedError("image_grid=True (photo grid prepended, mm_utils.py:447-450) is not on the streaming path")
     if isinstance(video, np.ndarray):
         frames = video
     else:
         frames = np.stack([np.asarray(x) for x in video])
     assert len(frames) == num_frames, (len(frames), num_frames)
-    if aspect_ratio == "pad" and frames.shape[1] != frames.shape[2]:
-        raise NotImplementedError("expand2square + resize is the ingest front-end, out of scope (SURVEY 8f f2)")
-    size = getattr(processor, "crop_size", None)
-    if isinstance(size, dict) and (frames.shape[1] != size["height"] or frames.shape[2] != size["width"]):
-        raise NotImplementedError(f"frames must already be {size['height']}x{size['width']} (resize is out of scope)")
     assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.shape[-1] == 3
-    return torch.from_numpy(np.ascontiguousarray(frames))
+    size = getattr(processor, "crop_size", None)
+    S = size["height"] if isinstance(size, dict) else 336
+    if frames.shape[1] == S and frames.shape[2] == S:
+        return torch.from_numpy(np.ascontiguousarray(frames))
+    from . import native
+    mean = getattr(processor, "image_mean", None) or (0.48145466, 0.4578275, 0.40821073)
+    dev = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    return native.ingest_frames(dev, pad_square=(aspect_ratio == "pad"), image_size=S, pad_rgb=tuple(int(x * 255) for x in mean))
 
 
 def tokenizer_MMODAL_token(prompt: str, tokenizer, MMODAL_token_index: int = IMAGE_TOKEN_INDEX, return_tensors=None):

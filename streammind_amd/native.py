@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass, field
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Sequence, Dict, Iterable, Optional, Tuple
 
 import torch
 
@@ -274,6 +274,21 @@ def pack_weight_fp8(w: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     scale = torch.empty(N, dtype=torch.float32, device=w.device)
     check(lib.sm_quant_pack_weight_fp8(w.data_ptr(), N, K, K, out.data_ptr(), scale.data_ptr(), _stream()), "sm_quant_pack_weight_fp8")
     return out, scale
+
+
+def ingest_frames(frames: torch.Tensor, pad_square: bool = True, image_size: int = 336,
+                  pad_rgb: Sequence[int] = (122, 116, 104)) -> torch.Tensor:
+    """f2: u8 frames [n, H, W, 3] of any size on the GPU -> u8 [n, image_size, image_size, 3]: optional expand2square with
+    `pad_rgb` (int(CLIP mean * 255)), PIL-exact bicubic shortest-edge resize, centre crop."""
+    lib = _lib.load()
+    assert frames.is_cuda and frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3 and frames.is_contiguous()
+    n, H, W, _ = frames.shape
+    out = torch.empty(n, image_size, image_size, 3, dtype=torch.uint8, device=frames.device)
+    tmp = torch.empty(lib.sm_ingest_tmp_bytes(n, H, W, int(pad_square), image_size), dtype=torch.uint8, device=frames.device)
+    rgb = (C.c_uint8 * 3)(*[int(v) for v in pad_rgb])
+    check(lib.sm_ingest_frames(frames.data_ptr(), n, H, W, int(pad_square), rgb, image_size, out.data_ptr(), tmp.data_ptr(), _stream()),
+          "sm_ingest_frames")
+    return out
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> Tuple[torch.Tensor, torch.Tensor]:

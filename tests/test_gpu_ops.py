@@ -2,6 +2,8 @@
 same seeded inputs.  Integer/index results are exact; floating point tolerances are stated per test."""
 import ctypes as C
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -270,3 +272,17 @@ def test_skinny_dual_fp8(nat):
     dg, du = O.fp8_quantize_rows(wg)[0], O.fp8_quantize_rows(wu)[0]
     ref = (O.silu(x.double() @ dg.double().t()) * (x.double() @ du.double().t())).float()
     assert relerr(y, ref) < 3e-5
+
+
+@pytest.mark.parametrize("H,W,pad", [(360, 640, True), (360, 640, False), (500, 280, True), (500, 280, False), (120, 160, True),
+                                      (336, 336, True), (337, 335, False), (1080, 1920, True)])
+def test_ingest_frames_bit_exact(nat, H, W, pad):
+    """f2: sm_ingest_frames (expand2square + PIL-exact bicubic resize + centre crop, uint8) against the oracle restatement of
+    PIL's ImagingResample -- byte-for-byte."""
+    rng = np.random.default_rng(H * 7 + W)
+    n = 1 if H * W > 1_000_000 else 3
+    base = rng.integers(0, 256, (n, H // 8 + 1, W // 8 + 1, 3), dtype=np.uint8).repeat(8, axis=1).repeat(8, axis=2)[:, :H, :W]
+    frames = (base.astype(np.int32) // 2 + rng.integers(0, 128, (n, H, W, 3))).astype(np.uint8)
+    got = nat.ingest_frames(torch.from_numpy(frames).cuda(), pad_square=pad, image_size=336)
+    want = O.ingest_frames(list(frames), "pad" if pad else None, 336)
+    assert torch.equal(got.cpu(), want)

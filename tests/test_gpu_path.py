@@ -1,5 +1,7 @@
 """Path-level parity on a real MI355X, through the C ABI (sm_model / sm_stream), against the oracle and the
 golden vectors minted from the reference."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -490,3 +492,31 @@ def test_full_width_teacher_forced_logits_match_prefill_and_oracle():
     nll, _ = native.cross_entropy(lg, torch.cat([labels[1:], torch.tensor([-100])]))
     loss = float(nll.sum() / int((labels[1:] != -100).sum()))
     assert abs(loss - float(O.causal_lm_loss(ref, labels.tolist()))) < 1e-2
+
+
+def test_process_video_non_336_sources_vs_reference_golden(gold):
+    """f2 end to end: streammind_amd.mm_utils.process_video on 360x640 / 500x280 / 120x160 sources (pad and crop modes) ->
+    device u8 frames -> the a1 preprocess kernel; against the reference's process_video pixel_values (golden g10, 2e-6:
+    the uint8 image is identical, the affine is fp32 on both sides)."""
+    from types import SimpleNamespace
+    from streammind_amd import mm_utils as M, _lib
+    lib = _lib.load()
+    g = gold("g10_ingest")
+    proc = SimpleNamespace(crop_size={"height": 336, "width": 336}, image_mean=list(O.CLIP_MEAN))
+    for name in ("landscape", "portrait", "small"):
+        H, W = g[f"{name}_hw"].tolist()
+        rng = np.random.default_rng(int(g[f"{name}_seed"]))
+        base = rng.integers(0, 256, (2, H // 8 + 1, W // 8 + 1, 3), dtype=np.uint8).repeat(8, axis=1).repeat(8, axis=2)[:, :H, :W]
+        frames = (base.astype(np.int32) // 2 + rng.integers(0, 128, (2, H, W, 3))).astype(np.uint8)
+        for ar in ("pad", None):
+            u8 = M.process_video(frames, proc, aspect_ratio=ar, num_frames=2)
+            assert u8.is_cuda and u8.shape == (2, 336, 336, 3)
+            assert int(u8.long().sum()) == int(g[f"{name}_{ar or 'none'}_u8sum"])
+            pix = torch.empty(2, 3, 336, 336, device="cuda")
+            patches = torch.empty(2 * 576, 640, dtype=torch.bfloat16, device="cuda")
+            mean, std = (C.c_float * 3)(*O.CLIP_MEAN), (C.c_float * 3)(*O.CLIP_STD)
+            _lib.check(lib.sm_preprocess_patches(u8.data_ptr(), 2, 336, 336, 14, mean, std, patches.data_ptr(), 640, pix.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+            from oracle.make_golden import sample_idx
+            idx = sample_idx(pix.numel(), 4096, 7)
+            assert np.abs(pix.flatten().cpu().numpy()[idx] - g[f"{name}_{ar or 'none'}_sample"]).max() < 2e-6

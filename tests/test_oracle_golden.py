@@ -199,3 +199,48 @@ def test_eval_metrics_hand_cases(gold):
     assert r["time_diffs"] == [0.0, 1.0]              # two wrong frames in turn 2 -> 2 / 2
     assert r["time_total"] == 3.0 and r["correct_time_total"] == 2.0
     assert torch.equal(M.relaxed_correct(torch.tensor([0, 1, 0]), torch.tensor([1, 0, 0]), 0), torch.tensor([False, False, True]))
+
+
+# ---------------------------------------------------------------------------------------------- f2: ingest front-end
+def _g10_frames(g, name):
+    H, W = g[f"{name}_hw"].tolist()
+    rng = np.random.default_rng(int(g[f"{name}_seed"]))
+    base = rng.integers(0, 256, (2, H // 8 + 1, W // 8 + 1, 3), dtype=np.uint8).repeat(8, axis=1).repeat(8, axis=2)[:, :H, :W]
+    return (base.astype(np.int32) // 2 + rng.integers(0, 128, (2, H, W, 3))).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["landscape", "portrait", "small"])
+@pytest.mark.parametrize("ar", ["pad", None])
+def test_g10_ingest_vs_reference_process_video(gold, name, ar):
+    """process_video of the reference on non-336 sources (golden g10): pixel_values sample within 2e-6, and the uint8 image
+    under it identical (checksum)."""
+    g = gold("g10_ingest")
+    u8 = O.ingest_frames(list(_g10_frames(g, name)), ar, 336)
+    assert int(u8.long().sum()) == int(g[f"{name}_{ar or 'none'}_u8sum"])
+    pv = O.preprocess_frames(u8)
+    from oracle.make_golden import sample_idx
+    idx = sample_idx(pv.numel(), 4096, 7)
+    assert np.abs(pv.flatten().numpy()[idx] - g[f"{name}_{ar or 'none'}_sample"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(48, 64, 33, 44), (64, 64, 21, 21), (20, 20, 33, 33), (10, 33, 33, 108), (72, 128, 33, 58), (34, 32, 33, 33)])
+def test_resize_restatement_is_bit_exact_with_pil(H, W, oh, ow):
+    """the numpy restatement of PIL's 8-bit bicubic ImagingResample against PIL itself (up- and down-scaling, odd sizes)."""
+    from PIL import Image
+    img = np.random.default_rng(H * 131 + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+    assert np.array_equal(O.resize_u8_bicubic(img, oh, ow), ref)
+
+
+def test_frame_sample_and_expand2square():
+    from streammind_amd import mm_utils as M
+    for dur, n in [(100, 8), (9, 8), (1800, 32), (17, 5)]:
+        assert M.frame_sample(dur, "uniform", n) == O.frame_sample(dur, "uniform", n)
+        assert len(M.frame_sample(dur, "uniform", n)) == n and max(M.frame_sample(dur, "uniform", n)) < dur
+    assert M.frame_sample(100, "uniform", 8) == [6, 18, 31, 43, 56, 68, 80, 93]        # worked by hand from mm_utils.py:379-389
+    assert M.frame_sample(100, "fps", local_fps=25.0) == [12, 37, 62, 87] == O.frame_sample(100, "fps", local_fps=25.0)
+    with pytest.raises(ImportError):
+        M.frame_sample(10, "random")
+    img = np.arange(2 * 4 * 3, dtype=np.uint8).reshape(2, 4, 3)
+    sq = O.expand2square_u8(img, (9, 8, 7))
+    assert sq.shape == (4, 4, 3) and (sq[0] == (9, 8, 7)).all() and (sq[3] == (9, 8, 7)).all() and np.array_equal(sq[1:3], img)
