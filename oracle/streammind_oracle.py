@@ -836,6 +836,18 @@ def teacher_forced_forward(input_ids: Sequence[int], labels: Optional[Sequence[i
     return logits, loss, new_labels
 
 
+def offline_generate(input_ids: Sequence[int], clips_pix: Sequence[Tensor], Wv, Wc, Wl, vcfg: VitCfg, ccfg: ConnCfg,
+                     lcfg: LmCfg, max_new_tokens: int, eos_token_id: Optional[int], stop_fn=None, prec: Prec = FP32,
+                     return_logits: bool = False):
+    """f4: model.generate(input_ids, images_or_videos=[clip, ...], modal_list=["video"], do_sample=False, ...)
+    (videollama2_mistral.py:261-318, non-score branch): all frames of every clip -> ViT -> one connector pass -> splice ->
+    greedy HF generate from inputs_embeds (new ids only).  generate() does not forward the model's sample_type / sample_per,
+    so every frame token is spliced ("all") whatever the model was configured with (pinned by golden g11)."""
+    tokens, feature_idx = teacher_forced_tokens(clips_pix, Wv, Wc, vcfg, ccfg, prec)
+    embeds, _ = teacher_forced_splice(input_ids, None, tokens, feature_idx, Wl["model.embed_tokens.weight"], "all", 0.5)
+    return greedy_generate(embeds, Wl, lcfg, max_new_tokens, eos_token_id, stop_fn, prec, "", None, return_logits)
+
+
 GATE_CLASS_WEIGHT = (0.15, 0.85)                                                                          # builder.py:345-347
 
 

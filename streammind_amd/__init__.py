@@ -47,3 +47,36 @@ def infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_i
     if cls_pred == 1:
         prompt += " " + outputs + " </s>[INST] <video>\n [/INST]"
     return outputs, prompt
+
+
+def infer_offline(model, video, instruct, tokenizer, do_sample=False, version="llama_2", max_new_tokens=1024):
+    """The package-level `infer` of the reference (streammind/__init__.py:38-91): a whole clip + an instruction -> the
+    reply (offline: every frame through the ViT and the connector, one generate).  Named infer_offline here because this
+    package's `infer` is the streaming tick of eval/video_score_stream_demo.py."""
+    tensor = [video if video.dtype == torch.uint8 else video.half()]
+    modal_index = MMODAL_TOKEN_INDEX["VIDEO"]
+    instruct = DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + instruct
+    conv = conv_templates[version].copy()
+    conv.append_message(conv.roles[0], instruct)
+    conv.append_message(conv.roles[1], None)
+    prompt = conv.get_prompt()
+    input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_index, return_tensors="pt").unsqueeze(0)
+    pad = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else -1
+    attention_masks = input_ids.ne(pad).long()
+    stop_str = conv.sep if conv.sep_style in [SeparatorStyle.SINGLE] else conv.sep2
+    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
+    output_ids = model.generate(input_ids, attention_mask=attention_masks, images_or_videos=tensor, modal_list=["video"],
+                                do_sample=do_sample, temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens,
+                                use_cache=True, stopping_criteria=[stopping_criteria], pad_token_id=tokenizer.eos_token_id)
+    return tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+
+
+def x_infer(video, question, model, tokenizer, mode="vanilla", do_sample=False, version="llama_2"):
+    """streammind/__init__.py:94-103"""
+    if mode == "mcqa":
+        question = f"{question}\nAnswer with the option's letter from the given choices directly and only give the best option."
+    elif mode == "openend":
+        question = f"{question}\nAnswer the question using a single word or a short phrase with multiple words."
+    elif mode != "vanilla":
+        raise ValueError(mode)
+    return infer_offline(model=model, tokenizer=tokenizer, video=video, instruct=question, do_sample=do_sample, version=version)

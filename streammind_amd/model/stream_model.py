@@ -297,44 +297,21 @@ class Videollama2MistralForCausalLM:
             raise NotImplementedError("teacher-forced forward: batch size 1 (eval/inference_video_ego4d_stream_parallel_new.py:186)")
         model_type, data_type = kwargs.pop("model_type", None), kwargs.pop("data_type", None)
         Xs, keys = images
-        # videollama2_arch.py:135-170: every clip through the ViT (last 600 frames), ONE connector pass over all frames
-        self.frame_feature = None
-        counts = []
-        all_logits = []
-        for clip in Xs:
-            if clip.shape[0] > 600:
-                clip = clip[-600:]
-            self._perceive(clip)
-            all_logits.append(self._tick_logits)
-            counts.append(int(clip.shape[0]))
-        feature_idx = [sum(counts[:i + 1]) for i in range(len(counts))]
+        sample_type, sample_per = getattr(self, "sample_type", "all"), getattr(self, "sample_per", 0.5)
+        ids, lab_in = input_ids[0].tolist(), (labels[0].tolist() if labels is not None else None)
         if model_type == "cls":
-            out, lab = gate_eval_outputs(torch.cat(all_logits), feature_idx)
+            sample_type = "all"
+        seq, is_frame, gate_lg, feature_idx = self._splice_clips(ids, Xs, keys, sample_type, sample_per)
+        if model_type == "cls":
+            out, lab = gate_eval_outputs(gate_lg, feature_idx)
             return out if data_type == "train" else (out, lab)
         if self.native.cfg.llm_layers == 0:
             raise RuntimeError("perception-only model: no LLM loaded")
-        sample_type, sample_per = getattr(self, "sample_type", "all"), getattr(self, "sample_per", 0.5)
-        ids, lab_in = input_ids[0].tolist(), (labels[0].tolist() if labels is not None else None)
-        starts = [0] + feature_idx[:-1]
-        seq: List[int] = []
         new_labels: List[int] = []
-        k = 0
-        for j, t in enumerate(ids):
-            if t in (MMODAL_TOKEN_INDEX[key.upper()] for key in keys):
-                n_clip = feature_idx[k] - starts[k]
-                if sample_type == "log":
-                    sel = exponential_sampling_indices(n_clip, sample_per)
-                elif sample_type == "similarity":
-                    sel = similarity_sampling_indices(self.stream.tokens(starts[k], n_clip), sample_per)
-                else:
-                    sel = list(range(n_clip))
-                seq.extend(-(starts[k] + f + 1) for f in sel)
-                new_labels.extend([IGNORE_INDEX] * len(sel))
-                k += 1
-            else:
-                seq.append(int(t))
-                if lab_in is not None:
-                    new_labels.append(int(lab_in[j]))
+        if lab_in is not None:
+            sentinels = [MMODAL_TOKEN_INDEX[key.upper()] for key in keys]
+            text_labels = iter(l for t, l in zip(ids, lab_in) if t not in sentinels)
+            new_labels = [IGNORE_INDEX if f else next(text_labels) for f in is_frame]
         if len(seq) > self.max_seq:
             raise ValueError(f"spliced sequence of {len(seq)} tokens exceeds max_seq={self.max_seq}")
         self.stream.set_kv_len(0)
@@ -355,6 +332,66 @@ class Videollama2MistralForCausalLM:
         return output
 
     __call__ = forward
+
+    # ---- f4: offline generate (videollama2_mistral.py:261-318, non-score branch), greedy
+    def _splice_clips(self, ids: Sequence[int], clips, keys, sample_type: str = "all", sample_per: float = 0.5):
+        """all clips -> ViT -> one connector pass (stream reset first); sentinels -> (optionally sub-sampled) frame indices.
+        -> (sequence of ids with frame positions as -(index+1), per-position 'is frame' flags, gate logits of every frame)."""
+        self.frame_feature = None
+        counts, all_logits = [], []
+        for clip in clips:
+            if clip.shape[0] > 600:
+                clip = clip[-600:]                                        # videollama2_arch.py:150-151
+            self._perceive(clip)
+            all_logits.append(self._tick_logits)
+            counts.append(int(clip.shape[0]))
+        feature_idx = [sum(counts[:i + 1]) for i in range(len(counts))]
+        starts = [0] + feature_idx[:-1]
+        sentinels = [MMODAL_TOKEN_INDEX[key.upper()] for key in keys]
+        seq: List[int] = []
+        is_frame: List[bool] = []
+        k = 0
+        for t in ids:
+            if t in sentinels:
+                n_clip = feature_idx[k] - starts[k]
+                if sample_type == "log":
+                    sel = exponential_sampling_indices(n_clip, sample_per)
+                elif sample_type == "similarity":
+                    sel = similarity_sampling_indices(self.stream.tokens(starts[k], n_clip), sample_per)
+                else:
+                    sel = list(range(n_clip))
+                seq.extend(-(starts[k] + f + 1) for f in sel)
+                is_frame.extend([True] * len(sel))
+                k += 1
+            else:
+                seq.append(int(t))
+                is_frame.append(False)
+        return seq, is_frame, torch.cat(all_logits), feature_idx
+
+    @torch.no_grad()
+    def generate(self, inputs: Optional[torch.Tensor] = None, images_or_videos=None, modal_list=None, **kwargs):
+        """model.generate(input_ids, images_or_videos=[clip, ...], modal_list=["video"], do_sample=False, max_new_tokens=..,
+        stopping_criteria=[...]) -> LongTensor [1, n_new] (new ids only: the inputs were embeddings).  As in the reference,
+        generate() splices EVERY frame token (it does not forward sample_type / sample_per)."""
+        kwargs.pop("position_ids", None)
+        kwargs.pop("attention_mask", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        if kwargs.pop("score_video", None):
+            raise NotImplementedError("score_video=True (pre-extracted feature files, prepare_inputs_labels_for_multimodal_score) is not built")
+        if kwargs.get("do_sample", False):
+            raise NotImplementedError("only greedy decoding (do_sample=False)")
+        if inputs.dim() != 2 or inputs.shape[0] != 1:
+            raise NotImplementedError("generate: batch size 1")
+        if self.native.cfg.llm_layers == 0:
+            raise RuntimeError("perception-only model: no LLM loaded")
+        ids = inputs[0].tolist()
+        if images_or_videos is not None:
+            seq, _, _, _ = self._splice_clips(ids, images_or_videos, modal_list or ["video"])
+        else:
+            seq = [int(t) for t in ids]
+        new_ids = self._generate(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"))
+        return torch.tensor([new_ids], dtype=torch.long)
 
     @torch.no_grad()
     def stream_generate_demo(self, inputs: Optional[torch.Tensor] = None, images_or_videos: Optional[torch.Tensor] = None,

@@ -520,3 +520,32 @@ def test_process_video_non_336_sources_vs_reference_golden(gold):
             from oracle.make_golden import sample_idx
             idx = sample_idx(pix.numel(), 4096, 7)
             assert np.abs(pix.flatten().cpu().numpy()[idx] - g[f"{name}_{ar or 'none'}_sample"]).max() < 2e-6
+
+
+def test_offline_generate_vs_reference_golden(tiny, gold, tiny_tokenizer):
+    """f4: model.generate(input_ids, images_or_videos=[clip], modal_list=["video"], do_sample=False) against the reference's
+    ids (golden g11) wherever the oracle's top-2 margin exceeds the bf16 logit tolerance; sample_type must not matter; the
+    package-level offline infer drives the same call."""
+    import streammind_amd
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    m, Wv, Wc, Wl = tiny
+    g = gold("g11_offline_generate_tiny")
+    frames = O.synthetic_frames(int(g["n_frames"]), TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    pix = O.preprocess_frames(frames, TV.image_size)
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+    ids = torch.from_numpy(g["input_ids"])[None]
+    want = g["ids_all"].tolist()
+    for st in ("all", "similarity"):
+        model.sample_type = st
+        out = model.generate(ids, attention_mask=torch.ones_like(ids), images_or_videos=[pix], modal_list=["video"], do_sample=False,
+                             max_new_tokens=int(g["max_new"]), use_cache=True, pad_token_id=tiny_tokenizer.eos_token_id)
+        got = out[0].tolist()
+        for j, (a, b) in enumerate(zip(got, want)):
+            if a != b:
+                assert float(g["margins_all"][j]) < 0.15, (st, j, got, want)
+                break
+    # u8 frames through the same path (the drop-in keeps frames as uint8) and the package-level API
+    text = streammind_amd.infer_offline(model, frames, "a b", tiny_tokenizer, version="mistral_instruct", max_new_tokens=4)
+    assert isinstance(text, str)
+    with pytest.raises(NotImplementedError):
+        model.generate(ids, images_or_videos=[pix], do_sample=True)

@@ -244,3 +244,14 @@ def test_frame_sample_and_expand2square():
     img = np.arange(2 * 4 * 3, dtype=np.uint8).reshape(2, 4, 3)
     sq = O.expand2square_u8(img, (9, 8, 7))
     assert sq.shape == (4, 4, 3) and (sq[0] == (9, 8, 7)).all() and (sq[3] == (9, 8, 7)).all() and np.array_equal(sq[1:3], img)
+
+
+def test_g11_offline_generate(gold, tiny_tokenizer):
+    """model.generate(inputs, images_or_videos=[clip], modal_list=["video"]) of the reference (golden g11): the new ids, and
+    that the model's sample_type does not reach generate()."""
+    g = gold("g11_offline_generate_tiny")
+    Wv, Wc, Wl = tiny_weights()
+    frames = O.synthetic_frames(int(g["n_frames"]), TINY_V.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    pix = O.preprocess_frames(frames, TINY_V.image_size)
+    ids = O.offline_generate(g["input_ids"].tolist(), [pix], Wv, Wc, Wl, TINY_V, TINY_C, TINY_L, int(g["max_new"]), tiny_tokenizer.eos_token_id)
+    assert ids == g["ids_all"].tolist() == g["ids_similarity"].tolist()
