@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         if (wn == 1) __builtin_amdgcn_s_barrier();
         // one k-step; TAIL = 0: steady state (issue step ks+3, leave the batches of ks+2 and ks+3 in flight), 1 / 2: the last
         // steps (nothing left to issue).  A compile-time switch: runtime branches around the waits cost ~8 % in this loop.
+#ifdef SM_GEMM_TIMELINE
+        long long ph[4] = {0, 0, 0, 0}, tp = clock64();
+#define PH(k) do { const long long t_ = clock64(); ph[k] += t_ - tp; tp = t_; } while (0)
+#else
+#define PH(k) do {} while (0)
+#endif
         auto kstep = [&](int ks, auto tail, int slot) {      // slot = ks & 3
             constexpr int TAIL = decltype(tail)::value;
             const char* sw = smem + slot * STAGE;
@@ -167,25 +173,33 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
+            PH(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            PH(1);
+            // no s_setprio around the MFMA cluster: measured 3-5 % slower with it in this two-group schedule (tools/gemm_timeline)
 #pragma unroll
             for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            PH(2);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            PH(3);
         };
         int ks = 0;
         for (; ks + 3 < KS; ++ks) kstep(ks, std::integral_constant<int, 0>{}, ks & 3);
         if (ks + 2 < KS) { kstep(ks, std::integral_constant<int, 1>{}, ks & 3); ++ks; }
         for (; ks < KS; ++ks) kstep(ks, std::integral_constant<int, 2>{}, ks & 3);
         if (wn == 0) __builtin_amdgcn_s_barrier();
+#ifdef SM_GEMM_TIMELINE
+        if (lane == 0 && blockIdx.x < 256) {
+            for (int k = 0; k < 4; ++k) g_gemm_timeline[(size_t)4096 * 8 + ((size_t)blockIdx.x * 8 + wave) * 4 + k] = ph[k];
+        }
+#endif
     } else {
         // ---- 256 x 128 (two blocks per CU): ring of 3 LDS slots, one 32-deep k-step each (W: packed 1-KiB chunks;
         // X: [256][32] bf16, 64-byte rows, chunk index XOR P[(row >> 2) & 3], P = {0,3,2,1}); loads run two k-steps

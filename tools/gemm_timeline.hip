@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 16156;
     struct { const char* name; int N, K, act, resid, obf; } shapes[] = {
         {"qkv", 3072, 1024, 0, 0, 1}, {"out", 1024, 1024, 0, 1, 0}, {"fc1", 4096, 1024, 1, 0, 1}, {"fc2", 1024, 4096, 0, 1, 0}};
-    long long* tl; hipMalloc(&tl, 4096 * 8 * 8);
+    long long* tl; hipMalloc(&tl, 4096 * 8 * 8 + 256 * 8 * 4 * 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_timeline), &tl, sizeof(tl));
     for (auto& sh : shapes) {
         void *w, *x, *ob; float *bias, *res, *of;
@@ -58,6 +58,19 @@ int main(int argc, char** argv) {
                st[nblk / 4], st[nblk / 2], st[3 * nblk / 4], st[nblk - 1], en[0], en[nblk / 4], en[nblk / 2], en[3 * nblk / 4], en[nblk - 1]);
         // per-round detail for the first 3 blocks on one CU: find blocks sharing HW_ID cu/se/xcc with block 0
         const long long cu0 = h[5] & 0xff00, x0 = h[6];   // cu_id/sh/se bits
+        {   // per-wave phase cycles of the k-loop (first 256 blocks): R work | wait at barrier 1 | M work | wait at barrier 2
+            std::vector<long long> phv(256 * 8 * 4);
+            hipMemcpy(phv.data(), tl + 4096 * 8, phv.size() * 8, hipMemcpyDeviceToHost);
+            const int nb = nblk < 256 ? nblk : 256;
+            double s4[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (int b = 0; b < nb; ++b)
+                for (int w = 0; w < 8; ++w)
+                    for (int k = 0; k < 4; ++k) s4[w >> 2][k] += (double)phv[((size_t)b * 8 + w) * 4 + k];
+            const double steps = (double)nb * 4 * (sh.K / 32);
+            for (int grp = 0; grp < 2; ++grp)
+                printf("   group %d cycles per k-step: R %.0f | barrier-1 wait %.0f | M %.0f | barrier-2 wait %.0f\n", grp, s4[grp][0] / steps,
+                       s4[grp][1] / steps, s4[grp][2] / steps, s4[grp][3] / steps);
+        }
         printf("   blocks on block-0's CU:");
         for (int b = 0; b < nblk; ++b)
             if ((h[b * 8 + 5] & 0xff00) == cu0 && h[b * 8 + 6] == x0)
