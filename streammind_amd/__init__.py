@@ -49,34 +49,39 @@ def infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_i
     return outputs, prompt
 
 
+def _generate_reply(model, tokenizer, prompt: str, clips, stop_str: str, do_sample: bool, max_new_tokens: int) -> str:
+    """tokenise `prompt` around its <video> sentinel, greedy-generate with the keyword stop, decode the new ids"""
+    ids = tokenizer_MMODAL_token(prompt, tokenizer, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
+    pad = -1 if tokenizer.pad_token_id is None else tokenizer.pad_token_id
+    new_ids = model.generate(ids, attention_mask=ids.ne(pad).long(), images_or_videos=clips, modal_list=["video"],
+                             do_sample=do_sample, temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens,
+                             use_cache=True, stopping_criteria=[KeywordsStoppingCriteria([stop_str], tokenizer, ids)],
+                             pad_token_id=tokenizer.eos_token_id)
+    return tokenizer.batch_decode(new_ids, skip_special_tokens=True)[0].strip()
+
+
 def infer_offline(model, video, instruct, tokenizer, do_sample=False, version="llama_2", max_new_tokens=1024):
-    """The package-level `infer` of the reference (streammind/__init__.py:38-91): a whole clip + an instruction -> the
-    reply (offline: every frame through the ViT and the connector, one generate).  Named infer_offline here because this
-    package's `infer` is the streaming tick of eval/video_score_stream_demo.py."""
-    tensor = [video if video.dtype == torch.uint8 else video.half()]
-    modal_index = MMODAL_TOKEN_INDEX["VIDEO"]
-    instruct = DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + instruct
+    """Offline whole-clip question answering -- what the reference's package-level `infer` does
+    (streammind/__init__.py:38-91): "<video>\n" + instruct in the `version` conversation template, every frame of `video`
+    through the ViT and the connector, ONE generate.  (This package's `infer` is the streaming tick of
+    eval/video_score_stream_demo.py, hence the different name.)"""
     conv = conv_templates[version].copy()
-    conv.append_message(conv.roles[0], instruct)
+    conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + instruct)
     conv.append_message(conv.roles[1], None)
-    prompt = conv.get_prompt()
-    input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_index, return_tensors="pt").unsqueeze(0)
-    pad = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else -1
-    attention_masks = input_ids.ne(pad).long()
-    stop_str = conv.sep if conv.sep_style in [SeparatorStyle.SINGLE] else conv.sep2
-    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
-    output_ids = model.generate(input_ids, attention_mask=attention_masks, images_or_videos=tensor, modal_list=["video"],
-                                do_sample=do_sample, temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens,
-                                use_cache=True, stopping_criteria=[stopping_criteria], pad_token_id=tokenizer.eos_token_id)
-    return tokenizer.batch_decode(output_ids, skip_special_tokens=True)[0].strip()
+    stop = conv.sep if conv.sep_style in [SeparatorStyle.SINGLE] else conv.sep2
+    clip = video if video.dtype == torch.uint8 else video.half()
+    return _generate_reply(model, tokenizer, conv.get_prompt(), [clip], stop, do_sample, max_new_tokens)
+
+
+_X_INFER_SUFFIX = {
+    "vanilla": "",
+    "mcqa": "\nAnswer with the option's letter from the given choices directly and only give the best option.",
+    "openend": "\nAnswer the question using a single word or a short phrase with multiple words.",
+}
 
 
 def x_infer(video, question, model, tokenizer, mode="vanilla", do_sample=False, version="llama_2"):
-    """streammind/__init__.py:94-103"""
-    if mode == "mcqa":
-        question = f"{question}\nAnswer with the option's letter from the given choices directly and only give the best option."
-    elif mode == "openend":
-        question = f"{question}\nAnswer the question using a single word or a short phrase with multiple words."
-    elif mode != "vanilla":
-        raise ValueError(mode)
-    return infer_offline(model=model, tokenizer=tokenizer, video=video, instruct=question, do_sample=do_sample, version=version)
+    """streammind/__init__.py:94-103: the three question styles of the offline benchmarks"""
+    if mode not in _X_INFER_SUFFIX:
+        raise ValueError(f"x_infer: unknown mode {mode!r}")
+    return infer_offline(model, video, question + _X_INFER_SUFFIX[mode], tokenizer, do_sample=do_sample, version=version)
