@@ -68,12 +68,19 @@ class StreamingSession:
     """One video stream on one GPU.  `model` is a streammind_amd.model.Videollama2MistralForCausalLM."""
 
     def __init__(self, model, tokenizer, batch_frames: int = 8, max_new_tokens: int = 1024, ring_slots: int = 3,
-                 keep_logits: bool = False):
+                 keep_logits: bool = False, source_hw: Optional[Tuple[int, int]] = None, aspect_ratio: Optional[str] = "pad"):
+        """source_hw: (H, W) of the decoded frames when they are not vit_image x vit_image -- they are then staged at their
+        native size and resized on the GPU by the ingest front-end (expand2square when aspect_ratio == "pad", PIL-exact
+        bicubic, centre crop: mm_utils.py:452-464) before perception, i.e. exactly what `process_video` would have produced."""
         self.model, self.tok = model, tokenizer
         cfg = model.native.cfg
         self.batch = min(batch_frames, cfg.max_frames_per_call)
         self.max_new = max_new_tokens
-        self.ring = FrameRing(ring_slots, self.batch, cfg.vit_image, cfg.vit_image, model.device)
+        self.image = cfg.vit_image
+        self.src_hw = tuple(source_hw) if source_hw is not None else (cfg.vit_image, cfg.vit_image)
+        self.pad_square = aspect_ratio == "pad"
+        self.pad_rgb = tuple(int(x * 255) for x in cfg.img_mean)
+        self.ring = FrameRing(ring_slots, self.batch, self.src_hw[0], self.src_hw[1], model.device)
         self.prompt: Optional[str] = None
         self.stats = StreamStats()
         self.keep_logits = keep_logits
@@ -103,6 +110,9 @@ class StreamingSession:
         dev_frames, ready, slot = self.ring.push(frames)
         torch.cuda.current_stream().wait_event(ready)
         base = self.model.stream.num_frames
+        if self.src_hw != (self.image, self.image):
+            from . import native
+            dev_frames = native.ingest_frames(dev_frames.contiguous(), self.pad_square, self.image, self.pad_rgb)
         logits, dec = self.model.stream.push_frames(dev_frames)
         self.ring.release(slot)
         dec_host = dec.cpu().tolist()                   # the one host sync of this batch

@@ -549,3 +549,22 @@ def test_offline_generate_vs_reference_golden(tiny, gold, tiny_tokenizer):
     assert isinstance(text, str)
     with pytest.raises(NotImplementedError):
         model.generate(ids, images_or_videos=[pix], do_sample=True)
+
+
+def test_streaming_session_with_native_size_frames(tiny, tiny_tokenizer):
+    """f2 inside the throughput-mode runtime: a session fed 90x160 frames (staged at native size, resized on the GPU) makes the
+    same decisions, gate logits and replies as one fed the frames `process_video(..., aspect_ratio="pad")` would have produced."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd.stream import StreamingSession
+    m, Wv, Wc, Wl = tiny
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (10, 12, 21, 3), dtype=np.uint8).repeat(8, axis=1).repeat(8, axis=2)[:, :90, :160]
+    frames = (base.astype(np.int32) // 2 + rng.integers(0, 128, (10, 90, 160, 3))).astype(np.uint8)
+    pre = O.ingest_frames(list(frames), "pad", TV.image_size)
+    outs = []
+    for src, hw in ((torch.from_numpy(frames), (90, 160)), (pre, None)):
+        model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+        sess = StreamingSession(model, tiny_tokenizer, batch_frames=4, max_new_tokens=4, keep_logits=True, source_hw=hw)
+        ev = list(sess.run(iter(src)))
+        outs.append((torch.cat(sess.stats.gate_logits), [(e.frame_index, e.new_ids) for e in ev]))
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
