@@ -567,7 +567,16 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
     const float den = wave_sum(w * l);
     for (int d = lane; d < dh; d += 64) {
         float num = 0.f;
-        for (int s = 0; s < splits; ++s) num += __shfl(w, s, 64) * part_o[((size_t)s * rows + row) * dh + d];
+        // the partial outputs are fetched 8 splits at a time (independent loads in flight together: with one load per loop
+        // trip this latency-only kernel paid a memory round trip per split), accumulated in split order
+        for (int s0 = 0; s0 < splits; s0 += 8) {
+            float po[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) po[u] = s0 + u < splits ? part_o[((size_t)(s0 + u) * rows + row) * dh + d] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < splits) num += __shfl(w, s0 + u, 64) * po[u];
+        }
         out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
     }
 }

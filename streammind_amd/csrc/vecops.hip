@@ -142,18 +142,24 @@ __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __rest
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* xr = x + (size_t)row * ldx;
     const int nv = D >> 2;
-    f32x4 v[8];
+    f32x4 v[8], gm[8];
     float s = 0.f;
+    // x and gamma loads all go out together: on the decode path this kernel is pure latency (one 16 KiB row), and fetching
+    // gamma only after the reduction added a second L2 round trip
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = tid + j * 256;
         v[j] = f32x4{0, 0, 0, 0};
+        gm[j] = f32x4{0, 0, 0, 0};
         if (c < nv) {
             v[j] = *(const f32x4*)(xr + c * 4);
-            s += LN ? (v[j][0] + v[j][1] + v[j][2] + v[j][3])
-                    : (v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+            gm[j] = *(const f32x4*)(gamma + c * 4);
         }
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        s += LN ? (v[j][0] + v[j][1] + v[j][2] + v[j][3])
+                : (v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3]);
     s = wave_sum(s);
     if (lane == 0) red[w] = s;
     __syncthreads();
@@ -178,11 +184,10 @@ __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __rest
     for (int j = 0; j < 8; ++j) {
         const int c = tid + j * 256;
         if (c >= nv) continue;
-        f32x4 gm = *(const f32x4*)(gamma + c * 4);
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float y = LN ? (v[j][e] - mu) * rstd * gm[e] + beta[c * 4 + e] : gm[e] * (v[j][e] * rstd);
+            float y = LN ? (v[j][e] - mu) * rstd * gm[j][e] + beta[c * 4 + e] : gm[j][e] * (v[j][e] * rstd);
             o[e] = apply_act(y, post_act);
         }
         if (of) *(f32x4*)(of + (size_t)row * ldo + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
