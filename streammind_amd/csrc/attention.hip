@@ -643,7 +643,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
-    int splits = cdiv(nk, 128);
+    int splits = cdiv(nk, 64);            // one 64-key tile per block while the cache is short: the kernel is a latency chain per tile
     if (splits > splits_max) splits = splits_max;
     const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
     splits = cdiv(nk, split_len);
