@@ -270,9 +270,9 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(n_frames: int = 4) -> dict:
+def cpu_baseline(n_frames: int = 12) -> dict:
     """the oracle (plain-torch CPU port of the reference arithmetic, fp32) on a bounded sample of the same workload:
-    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate)."""
+    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 12 frames ~ 10 s of CPU work."""
     from oracle import streammind_oracle as O
     torch.set_grad_enabled(False)
     cores = usable_cores()
