@@ -36,7 +36,7 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int alloc(size_t b, bool zero = false) {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         bytes = b;
         if (b == 0) return SM_OK;
@@ -44,7 +44,7 @@ struct DevBuf {
         if (zero) SM_HIP(hipMemset(p, 0, b));
         return SM_OK;
     }
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
     template <typename T> T* as() const { return (T*)p; }
 };
 
