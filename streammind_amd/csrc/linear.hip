@@ -381,7 +381,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
     }
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
 
-    const int KT = a.KS >> 1;
+    // split-K (prefill-sized M, few tiles): blockIdx.y owns k-tiles [kt0, KT) of the K loop and writes its raw fp32 partial tile
+    // to the workspace slab a.out_f32 + blockIdx.y * M * ldo (the launcher redirected the outputs; splitk_reduce_kernel sums the
+    // slabs in a fixed order and applies the real epilogue)
+    const int KTall = a.KS >> 1;
+    const int kt0 = (int)((long)KTall * blockIdx.y / gridDim.y), KT = (int)((long)KTall * (blockIdx.y + 1) / gridDim.y);
+    if (gridDim.y > 1) a.out_f32 += (size_t)blockIdx.y * a.M * a.ldo;
     const char* xbase = (const char*)a.x;
 
     // per-lane source addresses for the 4 + 4 staging loads of this wave
@@ -415,9 +420,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
         }
     };
 
-    stage(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+    stage(kt0, 0);
+    for (int kt = kt0; kt < KT; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < KT) {
             stage(kt + 1, buf ^ 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -492,6 +497,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
             store4(a, tile_m * GEMM_BM + ml, tile_n * GEMM_BN + chunk * 4, v, nullptr);
         }
     }
+}
+
+// sum of the split-K slabs (fixed order: deterministic) + the real epilogue; one thread per 4 outputs
+__global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, int S, int ldw) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = (a.N + 3) >> 2;
+    if (t >= (size_t)a.M * n4) return;
+    const int m = (int)(t / n4), n0 = (int)(t % n4) * 4;
+    f32x4 v = {0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) {
+        const float* p = ws + ((size_t)s * a.M + m) * ldw + n0;
+        if (n0 + 3 < a.N) v += *(const f32x4*)p;
+        else
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) v[r] += p[r];
+    }
+    store4(a, m, n0, v, nullptr);
+}
+
+// per-HIP-stream split-K workspace (grown on demand; steady state allocates nothing)
+#include <map>
+#include <mutex>
+static std::mutex g_ws_mu;
+static std::map<hipStream_t, std::pair<float*, size_t>> g_ws;
+static int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto& e = g_ws[st];
+    if (e.second < bytes) {
+        if (e.first) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+        SM_HIP(hipMalloc((void**)&e.first, bytes));
+        e.second = bytes;
+    }
+    *out = e.first;
+    return SM_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -611,6 +650,32 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         attr_set = true;
+    }
+    // split-K: a prefill-sized M gives too few 128x128 tiles for 256 CUs (Mistral o / down projections at M = 512: 128 tiles,
+    // 0.33 PFLOP/s -> 0.66 with the K loop split in 4); up to 4 blocks per tile, at most ~512 blocks.  SM_SPLITK=n forces n.
+    {
+        static int force_s = -1;
+        if (force_s < 0) { const char* e = getenv("SM_SPLITK"); force_s = e ? atoi(e) : 0; }
+        const int tiles = tiles_m * tiles_n, KTall = a.KS >> 1;
+        int S = force_s > 0 ? force_s : (tiles < 256 ? 512 / tiles : 1);      // <= 512 blocks: 576 measured worse than 384-432
+        if (S > 4) S = 4;
+        while (S > 1 && KTall / S < 8) --S;
+        if (p->vt || (p->N & 3) || p->M > 4096) S = 1;
+        if (S > 1) {
+            float* ws = nullptr;
+            int rc = splitk_workspace(st, (size_t)S * p->M * p->N * sizeof(float), &ws);
+            if (rc) return rc;
+            LinArgs b = a;                       // partial pass: raw fp32 accumulators into the slabs
+            b.out_f32 = ws; b.ldo = p->N; b.out_bf16 = nullptr; b.bias = nullptr; b.residual = nullptr; b.act = SM_ACT_NONE;
+            b.remap_in = 0; b.vt = nullptr;
+            SmProfScope prof(SM_PROF_GEMM, st);
+            gemm_kernel<0><<<dim3(tiles, S), 256, 2 * GEMM_STAGE_BYTES, st>>>(b, tiles_m, tiles_n);
+            SM_LAUNCH_CHECK();
+            const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
+            splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, S, p->N);
+            SM_LAUNCH_CHECK();
+            return SM_OK;
+        }
     }
     SmProfScope prof(SM_PROF_GEMM, st);
     const dim3 grid(tiles_m * tiles_n);

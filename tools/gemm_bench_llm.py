@@ -1,0 +1,26 @@
+"""tiled-GEMM micro-benchmark on the Mistral-7B prefill / teacher-forced shapes.   python tools/gemm_bench_llm.py [M]
+(SM_GEMM_TILE=128|256128|256 forces a tile variant)"""
+import os, sys, ctypes as C
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from streammind_amd import native, _lib
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+lib = _lib.load()
+tot = 0.0
+for name, N, K in [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 32000, 4096)]:
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    wp = native.pack_weight(w)
+    del w
+    for _ in range(2):
+        native.linear(x, wp, N, K, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        native.linear(x, wp, N, K, out_dtype=torch.float32)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 100
+    tot += us * (1 if name == "lm_head" else 32)
+    print(f"{name:8s} M={M} N={N} K={K}: {us:8.1f} us  {2 * M * N * K / us / 1e6:7.1f} TF/s  weights at {N * K * 2 / us / 1e6:5.2f} TB/s", flush=True)
+print(f"32 layers + head: {tot / 1e3:.2f} ms")
