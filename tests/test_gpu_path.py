@@ -568,3 +568,13 @@ def test_streaming_session_with_native_size_frames(tiny, tiny_tokenizer):
         ev = list(sess.run(iter(src)))
         outs.append((torch.cat(sess.stats.gate_logits), [(e.frame_index, e.new_ids) for e in ev]))
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
+def test_race_screen_short():
+    """tools/race_screen.py for a few seconds: repeated launches of the staggered-group GEMM, the LDS-DMA attention and the
+    full-size ViT batch must be bit-identical run to run (the long form ran 170 k GEMM launches without a mismatch)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "race_screen.py"), "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
