@@ -499,21 +499,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
     }
 }
 
-// sum of the split-K slabs (fixed order: deterministic) + the real epilogue; one thread per 4 outputs
-__global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, int S, int ldw) {
+// sum of the split-K slabs (fixed order: deterministic) + the real epilogue; one thread per 4 outputs.  ws2 != nullptr: the
+// slabs of the second (dual / SwiGLU) weight, combined by store4 as silu(v) * v2.
+__global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, const float* __restrict__ ws2, int S, int ldw) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n4 = (a.N + 3) >> 2;
     if (t >= (size_t)a.M * n4) return;
     const int m = (int)(t / n4), n0 = (int)(t % n4) * 4;
-    f32x4 v = {0, 0, 0, 0};
-    for (int s = 0; s < S; ++s) {
-        const float* p = ws + ((size_t)s * a.M + m) * ldw + n0;
-        if (n0 + 3 < a.N) v += *(const f32x4*)p;
-        else
+    f32x4 v = {0, 0, 0, 0}, v2 = {0, 0, 0, 0};
+    const size_t sstride = (size_t)a.M * ldw, o0 = (size_t)m * ldw + n0;
+    if (n0 + 3 < a.N) {
+        // slabs fetched 8 at a time (independent loads in flight together), summed in slab order
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            f32x4 t[8], t2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                t[u] = s0 + u < S ? *(const f32x4*)(ws + (size_t)(s0 + u) * sstride + o0) : f32x4{0, 0, 0, 0};
+                if (ws2) t2[u] = s0 + u < S ? *(const f32x4*)(ws2 + (size_t)(s0 + u) * sstride + o0) : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < S) { v += t[u]; if (ws2) v2 += t2[u]; }
+        }
+    } else {
+        for (int s = 0; s < S; ++s)
             for (int r = 0; r < 4; ++r)
-                if (n0 + r < a.N) v[r] += p[r];
+                if (n0 + r < a.N) { v[r] += ws[(size_t)s * sstride + o0 + r]; if (ws2) v2[r] += ws2[(size_t)s * sstride + o0 + r]; }
     }
-    store4(a, m, n0, v, nullptr);
+    store4(a, m, n0, v, ws2 ? &v2 : nullptr);
 }
 
 // per-HIP-stream split-K workspace (grown on demand; steady state allocates nothing)
@@ -546,6 +559,129 @@ static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual,
         if (dual) SK(false, false, true); else SK(false, false, false);
     }
 #undef SK
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// ---- 17..32 activation rows: weight-streaming with the activations SHARED through LDS.
+// skinny_kernel gives every block one 16-row group and lets its waves split K, so each block re-reads (and re-converts) the
+// whole activation matrix: at M = 32 fp32 that is 4 B of x per B of weight through L2/L1 and the kernel runs at 0.4-3 TB/s
+// (time scaled with the activation bytes, tools/skinny_bench.py).  Here a block is 8 waves x 16 rows = 128 weight rows over ONE
+// K slice: the x chunk (8 k-steps = 256 k, both 16-row column blocks) is converted once per block into B-fragment order in
+// LDS (hi and, in precise mode, lo) and every wave multiplies it with its own weight rows; the K slices of the grid's second
+// dimension are summed by splitk_reduce_kernel (fixed order), which also applies the epilogue.
+template <bool XF32, bool SPLIT, bool DUAL>
+__global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __restrict__ ws, float* __restrict__ ws2, int ks_per_split) {
+    constexpr int KC = 8;                                   // k-steps per staged chunk
+    __shared__ __attribute__((aligned(16))) bf16x8 xs[2][SPLIT ? 2 : 1][KC * 2 * 64];      // [buf][hi/lo][(ks, mb, lane)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int rg = blockIdx.x * 8 + wave;
+    const bool wave_on = rg < a.NRG;
+    const int KS = a.KS;
+    const int ks0 = blockIdx.y * ks_per_split, ks1 = min(ks0 + ks_per_split, KS);
+    const bf16x8* wp = a.w + (size_t)(wave_on ? rg : 0) * KS * 64 + lane;
+    const bf16x8* wp2 = DUAL ? a.w2 + (size_t)(wave_on ? rg : 0) * KS * 64 + lane : nullptr;
+    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+
+    // fill item = (ks_local, mb, lane'): 8 consecutive k of row mb*16 + (lane' & 15) -> one 16-byte B fragment (x2 in split mode)
+    auto fill = [&](int kbase, int buf) {
+#pragma unroll
+        for (int it = 0; it < (KC * 2 * 64) / 512; ++it) {
+            const int item = tid + it * 512;
+            const int l2 = item & 63, mb = (item >> 6) & 1, ksl = item >> 7;
+            const int m = mb * 16 + (l2 & 15), ks = kbase + ksl;
+            bf16x8 hi, lo;
+            const bool ok = m < a.M && ks < ks1;
+            const char* xr = (const char*)a.x + (size_t)(ok ? m : 0) * a.ldx * (XF32 ? 4 : 2);
+            load_x<XF32, SPLIT>(xr, (ok ? ks : 0) * 32 + (l2 >> 4) * 8, ok, hi, lo);
+            xs[buf][0][item] = hi;
+            if (SPLIT) xs[buf][SPLIT ? 1 : 0][item] = lo;
+        }
+    };
+    // weights of chunk c+1 are requested before chunk c is multiplied (two register sets), the x chunk c+1 is converted into
+    // the other LDS buffer meanwhile: one barrier per chunk, HBM latency hidden behind the previous chunk
+    bf16x8 wa[2][KC], wb[2][KC];
+    auto load_w = [&](int kb, int set) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            const int ks = min(kb + u, ks1 - 1);
+            wa[set][u] = __builtin_nontemporal_load(wp + (size_t)ks * 64);
+            if (DUAL) wb[set][u] = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+        }
+    };
+    auto compute = [&](int kb, int buf, int set) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {
+            if (kb + u >= ks1) break;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const bf16x8 xh = xs[buf][0][(u * 2 + mb) * 64 + lane];
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[set][u], xh, acc[mb], 0, 0, 0);
+                if (DUAL) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[set][u], xh, acc2[mb], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16x8 xl = xs[buf][SPLIT ? 1 : 0][(u * 2 + mb) * 64 + lane];
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[set][u], xl, acc[mb], 0, 0, 0);
+                    if (DUAL) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[set][u], xl, acc2[mb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    load_w(ks0, 0);
+    fill(ks0, 0);
+    for (int kb = ks0; kb < ks1; kb += 2 * KC) {             // unrolled by two so that the register set is a literal
+        __syncthreads();
+        if (kb + KC < ks1) { load_w(kb + KC, 1); fill(kb + KC, 1); }
+        compute(kb, 0, 0);
+        if (kb + KC >= ks1) break;
+        __syncthreads();
+        if (kb + 2 * KC < ks1) { load_w(kb + 2 * KC, 0); fill(kb + 2 * KC, 0); }
+        compute(kb + KC, 1, 1);
+    }
+    if (!wave_on) return;
+    // raw partial sums of this K slice: slab [blockIdx.y][m][n]; lane (g, i) owns row m = mb*16 + i, columns rg*16 + g*4 .. +3
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = mb * 16 + i, n0 = rg * 16 + g * 4;
+        if (m >= a.M || n0 >= a.N) continue;
+        const size_t o = ((size_t)blockIdx.y * a.M + m) * a.N + n0;
+        if (n0 + 3 < a.N) {
+            *(f32x4*)(ws + o) = acc[mb];
+            if (DUAL) *(f32x4*)(ws2 + o) = acc2[mb];
+        } else {
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < a.N) { ws[o + r] = acc[mb][r]; if (DUAL) ws2[o + r] = acc2[mb][r]; }
+        }
+    }
+}
+
+static int splitk_workspace(hipStream_t st, size_t bytes, float** out);
+static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
+    const int nb = (a.NRG + 7) / 8;
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("SM_SKINNY_LDS_BLOCKS"); target = e ? atoi(e) : 256; }
+    int S = target / nb;                                     // one block per CU, ONE round: 224 blocks beat 336-448 (tail round)
+    if (S < 1) S = 1;
+    int per = (a.KS + S - 1) / S;
+    per = (per + 7) / 8 * 8;                                 // whole chunks of 8 k-steps per slice
+    S = (a.KS + per - 1) / per;
+    float* ws = nullptr;
+    const size_t slab = (size_t)S * a.M * a.N;
+    int rc = splitk_workspace(st, slab * sizeof(float) * (dual ? 2 : 1), &ws);
+    if (rc) return rc;
+    float* ws2 = dual ? ws + slab : nullptr;
+    const dim3 grid(nb, S);
+#define SL(XF, SP, DU) skinny_lds_kernel<XF, SP, DU><<<grid, 512, 0, st>>>(a, ws, ws2, per)
+    if (xf32) {
+        if (split) { if (dual) SL(true, true, true); else SL(true, true, false); }
+        else       { if (dual) SL(true, false, true); else SL(true, false, false); }
+    } else {
+        if (dual) SL(false, false, true); else SL(false, false, false);
+    }
+#undef SL
+    SM_LAUNCH_CHECK();
+    const size_t nthr = (size_t)a.M * ((a.N + 3) / 4);
+    splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, ws2, S, a.N);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -611,7 +747,11 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
             if (fw == 8 && a.KS >= 8 && p->M <= 16) return launch_skinny<8>(a, xf32, split, dual, st);
             if (fw == 16 && a.KS >= 16 && !dual && p->M <= 16) return launch_skinny<16>(a, xf32, split, dual, st);
         }
-        if (p->M > 16) {                              // 17..32 activation rows: two MFMA column blocks share every weight load
+        if (p->M > 16) {                              // 17..32 activation rows
+            static int use_lds = -1;
+            if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
+            if (use_lds && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt) return launch_skinny_lds(a, xf32, split, dual, st);
+            // fallback: two MFMA column blocks share every weight load, activations re-read per block
             if (a.KS >= 32) return launch_skinny<8, 2>(a, xf32, split, dual, st);
             if (a.KS >= 8) return launch_skinny<4, 2>(a, xf32, split, dual, st);
             return launch_skinny<1, 2>(a, xf32, split, dual, st);
@@ -672,7 +812,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
             gemm_kernel<0><<<dim3(tiles, S), 256, 2 * GEMM_STAGE_BYTES, st>>>(b, tiles_m, tiles_n);
             SM_LAUNCH_CHECK();
             const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
-            splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, S, p->N);
+            splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, p->N);
             SM_LAUNCH_CHECK();
             return SM_OK;
         }
