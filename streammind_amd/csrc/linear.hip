@@ -51,6 +51,21 @@ extern "C" int sm_pack_weight(const void* w, int N, int K, int ldw, void* out, v
     return sm_pack_weight_ks(w, N, K, ldw, (K + 31) / 32, out, stream);
 }
 
+// fp32 -> bf16 hi (+ lo = bf16(x - hi), the next 8 mantissa bits) with the hardware RNE conversion (v_cvt_pk_bf16_f32)
+template <bool SPLIT>
+__device__ __forceinline__ void split_x(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo) {
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    bf16x8 H, L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        H[j] = h;
+        if (SPLIT) L[j] = (__bf16)(f[j] - (float)h);
+    }
+    hi = H;
+    if (SPLIT) lo = L;
+}
+
 // x fragment of the skinny kernels: 8 consecutive k of row m, as bf16 (hi) and optionally the bf16 residual (lo)
 template <bool XF32, bool SPLIT>
 __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16x8& hi, bf16x8& lo) {
@@ -60,17 +75,7 @@ __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16
             a = *(const f32x4*)(xrow + (size_t)k * 4);
             b = *(const f32x4*)(xrow + (size_t)k * 4 + 16);
         }
-        // hardware RNE conversions (v_cvt_pk_bf16_f32); lo = bf16(x - hi) carries the next 8 mantissa bits
-        const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        bf16x8 H, L;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const __bf16 h = (__bf16)f[j];
-            H[j] = h;
-            if (SPLIT) L[j] = (__bf16)(f[j] - (float)h);
-        }
-        hi = H;
-        if (SPLIT) lo = L;
+        split_x<SPLIT>(a, b, hi, lo);
     } else {
         union { bf16x8 v; u32x4 u; } H;
         H.u = u32x4{0, 0, 0, 0};
@@ -584,17 +589,35 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     const bf16x8* wp2 = DUAL ? a.w2 + (size_t)(wave_on ? rg : 0) * KS * 64 + lane : nullptr;
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 
-    // fill item = (ks_local, mb, lane'): 8 consecutive k of row mb*16 + (lane' & 15) -> one 16-byte B fragment (x2 in split mode)
-    auto fill = [&](int kbase, int buf) {
+    // fill item = (ks_local, mb, lane'): 8 consecutive k of row mb*16 + (lane' & 15) -> one 16-byte B fragment (x2 in split mode).
+    // Two halves: fill_load issues the (L2-resident) x loads, fill_store converts and writes LDS.  The weight loads of the
+    // same chunk are issued BETWEEN the two: VMEM returns in order, so x loads queued behind the HBM weight loads would make
+    // the conversion wait for the weights (measured: 7 us per chunk instead of ~3).
+    constexpr int NIT = (KC * 2 * 64) / 512;
+    f32x4 xa[NIT], xb[NIT];
+    bool xok[NIT];
+    auto fill_load = [&](int kbase) {
 #pragma unroll
-        for (int it = 0; it < (KC * 2 * 64) / 512; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int item = tid + it * 512;
             const int l2 = item & 63, mb = (item >> 6) & 1, ksl = item >> 7;
             const int m = mb * 16 + (l2 & 15), ks = kbase + ksl;
+            xok[it] = m < a.M && ks < ks1;
+            xa[it] = f32x4{0, 0, 0, 0}; xb[it] = f32x4{0, 0, 0, 0};
+            if (xok[it]) {
+                const char* px = (const char*)a.x + ((size_t)m * a.ldx + (size_t)ks * 32 + (l2 >> 4) * 8) * (XF32 ? 4 : 2);
+                xa[it] = *(const f32x4*)px;                              // bf16 x: the 8 values are the 16 bytes of xa
+                if (XF32) xb[it] = *(const f32x4*)(px + 16);
+            }
+        }
+    };
+    auto fill_store = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 512;
             bf16x8 hi, lo;
-            const bool ok = m < a.M && ks < ks1;
-            const char* xr = (const char*)a.x + (size_t)(ok ? m : 0) * a.ldx * (XF32 ? 4 : 2);
-            load_x<XF32, SPLIT>(xr, (ok ? ks : 0) * 32 + (l2 >> 4) * 8, ok, hi, lo);
+            if (XF32) split_x<SPLIT>(xa[it], xb[it], hi, lo);
+            else hi = __builtin_bit_cast(bf16x8, xa[it]);
             xs[buf][0][item] = hi;
             if (SPLIT) xs[buf][SPLIT ? 1 : 0][item] = lo;
         }
@@ -627,15 +650,16 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
             }
         }
     };
+    fill_load(ks0);
     load_w(ks0, 0);
-    fill(ks0, 0);
+    fill_store(0);
     for (int kb = ks0; kb < ks1; kb += 2 * KC) {             // unrolled by two so that the register set is a literal
         __syncthreads();
-        if (kb + KC < ks1) { load_w(kb + KC, 1); fill(kb + KC, 1); }
+        if (kb + KC < ks1) { fill_load(kb + KC); load_w(kb + KC, 1); fill_store(1); }
         compute(kb, 0, 0);
         if (kb + KC >= ks1) break;
         __syncthreads();
-        if (kb + 2 * KC < ks1) { load_w(kb + 2 * KC, 0); fill(kb + 2 * KC, 0); }
+        if (kb + 2 * KC < ks1) { fill_load(kb + 2 * KC); load_w(kb + 2 * KC, 0); fill_store(0); }
         compute(kb + KC, 1, 1);
     }
     if (!wave_on) return;
@@ -747,11 +771,15 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
             if (fw == 8 && a.KS >= 8 && p->M <= 16) return launch_skinny<8>(a, xf32, split, dual, st);
             if (fw == 16 && a.KS >= 16 && !dual && p->M <= 16) return launch_skinny<16>(a, xf32, split, dual, st);
         }
-        if (p->M > 16) {                              // 17..32 activation rows
+        static int lds_min_m = -1;                    // SM_SKINNY_LDS_MINM: smallest M sent to the LDS-shared kernel (tuning)
+        if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 17; }
+        {
             static int use_lds = -1;
             if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
-            if (use_lds && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt) return launch_skinny_lds(a, xf32, split, dual, st);
-            // fallback: two MFMA column blocks share every weight load, activations re-read per block
+            if (use_lds && p->M >= lds_min_m && !w8 && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt)
+                return launch_skinny_lds(a, xf32, split, dual, st);
+        }
+        if (p->M > 16) {       // fallback for 17..32 rows: two MFMA column blocks share every weight load, activations re-read per block
             if (a.KS >= 32) return launch_skinny<8, 2>(a, xf32, split, dual, st);
             if (a.KS >= 8) return launch_skinny<4, 2>(a, xf32, split, dual, st);
             return launch_skinny<1, 2>(a, xf32, split, dual, st);
