@@ -54,8 +54,9 @@ int sm_quant_pack_weight_fp8(const void* w_bf16, int N, int K, int ldw, void* ou
 
 /* ------------------------------------------------------------------------------------------------
  * Linear:  Y[M,N] = epilogue( X[M,K] . W[N,K]^T ).  Replaces every torch F.linear / cuBLAS GEMM+GEMV on
- * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 32 (<= 16 with fp8 weights) takes the weight-streaming
- * "skinny" kernel (HBM-bound, MFMA 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.
+ * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 32 takes the weight-streaming "skinny" kernels (HBM-bound, MFMA
+ * 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.  fp8 weights stream as fp8 for M <= 16;
+ * for more rows the call first expands them to a bf16 scratch image (row scale folded in) and runs the bf16 kernels.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sm_linear_t {
     const void* w;        /* packed bf16 [N][K]                                                     */
@@ -82,7 +83,7 @@ typedef struct sm_linear_t {
      * (row length vt_ld) instead of out_bf16.                                                      */
     void* vt;
     int vt_n0, vt_S, vt_dh, vt_ld;
-    /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 (sm_quant_pack_weight_fp8 image + per-row scales; M <= 16) */
+    /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 (sm_quant_pack_weight_fp8 image + per-row scales) */
     int w_dtype;
     const float* w_scale;
     const float* w2_scale;
@@ -196,7 +197,7 @@ typedef struct sm_config_t {
     int max_frames_per_call; /* frames batched through sm_vit_encode in one call                       */
     int gate_precise;        /* 1: hi/lo bf16 activation split in the connector+gate GEMVs (~fp32 acts) */
     int weights_fp8;         /* 1: gate + LLM linear weights are quantised to fp8 (per-row scale) at load time and every  */
-                             /*    LLM/gate product takes the weight-streaming kernel (prefill in 16-token chunks);        */
+                             /*    decode/gate product streams them as fp8 (prefill chunks expand them to bf16 per call); */
                              /*    BASELINE config 5, opt-in: numerics differ from the bf16 checkpoint                     */
 } sm_config_t;
 

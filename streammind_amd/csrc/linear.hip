@@ -151,6 +151,31 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
     return r.v;
 }
 
+// fp8 packed image -> the bf16 packed image the tiled kernels read, row scale folded in (bf16(q * s[n]), RNE): what M > 16
+// rows do with fp8 weights (prefill chunks, teacher-forced evaluation).  One lane = the 16 bytes of two k-steps.
+__global__ void dequant_fp8_kernel(const u32x4* __restrict__ in, const float* __restrict__ scale, int N, int KS, int KSP,
+                                   u32x4* __restrict__ out, size_t total_chunks) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total_chunks) return;
+    const int lane = (int)(c & 63);
+    const size_t rest = c >> 6;
+    const int kp = (int)(rest % KSP), rg = (int)(rest / KSP);
+    const int n = rg * 16 + (lane & 15);
+    const float sc = n < N ? scale[n] : 0.f;
+    const u32x4 q = in[c];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ks = 2 * kp + h;
+        if (ks >= KS) break;
+        const uint32_t lo = h ? q[2] : q[0], hi = h ? q[3] : q[1];
+        const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+        const f32x2 d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), e = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+        out[((size_t)rg * KS + ks) * 64 + lane] = u32x4{pack2bf(a[0] * sc, a[1] * sc), pack2bf(b[0] * sc, b[1] * sc),
+                                                        pack2bf(d[0] * sc, d[1] * sc), pack2bf(e[0] * sc, e[1] * sc)};
+    }
+}
+
 // same block/wave decomposition as skinny_kernel, weights streamed as fp8 pairs of k-steps
 template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
 __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
@@ -551,6 +576,29 @@ static int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
     return SM_OK;
 }
 
+// bf16 expansion of fp8 weights for M > 16 (per HIP stream, grown on demand; slot 0 = w, slot 1 = w2)
+static std::map<hipStream_t, std::pair<void*, size_t>> g_dq[2];
+static int dequant_fp8(hipStream_t st, int which, const void* w8, const float* scale, int N, int K, const void** out) {
+    const int KS = (K + 31) / 32, KSP = (KS + 1) / 2, NRG = (N + 15) / 16;
+    const size_t bytes = (size_t)NRG * KS * 1024;
+    void* dst;
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto& e = g_dq[which][st];
+        if (e.second < bytes) {
+            if (e.first) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+            SM_HIP(hipMalloc(&e.first, bytes));
+            e.second = bytes;
+        }
+        dst = e.first;
+    }
+    const size_t chunks = (size_t)NRG * KSP * 64;
+    dequant_fp8_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, st>>>((const u32x4*)w8, scale, N, KS, KSP, (u32x4*)dst, chunks);
+    SM_LAUNCH_CHECK();
+    *out = dst;
+    return SM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dispatch
 template <int WAVES>
 static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
@@ -746,19 +794,30 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     const bool w8 = p->w_dtype == SM_W_FP8;
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
-    SM_REQUIRE(!w8 || p->M <= 16, "sm_linear: fp8 weights are supported on the weight-streaming path only (M <= 16, got %d)", p->M);
     SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
     SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
     const bool xf32 = p->x_dtype == SM_X_F32;
-    if (p->M <= 16 || (p->M <= 32 && !w8)) {
+    if (w8 && p->M > 16) {
+        // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
+        // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes
+        const void *d0 = nullptr, *d1 = nullptr;
+        int rc = dequant_fp8(st, 0, p->w, p->w_scale, p->N, p->K, &d0);
+        if (!rc && p->w2) rc = dequant_fp8(st, 1, p->w2, p->w2_scale, p->N, p->K, &d1);
+        if (rc) return rc;
+        a.w = (const bf16x8*)d0;
+        if (p->w2) a.w2 = (const bf16x8*)d1;
+        a.wscale = a.wscale2 = nullptr;
+    }
+    const bool w8k = w8 && p->M <= 16;            // fp8 kernels in use
+    if (p->M <= 32) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
         const bool split = xf32 && p->precise;
         const bool dual = p->w2 != nullptr;
         SmProfScope prof(SM_PROF_SKINNY, st);
-        if (w8) {
+        if (w8k) {
             if (a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);
             if (a.KS >= 32) return launch_skinny_fp8<8>(a, xf32, split, dual, st);
             if (a.KS >= 8) return launch_skinny_fp8<4>(a, xf32, split, dual, st);
@@ -776,7 +835,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         {
             static int use_lds = -1;
             if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
-            if (use_lds && p->M >= lds_min_m && !w8 && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt)
+            if (use_lds && p->M >= lds_min_m && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt)
                 return launch_skinny_lds(a, xf32, split, dual, st);
         }
         if (p->M > 16) {       // fallback for 17..32 rows: two MFMA column blocks share every weight load, activations re-read per block

@@ -438,7 +438,6 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
             if (!rc) rc = s->vtc[l].alloc((size_t)kn * max_seq * 2, true);
         }
         s->chunk = max_seq < 2048 ? max_seq : 2048;            // prefill chunk (rows of the activation workspace)
-        if (c.weights_fp8) s->chunk = 16;                      // fp8 weights exist only for the weight-streaming kernels
         const size_t ch = s->chunk;
         A(emb, ch * ld * 4, false); A(xnb, ch * ld * 2, false);
         A(qkvf, ch * (qn + 2 * kn) * 4, false); A(qb, ch * qn * 2, false); A(ctxb, ch * qn * 2, false);
@@ -513,7 +512,7 @@ extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_tok
 
 // a5-a9: PreNet -> LN -> Mamba step -> +res -> LN_f -> PostNet -> 4-layer gate (V/O shortcut) -> logits, decisions
 extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
-    SM_REQUIRE(s && pooled && M >= 1 && M <= (s->m->c.weights_fp8 ? 16 : 32), "sm_stream_push_pooled: M=%d outside [1,%d]", M, s->m->c.weights_fp8 ? 16 : 32);
+    SM_REQUIRE(s && pooled && M >= 1 && M <= 32, "sm_stream_push_pooled: M=%d outside [1,32]", M);
     SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
     sm_model* m = s->m;
     const sm_config_t& c = m->c;
