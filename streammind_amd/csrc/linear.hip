@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 // passes on the store round trip (measured: 25 us of a 34 us QKV GEMM).  In-place residual is still safe: the
 // same lane reads an element before it writes it, and different passes touch different rows.  ACT is a
 // compile-time activation so the 64 inlined element epilogues stay small (I-cache).
-template <int ACT>
+template <int ACT, int THREADS>
 __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
                                                    const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
                                                    int ldo, bf16_t* __restrict__ out_bf16, int ldob, int m0, int n0,
@@ -366,19 +366,20 @@ __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem
     const int n = n0 + chunk * 4;
     f32x4 b4 = {0, 0, 0, 0};
     if (bias) b4 = *(const f32x4*)(bias + n);
+    constexpr int RPP = THREADS / 32;          // rows per pass
 #pragma unroll
-    for (int p0 = 0; p0 < 16; p0 += 4) {
+    for (int p0 = 0; p0 < 128 / RPP; p0 += 4) {
         f32x4 v[4], r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int ml = (p0 + u) * 8 + (tid >> 5);
+            const int ml = (p0 + u) * RPP + (tid >> 5);
             v[u] = *(const f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16));
             r[u] = f32x4{0, 0, 0, 0};
             if (residual && m0 + ml < M) r[u] = *(const f32x4*)(residual + (size_t)(m0 + ml) * ldr + n);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int m = m0 + (p0 + u) * 8 + (tid >> 5);
+            const int m = m0 + (p0 + u) * RPP + (tid >> 5);
             if (m >= M) continue;
             f32x4 o;
 #pragma unroll
@@ -393,9 +394,14 @@ __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem
     }
 }
 
-template <int ACT>   // compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
-__global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
+// WV = 8: the same tile on 8 waves (4(n) x 2(m), each 2x4 fragments): with one block per CU a 4-wave block leaves ONE wave
+// per SIMD, whose DMA issues, fragment reads and MFMAs then run strictly one after the other (~0.75 us per k-tile against
+// 0.27 us of MFMA issue); two waves per SIMD overlap each other.
+template <int ACT, int WV = 4>   // ACT: compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
+__global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NF = 16 / WV;                // 16-row weight fragments per wave: 4 (2 x 2 waves) or 2 (4 x 2 waves)
+    constexpr int J = 16 / WV;                 // W pieces (and X pieces) of 1 KiB each wave stages per k-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int wn = wave >> 1, wm = wave & 1;
@@ -420,11 +426,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
     const char* xbase = (const char*)a.x;
 
     // per-lane source addresses for the 4 + 4 staging loads of this wave
-    const char* wsrc[4];
-    const char* xsrc[4];
+    const char* wsrc[J];
+    const char* xsrc[J];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int c = wave * 4 + j;                 // W chunk: rg_local = c >> 1, ks_local = c & 1
+    for (int j = 0; j < J; ++j) {
+        int c = wave * J + j;                 // W chunk: rg_local = c >> 1, ks_local = c & 1
         int rgg = tile_n * 8 + (c >> 1);
         if (rgg >= a.NRG) rgg = a.NRG - 1;
         wsrc[j] = (const char*)a.w + ((size_t)rgg * a.KS + (c & 1)) * 1024 + lane * 16;
@@ -434,17 +440,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
         int chunk = (lane & 7) ^ (row & 7);
         xsrc[j] = xbase + ((size_t)mg * a.ldx + chunk * 8) * 2;
     }
-    f32x4 acc[4][4];
+    f32x4 acc[NF][4];
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
 
     auto stage = [&](int kt, int buf) {
         char* sb = smem + buf * GEMM_STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = wave * 4 + j;
+        for (int j = 0; j < J; ++j) {
+            int c = wave * J + j;
             glds16(wsrc[j] + (size_t)kt * 2048, sb + c * 1024);
             glds16(xsrc[j] + (size_t)kt * 128, sb + 16384 + c * 1024);
         }
@@ -455,7 +461,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
         const int buf = (kt - kt0) & 1;
         if (kt + 1 < KT) {
             stage(kt + 1, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (J == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -464,17 +471,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
         const char* sx = sw + 16384;
 #pragma unroll
         for (int ksl = 0; ksl < 2; ++ksl) {
-            bf16x8 wf[4], xf[4];
+            bf16x8 wf[NF], xf[4];
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
-                wf[nf] = *(const bf16x8*)(sw + (((wn * 4 + nf) * 2 + ksl) * 1024) + lane * 16);
+            for (int nf = 0; nf < NF; ++nf)
+                wf[nf] = *(const bf16x8*)(sw + (((wn * NF + nf) * 2 + ksl) * 1024) + lane * 16);
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
                 int ml = wm * 64 + mf * 16 + i;
                 xf[mf] = *(const bf16x8*)(sx + ml * 128 + (((ksl * 4 + g) ^ (ml & 7)) * 16));
             }
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf)
+            for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
                     acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
@@ -486,19 +493,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
     // XOR-swizzled with (m & 31) so both the fragment-shaped writes and the row-shaped reads are conflict-free),
     // then every wave walks whole rows: 512 B contiguous per row to HBM.
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) {
             int ml = wm * 64 + mf * 16 + i;
-            int chunk = wn * 16 + nf * 4 + g;
+            int chunk = (wn * NF + nf) * 4 + g;
             *(f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16)) = acc[nf][mf];
         }
     __syncthreads();
     if (a.vt && tile_n * GEMM_BN >= a.vt_n0) {
         // V^T side output: lanes walk m (= s, the contiguous dim of vt), one n per wave per pass
         const int nh = (a.N - a.vt_n0) / a.vt_dh;
-        for (int pass = 0; pass < 32; ++pass) {
-            const int nl = pass * 4 + wave;
+        for (int pass = 0; pass < 128 / WV; ++pass) {
+            const int nl = pass * WV + wave;
             const int n = tile_n * GEMM_BN + nl;
             if (n >= a.N) continue;
             const int c = n - a.vt_n0;
@@ -517,11 +524,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(LinArgs a, int tiles_m, in
         }
     } else if (ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * GEMM_BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
                (a.ldr & 3) == 0) {
-        tile_rows_epilogue<ACT>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16,
+        tile_rows_epilogue<ACT, WV * 64>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16,
                                 tile_m * GEMM_BM, tile_n * GEMM_BN, a.M, tid);
     } else {
-        for (int pass = 0; pass < 16; ++pass) {
-            const int ml = pass * 8 + (tid >> 5);
+        for (int pass = 0; pass < 128 / (WV * 2); ++pass) {
+            const int ml = pass * (WV * 2) + (tid >> 5);
             const int chunk = tid & 31;
             f32x4 v = *(const f32x4*)(smem + ml * 512 + ((chunk ^ (ml & 31)) * 16));
             store4(a, tile_m * GEMM_BM + ml, tile_n * GEMM_BN + chunk * 4, v, nullptr);
@@ -873,42 +880,52 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);
     static bool attr_set = false;
     if (!attr_set) {
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+#define GEMM_ATTR(ACT)                                                                                                       \
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<ACT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES)); \
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<ACT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES))
+        GEMM_ATTR(0); GEMM_ATTR(1); GEMM_ATTR(-1);
+#undef GEMM_ATTR
         attr_set = true;
     }
-    // split-K: a prefill-sized M gives too few 128x128 tiles for 256 CUs (Mistral o / down projections at M = 512: 128 tiles,
-    // 0.33 PFLOP/s -> 0.66 with the K loop split in 4); up to 4 blocks per tile, at most ~512 blocks.  SM_SPLITK=n forces n.
-    {
-        static int force_s = -1;
-        if (force_s < 0) { const char* e = getenv("SM_SPLITK"); force_s = e ? atoi(e) : 0; }
-        const int tiles = tiles_m * tiles_n, KTall = a.KS >> 1;
-        int S = force_s > 0 ? force_s : (tiles < 256 ? 512 / tiles : 1);      // <= 512 blocks: 576 measured worse than 384-432
-        if (S > 4) S = 4;
-        while (S > 1 && KTall / S < 8) --S;
-        if (p->vt || (p->N & 3) || p->M > 4096) S = 1;
-        if (S > 1) {
-            float* ws = nullptr;
-            int rc = splitk_workspace(st, (size_t)S * p->M * p->N * sizeof(float), &ws);
-            if (rc) return rc;
-            LinArgs b = a;                       // partial pass: raw fp32 accumulators into the slabs
-            b.out_f32 = ws; b.ldo = p->N; b.out_bf16 = nullptr; b.bias = nullptr; b.residual = nullptr; b.act = SM_ACT_NONE;
-            b.remap_in = 0; b.vt = nullptr;
-            SmProfScope prof(SM_PROF_GEMM, st);
-            gemm_kernel<0><<<dim3(tiles, S), 256, 2 * GEMM_STAGE_BYTES, st>>>(b, tiles_m, tiles_n);
-            SM_LAUNCH_CHECK();
-            const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
-            splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, p->N);
-            SM_LAUNCH_CHECK();
-            return SM_OK;
-        }
-    }
+    // Few tiles (a single frame through the ViT: 40-160 tiles; LLM prefill chunks): split-K so that ~256 blocks exist, but
+    // only for long K loops -- measured per shape (tools/gemm_small_sweep.py): at K = 1024 the reduce pass costs more than the
+    // shorter loop saves (ViT qkv 14.5 vs 21.2 us), at K = 4096 / 40 tiles 4 slabs win (38.4 -> 20.5 us).  SM_SPLITK=n forces n.
+    static int force_s = -1, use_w8 = -1;
+    if (force_s < 0) { const char* e = getenv("SM_SPLITK"); force_s = e ? atoi(e) : 0; }
+    if (use_w8 < 0) { const char* e = getenv("SM_GEMM_W8"); use_w8 = e ? atoi(e) : 2; }   // 0: 4-wave blocks, 1: 8 waves when blocks <= 256, 2: always
+    const int tiles = tiles_m * tiles_n, KTall = a.KS >> 1;
+    int S = tiles <= 128 ? 256 / tiles : 1;
+    if (S > 4) S = 4;
+    while (S > 1 && KTall / S < 16) --S;
+    if (force_s > 0) S = force_s;
+    if (S > KTall) S = KTall;
+    if (S < 1 || p->vt || (p->N & 3) || p->M > 4096) S = 1;
+    const bool wv8 = use_w8 == 2 || (use_w8 == 1 && tiles * S <= 256);
     SmProfScope prof(SM_PROF_GEMM, st);
-    const dim3 grid(tiles_m * tiles_n);
-    if (p->act == SM_ACT_NONE) gemm_kernel<0><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
-    else if (p->act == SM_ACT_QUICK_GELU) gemm_kernel<1><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
-    else gemm_kernel<-1><<<grid, 256, 2 * GEMM_STAGE_BYTES, st>>>(a, tiles_m, tiles_n);
+#define GEMM_LAUNCH(ACT, ARGS, GRID)                                                                                         \
+    do {                                                                                                                     \
+        if (wv8) gemm_kernel<ACT, 8><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                       \
+        else gemm_kernel<ACT, 4><<<GRID, 256, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                           \
+    } while (0)
+    if (S > 1) {
+        float* ws = nullptr;
+        int rc = splitk_workspace(st, (size_t)S * p->M * p->N * sizeof(float), &ws);
+        if (rc) return rc;
+        LinArgs b = a;                       // partial pass: raw fp32 accumulators into the slabs
+        b.out_f32 = ws; b.ldo = p->N; b.out_bf16 = nullptr; b.bias = nullptr; b.residual = nullptr; b.act = SM_ACT_NONE;
+        b.remap_in = 0; b.vt = nullptr;
+        GEMM_LAUNCH(0, b, dim3(tiles, S));
+        SM_LAUNCH_CHECK();
+        const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
+        splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, p->N);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
+    const dim3 grid(tiles);
+    if (p->act == SM_ACT_NONE) GEMM_LAUNCH(0, a, grid);
+    else if (p->act == SM_ACT_QUICK_GELU) GEMM_LAUNCH(1, a, grid);
+    else GEMM_LAUNCH(-1, a, grid);
+#undef GEMM_LAUNCH
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
