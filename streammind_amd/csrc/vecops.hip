@@ -357,28 +357,39 @@ extern "C" int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, 
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
-// block = (frame b, 64-column slab); 4 waves split the P patch rows, lanes own one column each -> coalesced 256 B rows
-__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, int S, int D, float* __restrict__ pooled,
-                                                   bf16_t* __restrict__ feats) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+// block = (frame b, 64-column slab); 16 waves split the P patch rows (4 rows in flight per wave: one frame alone is a
+// latency-bound 16-block launch), lanes own one column each -> coalesced 256 B rows
+__global__ __launch_bounds__(1024) void pool_kernel(const float* __restrict__ x, int S, int D, float* __restrict__ pooled,
+                                                    bf16_t* __restrict__ feats) {
+    __shared__ float red[16][64];
+    const int b = blockIdx.y, l = threadIdx.x & 63, c = blockIdx.x * 64 + l, w = threadIdx.x >> 6;
     const int P = S - 1;
     float s = 0.f;
     if (c < D) {
         const float* xb = x + ((size_t)b * S + 1) * D + c;
-        for (int r = w; r < P; r += 4) {
-            float v = xb[(size_t)r * D];
-            s += v;
-            if (feats) feats[((size_t)b * P + r) * D + c] = (bf16_t)f2bf(v);
+        for (int r0 = w; r0 < P; r0 += 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = r0 + u * 16 < P ? xb[(size_t)(r0 + u * 16) * D] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += v[u];
+                if (feats && r0 + u * 16 < P) feats[((size_t)b * P + r0 + u * 16) * D + c] = (bf16_t)f2bf(v[u]);
+            }
         }
     }
-    red[w][threadIdx.x & 63] = s;
+    red[w][l] = s;
     __syncthreads();
-    if (w == 0 && c < D) pooled[(size_t)b * D + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)P;
+    if (w == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][l];
+        pooled[(size_t)b * D + c] = t / (float)P;
+    }
 }
 extern "C" int sm_pool_patches(const float* x, int B, int S, int D, float* pooled, void* feats, void* stream) {
     SM_REQUIRE(x && pooled && B > 0 && S > 1, "sm_pool_patches: bad args");
-    pool_kernel<<<dim3(cdiv(D, 64), B), 256, 0, (hipStream_t)stream>>>(x, S, D, pooled, (bf16_t*)feats);
+    pool_kernel<<<dim3(cdiv(D, 64), B), 1024, 0, (hipStream_t)stream>>>(x, S, D, pooled, (bf16_t*)feats);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
