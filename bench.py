@@ -336,12 +336,21 @@ def main():
     if a.gpus > 1 and world == 1:
         print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
+    # test hook (1-GPU box): SM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and SM_BENCH_BACKEND=gloo swaps the backend, so the
+    # N > 1 control flow of this file can be exercised without N GPUs; the driver's runs never set them
+    if os.environ.get("SM_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("SM_BENCH_BACKEND", "nccl")
+    cdev = "cuda" if backend == "nccl" else "cpu"        # device of the few scalar collectives below
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SM_BENCH_FORCE_DIST") == "1":      # FORCE_DIST: exercise the RCCL calls with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from streammind_amd import _lib
     from streammind_amd.native import NativeModel, PathConfig
@@ -387,7 +396,7 @@ def main():
     if prof:
         lib.sm_prof_enable(0)
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(logits).all()
@@ -399,7 +408,7 @@ def main():
 
             def gather(tok):
                 try:
-                    out = allgather_gated_tokens(tok, cfg.conn_d_model)
+                    out = allgather_gated_tokens(tok if cdev == "cuda" else tok.cpu(), cfg.conn_d_model)
                     gathered["calls"] += 1
                     gathered["rows"] = int(sum(t.shape[0] for t in out)) if out is not None else 0
                 except Exception as e:               # never let the optional exchange take the scaling run down
@@ -411,7 +420,7 @@ def main():
     if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
         dec_leg = decode_leg(model, stream, cfg)
         if dist is not None:
-            t = torch.tensor([dec_leg["tokens_per_s"]], device="cuda", dtype=torch.float64)
+            t = torch.tensor([dec_leg["tokens_per_s"]], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
