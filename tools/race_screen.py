@@ -14,7 +14,9 @@ cases = []
 for (M, N, K, res, act, odt) in [(16156, 3072, 1024, False, 0, torch.bfloat16), (16156, 1024, 1024, True, 0, torch.float32),
                                   (16156, 4096, 1024, False, 1, torch.bfloat16), (16156, 1024, 4096, True, 0, torch.float32),
                                   (4616, 3072, 1024, False, 0, torch.bfloat16), (577, 1024, 4096, True, 0, torch.float32),
-                                  (512, 4096, 14336, True, 0, torch.float32), (8078, 4096, 1024, False, 1, torch.bfloat16)]:
+                                  (512, 4096, 14336, True, 0, torch.float32), (8078, 4096, 1024, False, 1, torch.bfloat16),
+                                  (577, 3072, 1024, False, 0, torch.bfloat16), (577, 4096, 1024, False, 1, torch.bfloat16),
+                                  (2308, 1024, 1024, True, 0, torch.float32), (328, 6144, 4096, False, 0, torch.float32)]:
     w = native.pack_weight((torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16())
     x = torch.randn(M, K, device="cuda").bfloat16()
     r = torch.randn(M, N, device="cuda") if res else None
