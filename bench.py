@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-decode", action="store_true", help="skip the Mistral-7B decode tokens/s leg")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (teacher-forced eval, ingest front-end, per-call latency)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -425,14 +426,14 @@ def main():
             dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
     tf_leg = None
-    if not a.no_decode and world == 1:
+    if not a.no_decode and world == 1 and not a.no_aux:
         try:
             tf_leg = teacher_forced_leg(model, stream, cfg)
         except Exception as e:                   # an auxiliary leg must never take the headline line down
             tf_leg = {"error": repr(e)[:200]}
 
     ing_leg = lat_leg = None
-    if world == 1:
+    if world == 1 and not a.no_aux:
         try:
             ing_leg = ingest_leg()
         except Exception as e:

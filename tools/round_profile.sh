@@ -10,7 +10,7 @@ rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d 
 grep '^{"metric"' $O/bench_profiled.log > $O/bench_profiled.json
 cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" $O/kernel_stats.csv
 rm -rf /tmp/pmc_f /tmp/pmc_w
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
 head -12 $O/kernel_stats.csv | cut -c1-160
