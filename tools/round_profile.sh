@@ -13,4 +13,7 @@ rm -rf /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
+rm -rf /tmp/pmc_m
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+python tools/pmc_mfma_summary.py /tmp/pmc_m $O/mfma_util.json
 head -12 $O/kernel_stats.csv | cut -c1-160
