@@ -249,8 +249,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
 // reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB>   // MB: 16-row activation blocks (M <= 16 * MB)
+// NORM: the activations are the raw fp32 residual stream and the RMSNorm in front of the product is computed here (decode:
+// q/k/v, gate/up and lm_head at one row) -- every block recomputes mean(x^2) of its rows from L2 while its first batch of weight
+// loads is already in flight, then builds each x fragment as bf16(gamma * (x * rstd)), sm_norm's own formula.  The row loads
+// are issued BEFORE the weight loads (vmcnt retires in order: waiting for them must not wait for HBM) and the partial sums
+// cross the waves behind a raw s_barrier (__syncthreads would drain vmcnt).
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false>   // MB: 16-row activation blocks (M <= 16 * MB)
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
+    static_assert(!NORM || (XF32 && !SPLIT && MB == 1), "fused RMSNorm: fp32 activations, one rounding, <= 16 rows");
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = blockIdx.x;
@@ -271,6 +277,115 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 
     constexpr int U = MB == 1 ? 4 : 2;
     int ks = wave;
+    // NORM: normalised bf16 rows [M][K] in LDS behind the reduction scratch
+    bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);
+    // x fragment of row i at k-step kk (NORM: normalised on the fly)
+    auto xfrag = [&](int mb, int kk, bf16x8& xh, bf16x8& xl) {
+        if constexpr (NORM) {
+            union { bf16x8 v; u32x4 u; } r;
+            r.u = u32x4{0, 0, 0, 0};
+            if (valid[0]) r.u = *(const u32x4*)(xs + (size_t)i * a.K + kk * 32 + g * 8);
+            xh = r.v;
+        } else {
+            load_x<XF32, SPLIT>(xrow[mb], kk * 32 + g * 8, valid[mb], xh, xl);
+        }
+    };
+    auto mfmas = [&](const bf16x8 (&wa)[U], const bf16x8 (&wb)[U], int k0) {
+        if constexpr (NORM) {
+            // two k-steps' x / gamma fragments at a time: all four at once cost 32 more VGPRs and a block per CU
+#pragma unroll
+            for (int u0 = 0; u0 < U; u0 += 2) {
+                bf16x8 xh[2], xl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) xfrag(0, k0 + (u0 + u) * WAVES, xh[u], xl[u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u0 + u], xh[u], acc[0], 0, 0, 0);
+                    if (DUAL) acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u0 + u], xh[u], acc2[0], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            bf16x8 xh[U], xl[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xfrag(mb, k0 + u * WAVES, xh[u], xl[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc[mb], 0, 0, 0);
+                if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc[mb], 0, 0, 0);
+                if (DUAL) {
+                    acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2[mb], 0, 0, 0);
+                    if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2[mb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if constexpr (NORM) {
+        // rows 0..M-1: wave w owns the f32x4 chunks {(u * WAVES + w) * 64 + lane}; the first four per lane (K <= 1024 * WAVES)
+        // stay in registers between the sum and the conversion, x AND gamma fetched together
+        float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;          // [WAVES][16]
+        const int nv = a.K >> 2;
+        f32x4 t[4], gm[4];
+        const float* xr = (const float*)a.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (u * WAVES + wave) * 64 + lane;
+            t[u] = c < nv ? *(const f32x4*)(xr + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+            gm[u] = c < nv ? *(const f32x4*)(a.ngamma + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+        }
+        bf16x8 wa0[U], wb0[U];
+        const bool have0 = ks + (U - 1) * WAVES < KS;
+        if (have0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                wa0[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
+                if (DUAL) wb0[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+            }
+        }
+        for (int m = 0; m < a.M; ++m) {
+            const float* xm = xr + (size_t)m * a.ldx;
+            if (m) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = (u * WAVES + wave) * 64 + lane;
+                    t[u] = c < nv ? *(const f32x4*)(xm + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+                }
+            }
+            float sq = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sq += t[u][0] * t[u][0] + t[u][1] * t[u][1] + t[u][2] * t[u][2] + t[u][3] * t[u][3];
+            for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {      // K > 1024 * WAVES: the rest, chunk by chunk
+                const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4);
+                sq += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) nsum[(m & 1) * WAVES + wave] = sq;            // two alternating slots of WAVES partials
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) tot += nsum[(m & 1) * WAVES + w];
+            const float rs = rsqrtf(tot / (float)a.K + a.neps);
+            // this wave's chunks of row m -> LDS as bf16(gamma * (x * rstd)), sm_norm's formula
+            bf16_t* xo = xs + (size_t)m * a.K;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (u * WAVES + wave) * 64 + lane;
+                if (c < nv) *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gm[u][0] * (t[u][0] * rs), gm[u][1] * (t[u][1] * rs)),
+                                                                   pack2bf(gm[u][2] * (t[u][2] * rs), gm[u][3] * (t[u][3] * rs))};
+            }
+            for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {
+                const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4), gq = *(const f32x4*)(a.ngamma + (size_t)c * 4);
+                *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gq[0] * (q[0] * rs), gq[1] * (q[1] * rs)), pack2bf(gq[2] * (q[2] * rs), gq[3] * (q[3] * rs))};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (have0) { mfmas(wa0, wb0, ks); ks += U * WAVES; }
+    }
     for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
         bf16x8 wa[U], wb[U];
 #pragma unroll
@@ -278,6 +393,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
             wa[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
             if (DUAL) wb[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
         }
+        if constexpr (NORM) { mfmas(wa, wb, ks); continue; }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             bf16x8 xh[U], xl[U];
@@ -300,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             bf16x8 xh, xl;
-            load_x<XF32, SPLIT>(xrow[mb], ks * 32 + g * 8, valid[mb], xh, xl);
+            xfrag(mb, ks, xh, xl);
             acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc[mb], 0, 0, 0);
             if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc[mb], 0, 0, 0);
             if (DUAL) {
@@ -781,6 +897,16 @@ static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hip
     return SM_OK;
 }
 
+template <int WAVES>
+static int launch_skinny_norm(const LinArgs& a, bool dual, hipStream_t st) {
+    dim3 grid(a.NRG), block(WAVES * 64);
+    const size_t sh = ((size_t)WAVES * (dual ? 8 : 4) * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
+    if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a);
+    else skinny_kernel<WAVES, true, false, false, 1, true><<<grid, block, sh, st>>>(a);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
     SM_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "sm_linear: bad dims M=%d N=%d K=%d", p->M, p->N, p->K);
@@ -800,6 +926,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     a.vt = (bf16_t*)p->vt; a.vt_n0 = p->vt_n0; a.vt_S = p->vt_S; a.vt_dh = p->vt_dh; a.vt_ld = p->vt_ld;
     const bool w8 = p->w_dtype == SM_W_FP8;
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
+    a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
+    SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && !w8 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
+               "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), bf16 weights, fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
     SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
     SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
@@ -824,6 +953,11 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const bool split = xf32 && p->precise;
         const bool dual = p->w2 != nullptr;
         SmProfScope prof(SM_PROF_SKINNY, st);
+        if (p->norm_gamma) {
+            if (a.KS >= 32) return launch_skinny_norm<8>(a, dual, st);
+            if (a.KS >= 8) return launch_skinny_norm<4>(a, dual, st);
+            return launch_skinny_norm<1>(a, dual, st);
+        }
         if (w8k) {
             if (a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);
             if (a.KS >= 32) return launch_skinny_fp8<8>(a, xf32, split, dual, st);

@@ -22,6 +22,8 @@ struct LinArgs {
     int vt_n0, vt_S, vt_dh, vt_ld;
     const float* wscale;        // fp8 weights (skinny path): per-output-row dequantisation scale, applied to the accumulator
     const float* wscale2;       //   ... of the second (dual) weight
+    const float* ngamma;        // fused RMSNorm of the activations (weight-streaming path): gamma [K], or nullptr
+    float neps;
 };
 
 static __device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }

@@ -602,6 +602,9 @@ extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M,
 }
 
 // ------------------------------------------------------------------------------------------------ LLM
+// SM_NO_FUSED_NORM=1: keep the separate RMSNorm launches on the decode path (A/B tuning switch)
+static const bool g_no_fused_norm = [] { const char* e = getenv("SM_NO_FUSED_NORM"); return e && atoi(e) != 0; }();
+
 // one pass of the decoder over n rows of s->emb (fp32 residual stream) at positions kv_len..kv_len+n-1
 static int llm_layers(sm_stream* s, int n, void* stream) {
     sm_model* m = s->m;
@@ -611,8 +614,11 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
     int rc;
     for (int l = 0; l < c.llm_layers; ++l) {
         const std::string p = "llm.model.layers." + std::to_string(l) + ".";
-        if ((rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-        {   sm_linear_t a = lin(m, m->slots.at(p + "qkv"), s->xnb.p, SM_X_BF16, n, ld);
+        // decode (one row, bf16 weights): both RMSNorms ride inside the weight-streaming products that consume them
+        const bool fuse_norm = n == 1 && !m->slots.at(p + "qkv").fp8 && (ld & 31) == 0 && !g_no_fused_norm;
+        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        {   sm_linear_t a = fuse_norm ? lin(m, m->slots.at(p + "qkv"), x, SM_X_F32, n, ld) : lin(m, m->slots.at(p + "qkv"), s->xnb.p, SM_X_BF16, n, ld);
+            if (fuse_norm) { a.norm_gamma = m->ptr<float>(p + "input_layernorm.weight"); a.norm_eps = c.llm_eps; }
             a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
             if ((rc = sm_linear(&a, stream))) return rc; }
         if ((rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
@@ -622,10 +628,11 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         {   sm_linear_t a = lin(m, m->slots.at(p + "o"), s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
         if (n <= 32) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel
             const Slot& gu = m->slots.at(p + "gu");
-            sm_linear_t a = lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
+            sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, n, ld) : lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
+            if (fuse_norm) { a.norm_gamma = m->ptr<float>(p + "post_attention_layernorm.weight"); a.norm_eps = c.llm_eps; }
             a.N = c.llm_mlp;
             if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
             else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
@@ -651,8 +658,11 @@ static int llm_head(sm_stream* s, int row, void* stream) {
     const sm_config_t& c = m->c;
     const int ld = c.llm_hidden;
     int rc;
-    if ((rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-    sm_linear_t a = lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, 1, ld);
+    const bool fuse_norm = !m->slots.at("llm.lm_head").fp8 && (ld & 31) == 0 && !g_no_fused_norm;
+    if (!fuse_norm && (rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+    sm_linear_t a = fuse_norm ? lin(m, m->slots.at("llm.lm_head"), s->emb.as<float>() + (size_t)row * ld, SM_X_F32, 1, ld)
+                              : lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, 1, ld);
+    if (fuse_norm) { a.norm_gamma = m->ptr<float>("llm.model.norm.weight"); a.norm_eps = c.llm_eps; }
     a.out_f32 = s->lmlog.as<float>(); a.ldo = c.llm_vocab;
     if ((rc = sm_linear(&a, stream))) return rc;
     return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);

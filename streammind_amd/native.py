@@ -309,8 +309,9 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
 def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None,
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
-           w2_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Operator-level entry used by the parity tests: y = epilogue(x @ W^T)."""
+           w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
+           norm_eps: float = 0.0) -> torch.Tensor:
+    """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)
     M = x.shape[0]
@@ -323,6 +324,8 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
         a.w_dtype, a.w_scale, a.w2_scale = _lib.SM_W_FP8, w_scale.data_ptr(), _p(w2_scale)
     if residual is not None:
         a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
+    if norm_gamma is not None:
+        a.norm_gamma, a.norm_eps = norm_gamma.data_ptr(), float(norm_eps)
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     if out_dtype == torch.float32:
         a.out_f32, a.ldo = out.data_ptr(), N

@@ -274,6 +274,34 @@ def test_skinny_dual_fp8(nat):
     assert relerr(y, ref) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,dual", [(1, 256, 4096, False), (1, 512, 4096, True), (3, 64, 256, False), (16, 48, 1024, True),
+                                         (1, 32000, 4096, False), (2, 96, 64, False), (1, 128, 9216, False)])
+def test_skinny_linear_fused_rmsnorm(nat, M, N, K, dual):
+    """decode path: MistralRMSNorm folded into the weight-streaming product (norm_gamma).  Against the unfused pair
+    sm_norm -> sm_linear within one bf16 ulp of a few activations (the row sum is taken in a different order), and against
+    the fp32 definition bf16(gamma * x * rsqrt(mean x^2 + eps)) @ W^T."""
+    x = rnd((M, K), 1, 3.0)
+    gamma = 1.0 + rnd((K,), 2, 0.2)
+    w = O.bf16_round(rnd((N, K), 3, K ** -0.5))
+    wp = nat.pack_weight(w.cuda().bfloat16())
+    w2 = O.bf16_round(rnd((N, K), 4, K ** -0.5)) if dual else None
+    w2p = nat.pack_weight(w2.cuda().bfloat16()) if dual else None
+    eps = 1e-5
+    y = nat.linear(x.cuda(), wp, N, K, w2p=w2p, norm_gamma=gamma.cuda(), norm_eps=eps)
+    xn = O.bf16_round(gamma * (x * torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + eps).float()))
+    f = (lambda t: (O.silu(t.double() @ w.double().t()) * (t.double() @ w2.double().t())).float()) if dual else \
+        (lambda t: (t.double() @ w.double().t()).float())
+    assert relerr(y, f(xn)) < 2e-3                      # a handful of activations may round the other way (2^-9 each)
+    from streammind_amd._lib import load, check
+    xg, gg = x.cuda(), gamma.cuda()
+    xn_gpu = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    check(load().sm_norm(xg.data_ptr(), M, K, K, gg.data_ptr(), None, eps, 0, None, xn_gpu.data_ptr(), K,
+                         torch.cuda.current_stream().cuda_stream))
+    y2 = nat.linear(xn_gpu, wp, N, K, w2p=w2p)
+    assert relerr(y, y2.cpu()) < 2e-3
+    assert (y.cpu() == y2.cpu()).float().mean() > 0.5   # and mostly identical bit for bit
+
+
 @pytest.mark.parametrize("M,N,K,dual", [(20, 512, 1056, False), (28, 1024, 512, True), (48, 384, 1024, False), (300, 768, 4096, False)])
 def test_linear_fp8_weights_more_than_16_rows(nat, M, N, K, dual):
     """fp8 weights with M > 16 rows (prefill chunks, teacher-forced evaluation): the packed fp8 image is expanded to a bf16
