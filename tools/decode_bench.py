@@ -10,5 +10,5 @@ model = NativeModel(cfg)
 bench.random_weights_into(model, cfg, 1)
 bench.random_llm_weights_into(model, cfg, 2)
 model.finalize()
-s = model.open_stream(max_frames=512, max_seq=1024)
+s = model.open_stream(max_frames=512, max_seq=int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
 print(bench.decode_leg(model, s, cfg, n_new=int(sys.argv[1]) if len(sys.argv) > 1 else 64))
