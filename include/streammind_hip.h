@@ -90,7 +90,7 @@ typedef struct sm_linear_t {
     /* fused RMSNorm of the activations (MistralRMSNorm in front of q/k/v, gate/up and lm_head at decode time):
      * norm_gamma != NULL: x is the raw fp32 residual stream [M][ldx] and the product runs on
      * bf16(norm_gamma * (x * rsqrt(mean(x^2) + norm_eps))) -- what sm_norm would have written -- without the extra launch.
-     * Weight-streaming path only (M <= 16, bf16 weights, x_dtype SM_X_F32, precise = 0).              */
+     * Weight-streaming path only (M <= 16, M*K <= 16384, bf16 or fp8 weights, x_dtype SM_X_F32, precise = 0). */
     const float* norm_gamma;
     float norm_eps;
 } sm_linear_t;

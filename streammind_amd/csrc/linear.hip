@@ -176,9 +176,72 @@ __global__ void dequant_fp8_kernel(const u32x4* __restrict__ in, const float* __
     }
 }
 
+// ---- fused RMSNorm of the weight-streaming kernels (NORM): the activations are the raw fp32 residual stream.  Every block
+// recomputes mean(x^2) of its rows from L2 while its first batch of weight loads is already in flight, writes the normalised
+// rows bf16(gamma * (x * rstd)) -- sm_norm's own formula -- to LDS ONCE and reads its x fragments from there (re-reading x and
+// gamma per k-step made the kernels texture-address bound).  norm_issue goes BEFORE the caller's first weight loads (vmcnt
+// retires in order: waiting for the row must not wait for HBM); the partial sums cross the waves behind raw s_barriers
+// (__syncthreads would drain vmcnt).  Wave w owns the f32x4 chunks {(u * WAVES + w) * 64 + lane}; the first four per lane
+// (K <= 1024 * WAVES) stay in registers between the sum and the conversion.
+template <int WAVES>
+__device__ __forceinline__ void norm_issue(const LinArgs& a, int wave, int lane, f32x4 (&t)[4], f32x4 (&gm)[4]) {
+    const int nv = a.K >> 2;
+    const float* xr = (const float*)a.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = (u * WAVES + wave) * 64 + lane;
+        t[u] = c < nv ? *(const f32x4*)(xr + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+        gm[u] = c < nv ? *(const f32x4*)(a.ngamma + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+    }
+}
+template <int WAVES>
+__device__ __forceinline__ void norm_finish(const LinArgs& a, float* nsum, bf16_t* xs, int wave, int lane, f32x4 (&t)[4], const f32x4 (&gm)[4]) {
+    const int nv = a.K >> 2;
+    const float* xr = (const float*)a.x;
+    for (int m = 0; m < a.M; ++m) {
+        const float* xm = xr + (size_t)m * a.ldx;
+        if (m) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = (u * WAVES + wave) * 64 + lane;
+                t[u] = c < nv ? *(const f32x4*)(xm + (size_t)c * 4) : f32x4{0, 0, 0, 0};
+            }
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq += t[u][0] * t[u][0] + t[u][1] * t[u][1] + t[u][2] * t[u][2] + t[u][3] * t[u][3];
+        for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {      // K > 1024 * WAVES: the rest, chunk by chunk
+            const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4);
+            sq += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        }
+        sq = wave_sum(sq);
+        if (lane == 0) nsum[(m & 1) * WAVES + wave] = sq;            // two alternating slots of WAVES partials
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) tot += nsum[(m & 1) * WAVES + w];
+        const float rs = rsqrtf(tot / (float)a.K + a.neps);
+        bf16_t* xo = xs + (size_t)m * a.K;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (u * WAVES + wave) * 64 + lane;
+            if (c < nv) *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gm[u][0] * (t[u][0] * rs), gm[u][1] * (t[u][1] * rs)),
+                                                               pack2bf(gm[u][2] * (t[u][2] * rs), gm[u][3] * (t[u][3] * rs))};
+        }
+        for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {
+            const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4), gq = *(const f32x4*)(a.ngamma + (size_t)c * 4);
+            *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gq[0] * (q[0] * rs), gq[1] * (q[1] * rs)), pack2bf(gq[2] * (q[2] * rs), gq[3] * (q[3] * rs))};
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 // same block/wave decomposition as skinny_kernel, weights streamed as fp8 pairs of k-steps
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL>
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, bool NORM = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
+    static_assert(!NORM || (XF32 && !SPLIT), "fused RMSNorm: fp32 activations, one rounding");
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rg = blockIdx.x;
@@ -191,12 +254,20 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
     f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
     constexpr int U = DUAL ? 2 : 4;
     int kp = wave;
+    bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);     // NORM: normalised bf16 rows [M][K]
     auto body = [&](u32x4 q, u32x4 q2, int kpi) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ks = 2 * kpi + h;
             bf16x8 xh, xl;
-            load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid && ks < KS, xh, xl);
+            if constexpr (NORM) {
+                union { bf16x8 v; u32x4 u; } r;
+                r.u = u32x4{0, 0, 0, 0};
+                if (valid && ks < KS) r.u = *(const u32x4*)(xs + (size_t)i * a.K + ks * 32 + g * 8);
+                xh = r.v;
+            } else {
+                load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid && ks < KS, xh, xl);
+            }
             const bf16x8 wf = fp8x8_to_bf16(h ? q[2] : q[0], h ? q[3] : q[1]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xh, acc, 0, 0, 0);
             if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xl, acc, 0, 0, 0);
@@ -207,6 +278,25 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
             }
         }
     };
+    if constexpr (NORM) {
+        f32x4 t[4], gm[4];
+        norm_issue<WAVES>(a, wave, lane, t, gm);
+        u32x4 q0[U], q20[U];
+        const bool have0 = kp + (U - 1) * WAVES < KSP;
+        if (have0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                q0[u] = __builtin_nontemporal_load(wp + (size_t)(kp + u * WAVES) * 64);
+                if (DUAL) q20[u] = __builtin_nontemporal_load(wp2 + (size_t)(kp + u * WAVES) * 64);
+            }
+        }
+        norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
+        if (have0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) body(q0[u], DUAL ? q20[u] : q0[u], kp + u * WAVES);
+            kp += U * WAVES;
+        }
+    }
     for (; kp + (U - 1) * WAVES < KSP; kp += U * WAVES) {
         u32x4 q[U], q2[U];
 #pragma unroll
@@ -249,11 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
 // reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
-// NORM: the activations are the raw fp32 residual stream and the RMSNorm in front of the product is computed here (decode:
-// q/k/v, gate/up and lm_head at one row) -- every block recomputes mean(x^2) of its rows from L2 while its first batch of weight
-// loads is already in flight, then builds each x fragment as bf16(gamma * (x * rstd)), sm_norm's own formula.  The row loads
-// are issued BEFORE the weight loads (vmcnt retires in order: waiting for them must not wait for HBM) and the partial sums
-// cross the waves behind a raw s_barrier (__syncthreads would drain vmcnt).
+// NORM: RMSNorm of the activations fused in front (norm_issue / norm_finish above; decode q/k/v, gate/up, lm_head at one row)
 template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false>   // MB: 16-row activation blocks (M <= 16 * MB)
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
     static_assert(!NORM || (XF32 && !SPLIT && MB == 1), "fused RMSNorm: fp32 activations, one rounding, <= 16 rows");
@@ -324,18 +410,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
         }
     };
     if constexpr (NORM) {
-        // rows 0..M-1: wave w owns the f32x4 chunks {(u * WAVES + w) * 64 + lane}; the first four per lane (K <= 1024 * WAVES)
-        // stay in registers between the sum and the conversion, x AND gamma fetched together
-        float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;          // [WAVES][16]
-        const int nv = a.K >> 2;
+        float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;
         f32x4 t[4], gm[4];
-        const float* xr = (const float*)a.x;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = (u * WAVES + wave) * 64 + lane;
-            t[u] = c < nv ? *(const f32x4*)(xr + (size_t)c * 4) : f32x4{0, 0, 0, 0};
-            gm[u] = c < nv ? *(const f32x4*)(a.ngamma + (size_t)c * 4) : f32x4{0, 0, 0, 0};
-        }
+        norm_issue<WAVES>(a, wave, lane, t, gm);
         bf16x8 wa0[U], wb0[U];
         const bool have0 = ks + (U - 1) * WAVES < KS;
         if (have0) {
@@ -345,45 +422,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
                 if (DUAL) wb0[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
             }
         }
-        for (int m = 0; m < a.M; ++m) {
-            const float* xm = xr + (size_t)m * a.ldx;
-            if (m) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = (u * WAVES + wave) * 64 + lane;
-                    t[u] = c < nv ? *(const f32x4*)(xm + (size_t)c * 4) : f32x4{0, 0, 0, 0};
-                }
-            }
-            float sq = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sq += t[u][0] * t[u][0] + t[u][1] * t[u][1] + t[u][2] * t[u][2] + t[u][3] * t[u][3];
-            for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {      // K > 1024 * WAVES: the rest, chunk by chunk
-                const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4);
-                sq += q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-            }
-            sq = wave_sum(sq);
-            if (lane == 0) nsum[(m & 1) * WAVES + wave] = sq;            // two alternating slots of WAVES partials
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) tot += nsum[(m & 1) * WAVES + w];
-            const float rs = rsqrtf(tot / (float)a.K + a.neps);
-            // this wave's chunks of row m -> LDS as bf16(gamma * (x * rstd)), sm_norm's formula
-            bf16_t* xo = xs + (size_t)m * a.K;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = (u * WAVES + wave) * 64 + lane;
-                if (c < nv) *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gm[u][0] * (t[u][0] * rs), gm[u][1] * (t[u][1] * rs)),
-                                                                   pack2bf(gm[u][2] * (t[u][2] * rs), gm[u][3] * (t[u][3] * rs))};
-            }
-            for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {
-                const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4), gq = *(const f32x4*)(a.ngamma + (size_t)c * 4);
-                *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gq[0] * (q[0] * rs), gq[1] * (q[1] * rs)), pack2bf(gq[2] * (q[2] * rs), gq[3] * (q[3] * rs))};
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        norm_finish<WAVES>(a, nsum, xs, wave, lane, t, gm);
         if (have0) { mfmas(wa0, wb0, ks); ks += U * WAVES; }
     }
     for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
@@ -898,10 +937,13 @@ static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hip
 }
 
 template <int WAVES>
-static int launch_skinny_norm(const LinArgs& a, bool dual, hipStream_t st) {
+static int launch_skinny_norm(const LinArgs& a, bool dual, bool fp8, hipStream_t st) {
     dim3 grid(a.NRG), block(WAVES * 64);
     const size_t sh = ((size_t)WAVES * (dual ? 8 : 4) * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
-    if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a);
+    if (fp8) {
+        if (dual) skinny_fp8_kernel<WAVES, true, false, true, true><<<grid, block, sh, st>>>(a);
+        else skinny_fp8_kernel<WAVES, true, false, false, true><<<grid, block, sh, st>>>(a);
+    } else if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a);
     else skinny_kernel<WAVES, true, false, false, 1, true><<<grid, block, sh, st>>>(a);
     SM_LAUNCH_CHECK();
     return SM_OK;
@@ -927,8 +969,8 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     const bool w8 = p->w_dtype == SM_W_FP8;
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
-    SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && !w8 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
-               "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), bf16 weights, fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
+    SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
+               "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
     SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
     SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
@@ -954,9 +996,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const bool dual = p->w2 != nullptr;
         SmProfScope prof(SM_PROF_SKINNY, st);
         if (p->norm_gamma) {
-            if (a.KS >= 32) return launch_skinny_norm<8>(a, dual, st);
-            if (a.KS >= 8) return launch_skinny_norm<4>(a, dual, st);
-            return launch_skinny_norm<1>(a, dual, st);
+            if (a.KS >= 32) return launch_skinny_norm<8>(a, dual, w8k, st);
+            if (a.KS >= 8) return launch_skinny_norm<4>(a, dual, w8k, st);
+            return launch_skinny_norm<1>(a, dual, w8k, st);
         }
         if (w8k) {
             if (a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);

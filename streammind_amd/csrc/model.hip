@@ -614,8 +614,8 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
     int rc;
     for (int l = 0; l < c.llm_layers; ++l) {
         const std::string p = "llm.model.layers." + std::to_string(l) + ".";
-        // decode (one row, bf16 weights): both RMSNorms ride inside the weight-streaming products that consume them
-        const bool fuse_norm = n == 1 && !m->slots.at(p + "qkv").fp8 && (ld & 31) == 0 && !g_no_fused_norm;
+        // decode (one row): both RMSNorms ride inside the weight-streaming products that consume them
+        const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
         if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
         {   sm_linear_t a = fuse_norm ? lin(m, m->slots.at(p + "qkv"), x, SM_X_F32, n, ld) : lin(m, m->slots.at(p + "qkv"), s->xnb.p, SM_X_BF16, n, ld);
             if (fuse_norm) { a.norm_gamma = m->ptr<float>(p + "input_layernorm.weight"); a.norm_eps = c.llm_eps; }
@@ -658,7 +658,7 @@ static int llm_head(sm_stream* s, int row, void* stream) {
     const sm_config_t& c = m->c;
     const int ld = c.llm_hidden;
     int rc;
-    const bool fuse_norm = !m->slots.at("llm.lm_head").fp8 && (ld & 31) == 0 && !g_no_fused_norm;
+    const bool fuse_norm = (ld & 31) == 0 && !g_no_fused_norm;
     if (!fuse_norm && (rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
     sm_linear_t a = fuse_norm ? lin(m, m->slots.at("llm.lm_head"), s->emb.as<float>() + (size_t)row * ld, SM_X_F32, 1, ld)
                               : lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, 1, ld);

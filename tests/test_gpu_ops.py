@@ -299,7 +299,15 @@ def test_skinny_linear_fused_rmsnorm(nat, M, N, K, dual):
                          torch.cuda.current_stream().cuda_stream))
     y2 = nat.linear(xn_gpu, wp, N, K, w2p=w2p)
     assert relerr(y, y2.cpu()) < 2e-3
-    assert (y.cpu() == y2.cpu()).float().mean() > 0.5   # and mostly identical bit for bit
+    # (not bit-identical in general: the row sum is taken in another order, and ONE activation rounding the other way after a
+    #  1-ulp change of rstd moves the low bits of every output)
+    if not dual or N % 16 == 0:
+        # the same with fp8 weights (config 5): against the unfused fp8 pair
+        wq, sc = nat.pack_weight_fp8(w.cuda().bfloat16())
+        w2q, sc2 = nat.pack_weight_fp8(w2.cuda().bfloat16()) if dual else (None, None)
+        y8 = nat.linear(x.cuda(), wq, N, K, w2p=w2q, w_scale=sc, w2_scale=sc2, norm_gamma=gamma.cuda(), norm_eps=eps)
+        y8u = nat.linear(xn_gpu, wq, N, K, w2p=w2q, w_scale=sc, w2_scale=sc2)
+        assert relerr(y8, y8u.cpu()) < 2e-3
 
 
 @pytest.mark.parametrize("M,N,K,dual", [(20, 512, 1056, False), (28, 1024, 512, True), (48, 384, 1024, False), (300, 768, 4096, False)])
