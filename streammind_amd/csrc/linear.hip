@@ -361,6 +361,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) { acc[mb] = f32x4{0, 0, 0, 0}; acc2[mb] = f32x4{0, 0, 0, 0}; }
 
+    // residual rows of the epilogue, fetched now (wave 0 stores): at the end of the kernel the load was a bare L2 round trip
+    // on the critical path of every o / down projection of the decode step
+    const bool pre_res = MB == 1 && !DUAL && a.residual && !a.bias && a.act == SM_ACT_NONE && !a.wscale && a.remap_in == 0 &&
+                         (a.N & 3) == 0 && (a.ldr & 3) == 0;
+    f32x4 res0 = {0, 0, 0, 0};
+    if (pre_res && wave == 0 && i < a.M) res0 = *(const f32x4*)(a.residual + (size_t)i * a.ldr + rg * 16 + g * 4);
     constexpr int U = MB == 1 ? 4 : 2;
     int ks = wave;
     // NORM: normalised bf16 rows [M][K] in LDS behind the reduction scratch
@@ -488,6 +494,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
                 acc[mb][r] = s;
                 if (DUAL) acc2[mb][r] = s2;
             }
+    }
+    if (pre_res) {
+        LinArgs b = a;
+        b.residual = nullptr;
+        store4(b, i, rg * 16 + g * 4, acc[0] + res0, nullptr);
+        return;
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) store4(a, mb * 16 + i, rg * 16 + g * 4, acc[mb], DUAL ? &acc2[mb] : nullptr);
