@@ -147,6 +147,32 @@ def _load_tokens(stream, emb):
     stream.write_tokens(0, emb.float().cuda().contiguous())
 
 
+def test_llm_decode_is_deterministic_and_matches_unfused_norm(tiny):
+    """the decode step with the RMSNorms fused into the weight-streaming products (raw barriers, counted waits): the same
+    prompt decoded three times gives identical ids, and its prefill -> first-step logits agree with a one-row prefill of the
+    same position (the tiled / unfused path) within the bf16 tolerance."""
+    m, _, _, Wl = tiny
+    emb = torch.randn(20, TL.hidden, generator=torch.Generator().manual_seed(5))
+    s = m.open_stream(max_frames=32, max_seq=128)
+    _load_tokens(s, emb)
+    ids = (-torch.arange(1, emb.shape[0] + 1, dtype=torch.int32)).cuda()
+    runs = []
+    for _ in range(3):
+        s.set_kv_len(0)
+        s.prefill(ids)
+        runs.append(s.decode(24).cpu())
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    # logits after decoding one token == logits of a prefill that ends with that token (same cache, same position)
+    s.set_kv_len(0)
+    s.prefill(ids)
+    first = s.decode(1)
+    lg_dec, _ = s.logits()
+    s.set_kv_len(0)
+    s.prefill(torch.cat([ids, first.to(torch.int32).cuda()]))
+    lg_pre, _ = s.logits()
+    assert maxdiff(lg_dec, lg_pre.cpu()) < 3e-2
+
+
 def test_stream_end_to_end_vs_reference_golden(tiny, gold, tiny_tokenizer):
     """The reference's own streaming loop (golden g6: stream_generate_demo driven like video_score_stream_demo.py) vs
     the drop-in API: per-frame gate logits (5e-3: bf16 ViT) and decisions, fire positions, and -- with the prompt
