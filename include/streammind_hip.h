@@ -36,6 +36,10 @@ extern "C" {
 #define SM_X_F32 1
 #define SM_W_BF16 0
 #define SM_W_FP8 1
+#define SM_TILE_AUTO 0
+#define SM_TILE_128 128
+#define SM_TILE_256 256
+#define SM_TILE_256x128 256128
 
 const char* sm_last_error(void);
 int sm_abi_version(void);
@@ -93,6 +97,10 @@ typedef struct sm_linear_t {
      * Weight-streaming path only (M <= 16, M*K <= 16384, bf16 or fp8 weights, x_dtype SM_X_F32, precise = 0). */
     const float* norm_gamma;
     float norm_eps;
+    /* tile choice of the LDS-tiled GEMM (M > 32): 0 = automatic (256x256 once that grid fills >= 3/4 of the chip, else
+     * 128x128), SM_TILE_128 / SM_TILE_256 / SM_TILE_256x128 force one kernel.  A tuning and test knob: results are the
+     * same up to fp32 summation order. */
+    int tile_hint;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 

@@ -30,6 +30,7 @@ GPU-vs-oracle differences reduce to fp32 summation order.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -948,6 +949,19 @@ def feature_stride(feats: Tensor, fps: int = 25, target: int = 2) -> Tensor:
 
 def stride_output_path(path: str) -> str:
     return path.replace("features_video_encode_ddp", "features_video_encode_ddp_fps")
+
+
+feature_cache_stride = feature_stride
+
+
+def feature_cache_chunks(video_path: str, duration: int, chunk: int = 500) -> List[Tuple[str, int, int]]:
+    """encode_all_videos_score's chunking and naming (videollama2_arch.py:243-257,277-281): frames [start, min(start+500,
+    duration)) per chunk; the file NAME always says start+500, also for the short last chunk; directory = the video's own with
+    `features_video` -> `features_video_encode_ddp`; `half` = the file name up to "_224p.mkv".  -> [(path, first, end)]"""
+    half = os.path.basename(video_path).split("_224p.mkv")[0]
+    out_dir = os.path.dirname(video_path.replace("features_video", "features_video_encode_ddp"))
+    return [(os.path.join(out_dir, f"{half}_encode_feature_frame_{s}_{s + chunk}.pt"), s, min(s + chunk, duration))
+            for s in range(0, duration, chunk)]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -13,8 +13,14 @@ from .conversation import SeparatorStyle, conv_templates
 from .mm_utils import KeywordsStoppingCriteria, process_video, tokenizer_MMODAL_token
 
 
-def model_init(model_path=None, model_base=None, model_name="VideoLLaMA2-7B"):
+def model_init(model_path=None, model_name="VideoLLaMA2-7B", model_base=None):
+    """streammind/__init__.py:14-35 (positional order of the package API; the evaluation scripts' local variant,
+    eval/video_score_stream_demo.py:42-63, passes model_base by position 2 -- use the keyword there)."""
     from .model import load_pretrained_model
+    from .mm_utils import get_model_name_from_path
+    if model_path is None:
+        raise FileNotFoundError("model_init: the reference's default is the hub id DAMO-NLP-SG/VideoLLaMA2-7B; there is no network here, pass a local checkpoint directory")
+    model_name = get_model_name_from_path(model_path) if model_name is None else model_name
     tokenizer, model, processor, context_len = load_pretrained_model(model_path, model_base, model_name)
     if tokenizer.unk_token is not None:
         tokenizer.pad_token = tokenizer.unk_token

@@ -30,7 +30,7 @@ class sm_linear_t(C.Structure):
         ("remap_in", i32), ("remap_out", i32), ("remap_off", i32),
         ("vt", vp), ("vt_n0", i32), ("vt_S", i32), ("vt_dh", i32), ("vt_ld", i32),
         ("w_dtype", i32), ("w_scale", vp), ("w2_scale", vp),
-        ("norm_gamma", vp), ("norm_eps", f32),
+        ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32),
     ]
 
 

@@ -59,4 +59,16 @@ conv_mistral_instruct = Conversation(
     roles=("USER", "ASSISTANT"), version="llama_v2", messages=[], offset=0,
     sep_style=SeparatorStyle.LLAMA_2, sep="", sep2="</s>")
 
-conv_templates = {"mistral_instruct": conv_mistral_instruct}
+# conversation.py:452-463: the template the package-level offline `infer` / `x_infer` select for Mistral checkpoints
+# (model_init returns version "llama_2", streammind/__init__.py:27-33); same LLAMA_2 style, other system text, "<s>" separator
+conv_llama_2 = Conversation(
+    system="You are a helpful, respectful and honest assistant. Always answer as helpfully as possible, while being safe.  "
+           "Your answers should not include any harmful, unethical, racist, sexist, toxic, dangerous, or illegal content. "
+           "Please ensure that your responses are socially unbiased and positive in nature.\n\n"
+           "If a question does not make any sense, or is not factually coherent, explain why instead of answering something "
+           "not correct. If you don't know the answer to a question, please don't share false information.",
+    roles=("USER", "ASSISTANT"), version="llama_v2", messages=[], offset=0,
+    sep_style=SeparatorStyle.LLAMA_2, sep="<s>", sep2="</s>")
+
+default_conversation = conv_mistral_instruct
+conv_templates = {"mistral_instruct": conv_mistral_instruct, "llama_2": conv_llama_2}

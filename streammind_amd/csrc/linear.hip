@@ -1056,9 +1056,10 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
         const bool ok = !p->vt || p->vt_n0 % 256 == 0;
         int bn = (ok && t256 >= 192) ? 256 : 0;
-        if (force == 128) bn = 0;
-        if (force == 256128 && ok) bn = 128;
-        if (force == 256 && ok) bn = 256;
+        const int hint = p->tile_hint ? p->tile_hint : force;
+        if (hint == 128) bn = 0;
+        if (hint == 256128 && ok) bn = 128;
+        if (hint == 256 && ok) bn = 256;
         if (bn) {
             SmProfScope prof(SM_PROF_GEMM, st);
             return launch_gemm256(a, p->act, bn, st);

@@ -25,6 +25,14 @@ __global__ void f32_to_bf16_kernel(const float* in, bf16_t* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (bf16_t)f2bf(in[i]);
 }
+__global__ void f16_to_bf16_kernel(const _Float16* in, bf16_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16_t)f2bf((float)in[i]);
+}
+__global__ void f16_to_f32_kernel(const _Float16* in, float* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
 __global__ void embed_last_kernel(const int32_t* tok, const bf16_t* table, int D, float* out) {
     int id = *tok;
     for (int c = threadIdx.x; c < D; c += blockDim.x) out[c] = bf2f(table[(size_t)id * D + c]);
@@ -52,7 +60,9 @@ struct Slot {            // one tensor the path reads
     DevBuf buf;
     int kind = 0;        // 0 = fp32 vector/matrix (as is), 1 = packed linear (possibly a fused group), 2 = bf16 row-major
     int N = 0, K = 0;    // logical dims of the (fused) matrix
-    int parts = 1, loaded = 0;
+    int parts = 1;
+    uint32_t loaded = 0; // bit i: part i has been handed over (a reload overwrites, it does not count twice)
+    bool complete() const { return loaded == (parts >= 32 ? 0xffffffffu : (1u << parts) - 1u); }
     int Klogical = 0;    // > 0: checkpoint K (the packed image pads it to K); patch embedding only
     bool fp8 = false;    // packed as fp8 + per-row scales (weights_fp8 mode, gate + LLM linears)
     DevBuf scale;        // fp32 [N]
@@ -61,7 +71,7 @@ struct Slot {            // one tensor the path reads
 struct sm_model {
     sm_config_t c;
     std::unordered_map<std::string, Slot> slots;           // canonical name -> storage
-    struct Route { std::string slot; int row0; int rows; };   // checkpoint name -> (slot, first row, row count of this part)
+    struct Route { std::string slot; int row0; int rows; int part; };   // checkpoint name -> (slot, first row, row count, index of this part)
     std::unordered_map<std::string, Route> routes;
     std::vector<std::string> ignored_prefixes;
     bool finalized = false;
@@ -82,17 +92,17 @@ struct sm_model {
 static void add_linear(sm_model* m, const std::string& slot, int N, int K, const std::vector<std::string>& names, int rows_each) {
     Slot& s = m->slots[slot];
     s.kind = 1; s.N = N; s.K = K; s.parts = (int)names.size();
-    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each};
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each, (int)i};
 }
 static void add_f32(sm_model* m, const std::string& name, int N, int K = 1) {
     Slot& s = m->slots[name];
     s.kind = 0; s.N = N; s.K = K;
-    m->routes[name] = {name, 0, N};
+    m->routes[name] = {name, 0, N, 0};
 }
 static void add_f32_fused(sm_model* m, const std::string& slot, int N, const std::vector<std::string>& names, int rows_each) {
     Slot& s = m->slots[slot];
     s.kind = 0; s.N = N; s.K = 1; s.parts = (int)names.size();
-    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each};
+    for (size_t i = 0; i < names.size(); ++i) m->routes[names[i]] = {slot, (int)i * rows_each, rows_each, (int)i};
 }
 
 extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
@@ -168,20 +178,21 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     m->ignored_prefixes.push_back("proj.cls_net.cls_model.model.embed_tokens.");
     m->ignored_prefixes.push_back("vit.post_layernorm.");
     m->ignored_prefixes.push_back("vit.embeddings.position_ids");
+    m->ignored_prefixes.push_back("vit.visual_projection.");        // CLIPVisionModelWithProjection / full CLIP directories
     // ---- LLM
     if (c.llm_layers > 0) {
         const int ld = c.llm_hidden, dh = ld / c.llm_heads, qn = c.llm_heads * dh, kn = c.llm_kv_heads * dh;
         SM_REQUIRE(qn == kn * (c.llm_heads / c.llm_kv_heads), "llm heads");
         Slot& e = m->slots["llm.embed"]; e.kind = 2; e.N = c.llm_vocab; e.K = ld;
-        m->routes["llm.model.embed_tokens.weight"] = {"llm.embed", 0, c.llm_vocab};
+        m->routes["llm.model.embed_tokens.weight"] = {"llm.embed", 0, c.llm_vocab, 0};
         for (int l = 0; l < c.llm_layers; ++l) {
             std::string p = "llm.model.layers." + std::to_string(l) + ".";
             // q, k, v fused; all three blocks must start on a 16-row boundary of the packed image
             SM_REQUIRE(qn % 16 == 0 && kn % 16 == 0, "llm q/k widths must be multiples of 16");
             Slot& s = m->slots[p + "qkv"]; s.kind = 1; s.N = qn + 2 * kn; s.K = ld; s.parts = 3;
-            m->routes[p + "self_attn.q_proj.weight"] = {p + "qkv", 0, qn};
-            m->routes[p + "self_attn.k_proj.weight"] = {p + "qkv", qn, kn};
-            m->routes[p + "self_attn.v_proj.weight"] = {p + "qkv", qn + kn, kn};
+            m->routes[p + "self_attn.q_proj.weight"] = {p + "qkv", 0, qn, 0};
+            m->routes[p + "self_attn.k_proj.weight"] = {p + "qkv", qn, kn, 1};
+            m->routes[p + "self_attn.v_proj.weight"] = {p + "qkv", qn + kn, kn, 2};
             add_linear(m, p + "o", ld, qn, {p + "self_attn.o_proj.weight"}, ld);
             add_linear(m, p + "gu", 2 * c.llm_mlp, ld, {p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"}, c.llm_mlp);
             add_linear(m, p + "down", ld, c.llm_mlp, {p + "mlp.down_proj.weight"}, ld);
@@ -213,7 +224,7 @@ static std::string canon(const std::string& name, const sm_config_t& c) {
 extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void* data, int dtype, int ndim,
                                     const int64_t* shape, void* stream) {
     SM_REQUIRE(m && name_c && data && shape && ndim >= 1 && ndim <= 4, "sm_model_load_tensor: bad args");
-    SM_REQUIRE(dtype == SM_DT_BF16 || dtype == SM_DT_F32, "sm_model_load_tensor: dtype must be bf16 or f32");
+    SM_REQUIRE(dtype == SM_DT_BF16 || dtype == SM_DT_F32 || dtype == SM_DT_F16, "sm_model_load_tensor: dtype must be bf16, f16 or f32");
     hipStream_t st = (hipStream_t)stream;
     std::string name = canon(name_c, m->c);
     auto it = m->routes.find(name);
@@ -238,10 +249,11 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
                    name_c, (long long)rows, (long long)cols, it->second.rows, s.Klogical ? s.Klogical : s.K);
         DevBuf tmp;
         const bf16_t* src = (const bf16_t*)data;
-        if (dtype == SM_DT_F32) {
+        if (dtype != SM_DT_BF16) {      // fp32 / fp16 (the reference loads fp16, model/builder.py:54) -> bf16, round to nearest even
             int rc = tmp.alloc(n * 2);
             if (rc) return rc;
-            f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
+            if (dtype == SM_DT_F32) f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
+            else f16_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const _Float16*)data, tmp.as<bf16_t>(), n);
             src = tmp.as<bf16_t>();
         }
         if (s.kind == 1 && s.fp8) {
@@ -271,10 +283,11 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
         if (!s.buf.p) { int rc = s.buf.alloc((size_t)s.N * s.K * 4); if (rc) return rc; }
         float* dst = s.buf.as<float>() + (size_t)row0 * s.K;
         if (dtype == SM_DT_F32) SM_HIP(hipMemcpyAsync(dst, data, n * 4, hipMemcpyDeviceToDevice, st));
+        else if (dtype == SM_DT_F16) f16_to_f32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const _Float16*)data, dst, n);
         else bf16_to_f32_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const bf16_t*)data, dst, n);
     }
     SM_LAUNCH_CHECK();
-    s.loaded += 1;
+    s.loaded |= 1u << it->second.part;
     return SM_OK;
 }
 
@@ -283,7 +296,7 @@ extern "C" int sm_model_missing(sm_model* m, char* buf, size_t buflen) {
     std::string out;
     int cnt = 0;
     for (auto& kv : m->slots)
-        if (kv.second.loaded < kv.second.parts) { out += kv.first; out += "\n"; ++cnt; }
+        if (!kv.second.complete()) { out += kv.first; out += "\n"; ++cnt; }
     snprintf(buf, buflen, "%s", out.c_str());
     return cnt;
 }
@@ -291,8 +304,8 @@ extern "C" int sm_model_missing(sm_model* m, char* buf, size_t buflen) {
 extern "C" int sm_model_finalize(sm_model* m, void* stream) {
     SM_REQUIRE(m, "sm_model_finalize: null model");
     for (auto& kv : m->slots)
-        SM_REQUIRE(kv.second.loaded >= kv.second.parts, "sm_model_finalize: tensor group '%s' incomplete (%d of %d parts)",
-                   kv.first.c_str(), kv.second.loaded, kv.second.parts);
+        SM_REQUIRE(kv.second.complete(), "sm_model_finalize: tensor group '%s' incomplete (%d of %d parts)",
+                   kv.first.c_str(), __builtin_popcount(kv.second.loaded), kv.second.parts);
     const sm_config_t& c = m->c;
     const int D = c.vit_hidden, B = m->Bmax, S = m->S;
     const size_t rows = (size_t)B * S;

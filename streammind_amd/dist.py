@@ -1,48 +1,259 @@
-"""Multi-GPU plumbing of the streaming path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm,
-"gloo" on CPU for tests).
+"""Multi-GPU plumbing of the streaming path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on
+ROCm, "gloo" on CPU for the tests).
 
 The reference's inference path issues NO collective per frame or token: ranks own whole streams, split
 contiguously (`EvalDistributedSampler`, eval/inference_video_score_stream_ddp.py:191-213).  The one exchange step the
-north-star adds is a variable-size all-gather of the frame tokens of streams whose gate fired on this tick, following
-the reference's own two-phase pattern `allgather_diff_shape` (streammind/dist.py:122-146): sizes first, then the padded
-payload -- and nothing at all on silent ticks (the size exchange doubles as the "did anyone fire" flag word)."""
+north-star adds is a variable-size all-gather of the frame tokens of streams whose gate fired, following the reference's own
+two-phase pattern `allgather_diff_shape` (streammind/dist.py:122-146): sizes first, then the padded payload.
+
+Two forms:
+  * `allgather_gated_tokens`  -- the blocking two-phase exchange (sizes, host read, payload): simple, one host sync per call.
+  * `GatedTokenExchange`      -- the form the streaming loop uses: ranks fire on DIFFERENT ticks, so some word has to tell a
+    rank that a peer fired; that word is a 4-byte-per-rank count all-gather issued ASYNCHRONOUSLY on a side stream every tick
+    and read back one tick later from pinned memory (its event is long complete: no host stall, no bubble in the compute
+    stream).  The payload collective is launched only for ticks whose counts say that somebody fired; a silent tick moves no
+    payload and blocks nobody.
+
+Also here: the thin process-group helpers callers of the reference's `videollama2.dist` use (streammind/dist.py:16-119,
+149-215), same names and degradation rules (everything is a no-op in a single process)."""
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+import datetime
+import functools
+import os
+import sys
+from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch
 import torch.distributed as tdist
 
+_state = {"rank": 0, "local_rank": 0, "world": 1, "device": "cpu", "initialized": False}
 
+
+# ------------------------------------------------------------------------------------------------ reference-named helpers
+def initialized() -> bool:
+    return _state["initialized"]
+
+
+def initialize(fork=False, backend="nccl", gpu_id_if_not_distibuted=0, timeout=30):
+    """streammind/dist.py:20-49: RANK unset -> single process on one GPU; else one rank per GPU, init_process_group."""
+    if not torch.cuda.is_available():
+        print("[dist initialize] cuda is not available, use cpu instead", file=sys.stderr)
+        return
+    if "RANK" not in os.environ:
+        torch.cuda.set_device(gpu_id_if_not_distibuted)
+        _state["device"] = torch.device("cuda", torch.cuda.current_device())
+        print(f'[dist initialize] env variable "RANK" is not set, use {_state["device"]} as the device', file=sys.stderr)
+        return
+    global_rank, num_gpus = int(os.environ["RANK"]), torch.cuda.device_count()
+    local_rank = global_rank % num_gpus
+    torch.cuda.set_device(local_rank)
+    if not tdist.is_initialized():
+        tdist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout * 60))
+    _state.update(rank=tdist.get_rank(), local_rank=local_rank, world=tdist.get_world_size(),
+                  device=torch.device("cuda", local_rank), initialized=True)
+    print(f"[lrk={get_local_rank()}, rk={get_rank()}]")
+
+
+def get_rank() -> int:
+    return _state["rank"]
+
+
+def get_local_rank() -> int:
+    return _state["local_rank"]
+
+
+def get_world_size() -> int:
+    return _state["world"]
+
+
+def get_device():
+    return _state["device"]
+
+
+def is_master() -> bool:
+    return _state["rank"] == 0
+
+
+def is_local_master() -> bool:
+    return _state["local_rank"] == 0
+
+
+def barrier():
+    if _state["initialized"]:
+        tdist.barrier()
+
+
+def _comm_device(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.is_cuda or tdist.get_backend() != "nccl") else t.cuda()
+
+
+def allreduce(t: torch.Tensor, async_op=False):
+    if not _state["initialized"]:
+        return None
+    cu = _comm_device(t.detach())
+    ret = tdist.all_reduce(cu, async_op=async_op)
+    if cu is not t:
+        t.copy_(cu.cpu())
+    return ret
+
+
+def allgather(t: torch.Tensor, cat=True) -> Union[List[torch.Tensor], torch.Tensor]:
+    if _state["initialized"]:
+        t = _comm_device(t)
+        ls = [torch.empty_like(t) for _ in range(_state["world"])]
+        tdist.all_gather(ls, t)
+    else:
+        ls = [t]
+    return torch.cat(ls, dim=0) if cat else ls
+
+
+def allgather_diff_shape(t: torch.Tensor, cat=True) -> Union[List[torch.Tensor], torch.Tensor]:
+    """streammind/dist.py:122-146: sizes first, pad dim 0 to the maximum, gather, trim"""
+    if _state["initialized"]:
+        ls = allgather_gated_tokens(_comm_device(t), None) or [t.new_empty((0, *t.shape[1:])) for _ in range(_state["world"])]
+    else:
+        ls = [t]
+    return torch.cat(ls, dim=0) if cat else ls
+
+
+def broadcast(t: torch.Tensor, src_rank) -> None:
+    if _state["initialized"]:
+        cu = _comm_device(t.detach())
+        tdist.broadcast(cu, src=src_rank)
+        if cu is not t:
+            t.copy_(cu.cpu())
+
+
+def master_only(func):
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        force = kwargs.pop("force", False)
+        ret = func(*args, **kwargs) if (force or is_master()) else None
+        barrier()
+        return ret
+    return wrapper
+
+
+def finalize():
+    if _state["initialized"]:
+        tdist.destroy_process_group()
+        _state["initialized"] = False
+
+
+# ------------------------------------------------------------------------------------------------ stream partition
 def partition_streams(n_streams: int, world: int, rank: int) -> Tuple[int, int]:
     """[beg, end) of the streams rank `rank` owns: np.linspace blocks, exactly EvalDistributedSampler's split."""
     seps = np.linspace(0, n_streams, world + 1, dtype=int)
     return int(seps[rank]), int(seps[rank + 1])
 
 
-def allgather_gated_tokens(tokens: Optional[torch.Tensor], d_model: int, group=None) -> Optional[List[torch.Tensor]]:
-    """tokens: [n_fired, d_model] of THIS rank for this tick (None / 0 rows when its gate stayed silent).
-    Returns None when no rank fired (payload collective skipped), else the list of per-rank token tensors.
+# ------------------------------------------------------------------------------------------------ gated-token exchange
+def _default_device(group) -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if tdist.get_backend(group) == "nccl" else torch.device("cpu")
 
-    Phase 1: all-gather of one int32 count per rank (latency-bound, 4 B x world).  Phase 2 (only if max > 0):
-    all-gather of the payload padded to the max count.  Messages are <= ~1 MB on an 8-GPU xGMI node, i.e. far below
-    the per-link bandwidth regime: RCCL's direct all-gather is one hop per peer."""
+
+def allgather_gated_tokens(tokens: Optional[torch.Tensor], d_model: Optional[int], group=None) -> Optional[List[torch.Tensor]]:
+    """Blocking form.  tokens: [n_fired, ...] of THIS rank (None / 0 rows when its gate stayed silent; then d_model gives the
+    row width).  Returns None when no rank fired (payload collective skipped), else the list of per-rank tensors.
+
+    Phase 1: all-gather of one int32 count per rank (latency-bound, 4 B x world) and a host read of it.  Phase 2 (only if
+    max > 0): all-gather of the payload padded to the max count.  Messages are <= ~1 MB on an 8-GPU xGMI node, far below the
+    per-link bandwidth regime: RCCL's direct all-gather is one hop per peer."""
     world = tdist.get_world_size(group)
-    dev = tokens.device if tokens is not None else (torch.device("cuda", torch.cuda.current_device())
-                                                    if tdist.get_backend(group) == "nccl" else torch.device("cpu"))
+    dev = tokens.device if tokens is not None else _default_device(group)
     n = 0 if tokens is None else int(tokens.shape[0])
     cnt = torch.tensor([n], dtype=torch.int32, device=dev)
     counts = torch.empty(world, dtype=torch.int32, device=dev)
     tdist.all_gather_into_tensor(counts, cnt, group=group)
     counts = counts.tolist()
+    return _payload_allgather(tokens, counts, d_model, dev, group)
+
+
+def _payload_allgather(tokens, counts, d_model, dev, group):
     mx = max(counts)
     if mx == 0:
         return None
+    world = len(counts)
+    n = 0 if tokens is None else int(tokens.shape[0])
+    tail = tuple(tokens.shape[1:]) if tokens is not None else (d_model,)
     dtype = tokens.dtype if tokens is not None else torch.float32
-    pad = torch.zeros(mx, d_model, dtype=dtype, device=dev)
+    pad = torch.zeros((mx, *tail), dtype=dtype, device=dev)
     if n:
         pad[:n] = tokens
-    out = torch.empty(world * mx, d_model, dtype=dtype, device=dev)
+    out = torch.empty((world * mx, *tail), dtype=dtype, device=dev)
     tdist.all_gather_into_tensor(out, pad, group=group)
     return [out[r * mx: r * mx + counts[r]] for r in range(world)]
+
+
+class GatedTokenExchange:
+    """Pipelined exchange for ranks that fire on different ticks.
+
+        ex = GatedTokenExchange(d_model)
+        for every tick:                      # same number of ticks on every rank (one per perceive call / frame)
+            prev = ex.tick(tokens_or_None)   # result of the PREVIOUS tick: None (nobody fired) or [per-rank tensors]
+        last = ex.flush()                    # result of the final tick
+
+    Per tick the only traffic is the asynchronous 4-byte-per-rank count all-gather (on a side stream under nccl); its host
+    read happens one tick later from pinned memory.  `payload_collectives` counts the ticks that moved tokens,
+    `host_waits_us` what the deferred reads cost (~0 when a tick of compute sits between post and read)."""
+
+    def __init__(self, d_model: int, group=None, dtype: torch.dtype = torch.float32, device: Optional[torch.device] = None):
+        self.group, self.d_model, self.dtype = group, d_model, dtype
+        self.world = tdist.get_world_size(group)
+        self.dev = device or _default_device(group)
+        self.cuda = self.dev.type == "cuda"
+        self.side = torch.cuda.Stream(self.dev) if self.cuda else None
+        self._pending = None          # (counts host tensor, ready event | work handle, this rank's tokens of that tick)
+        self.ticks = self.payload_collectives = 0
+        self.host_wait_s = 0.0
+
+    def _post(self, tokens: Optional[torch.Tensor]):
+        n = 0 if tokens is None else int(tokens.shape[0])
+        if self.cuda:
+            cnt = torch.tensor([n], dtype=torch.int32).pin_memory().to(self.dev, non_blocking=True)
+            counts = torch.empty(self.world, dtype=torch.int32, device=self.dev)
+            host = torch.empty(self.world, dtype=torch.int32).pin_memory()
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))        # the count upload is ordered before the collective
+            with torch.cuda.stream(self.side):
+                tdist.all_gather_into_tensor(counts, cnt, group=self.group)
+                host.copy_(counts, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            for t in (cnt, counts):
+                t.record_stream(self.side)
+            self._pending = (host, ev, tokens)
+        else:
+            cnt = torch.tensor([n], dtype=torch.int32)
+            host = torch.empty(self.world, dtype=torch.int32)
+            work = tdist.all_gather_into_tensor(host, cnt, group=self.group, async_op=True)
+            self._pending = (host, work, tokens)
+
+    def _collect(self) -> Optional[List[torch.Tensor]]:
+        if self._pending is None:
+            return None
+        host, ready, tokens = self._pending
+        self._pending = None
+        import time
+        t0 = time.perf_counter()
+        ready.synchronize() if self.cuda else ready.wait()
+        self.host_wait_s += time.perf_counter() - t0
+        counts = host.tolist()
+        if max(counts) == 0:
+            return None
+        self.payload_collectives += 1
+        if tokens is not None and tokens.dtype != self.dtype:
+            tokens = tokens.to(self.dtype)
+        if tokens is None and self.dtype != torch.float32:
+            tokens = torch.empty(0, self.d_model, dtype=self.dtype, device=self.dev)
+        return _payload_allgather(tokens, counts, self.d_model, self.dev, self.group)
+
+    def tick(self, tokens: Optional[torch.Tensor]) -> Optional[List[torch.Tensor]]:
+        prev = self._collect()
+        self._post(tokens)
+        self.ticks += 1
+        return prev
+
+    def flush(self) -> Optional[List[torch.Tensor]]:
+        return self._collect()

@@ -76,6 +76,44 @@ def tokenizer_MMODAL_token(prompt: str, tokenizer, MMODAL_token_index: int = IMA
     return input_ids
 
 
+def tokenizer_image_token(prompt: str, tokenizer, image_token_index: int = IMAGE_TOKEN_INDEX, return_tensors=None):
+    """mm_utils.py:545-565: the `<image>` form of the same split-and-rejoin."""
+    return tokenizer_MMODAL_token(prompt, tokenizer, image_token_index, return_tensors)
+
+
+def get_model_name_from_path(model_path: str) -> str:
+    """mm_utils.py:607-613: last path component, `<parent>_<checkpoint-N>` for trainer checkpoints."""
+    parts = model_path.strip("/").split("/")
+    return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]
+
+
+def expand2square(img, background_color):
+    """mm_utils.py:257-268 on a PIL image or an HWC uint8 array: centre the picture on a square canvas of `background_color`
+    (the streaming path does this on the GPU inside sm_ingest_frames; this host form serves callers that hold single images)."""
+    arr = np.asarray(img)
+    h, w = arr.shape[:2]
+    if h == w:
+        return img
+    side = max(h, w)
+    out = np.empty((side, side, arr.shape[2]), dtype=arr.dtype)
+    out[...] = np.asarray(background_color, dtype=arr.dtype)
+    y0, x0 = ((side - h) // 2, 0) if w > h else (0, (side - w) // 2)
+    out[y0:y0 + h, x0:x0 + w] = arr
+    if isinstance(img, np.ndarray):
+        return out
+    from PIL import Image
+    return Image.fromarray(out, mode=img.mode)
+
+
+def process_image(image, processor=None, aspect_ratio="pad", num_frames: int = NUM_FRAMES, image_grid: bool = False) -> torch.Tensor:
+    """mm_utils.py:356-374 for an already decoded picture (PIL image or HWC uint8 array; opening a path is left to the caller):
+    the image repeated `num_frames` times through the same front-end as process_video."""
+    if isinstance(image, str):
+        raise NotImplementedError("image decoding is outside this build: pass a PIL image or an HWC uint8 array")
+    frame = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image)
+    return process_video([frame] * num_frames, processor, aspect_ratio=aspect_ratio, num_frames=num_frames, image_grid=image_grid)
+
+
 class KeywordsStoppingCriteria:
     """stop when the tail ids equal a keyword's ids or the decoded tail contains a keyword (mm_utils.py:616-647).
     Callable as criterion(output_ids[LongTensor 1 x n], scores) like an HF StoppingCriteria."""

@@ -171,7 +171,7 @@ class Videollama2MistralForCausalLM:
 
     def __init__(self, native: NativeModel, max_frames: int = 4096, max_seq: int = 4096, eos_token_id: Optional[int] = 2):
         self.native = native
-        self.config = native.cfg
+        self.config = native.cfg                       # load_pretrained_model replaces it by the checkpoint's config.json namespace
         self.vision_tower = CLIPVisionTower(native)
         self.mm_projector = Video_Mamba_seq(native)
         self.stream: NativeStream = native.open_stream(max_frames=max_frames, max_seq=max_seq)
@@ -436,59 +436,3 @@ def build_from_state_dicts(cfg: PathConfig, vision_sd: Dict[str, torch.Tensor], 
         raise ValueError(f"checkpoint is missing tensors for: {miss[:8]}{' ...' if len(miss) > 8 else ''}")
     nat.finalize()
     return Videollama2MistralForCausalLM(nat, **kw)
-
-
-def _read_safetensors_dir(path: str):
-    from safetensors import safe_open
-    idx = os.path.join(path, "model.safetensors.index.json")
-    files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else \
-        [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
-    for f in files:
-        with safe_open(os.path.join(path, f), framework="pt") as sf:
-            for k in sf.keys():
-                yield k, sf.get_tensor(k)
-
-
-def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7B", load_8bit=False, load_4bit=False,
-                          device_map="auto", device="cuda", use_flash_attn=False, **kwargs):
-    """-> (tokenizer, model, image_processor, context_len), as streammind/model/builder.py:30-210 for a merged (non-LoRA)
-    Mistral checkpoint directory: config.json (+ mm_* keys, videollama2_arch.py:69-73), *.safetensors, optional
-    mm_projector.bin, and the CLIP tower directory named by config.mm_vision_tower."""
-    if load_8bit or load_4bit:
-        raise NotImplementedError("bitsandbytes quantisation is not part of the MI355X path")
-    if model_base is not None:
-        raise NotImplementedError("LoRA / base-model merging is a training-side feature (out of scope)")
-    from transformers import AutoTokenizer, CLIPImageProcessor
-    cfgj = json.load(open(os.path.join(model_path, "config.json")))
-    if "mamba" not in cfgj.get("mm_projector_type", ""):
-        raise ValueError(f"Unsupported projector type {cfgj.get('mm_projector_type')}!!!")      # videollama2_arch.py:321
-    tower_dir = cfgj["mm_vision_tower"]
-    vj = json.load(open(os.path.join(tower_dir, "config.json")))
-    vj = vj.get("vision_config", vj)
-    cfg = PathConfig(
-        vit_image=vj["image_size"], vit_patch=vj["patch_size"], vit_hidden=vj["hidden_size"], vit_heads=vj["num_attention_heads"],
-        vit_mlp=vj["intermediate_size"], vit_layers=vj["num_hidden_layers"], vit_select_layer=cfgj.get("mm_vision_select_layer", -2),
-        vit_eps=vj.get("layer_norm_eps", 1e-5), conn_d_model=cfgj["hidden_size"],
-        llm_layers=cfgj["num_hidden_layers"], llm_heads=cfgj["num_attention_heads"], llm_kv_heads=cfgj["num_key_value_heads"],
-        llm_mlp=cfgj["intermediate_size"], llm_vocab=cfgj["vocab_size"], llm_eps=cfgj.get("rms_norm_eps", 1e-5),
-        llm_rope_theta=cfgj.get("rope_theta", 1e4), max_frames_per_call=kwargs.pop("max_frames_per_call", 8))
-    dev = "cuda:0" if device == "cuda" else device
-    nat = NativeModel(cfg, dev)
-    for k, v in _read_safetensors_dir(model_path):
-        nat.load_tensor(k, v)
-    pbin = os.path.join(model_path, "mm_projector.bin")
-    if os.path.exists(pbin):
-        for k, v in torch.load(pbin, map_location="cpu").items():
-            nat.load_tensor(k, v)
-    if nat.missing():                                   # the tower is delay-loaded from its own checkpoint (clip_encoder.py:18-29)
-        for k, v in _read_safetensors_dir(tower_dir):
-            if k.startswith("vision_model.") or not k.startswith("text_model."):
-                nat.load_tensor("model.vision_tower.vision_tower." + k, v)
-    if nat.missing():
-        raise ValueError(f"checkpoint incomplete, missing: {nat.missing()[:8]}")
-    nat.finalize()
-    tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
-    image_processor = CLIPImageProcessor.from_pretrained(tower_dir)
-    context_len = cfgj.get("max_sequence_length", 2048)                      # builder.py:205-208
-    model = Videollama2MistralForCausalLM(nat, max_seq=kwargs.pop("max_seq", 4096), eos_token_id=tokenizer.eos_token_id)
-    return tokenizer, model, image_processor, context_len

@@ -111,13 +111,11 @@ class NativeModel:
 
     def load_tensor(self, name: str, t: torch.Tensor) -> bool:
         """Hand one checkpoint tensor over (any device; bf16/fp16/fp32).  Returns False if the path ignores it."""
-        if t.dtype == torch.float16:
-            t = t.float()
-        if t.dtype not in (torch.bfloat16, torch.float32):
+        if t.dtype not in (torch.bfloat16, torch.float32, torch.float16):
             t = t.float()
         t = t.to(self.device).contiguous()
         shape = (C.c_int64 * max(1, t.dim()))(*([int(s) for s in t.shape] or [1]))
-        dt = _lib.SM_DT_BF16 if t.dtype == torch.bfloat16 else _lib.SM_DT_F32
+        dt = {torch.bfloat16: _lib.SM_DT_BF16, torch.float32: _lib.SM_DT_F32, torch.float16: _lib.SM_DT_F16}[t.dtype]
         rc = check(self.lib.sm_model_load_tensor(self.h, name.encode(), t.data_ptr(), dt, max(1, t.dim()), shape, _stream()),
                    f"sm_model_load_tensor({name})")
         torch.cuda.current_stream().synchronize()      # `t` may be a temporary
@@ -310,7 +308,8 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None,
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
            w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
-           norm_eps: float = 0.0) -> torch.Tensor:
+           norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)
@@ -326,7 +325,13 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
         a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
     if norm_gamma is not None:
         a.norm_gamma, a.norm_eps = norm_gamma.data_ptr(), float(norm_eps)
-    out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    a.tile_hint = tile_hint
+    if remap is not None:       # (remap_in, remap_out, remap_off): patch-embed row scatter + broadcast residual rows
+        a.remap_in, a.remap_out, a.remap_off = remap
+        assert out is not None, "a remapped product writes into a caller-provided [rows][N] buffer"
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    out_dtype = out.dtype
     if out_dtype == torch.float32:
         a.out_f32, a.ldo = out.data_ptr(), N
     else:

@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from streammind_amd.dist import allgather_gated_tokens, partition_streams
+from streammind_amd.dist import GatedTokenExchange, allgather_gated_tokens, partition_streams
 
 
 def test_partition_matches_reference_linspace_blocks():
@@ -54,3 +54,59 @@ def test_allgather_gated_tokens_world2_gloo():
         assert p.exitcode == 0
     for rank, res in got:
         assert all(res), (rank, res)
+
+
+def _worker_natural_fires(rank, world, port, q):
+    """ranks fire on DIFFERENT ticks and never together; most ticks are silent on every rank"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d, n_ticks = 8, 12
+    fire_at = {0: {2: 3, 9: 1}, 1: {5: 2, 10: 4}}          # rank -> {tick: n tokens}
+    ex = GatedTokenExchange(d)
+    got = {}
+    for t in range(n_ticks):
+        n = fire_at[rank].get(t, 0)
+        tok = (torch.arange(n * d, dtype=torch.float32).reshape(n, d) + 1000 * rank + 10 * t) if n else None
+        prev = ex.tick(tok)
+        if prev is not None:
+            got[t - 1] = prev
+    last = ex.flush()
+    if last is not None:
+        got[n_ticks - 1] = last
+    ok = sorted(got) == [2, 5, 9, 10]                        # exactly the ticks on which SOMEBODY fired, on both ranks
+    for t, per_rank in got.items():
+        for r in range(world):
+            n = fire_at[r].get(t, 0)
+            want = torch.arange(n * d, dtype=torch.float32).reshape(n, d) + 1000 * r + 10 * t
+            ok = ok and per_rank[r].shape == (n, d) and torch.equal(per_rank[r], want)
+    ok = ok and ex.ticks == n_ticks and ex.payload_collectives == 4      # 8 silent ticks moved no payload
+    q.put((rank, [ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gated_token_exchange_natural_fires_world2_gloo():
+    """the exchange with ranks firing on different ticks -- the count word travels asynchronously every tick,
+    the payload collective runs only for the four ticks on which one of the ranks fired, results arrive one tick later."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_natural_fires, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in got:
+        assert all(res), (rank, res)
+
+
+def test_reference_named_dist_helpers_single_process():
+    """streammind/dist.py helpers keep their names and their single-process degradation (RANK unset -> no process group)"""
+    import videollama2.dist as rd
+    assert not rd.initialized() and rd.get_rank() == 0 and rd.get_world_size() == 1 and rd.is_master()
+    t = torch.arange(6.0).reshape(3, 2)
+    assert torch.equal(rd.allgather(t), t) and torch.equal(rd.allgather_diff_shape(t), t) and rd.allreduce(t) is None
+    rd.barrier(); rd.broadcast(t, 0)
+    assert rd.master_only(lambda: 7)() == 7

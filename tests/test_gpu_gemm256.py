@@ -1,0 +1,148 @@
+"""Oracle parity of the 256x256 / 256x128 MFMA GEMM (csrc/gemm256.hip) -- the kernel behind the headline frames/s -- at the
+shapes and the batch the bench runs it with (28 frames = 16156 token rows), through the C ABI (sm_linear with tile_hint).
+
+Reference arithmetic: fp64 matmul of the SAME bf16 operands on the host (the oracle's definition of every linear on the
+path: bf16 operands, wide accumulate), then bias / quick_gelu / residual in fp64.  Bars as in test_tiled_gemm: 1e-5 relative
+for fp32 outputs (fp32 accumulation order), 5e-3 for bf16 outputs (one extra rounding, 2^-8)."""
+import pytest
+import torch
+
+from oracle import streammind_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+SM_TILE_128, SM_TILE_256, SM_TILE_256x128 = 128, 256, 256128
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from streammind_amd import native, _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads() * 2)))
+    return native
+
+
+def rnd(shape, seed, std=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * std
+
+
+def relerr(a, b):
+    return ((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().clamp_min(1e-6)).item()
+
+
+def ref_linear(x, w, bias, act, res):
+    """fp64 on the host, row-chunked (M = 16156 x N = 4096 fits easily, the chunks keep the working set in cache)"""
+    out = torch.empty(x.shape[0], w.shape[0], dtype=torch.float64)
+    wt = w.double().t().contiguous()
+    for i in range(0, x.shape[0], 2048):
+        t = x[i:i + 2048].double() @ wt
+        if bias is not None:
+            t += bias.double()
+        if act == 1:
+            t = O.quick_gelu(t)
+        elif act == 2:
+            t = O.leaky_relu(t)
+        if res is not None:
+            t += res[i:i + 2048].double()
+        out[i:i + 2048] = t
+    return out
+
+
+VIT_M = 28 * 577          # the bench's batch: 63.1 row tiles of 256
+
+
+# (name, M, N, K, act, residual, out dtype): the four GEMMs of a CLIP-ViT-L layer at 28 frames + ragged variants
+SHAPES = [
+    ("qkv", VIT_M, 3072, 1024, 0, False, torch.bfloat16),
+    ("out_proj", VIT_M, 1024, 1024, 0, True, torch.float32),
+    ("fc1", VIT_M, 4096, 1024, 1, False, torch.bfloat16),
+    ("fc2", VIT_M, 1024, 4096, 0, True, torch.float32),
+    ("ragged_f32_res", VIT_M + 77, 1000, 1024, 0, True, torch.float32),
+    ("ragged_bf16", VIT_M + 77, 1000, 1024, 0, False, torch.bfloat16),
+    ("ragged_gelu", VIT_M + 77, 1000, 1024, 1, False, torch.bfloat16),
+    ("ragged_n_not_x4_gelu_res", 49000, 250, 4096, 1, True, torch.float32),      # N % 4 != 0: the generic (unvectorised) epilogue
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,act,use_res,out_dtype", SHAPES, ids=[s[0] for s in SHAPES])
+def test_gemm256_vit_batch_shapes_vs_fp64(nat, name, M, N, K, act, use_res, out_dtype):
+    """automatic dispatch at these sizes IS gemm256_kernel<*, 2> (>= 192 tiles of 256x256); the residual is added IN PLACE
+    (residual == output buffer) exactly as vit_body does for out_proj / fc2."""
+    w = O.bf16_round(rnd((N, K), 11, K ** -0.5))
+    x = O.bf16_round(rnd((M, K), 12))
+    bias = rnd((N,), 13, 0.1)
+    res = rnd((M, N), 14) if use_res else None
+    assert -(-M // 256) * -(-N // 256) >= 192
+    wp = nat.pack_weight(w.cuda().bfloat16())
+    if use_res:
+        buf = res.cuda().clone()
+        y = nat.linear(x.cuda().bfloat16(), wp, N, K, bias=bias.cuda(), act=act, residual=buf, out=buf)
+    else:
+        y = nat.linear(x.cuda().bfloat16(), wp, N, K, bias=bias.cuda(), act=act, out_dtype=out_dtype)
+    ref = ref_linear(x, w, bias, act, res)
+    assert relerr(y, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
+    # and the forced 256x128 tile (two blocks per CU) on the same inputs
+    if use_res:
+        buf = res.cuda().clone()
+        y2 = nat.linear(x.cuda().bfloat16(), wp, N, K, bias=bias.cuda(), act=act, residual=buf, out=buf, tile_hint=SM_TILE_256x128)
+    else:
+        y2 = nat.linear(x.cuda().bfloat16(), wp, N, K, bias=bias.cuda(), act=act, out_dtype=out_dtype, tile_hint=SM_TILE_256x128)
+    assert relerr(y2, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
+
+
+def test_gemm256_patch_embed_remap_vs_fp64(nat):
+    """the patch-embedding product of 28 frames: K = 588 zero-padded to 640, rows scattered to token rows b*577 + 1 + p with
+    the position embedding (rows 1..576) added as a broadcast residual (remap_in/out/off) -- clip_encoder.py:50 -> HF
+    CLIPVisionEmbeddings."""
+    B, P, S, D, K, Kp = 28, 576, 577, 1024, 588, 640
+    w = torch.zeros(D, Kp)
+    w[:, :K] = O.bf16_round(rnd((D, K), 21, K ** -0.5))
+    x = torch.zeros(B * P, Kp)
+    x[:, :K] = O.bf16_round(rnd((B * P, K), 22))
+    pos = rnd((S, D), 23)
+    out = torch.full((B * S, D), 7.0, device="cuda")
+    nat.linear(x.cuda().bfloat16(), nat.pack_weight(w.cuda().bfloat16()), D, Kp, residual=pos.cuda(), remap=(P, S, 1), out=out)
+    ref = (x.double() @ w.double().t()).reshape(B, P, D) + pos[1:].double()
+    got = out.cpu().reshape(B, S, D)
+    assert (got[:, 0] == 7.0).all()                               # CLS rows are not touched by this product
+    assert relerr(got[:, 1:], ref) < 1e-5
+
+
+@pytest.mark.parametrize("tile", [SM_TILE_256, SM_TILE_256x128, SM_TILE_128])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 256), (577, 1024, 1024), (1000, 200, 4096), (257, 130, 96), (4700, 1024, 64)])
+@pytest.mark.parametrize("act,out_dtype", [(0, torch.float32), (1, torch.bfloat16), (2, torch.float32), (2, torch.bfloat16)])
+def test_gemm_forced_tiles_small_and_ragged(nat, tile, M, N, K, act, out_dtype):
+    """every tile kernel forced on small / ragged problems: both wave layouts of gemm256 (256x256: WN = 2, 256x128: WN = 1),
+    the runtime-activation instantiation (<-1>: leaky_relu), short K loops (1..3 k-steps: the counted-wait tails), M and N
+    tails, and the 128x128 kernel on the same inputs."""
+    if tile == SM_TILE_128 and K % 64:
+        pytest.skip("the 128x128 kernel needs K padded to 64")
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = O.bf16_round(rnd((M, K), 2))
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4)
+    y = nat.linear(x.cuda().bfloat16(), nat.pack_weight(w.cuda().bfloat16()), N, K, bias=bias.cuda(), act=act, residual=res.cuda(),
+                   out_dtype=out_dtype, tile_hint=tile)
+    ref = ref_linear(x, w, bias, act, res)
+    assert relerr(y, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
+
+
+def test_vit_attention_28_frames(nat):
+    """vit_attn_kernel at the bench's batch (28 frames x 16 heads, S = 577) against the oracle's mixed-precision statement."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    B, S, H, dh = 28, 577, 16, 64
+    D = H * dh
+    qkv = O.bf16_round(rnd((B * S, 3 * D), 31))
+    qg = qkv.cuda().bfloat16()
+    ctx = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
+    check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, torch.cuda.current_stream().cuda_stream))
+    q = qkv[:, :D].reshape(B, S, H, dh).transpose(1, 2)
+    k = qkv[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
+    v = qkv[:, 2 * D:].reshape(B, S, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    e = torch.exp(s - s.max(-1, keepdim=True).values)
+    ref = ((O.bf16_round(e) @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * S, D)
+    assert relerr(ctx, ref) < 8e-3

@@ -1,0 +1,130 @@
+"""The weights-in boundary (streammind/model/builder.py:30-210) on a real MI355X: checkpoint directories laid
+out as the REFERENCE's own objects write them (golden g12: names, shapes, dtypes and config files recorded from the reference
+model's `save_pretrained` and HF `CLIPVisionModel.save_pretrained`; the weights are regenerated from the goldens' seeds), loaded
+through `from videollama2 import model_init`, then driven through the reference's streaming loop and compared with golden g6
+(the reference's own stream_generate_demo trace on the same weights)."""
+import json
+import os
+import shutil
+
+import pytest
+import torch
+
+from oracle import streammind_oracle as O
+from oracle.make_golden import TINY_V as TV, TINY_C as TC, TINY_G as TG, TINY_L as TL
+from tests.util_models import check_stream_against_g6, conn_gate_weights
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _weights():
+    return O.make_vit_weights(TV, 41), conn_gate_weights(TC, TG, 86), O.make_lm_weights(TL, 44)
+
+
+def _tensor(k, shape, Wv, Wc, Wl):
+    if "vision_tower.vision_tower." in k:
+        t = Wv[k.split("vision_tower.vision_tower.")[1]]
+    elif k.startswith("model.mm_projector."):
+        t = Wc[k[len("model.mm_projector."):]]
+    else:
+        t = Wl[k]
+    return t.reshape(shape).to(torch.float16).contiguous()          # fp16 on disk: builder.py:54
+
+
+def _write_tokenizer(d):
+    shutil.copy(os.path.join(GOLD, "tiny_tokenizer", "tokenizer.json"), os.path.join(d, "tokenizer.json"))
+    json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>",
+               "model_max_length": 2048, "padding_side": "right"}, open(os.path.join(d, "tokenizer_config.json"), "w"))
+
+
+def _write_checkpoint(tmp_path, g, layout):
+    from safetensors.torch import save_file
+    Wv, Wc, Wl = _weights()
+    ck, tower = tmp_path / "StreamMind-tiny", tmp_path / "clip-tiny"
+    ck.mkdir(); tower.mkdir()
+    cfg = json.loads(str(g["config_json"]))
+    cfg["mm_vision_tower"] = str(tower)
+    cfg["_name_or_path"] = "mistralai/Mistral-7B-Instruct-v0.2"
+    # the reference hard-wires the gate (MistralConfig defaults, 4096 wide); the goldens shrank it by patching that constructor
+    # (oracle/make_golden.py _ref_stream_model) -- the checkpoint states the shrunken gate through the build's own key
+    cfg["mm_gate_config"] = {"num_attention_heads": TG.heads, "num_key_value_heads": TG.kv_heads, "intermediate_size": TG.mlp}
+    lm_keys = json.loads(str(g["lm_keys"]))
+    tensors = {k: _tensor(k, shp, Wv, Wc, Wl) for k, (shp, _) in lm_keys.items()}
+    assert all(dt == "float16" for _, dt in lm_keys.values())
+    vcfg = json.loads(str(g["tower_config_json"]))
+    if layout == "as_saved_by_the_reference":
+        # ONE model.safetensors with LM + projector + tower, exactly the reference object's save_pretrained (transformers 5 names)
+        save_file(tensors, str(ck / "model.safetensors"))
+        json.dump(vcfg, open(tower / "config.json", "w"))
+    else:
+        # transformers-4.44-era layout: sharded LM safetensors + index WITHOUT tower and projector, projector in mm_projector.bin,
+        # rope_theta at top level; the tower directory is a FULL CLIP checkpoint (pytorch_model.bin with vision_model.*, text_model.*,
+        # visual_projection, text_projection, logit_scale; config.json with a nested vision_config)
+        cfg["rope_theta"] = cfg.pop("rope_parameters")["rope_theta"]
+        cfg["sliding_window"] = 4096
+        lm = {k: v for k, v in tensors.items() if "vision_tower" not in k and "mm_projector" not in k}
+        names = sorted(lm)
+        shards = {"model-00001-of-00002.safetensors": names[:len(names) // 2], "model-00002-of-00002.safetensors": names[len(names) // 2:]}
+        for f, ks in shards.items():
+            save_file({k: lm[k] for k in ks}, str(ck / f))
+        json.dump({"metadata": {}, "weight_map": {k: f for f, ks in shards.items() for k in ks}}, open(ck / "model.safetensors.index.json", "w"))
+        torch.save({k: v for k, v in tensors.items() if "mm_projector" in k}, str(ck / "mm_projector.bin"))
+        full = {"vision_model." + k.split("vision_tower.vision_tower.")[1]: v.float() for k, v in tensors.items() if "vision_tower" in k}
+        full.update({"text_model.embeddings.token_embedding.weight": torch.zeros(8, 16), "visual_projection.weight": torch.zeros(16, TV.hidden),
+                     "text_projection.weight": torch.zeros(16, 16), "logit_scale": torch.tensor(2.6)})
+        torch.save(full, str(tower / "pytorch_model.bin"))
+        json.dump({"model_type": "clip", "projection_dim": 16, "text_config": {}, "vision_config": vcfg}, open(tower / "config.json", "w"))
+    json.dump(cfg, open(ck / "config.json", "w"))
+    open(tower / "preprocessor_config.json", "w").write(str(g["preprocessor_config_json"]))
+    _write_tokenizer(str(ck))
+    return str(ck), (Wv, Wc, Wl)
+
+
+@pytest.mark.parametrize("layout", ["as_saved_by_the_reference", "hf444_sharded_projector_bin_full_clip_tower"])
+def test_model_init_from_checkpoint_then_reference_stream_loop(tmp_path, gold, layout):
+    from videollama2 import model_init                 # the reference's import name
+    ck, (Wv, Wc, Wl) = _write_checkpoint(tmp_path, gold("g12_checkpoint_layout"), layout)
+    model, processor, tokenizer, version = model_init(ck, "VideoLLaMA2-7B")
+    assert version == "llama_2" and tokenizer.pad_token == tokenizer.unk_token
+    assert model.config.mm_projector_type == "mamba" and model.native.cfg.vit_layers_run == TV.layers - 1
+    assert sorted(model.native.ignored) != [] or layout.startswith("as_saved")      # q/k of the gate, post_layernorm: never read
+    if layout.startswith("hf444"):
+        assert model.max_seq == 4096                  # capped at the checkpoint's sliding window
+
+    def to_video(frame_u8):                           # eval/video_score_stream_demo.py:285-287: processor([img], num_frames=1)
+        return processor([frame_u8[0].numpy()], num_frames=1)
+    check_stream_against_g6(model, tokenizer, gold("g6_stream_tiny"), Wv, Wc, Wl, (TV, TC, TG, TL), to_video)
+
+
+def test_loader_errors(tmp_path, gold):
+    from streammind_amd.model.builder import load_pretrained_model
+    g = gold("g12_checkpoint_layout")
+    ck, _ = _write_checkpoint(tmp_path, g, "as_saved_by_the_reference")
+    cfgp = os.path.join(ck, "config.json")
+    cfg = json.load(open(cfgp))
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B", load_4bit=True)
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(ck, "base", "VideoLLaMA2-7B")
+    json.dump(dict(cfg, mm_projector_type="stc_connector"), open(cfgp, "w"))
+    with pytest.raises(ValueError, match="Unsupported projector type"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B")
+    json.dump(dict(cfg, mm_vision_tower="openai/clip-vit-large-patch14-336"), open(cfgp, "w"))
+    with pytest.raises(FileNotFoundError, match="not a local directory"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B")
+    json.dump(dict(cfg, sliding_window=128), open(cfgp, "w"))
+    with pytest.raises(ValueError, match="sliding_window"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B", max_seq=256)
+    # a checkpoint that lost one half of a fused pair must not finalize -- even when the other half arrives twice (here:
+    # gate_proj of the gate is in model.safetensors AND in mm_projector.bin, its up_proj nowhere)
+    from safetensors.torch import load_file, save_file
+    json.dump(cfg, open(cfgp, "w"))
+    sd = load_file(os.path.join(ck, "model.safetensors"))
+    sd.pop("model.mm_projector.cls_net.cls_model.model.layers.1.mlp.up_proj.weight")
+    save_file(sd, os.path.join(ck, "model.safetensors"))
+    k = "model.mm_projector.cls_net.cls_model.model.layers.1.mlp.gate_proj.weight"
+    torch.save({k: sd[k]}, os.path.join(ck, "mm_projector.bin"))
+    with pytest.raises(ValueError, match="incomplete.*layers.1.gu"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B")

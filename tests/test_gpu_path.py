@@ -177,41 +177,12 @@ def test_stream_end_to_end_vs_reference_golden(tiny, gold, tiny_tokenizer):
     """The reference's own streaming loop (golden g6: stream_generate_demo driven like video_score_stream_demo.py) vs
     the drop-in API: per-frame gate logits (5e-3: bf16 ViT) and decisions, fire positions, and -- with the prompt
     teacher-forced from the golden after every fire -- the generated ids wherever the oracle's top-2 margin exceeds
-    the bf16 logit tolerance."""
-    import streammind_amd
+    twice the bf16 logit tolerance (tests/util_models.check_stream_against_g6)."""
     from streammind_amd.model import Videollama2MistralForCausalLM
+    from tests.util_models import check_stream_against_g6
     m, Wv, Wc, Wl = tiny
-    g = gold("g6_stream_tiny")
-    n = int(g["n_frames"])
-    frames = O.synthetic_frames(n, TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
     model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
-    prompt, fires = None, 0
-    st = O.StreamOracleState()
-    for i in range(n):
-        golden_prompt_before = prompt
-        text, prompt = streammind_amd.infer(model, frames[i:i + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=int(g["max_new"]))
-        assert maxdiff(model.last_gate_logits, torch.as_tensor(g["gate_logits"][i])) < 5e-3
-        pred = int(g["preds"][i])
-        assert (text is not None) == bool(pred)
-        # oracle twin on the same frames (mixed-precision LLM) for margins
-        r = O.stream_frame(frames[i], st, Wv, Wc, Wl, TV, TC, TG, TL, tiny_tokenizer, max_new_tokens=int(g["max_new"]))
-        if pred:
-            want = g[f"new_ids{fires}"].tolist()
-            assert r.new_ids == want
-            ids_in = O.tokenize_with_video(golden_prompt_before or O.initial_prompt(), tiny_tokenizer)
-            emb = O.splice_embeds(ids_in, O.connector_scan(O.pool_patches(st.feats), Wc, TC), st.interval_ids, Wl["model.embed_tokens.weight"])
-            _, trace = O.greedy_generate(emb, Wl, TL, len(want), tiny_tokenizer.eos_token_id, return_logits=True)
-            got = model.last_new_ids
-            for j, (a, b) in enumerate(zip(got, want)):
-                margin = float(torch.topk(trace[j], 2).values.diff().abs())
-                if a != b:
-                    assert margin < 0.15, (i, j, got, want, margin)
-                    break
-            fires += 1
-            prompt = st.prompt                       # teacher-force the reference's prompt for the next ticks
-    assert model.interval_id_list == g["interval_ids"].tolist()
-    assert fires == int(g["n_fires"])
-    assert st.prompt == str(g["final_prompt"])
+    check_stream_against_g6(model, tiny_tokenizer, gold("g6_stream_tiny"), Wv, Wc, Wl, (TV, TC, TG, TL))
 
 
 def test_clip_tower_and_projector_dropins(tiny):
@@ -324,31 +295,69 @@ def test_more_than_600_new_frames_keeps_last_600_rule(tiny, tiny_tokenizer):
         model.frame_feature = torch.zeros(1)
 
 
-def test_full_size_perception_vs_fp32_oracle():
-    """FULL-SIZE silent-frame path (CLIP-ViT-L/14-336, 23 layers, bf16 MFMA) -> connector -> 872 M-parameter gate against
-    the fp32 oracle (the arithmetic pinned to the reference): pooled features and gate logits.  The connector+gate alone
-    are within 1e-3 of the reference (test_conn_gate_full_size_golden).  End to end, with the bf16-operand ViT in front, the
-    measured gate-logit deviation from the fp32 oracle is 4.3e-4 (pooled features 7e-3 on magnitudes up to 27); asserted
-    at 2e-3 / 2e-2, and the decisions must agree wherever the oracle margin exceeds the tolerance."""
+@pytest.fixture(scope="module")
+def fullsize():
+    """FULL-SIZE perception model (CLIP-ViT-L/14-336 run to hidden_states[-2], connector, 872 M-parameter gate), 28 frames per call"""
     vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
     Wv = O.make_vit_weights(vcfg, 101)
     Wc = conn_gate_weights(ccfg, gcfg, 102)
-    m = build_native(vcfg, ccfg, gcfg, Wv, Wc, max_frames_per_call=2)
+    m = build_native(vcfg, ccfg, gcfg, Wv, Wc, max_frames_per_call=28)
+    return m, Wv, Wc, vcfg, ccfg, gcfg
+
+
+def _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg):
+    torch.set_num_threads(max(16, torch.get_num_threads()))
+    feats = torch.cat([O.vit_features(O.preprocess_frames(frames[i:i + 4]), Wv, vcfg, O.FP32) for i in range(0, frames.shape[0], 4)])
+    pooled = O.pool_patches(feats)
+    tok = O.connector_scan(pooled, Wc, ccfg)
+    return pooled, tok, O.gate_logits_shortcut(tok, Wc, gcfg)
+
+
+def test_full_size_perception_vs_fp32_oracle(fullsize):
+    """FULL-SIZE silent-frame path (CLIP-ViT-L/14-336, 23 layers, bf16 MFMA) -> connector -> 872 M-parameter gate against
+    the fp32 oracle (the arithmetic pinned to the reference): pooled features and gate logits, 2 frames per call (the
+    128x128 GEMM).  The connector+gate alone are within 1e-3 of the reference (test_conn_gate_full_size_golden).  End to
+    end, with the bf16-operand ViT in front, the gate logits are asserted at the north-star's 1e-3 (measured 4.3e-4; pooled
+    features 7e-3 on magnitudes up to 27, asserted at 2e-2), and the decisions must agree wherever the oracle margin
+    exceeds twice the tolerance."""
+    m, Wv, Wc, vcfg, ccfg, gcfg = fullsize
     frames = O.synthetic_frames(2, 336, seed=55, scene_len=1)
     s = m.open_stream(max_frames=8, max_seq=64)
     lg, dec = s.push_frames(frames.cuda())
-    torch.set_num_threads(16)
-    feats = O.vit_features(O.preprocess_frames(frames), Wv, vcfg, O.FP32)
-    pooled = O.pool_patches(feats)
-    tok = O.connector_scan(pooled, Wc, ccfg)
-    ref = O.gate_logits_shortcut(tok, Wc, gcfg)
+    pooled, tok, ref = _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg)
     dp = maxdiff(m.vit_encode(frames.cuda()), pooled)
     dl = maxdiff(lg, ref)
     print(f"full-size: pooled max|diff| {dp:.3e} (|pooled| max {pooled.abs().max():.2f}); gate logits max|diff| {dl:.3e}; ref logits {ref.tolist()}")
-    assert dp < 2e-2 and dl < 2e-3
+    assert dp < 2e-2 and dl < 1e-3, (dp, dl)
     for j in range(2):
-        if abs(float(ref[j, 1] - ref[j, 0])) > 4e-3:
+        if abs(float(ref[j, 1] - ref[j, 0])) > 2e-3:
             assert int(dec[j]) == O.gate_decision(ref[j])
+
+
+def test_full_size_28_frames_one_call_vs_fp32_oracle(fullsize):
+    """The bench's own step: 28 FULL-SIZE frames in ONE push_frames call (16156 token rows: every ViT GEMM runs
+    gemm256_kernel, the attention runs at B = 28, the connector + gate take one 28-row weight pass) against the fp32 oracle:
+    pooled features, all 28 frame tokens, all 28 gate logits (north-star bound 1e-3) and decisions.  Also: the same frames
+    pushed 2 per call (128x128 GEMM, other summation order) agree to the same bound, i.e. the batch size is not visible."""
+    m, Wv, Wc, vcfg, ccfg, gcfg = fullsize
+    frames = O.synthetic_frames(28, 336, seed=56, scene_len=5)
+    fg = frames.cuda()
+    s = m.open_stream(max_frames=32, max_seq=64)
+    lg, dec = s.push_frames(fg)
+    pooled_gpu = m.vit_encode(fg)
+    pooled, tok, ref = _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg)
+    dp, dt, dl = maxdiff(pooled_gpu, pooled), maxdiff(s.tokens(), tok), maxdiff(lg, ref)
+    print(f"full-size x28: pooled max|diff| {dp:.3e} (max |pooled| {pooled.abs().max():.2f}); tokens {dt:.3e} (max {tok.abs().max():.2f}); "
+          f"gate logits max|diff| {dl:.3e}; min oracle margin {float((ref[:, 1] - ref[:, 0]).abs().min()):.3e}")
+    # pooled features: 23 layers of bf16-operand GEMMs against fp32 -- 1e-3 of the largest feature (max over 28 x 1024 values;
+    # the 2-frame test's 2e-2 absolute is the same relative budget on 14x fewer values); gate logits: the north-star's 1e-3
+    assert dp < 1.2e-3 * float(pooled.abs().max()) and dl < 1e-3, (dp, dl)
+    for j in range(28):
+        if abs(float(ref[j, 1] - ref[j, 0])) > 2e-3:
+            assert int(dec[j]) == O.gate_decision(ref[j])
+    s2 = m.open_stream(max_frames=32, max_seq=64)
+    lg2 = torch.cat([s2.push_frames(fg[i:i + 2].contiguous())[0] for i in range(0, 28, 2)])
+    assert maxdiff(lg2, ref) < 1e-3 and maxdiff(lg2, lg) < 1e-3
 
 
 def test_full_width_llm_two_layers_prefill_and_decode():
@@ -568,7 +577,7 @@ def test_offline_generate_vs_reference_golden(tiny, gold, tiny_tokenizer):
         got = out[0].tolist()
         for j, (a, b) in enumerate(zip(got, want)):
             if a != b:
-                assert float(g["margins_all"][j]) < 0.15, (st, j, got, want)
+                assert float(g["margins_all"][j]) < 2 * 3e-2, (st, j, got, want)     # twice the stated logit tolerance
                 break
     # u8 frames through the same path (the drop-in keeps frames as uint8) and the package-level API
     text = streammind_amd.infer_offline(model, frames, "a b", tiny_tokenizer, version="mistral_instruct", max_new_tokens=4)

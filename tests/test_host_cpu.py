@@ -1,7 +1,9 @@
 """Host-side mirrors of the reference's text / bookkeeping interface against the goldens (CPU only)."""
 import json
+import os
 
 import numpy as np
+import pytest
 import torch
 
 from streammind_amd import conversation, mm_utils
@@ -65,16 +67,80 @@ def test_sentinel_expansion_and_errors():
         assert "inputs_embeds" in str(e)
 
 
-def test_feature_cache_stride_and_names(tmp_path):
+def test_feature_cache_plumbing_vs_reference_golden(tmp_path, gold):
+    """config-1 plumbing (golden g13 = the reference's own process_clip_encoder.process_file run on a 31-frame chunk,
+    and encode_all_videos_score's chunking / naming statements evaluated for a 1234-frame video): the drop-in's stride writes the
+    same file under the same relative path with the same frames; chunk boundaries, names and the rank slicing agree."""
+    import json
     from streammind_amd import feature_cache as fc
     from oracle import streammind_oracle as O
-    x = torch.arange(1 * 500 * 2 * 3, dtype=torch.float32).reshape(1, 500, 2, 3).to(torch.bfloat16)
-    d = tmp_path / "features_video_encode_ddp" / "vid"
-    d.mkdir(parents=True)
-    p = d / fc.chunk_name("vid", 0, 500)
-    torch.save(x, p)
-    out = fc.process_file(str(p))
-    assert out == O.stride_output_path(str(p)) and "features_video_encode_ddp_fps" in out
+    g = gold("g13_feature_cache_plumbing")
+    n, P, C = int(g["n"]), int(g["P"]), int(g["C"])
+    x = torch.arange(n * P * C, dtype=torch.float32).reshape(1, n, P, C).to(torch.bfloat16)
+    src = tmp_path / str(g["src_rel"])
+    src.parent.mkdir(parents=True)
+    torch.save(x, src)
+    out = fc.process_file(str(src))
+    assert os.path.relpath(out, tmp_path) == str(g["out_rel"]) == os.path.relpath(O.stride_output_path(str(src)), tmp_path)
     y = torch.load(out)
-    assert tuple(y.shape) == (1, 42, 2, 3) and torch.equal(y, O.feature_stride(x))
-    assert fc.chunk_name("v", 500, 1000) == "v_encode_feature_frame_500_1000.pt"
+    assert list(y.shape) == g["out_shape"].tolist() and fc.SEGMENT == int(g["segment"])
+    assert y[0, :, 0, 0].float().tolist() == g["kept_frames"].tolist() and torch.equal(y, O.feature_stride(x))
+    # chunking + naming of the bulk encoder
+    vp, dur = str(g["video_path"]), int(g["duration"])
+    want_paths, want_lens = json.loads(str(g["chunk_paths"])), g["chunk_lens"].tolist()
+    assert [c[0] for c in O.feature_cache_chunks(vp, dur)] == want_paths
+    d, half = fc.output_dir(vp)
+    starts = list(range(0, dur, fc.CHUNK))
+    assert [os.path.join(d, fc.chunk_name(half, s)) for s in starts] == want_paths
+    assert [min(s + fc.CHUNK, dur) - s for s in starts] == want_lens
+    vids = [f"v{i}" for i in range(10)]
+    assert fc.rank_slice(vids, 1, 4) == ["v2", "v3"] and sum(len(fc.rank_slice(vids, r, 4)) for r in range(4)) == 8   # remainder dropped, as in the reference
+
+
+def test_reference_import_names_resolve_to_the_dropin():
+    """SURVEY fact 0.3 / 8b last line: the reference's callers import `videollama2.*` (and the directory is `streammind/`);
+    both names resolve to the SAME module objects as streammind_amd -- the import block of eval/video_score_stream_demo.py:19-38
+    works unedited."""
+    import streammind_amd
+    from videollama2.constants import NUM_FRAMES
+    from videollama2.model import Videollama2LlamaForCausalLM, Videollama2MistralForCausalLM, Videollama2MixtralForCausalLM
+    from videollama2.model.builder import load_pretrained_model
+    from videollama2.conversation import conv_templates, SeparatorStyle
+    from videollama2.mm_utils import process_video, tokenizer_MMODAL_token, get_model_name_from_path, KeywordsStoppingCriteria
+    from videollama2.constants import NUM_FRAMES, DEFAULT_MMODAL_TOKEN, DEFAULT_MMODAL_START_TOKEN, DEFAULT_MMODAL_END_TOKEN, MMODAL_TOKEN_INDEX
+    from videollama2.mm_utils import tokenizer_MMODAL_token, tokenizer_image_token, expand2square, process_video, process_image
+    from videollama2 import model_init, x_infer
+    from videollama2 import conversation as conversation_lib
+    import videollama2, streammind
+    import streammind.model.builder as b2
+    import streammind_amd.model.builder as b3
+    assert videollama2 is streammind_amd and streammind is streammind_amd and b2 is b3
+    assert load_pretrained_model is b3.load_pretrained_model and model_init is streammind_amd.model_init
+    assert Videollama2MistralForCausalLM is streammind_amd.model.Videollama2MistralForCausalLM
+    assert NUM_FRAMES == 8 and MMODAL_TOKEN_INDEX["VIDEO"] == -201 and "llama_2" in conv_templates
+    assert get_model_name_from_path("/a/b/run1/checkpoint-500/") == "run1_checkpoint-500" and get_model_name_from_path("x/VideoLLaMA2-7B") == "VideoLLaMA2-7B"
+    with pytest.raises(NotImplementedError):
+        Videollama2LlamaForCausalLM()
+    img = np.zeros((4, 10, 3), np.uint8) + 9
+    sq = expand2square(img, (1, 2, 3))
+    assert sq.shape == (10, 10, 3) and sq[0, 0].tolist() == [1, 2, 3] and sq[3, 0].tolist() == [9, 9, 9] and (sq[7:] == [1, 2, 3]).all()
+
+
+def test_checkpoint_config_to_path_dims(gold):
+    """config.json as the REFERENCE's model object writes it (golden g12) -> the native path's dimensions; rope_theta under
+    either transformers spelling; the gate defaults are the reference's hard-wired MistralConfig(vocab_size=2, layers=4)."""
+    import json
+    from streammind_amd.model.builder import path_config_from_checkpoint
+    g = gold("g12_checkpoint_layout")
+    cfgj, vj = json.loads(str(g["config_json"])), json.loads(str(g["tower_config_json"]))
+    c = path_config_from_checkpoint(cfgj, vj)
+    assert (c.vit_image, c.vit_patch, c.vit_hidden, c.vit_heads, c.vit_mlp, c.vit_layers, c.vit_layers_run) == (56, 14, 128, 2, 256, 3, 2)
+    assert (c.conn_d_model, c.llm_layers, c.llm_heads, c.llm_kv_heads, c.llm_mlp, c.llm_vocab) == (256, 2, 2, 1, 512, 384)
+    assert c.llm_rope_theta == 1e6 and abs(c.llm_eps - 1e-5) < 1e-12
+    assert (c.gate_layers, c.gate_heads, c.gate_kv_heads, c.gate_mlp, c.gate_eps) == (4, 32, 8, 14336, 1e-6)
+    old = dict(cfgj); old.pop("rope_parameters"); old["rope_theta"] = 5e5
+    old["mm_gate_config"] = {"num_attention_heads": 2, "num_key_value_heads": 1, "intermediate_size": 512}
+    c2 = path_config_from_checkpoint(old, vj)
+    assert c2.llm_rope_theta == 5e5 and (c2.gate_heads, c2.gate_kv_heads, c2.gate_mlp, c2.gate_layers) == (2, 1, 512, 4)
+    with pytest.raises(ValueError, match="select feature"):
+        path_config_from_checkpoint(dict(cfgj, mm_vision_select_feature="cls_patch"), vj)

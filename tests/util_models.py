@@ -51,3 +51,43 @@ def fp8_view(W: dict, skip=("embed_tokens",)) -> dict:
         else:
             out[k] = v
     return out
+
+
+LOGIT_TOL = 3e-2          # bf16-activation budget on the tiny LLM's O(1) logits (stated in test_llm_tiny_prefill_decode)
+
+
+def check_stream_against_g6(model, tokenizer, g, Wv, Wc, Wl, cfgs, to_video=lambda fr: fr):
+    """Drive `streammind_amd.infer` frame by frame exactly like eval/video_score_stream_demo.py:283-299 and compare with golden
+    g6 (the reference's own stream_generate_demo trace): gate logits of every frame (5e-3: bf16 ViT in front), decisions, fire
+    positions, and -- with the reference's prompt teacher-forced after every fire -- the generated ids, which must equal the
+    reference's wherever the oracle's top-2 logit margin exceeds TWICE the stated logit tolerance (2 x 3e-2)."""
+    import streammind_amd
+    TV, TC, TG, TL = cfgs
+    n = int(g["n_frames"])
+    frames = O.synthetic_frames(n, TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
+    prompt, fires = None, 0
+    st = O.StreamOracleState()
+    for i in range(n):
+        golden_prompt_before = prompt
+        text, prompt = streammind_amd.infer(model, to_video(frames[i:i + 1]), "", tokenizer, prompt=prompt, max_new_tokens=int(g["max_new"]))
+        d = (model.last_gate_logits.float().cpu() - torch.as_tensor(g["gate_logits"][i])).abs().max().item()
+        assert d < 5e-3, (i, d)
+        pred = int(g["preds"][i])
+        assert (text is not None) == bool(pred), (i, text, pred)
+        r = O.stream_frame(frames[i], st, Wv, Wc, Wl, TV, TC, TG, TL, tokenizer, max_new_tokens=int(g["max_new"]))
+        if pred:
+            want = g[f"new_ids{fires}"].tolist()
+            assert r.new_ids == want
+            ids_in = O.tokenize_with_video(golden_prompt_before or O.initial_prompt(), tokenizer)
+            emb = O.splice_embeds(ids_in, O.connector_scan(O.pool_patches(st.feats), Wc, TC), st.interval_ids, Wl["model.embed_tokens.weight"])
+            _, trace = O.greedy_generate(emb, Wl, TL, len(want), tokenizer.eos_token_id, return_logits=True)
+            for j, (a, b) in enumerate(zip(model.last_new_ids, want)):
+                margin = float(torch.topk(trace[j], 2).values.diff().abs())
+                if a != b:
+                    assert margin < 2 * LOGIT_TOL, (i, j, model.last_new_ids, want, margin)
+                    break
+            fires += 1
+            prompt = st.prompt                       # teacher-force the reference's prompt for the next ticks
+    assert model.interval_id_list == g["interval_ids"].tolist()
+    assert fires == int(g["n_fires"])
+    assert st.prompt == str(g["final_prompt"])
