@@ -261,6 +261,49 @@ def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens
             "kv_len_end": stream.kv_len}
 
 
+def streams_x1_leg(model, frames, S, ticks=20):
+    """The reference-shaped mode at batch throughput (eval/video_score_stream_demo.py:283-299 decides after EVERY frame): S
+    concurrent streams, ONE new frame per stream per tick, pushed as one group call (sm_group_push_frames: one ViT batch of
+    S x 577 rows, one connector + gate weight pass).  Gate decisions are available after every tick (one frame of latency per
+    stream instead of S frames of buffering)."""
+    streams = [model.open_stream(max_frames=ticks + 8, max_seq=64) for _ in range(S)]
+    grp = model.open_group(streams)
+    n = frames.shape[0]
+    for t in range(3):
+        grp.push_frames(frames[(t * S) % (n - S + 1):][:S])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(ticks):
+        lg, dec = grp.push_frames(frames[((t + 3) * S) % (n - S + 1):][:S])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / ticks
+    assert torch.isfinite(lg).all()
+    grp.close()
+    for st in streams:
+        st.close()
+    return {"streams": S, "frames_per_stream_per_tick": 1, "ms_per_tick": round(dt * 1e3, 3), "frames_per_s": round(S / dt, 1),
+            "decision_latency_frames": 1}
+
+
+def class_roofline(lib, cls, run, units, per_unit, bound, peak, unit, kernel):
+    """HIP-event durations of one kernel class (sm_prof_*: events on the launch stream around every launch of the class) over
+    `run()`; achieved = algorithmic work of the run / summed launch durations."""
+    lib.sm_prof_reset()
+    lib.sm_prof_enable(1 << cls)
+    run()
+    torch.cuda.synchronize()
+    lib.sm_prof_enable(0)
+    cnt, ms = C.c_int(), C.c_float()
+    lib.sm_prof_read(cls, C.byref(cnt), C.byref(ms))
+    if not cnt.value:
+        return None
+    scale = 1e12 if unit == "TFLOP/s" else 1e9
+    ach = units * per_unit / (ms.value * 1e-3) / scale
+    return {"kernel": kernel, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+            "traffic": None, "launches": cnt.value, "avg_launch_us": round(ms.value * 1e3 / cnt.value, 2),
+            "work_per_launch": units * per_unit / cnt.value}
+
+
 def synthetic_frames_gpu(n: int, size: int, seed: int, rank: int) -> torch.Tensor:
     """seeded u8 HWC frames generated on the GPU: slowly drifting low-pass scene with cuts + per-pixel noise."""
     g = torch.Generator(device="cuda").manual_seed(seed * 1000003 + rank)
@@ -293,7 +336,9 @@ def usable_cores() -> int:
 
 def cpu_baseline(n_frames: int = 12) -> dict:
     """the oracle (plain-torch CPU port of the reference arithmetic, fp32) on a bounded sample of the same workload:
-    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 12 frames ~ 10 s of CPU work."""
+    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 12 frames ~ 10 s of CPU work.
+    Plus the other CPU items of SURVEY 8d: BASELINE configs[0] (8 frames through the tower, fp32 and bf16, then the [:, ::12]
+    stride) and Mistral-7B decode tokens/s (4 of 32 layers timed, x8 extrapolated -- flagged)."""
     from oracle import streammind_oracle as O
     torch.set_grad_enabled(False)
     cores = usable_cores()
@@ -311,15 +356,43 @@ def cpu_baseline(n_frames: int = 12) -> dict:
         tok = O.connector_step(pooled, st, Wc, ccfg)
         O.gate_decision(O.gate_logits_shortcut(tok[None], Wc, gcfg)[0])
     dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} frames x (preprocess + CLIP-ViT-L/14-336 23 layers + pool + connector step + 4-layer gate), "
-                      f"oracle/streammind_oracle.py fp32, torch CPU threads={cores}"}
+    out = {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n_frames} frames x (preprocess + CLIP-ViT-L/14-336 23 layers + pool + connector step + 4-layer gate), "
+                     f"oracle/streammind_oracle.py fp32, torch CPU threads={cores}"}
+    try:        # configs[0]: 8 frames as ONE batch through a1 + a2, then the cached-feature stride (process_clip_encoder.py:75)
+        pix = O.preprocess_frames(frames[:8])
+        t0 = time.perf_counter(); f32 = O.vit_features(pix, Wv, vcfg); t_f32 = time.perf_counter() - t0
+        W16 = {k: v.to(torch.bfloat16) for k, v in Wv.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            O.vit_features(pix[:1].to(torch.bfloat16), W16, vcfg)
+            t0 = time.perf_counter(); O.vit_features(pix.to(torch.bfloat16), W16, vcfg); t_bf = time.perf_counter() - t0
+        strided = O.feature_stride(f32[None])
+        out["config0_8_frames"] = {"fp32_frames_per_s": round(8 / t_f32, 3), "bf16_frames_per_s": round(8 / t_bf, 3),
+                                   "stride_out_frames": int(strided.shape[1]), "note": "CLIPVisionTower arithmetic (oracle port), batch of 8; bf16 = torch CPU autocast"}
+    except Exception as e:
+        out["config0_8_frames"] = {"error": repr(e)[:200]}
+    try:        # decode: 4 of the 32 Mistral-7B layers (3.5 GB fp32), 8 single-token steps over a 64-token cache
+        lcfg = O.LmCfg(hidden=4096, layers=4, heads=32, kv_heads=8, mlp=14336, vocab=64, eps=1e-5, rope_theta=1e6)
+        Wl = O.make_lm_weights(lcfg, 21)
+        cache = O.KVCache()
+        O.lm_forward(torch.randn(64, 4096) * 0.1, Wl, lcfg, cache)
+        x = torch.randn(1, 4096) * 0.1
+        O.lm_forward(x, Wl, lcfg, cache)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            O.lm_forward(x, Wl, lcfg, cache)
+        t4 = (time.perf_counter() - t0) / 8
+        out["decode_tokens_per_s"] = {"value": round(1.0 / (8 * t4), 3), "extrapolated": True,
+                                      "note": "4 of 32 layers timed (fp32 weights, 64..72-token cache), x8; final norm + lm_head (0.26 G MAC) not included"}
+    except Exception as e:
+        out["decode_tokens_per_s"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=64, help="timed steps; 64 x 28 frames + warm-up = the 1800-frame (60 s x 30 fps) stream")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=28, help="frames per step (28 x 577 tokens = 63.1 tiles of 256 rows: every "
                                                            "ViT GEMM is a whole number of 256-CU rounds)")
@@ -334,8 +407,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world == 1:
-        print("bench.py: --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: N > 1 must be launched with torch.distributed.run, one rank per GPU "
+              "(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N)", file=sys.stderr)
         sys.exit(2)
     # test hook (1-GPU box): SM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and SM_BENCH_BACKEND=gloo swaps the backend, so the
     # N > 1 control flow of this file can be exercised without N GPUs; the driver's runs never set them
@@ -352,6 +426,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world == a.gpus or os.environ.get("SM_BENCH_FORCE_DIST") == "1", (dist.get_world_size(), world, a.gpus)
 
     from streammind_amd import _lib
     from streammind_amd.native import NativeModel, PathConfig
@@ -365,15 +440,41 @@ def main():
     model.finalize()
     n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
     frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
-    stream = model.open_stream(max_frames=B * (a.steps + a.warmup + 8) + 16 + 256, max_seq=2048)
+    stream = model.open_stream(max_frames=B * (a.steps + a.warmup + 16) + 16 + 256, max_seq=2048)
     torch.cuda.synchronize()
 
     def step(i):
         off = (i * B) % (n_pool - B + 1)
         return stream.push_frames(frames[off:off + B])
 
+    # N > 1 (BASELINE configs[3]): every step is one exchange tick.  Ranks "fire" on DIFFERENT, rank-specific steps (the random
+    # gate's own decisions are not a workload): on its fire steps a rank contributes the frame tokens of the segment since its
+    # last fire; every tick posts the asynchronous 4-byte-per-rank count word, the payload all-gather runs only for ticks on
+    # which some rank fired (streammind_amd.dist.GatedTokenExchange).  An exchange error is a hard failure of the run.
+    ex, seg_start, rows_seen = None, 0, 0
+    if dist is not None:
+        from streammind_amd.dist import GatedTokenExchange
+        ex = GatedTokenExchange(cfg.conn_d_model, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
+
+    def fires(i):                        # ~ every 9th step per rank, never the same step on two ranks of an 8-GPU node
+        return (i % 9) == (rank % 9)
+
+    def exchange(i):
+        nonlocal seg_start, rows_seen
+        tok = None
+        if fires(i):
+            T = stream.num_frames
+            tok = stream.tokens(seg_start, T - seg_start)
+            tok = tok if cdev == "cuda" else tok.cpu()
+            seg_start = T
+        prev = ex.tick(tok)
+        if prev is not None:
+            rows_seen += int(sum(t.shape[0] for t in prev))
+
     for i in range(a.warmup):
         step(i)
+        if ex is not None:
+            exchange(i)
     prof = not a.no_prof
     torch.cuda.synchronize()
     if dist is not None:
@@ -389,37 +490,52 @@ def main():
         if prof and i == a.steps - prof_steps:
             lib.sm_prof_enable(1)
         logits, dec = step(a.warmup + i)
+        if ex is not None:
+            exchange(a.warmup + i)
+    if ex is not None:
+        last = ex.flush()
+        if last is not None:
+            rows_seen += int(sum(t.shape[0] for t in last))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if prof:
         lib.sm_prof_enable(0)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([B * a.steps / dt_local], device=cdev, dtype=torch.float64)
+        allv = torch.empty(dist.get_world_size(), device=cdev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allv, mine)
+        per_rank = [round(v, 1) for v in allv.tolist()]
     assert torch.isfinite(logits).all()
     dec_leg = e2e = None
     if not a.no_decode and not a.no_e2e:
-        gather, gathered = None, {"calls": 0, "ok": True}
+        gather, gathered = None, {"calls": 0}
         if dist is not None:
             from streammind_amd.dist import allgather_gated_tokens
 
-            def gather(tok):
-                try:
-                    out = allgather_gated_tokens(tok if cdev == "cuda" else tok.cpu(), cfg.conn_d_model)
-                    gathered["calls"] += 1
-                    gathered["rows"] = int(sum(t.shape[0] for t in out)) if out is not None else 0
-                except Exception as e:               # never let the optional exchange take the scaling run down
-                    gathered["ok"] = False
-                    gathered["error"] = repr(e)[:200]
+            def gather(tok):                             # every rank fires on the same scheduled tick here: the blocking two-phase form
+                out = allgather_gated_tokens(tok if cdev == "cuda" else tok.cpu(), cfg.conn_d_model)
+                gathered["calls"] += 1
+                gathered["rows"] = int(sum(t.shape[0] for t in out)) if out is not None else 0
         e2e = e2e_leg(model, stream, cfg, frames, B, gather=gather)
         if dist is not None:
             e2e["allgather_gated_tokens"] = gathered
     if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
         dec_leg = decode_leg(model, stream, cfg)
+        if prof and world == 1:
+            try:       # the weight-streaming kernels of a decode step in isolation (HIP events around each launch)
+                r = class_roofline(lib, 1, lambda: stream.decode(16), 16, dec_leg["roofline"]["bytes_per_token"], "hbm", HBM_PEAK_GBS, "GB/s",
+                                   "skinny_kernel family (weight-streaming GEMV, fused RMSNorm / SwiGLU epilogues), launches of one decode step")
+                dec_leg["roofline"]["gemv_kernels_only"] = r
+            except Exception as e:
+                dec_leg["roofline"]["gemv_kernels_only"] = {"error": repr(e)[:200]}
         if dist is not None:
             t = torch.tensor([dec_leg["tokens_per_s"]], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -442,6 +558,31 @@ def main():
             lat_leg = latency_leg(model, frames)
         except Exception as e:
             lat_leg = {"error": repr(e)[:200]}
+    streams_leg = None
+    if world == 1 and not a.no_aux:
+        try:
+            streams_leg = streams_x1_leg(model, frames, B)
+        except Exception as e:
+            streams_leg = {"error": repr(e)[:200]}
+    # rooflines of the other kernels of a step, each from its own HIP-event pass over a few steps (bracketing a class breaks the
+    # back-to-back dispatch, so these passes are outside the timed region)
+    more_roof = {}
+    if prof and world == 1 and not a.no_aux:
+        try:
+            S_tok = cfg.n_patches + 1
+            attn_flops = cfg.vit_layers_run * 4.0 * S_tok * S_tok * cfg.vit_hidden            # per frame: QK^T + PV
+            more_roof["vit_attention"] = class_roofline(
+                lib, 2, lambda: [step(j) for j in range(3)], 3 * B, attn_flops, "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                "vit_attn_kernel (non-causal flash-style attention, S = 577, 16 heads x 64)")
+            d, di = cfg.conn_d_model, cfg.conn_expand * cfg.conn_d_model
+            gdh = d // cfg.gate_heads
+            conn_bytes = 2.0 * (cfg.vit_hidden * d + d * 2 * di + di * (cfg.conn_dt_rank + 2 * cfg.conn_d_state) + cfg.conn_dt_rank * di + di * d + d * d)
+            gate_bytes = 2.0 * (cfg.gate_layers * (d * cfg.gate_kv_heads * gdh + d * d + 3 * d * cfg.gate_mlp) + 2 * d)
+            more_roof["connector_gate_pass"] = class_roofline(
+                lib, 1, lambda: [step(j) for j in range(3)], 3, conn_bytes + gate_bytes, "hbm", HBM_PEAK_GBS, "GB/s",
+                f"skinny_lds_kernel + split-K reduce (weight-streaming linears of the connector + V/O-only gate, {B} rows per pass)")
+        except Exception as e:
+            more_roof["error"] = repr(e)[:200]
 
     roof = None
     if prof:
@@ -451,15 +592,19 @@ def main():
             flops_per_launch = vit_linear_flops_per_frame(cfg) * B * prof_steps / cnt.value
             avg_s = ms.value * 1e-3 / cnt.value
             ach = flops_per_launch / avg_s / 1e12
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-            if os.path.exists(tf):
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
+            # being profiled): the newest committed summary is quoted and its source named
+            traffic = traffic_src = None
+            for rnd in ("r02", "r01"):
+                tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic.json")
+                if os.path.exists(tf):
+                    traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
+                    break
             big = B * (cfg.n_patches + 1) >= 192 * 64
             roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups)" if big else
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 8 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch}
     fp8_leg = None
     if not a.no_decode and not a.no_fp8 and world == 1:
@@ -489,9 +634,9 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
-                                   "4-layer Mistral event gate, synthetic 336x336 30 fps stream (1800-frame pool), "
-                                   f"{B} frames per step, one stream per GPU, random-init weights of the true shapes",
-                       "frames_per_step": B, "streams_per_gpu": 1, "parallelism": f"replicas x{world} (stream-sharded, no collective)"},
+                                   f"4-layer Mistral event gate, synthetic 336x336 30 fps stream ({n_pool}-frame pool = {n_pool / 30:.1f} s, "
+                                   f"{a.steps * B} frames timed), {B} frames per step, one stream per GPU, random-init weights of the true shapes",
+                       "frames_per_step": B, "streams_per_gpu": 1, "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,
@@ -499,8 +644,15 @@ def main():
             "teacher_forced_eval": tf_leg,
             "ingest_frontend": ing_leg,
             "per_call_latency": lat_leg,
+            "streams_x1": streams_leg,
+            "rooflines_other": more_roof or None,
             "decode_fp8_weights": fp8_leg,
         }
+        if per_rank is not None:
+            out["per_rank_frames_per_s"] = per_rank          # each rank's own N=1-equivalent rate (its own clock)
+            out["gated_token_exchange"] = {"ticks": ex.ticks, "payload_collectives": ex.payload_collectives, "rows_received": rows_seen,
+                                           "host_wait_ms_total": round(ex.host_wait_s * 1e3, 3),
+                                           "fire_schedule": "rank r fires on steps i with i % 9 == r % 9 (never two ranks of one node together)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -286,6 +286,25 @@ int sm_stream_read_logits(sm_stream* s, float* out_opt, int32_t* next_token_out_
 int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stream groups: one tick of S streams of ONE model as one ViT batch and one connector + gate weight pass.
+ * Replaces S model objects each serving one frame per call (the reference holds the stream state on the model object and
+ * supports batch size 1 only: language_model/videollama2_mistral.py:159-162, eval/video_score_stream_demo.py:283-299,
+ * eval/inference_video_score_stream_ddp.py:325).  Per stream the results are those of its own sm_stream_push_frames calls
+ * (same arithmetic; fp32 summation order of the skinny products may differ with the row count).  The group borrows the
+ * streams: they stay usable on their own (LLM prefill / decode of a stream that fired), must outlive the group, and a
+ * group call must not overlap another call on one of its streams.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sm_stream_group sm_stream_group;
+int sm_group_create(sm_stream** streams, int S, sm_stream_group** out);
+void sm_group_destroy(sm_stream_group* g);
+int sm_group_size(sm_stream_group* g);
+/* frames u8 [S][F][H][W][3] (the F new frames of stream 0, then of stream 1, ...), S*F <= max_frames_per_call, F <= 32 (16 with
+ * fp8 weights); logits fp32 [S][F][2], decisions int32 [S][F] (either may be NULL) */
+int sm_group_push_frames(sm_stream_group* g, const uint8_t* frames, int F, float* logits, int32_t* decisions, void* stream);
+/* the same from pooled ViT features fp32 [S][F][vit_hidden] */
+int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int F, float* logits, int32_t* decisions, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline leg; no reference counterpart -- the reference has only commented-out
  * time.time() pairs, builder.py:741-745).  Class bits: 0 tiled GEMM, 1 skinny linear, 2 attention.
  * While enabled, each launch of the class is bracketed by HIP events on its own stream.

@@ -100,6 +100,11 @@ SIGNATURES = {
     "sm_stream_read_tokens": (i32, [vp, i32, i32, vp, vp]),
     "sm_stream_read_logits": (i32, [vp, vp, vp, vp]),
     "sm_stream_write_tokens": (i32, [vp, i32, i32, vp, vp]),
+    "sm_group_create": (i32, [C.POINTER(vp), i32, C.POINTER(vp)]),
+    "sm_group_destroy": (None, [vp]),
+    "sm_group_size": (i32, [vp]),
+    "sm_group_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_group_push_pooled": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_prof_enable": (i32, [i32]),
     "sm_prof_reset": (i32, []),
     "sm_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f32)]),

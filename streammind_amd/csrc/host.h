@@ -28,6 +28,17 @@ extern thread_local char g_sm_err[512];
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Per-segment (= per-stream) base pointers handed to kernels BY VALUE: a connector pass covers at most SM_MAX_SEG streams
+// (one weight pass = at most 32 rows), so no device-side pointer table has to be built or uploaded per call.
+#define SM_MAX_SEG 32
+struct SmSegStates { float* p[SM_MAX_SEG]; };
+int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,
+                           const float* conv_b, float* xc, void* stream);                                    // vecops.hip
+int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank, const float* xz, int S,
+                          int F, int di, int d_state, const float* A_log, const float* Dp, const SmSegStates& st, float* y,
+                          void* stream);
+int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& dst, void* stream);
+
 // Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that
 // class is bracketed by HIP events recorded ON THE LAUNCH STREAM; sm_prof_read() synchronises and sums.
 enum { SM_PROF_GEMM = 0, SM_PROF_SKINNY = 1, SM_PROF_ATTN = 2, SM_PROF_NCLS = 3 };

@@ -406,13 +406,37 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
 
 // ------------------------------------------------------------------------------------------------ stream
 #define SM_DECODE_SPLITS 32
+// connector + gate scratch of one weight pass (<= 32 rows); owned by a stream, or by a stream group
+struct ConnScratch {
+    DevBuf pooled, t0, u, xz, xc, xdbl, delta, y, r, lnf, tokrows, h, hn, v, vrep, act, hfin, logits2;
+    int alloc(const sm_model* m) {
+        const sm_config_t& c = m->c;
+        const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
+        const int gdh = c.gate_hidden / c.gate_heads;
+        const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
+        int rc = 0;
+#define A(buf, bytes, z) if (!rc) rc = buf.alloc((bytes), z)
+        A(pooled, (size_t)(m->Bmax > 32 ? m->Bmax : 32) * c.conn_mm_hidden * 4, false);
+        A(t0, (size_t)32 * d * 4, false); A(u, (size_t)32 * d * 4, false);
+        A(xz, (size_t)32 * 2 * di * 4, false); A(xc, (size_t)32 * di * 4, false);
+        A(xdbl, (size_t)32 * xd * 4, true); A(delta, (size_t)32 * di * 4, false);
+        A(y, (size_t)32 * di * 4, false); A(r, (size_t)32 * d * 4, false); A(lnf, (size_t)32 * d * 4, false);
+        A(tokrows, (size_t)32 * d * 4, false);
+        A(h, (size_t)32 * d * 4, false); A(hn, (size_t)32 * d * 4, false);
+        A(v, (size_t)32 * c.gate_kv_heads * gdh * 4, false); A(vrep, (size_t)32 * c.gate_heads * gdh * 4, false);
+        A(act, (size_t)32 * c.gate_mlp * 4, false); A(hfin, (size_t)32 * d * 4, false);
+        A(logits2, (size_t)32 * 2 * 4, false);
+#undef A
+        return rc;
+    }
+};
+
 struct sm_stream {
     sm_model* m;
     int max_frames, max_seq;
     int T = 0, kv_len = 0;
     DevBuf conv_state, ssm_state, tokens;
-    // connector/gate scratch for up to 16 frames per call
-    DevBuf pooled, t0, u, xz, xc, xdbl, delta, y, r, lnf, h, hn, v, vrep, act, hfin, logits2;
+    ConnScratch w;
     // LLM
     std::vector<DevBuf> kc, vtc;
     DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok, attn_ws;
@@ -424,23 +448,13 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
     const sm_config_t& c = m->c;
     sm_stream* s = new sm_stream();
     s->m = m; s->max_frames = max_frames;
-    const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
-    const int gdh = c.gate_hidden / c.gate_heads;
-    const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
+    const int d = c.conn_d_model, di = c.conn_expand * d, ds = c.conn_d_state;
     int rc = 0;
 #define A(buf, bytes, z) if (!rc) rc = s->buf.alloc((bytes), z)
     A(conv_state, (size_t)di * c.conn_d_conv * 4, true);
     A(ssm_state, (size_t)di * ds * 4, true);
     A(tokens, (size_t)max_frames * d * 4, false);
-    A(pooled, (size_t)(m->Bmax > 32 ? m->Bmax : 32) * c.conn_mm_hidden * 4, false);
-    A(t0, (size_t)32 * d * 4, false); A(u, (size_t)32 * d * 4, false);
-    A(xz, (size_t)32 * 2 * di * 4, false); A(xc, (size_t)32 * di * 4, false);
-    A(xdbl, (size_t)32 * xd * 4, true); A(delta, (size_t)32 * di * 4, false);
-    A(y, (size_t)32 * di * 4, false); A(r, (size_t)32 * d * 4, false); A(lnf, (size_t)32 * d * 4, false);
-    A(h, (size_t)32 * d * 4, false); A(hn, (size_t)32 * d * 4, false);
-    A(v, (size_t)32 * c.gate_kv_heads * gdh * 4, false); A(vrep, (size_t)32 * c.gate_heads * gdh * 4, false);
-    A(act, (size_t)32 * c.gate_mlp * 4, false); A(hfin, (size_t)32 * d * 4, false);
-    A(logits2, (size_t)32 * 2 * 4, false);
+    if (!rc) rc = s->w.alloc(m);
     if (!rc && c.llm_layers > 0) {
         SM_REQUIRE(max_seq > 0 && max_seq % 64 == 0, "sm_stream_open: max_seq must be a positive multiple of 64");
         s->max_seq = max_seq;
@@ -523,12 +537,13 @@ extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_tok
     return SM_OK;
 }
 
-// a5-a9: PreNet -> LN -> Mamba step -> +res -> LN_f -> PostNet -> 4-layer gate (V/O shortcut) -> logits, decisions
-extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
-    SM_REQUIRE(s && pooled && M >= 1 && M <= 32, "sm_stream_push_pooled: M=%d outside [1,32]", M);
-    SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
-    sm_model* m = s->m;
+// a5-a9 for S streams x F new frames each (rows stream-major, M = S*F <= 32: ONE pass over the connector + gate weights):
+// PreNet -> LN -> Mamba step on each stream's own conv / ssm state -> +res -> LN_f -> PostNet -> frame tokens (appended to
+// each stream's store) -> 4-layer gate (V/O shortcut) on every token independently -> logits [M][2], decisions [M]
+static int conn_gate_pass(sm_model* m, ConnScratch& w, const float* pooled, int S, int F, const SmSegStates& conv, const SmSegStates& ssm,
+                          const SmSegStates& tokdst, float* logits, int32_t* decisions, void* stream) {
     const sm_config_t& c = m->c;
+    const int M = S * F;
     const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
     const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
     const int pr = c.gate_precise;
@@ -539,61 +554,73 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
         a.precise = pr;
         return a;
     };
-    float* tok = s->tokens.as<float>() + (size_t)s->T * d;
+    float* tok = S == 1 ? tokdst.p[0] : w.tokrows.as<float>();     // one stream: PostNet writes straight into its token store
     {   // PreNet: leaky_relu(W x + b)                                         builder.py:166-170
         sm_linear_t a = L("proj.pre", pooled, c.conn_mm_hidden);
-        a.bias = m->ptr<float>("proj.pre_net.fc3.bias"); a.act = SM_ACT_LEAKY_RELU; a.out_f32 = s->t0.as<float>(); a.ldo = d;
+        a.bias = m->ptr<float>("proj.pre_net.fc3.bias"); a.act = SM_ACT_LEAKY_RELU; a.out_f32 = w.t0.as<float>(); a.ldo = d;
         if ((rc = sm_linear(&a, stream))) return rc;
     }
     // Block: hidden = Mamba(LN(residual)), residual = t0                      block.py:51-67
-    if ((rc = sm_norm(s->t0.as<float>(), M, d, d, m->ptr<float>(sp + "norm.weight"), m->ptr<float>(sp + "norm.bias"), c.conn_eps, 0, s->u.as<float>(), nullptr, d, stream))) return rc;
-    {   sm_linear_t a = L("proj.in_proj", s->u.as<float>(), d); a.out_f32 = s->xz.as<float>(); a.ldo = 2 * di;
+    if ((rc = sm_norm(w.t0.as<float>(), M, d, d, m->ptr<float>(sp + "norm.weight"), m->ptr<float>(sp + "norm.bias"), c.conn_eps, 0, w.u.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L("proj.in_proj", w.u.as<float>(), d); a.out_f32 = w.xz.as<float>(); a.ldo = 2 * di;
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_mamba_conv_step(s->xz.as<float>(), M, di, c.conn_d_conv, s->conv_state.as<float>(), m->ptr<float>(sp + "mixer.conv1d.weight"), m->ptr<float>(sp + "mixer.conv1d.bias"), s->xc.as<float>(), stream))) return rc;
-    {   sm_linear_t a = L("proj.x_proj", s->xc.as<float>(), di); a.out_f32 = s->xdbl.as<float>(); a.ldo = xd;
+    if ((rc = sm_mamba_conv_step_seg(w.xz.as<float>(), S, F, di, c.conn_d_conv, conv, m->ptr<float>(sp + "mixer.conv1d.weight"), m->ptr<float>(sp + "mixer.conv1d.bias"), w.xc.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L("proj.x_proj", w.xc.as<float>(), di); a.out_f32 = w.xdbl.as<float>(); a.ldo = xd;
         if ((rc = sm_linear(&a, stream))) return rc; }
     {   // dt = softplus(W_dt dt_r + b): K = dt_rank is padded to 32 inside the packed weight (zeros), x_dbl rows are xd wide
-        sm_linear_t a = L("proj.dt_proj", s->xdbl.as<float>(), xd);
-        a.bias = m->ptr<float>(sp + "mixer.dt_proj.bias"); a.act = SM_ACT_SOFTPLUS; a.out_f32 = s->delta.as<float>(); a.ldo = di;
+        sm_linear_t a = L("proj.dt_proj", w.xdbl.as<float>(), xd);
+        a.bias = m->ptr<float>(sp + "mixer.dt_proj.bias"); a.act = SM_ACT_SOFTPLUS; a.out_f32 = w.delta.as<float>(); a.ldo = di;
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_mamba_ssm_step(s->xc.as<float>(), s->delta.as<float>(), s->xdbl.as<float>(), xd, R, s->xz.as<float>(), M, di, ds, m->ptr<float>(sp + "mixer.A_log"), m->ptr<float>(sp + "mixer.D"), s->ssm_state.as<float>(), s->y.as<float>(), stream))) return rc;
-    {   sm_linear_t a = L("proj.out_proj", s->y.as<float>(), di);
-        a.residual = s->t0.as<float>(); a.ldr = d; a.out_f32 = s->r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
+    if ((rc = sm_mamba_ssm_step_seg(w.xc.as<float>(), w.delta.as<float>(), w.xdbl.as<float>(), xd, R, w.xz.as<float>(), S, F, di, ds, m->ptr<float>(sp + "mixer.A_log"), m->ptr<float>(sp + "mixer.D"), ssm, w.y.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L("proj.out_proj", w.y.as<float>(), di);
+        a.residual = w.t0.as<float>(); a.ldr = d; a.out_f32 = w.r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_norm(s->r.as<float>(), M, d, d, m->ptr<float>("proj.mamba_model.norm_fn.weight"), m->ptr<float>("proj.mamba_model.norm_fn.bias"), c.conn_eps, SM_ACT_LEAKY_RELU, s->lnf.as<float>(), nullptr, d, stream))) return rc;
-    {   sm_linear_t a = L("proj.post", s->lnf.as<float>(), d);
+    if ((rc = sm_norm(w.r.as<float>(), M, d, d, m->ptr<float>("proj.mamba_model.norm_fn.weight"), m->ptr<float>("proj.mamba_model.norm_fn.bias"), c.conn_eps, SM_ACT_LEAKY_RELU, w.lnf.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L("proj.post", w.lnf.as<float>(), d);
         a.bias = m->ptr<float>("proj.post_net.fc3.bias"); a.out_f32 = tok; a.ldo = d;
         if ((rc = sm_linear(&a, stream))) return rc; }
+    if (S > 1 && (rc = sm_scatter_rows(tok, S, F, d, tokdst, stream))) return rc;
     // ---- gate on each of the M tokens independently (seq-len 1 each; builder.py:553-562)
     const int gdh = c.gate_hidden / c.gate_heads, kvn = c.gate_kv_heads * gdh, qn = c.gate_heads * gdh;
-    const float* hcur = tok;       // layer 0 reads the token, writes s->h
+    const float* hcur = tok;       // layer 0 reads the token, writes w.h
     for (int l = 0; l < c.gate_layers; ++l) {
         const std::string p = "proj.cls_net.cls_model.model.layers." + std::to_string(l) + ".";
-        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.gate_eps, 0, s->hn.as<float>(), nullptr, d, stream))) return rc;
-        {   sm_linear_t a = L(p + "v", s->hn.as<float>(), d); a.out_f32 = s->v.as<float>(); a.ldo = kvn;
+        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.gate_eps, 0, w.hn.as<float>(), nullptr, d, stream))) return rc;
+        {   sm_linear_t a = L(p + "v", w.hn.as<float>(), d); a.out_f32 = w.v.as<float>(); a.ldo = kvn;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_repeat_kv(s->v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, s->vrep.as<float>(), stream))) return rc;
-        {   sm_linear_t a = L(p + "o", s->vrep.as<float>(), qn);
-            a.residual = hcur; a.ldr = d; a.out_f32 = s->h.as<float>(); a.ldo = d;
+        if ((rc = sm_repeat_kv(w.v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, w.vrep.as<float>(), stream))) return rc;
+        {   sm_linear_t a = L(p + "o", w.vrep.as<float>(), qn);
+            a.residual = hcur; a.ldr = d; a.out_f32 = w.h.as<float>(); a.ldo = d;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        hcur = s->h.as<float>();
-        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.gate_eps, 0, s->hn.as<float>(), nullptr, d, stream))) return rc;
+        hcur = w.h.as<float>();
+        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.gate_eps, 0, w.hn.as<float>(), nullptr, d, stream))) return rc;
         {   const Slot& gu = m->slots.at(p + "gu");
-            sm_linear_t a = L(p + "gu", s->hn.as<float>(), d);
+            sm_linear_t a = L(p + "gu", w.hn.as<float>(), d);
             a.N = c.gate_mlp;
             if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.gate_mlp / 16) * ((((d + 31) / 32) + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.gate_mlp; }
             else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.gate_mlp / 16) * ((d + 31) / 32) * 512;
-            a.out_f32 = s->act.as<float>(); a.ldo = c.gate_mlp;
+            a.out_f32 = w.act.as<float>(); a.ldo = c.gate_mlp;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        {   sm_linear_t a = L(p + "down", s->act.as<float>(), c.gate_mlp);
-            a.residual = hcur; a.ldr = d; a.out_f32 = s->h.as<float>(); a.ldo = d;
+        {   sm_linear_t a = L(p + "down", w.act.as<float>(), c.gate_mlp);
+            a.residual = hcur; a.ldr = d; a.out_f32 = w.h.as<float>(); a.ldo = d;
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
-    if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>("proj.cls_net.cls_model.model.norm.weight"), nullptr, c.gate_eps, 0, s->hfin.as<float>(), nullptr, d, stream))) return rc;
-    float* lg = logits ? logits : s->logits2.as<float>();
-    {   sm_linear_t a = L("proj.gate_head", s->hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
+    if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>("proj.cls_net.cls_model.model.norm.weight"), nullptr, c.gate_eps, 0, w.hfin.as<float>(), nullptr, d, stream))) return rc;
+    float* lg = logits ? logits : w.logits2.as<float>();
+    {   sm_linear_t a = L("proj.gate_head", w.hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
         if ((rc = sm_linear(&a, stream))) return rc; }
     if (decisions && (rc = sm_gate_decide(lg, M, decisions, stream))) return rc;
+    return SM_OK;
+}
+
+extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(s && pooled && M >= 1 && M <= 32, "sm_stream_push_pooled: M=%d outside [1,32]", M);
+    SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
+    SmSegStates conv, ssm, tok;
+    conv.p[0] = s->conv_state.as<float>(); ssm.p[0] = s->ssm_state.as<float>();
+    tok.p[0] = s->tokens.as<float>() + (size_t)s->T * s->m->c.conn_d_model;
+    int rc = conn_gate_pass(s->m, s->w, pooled, 1, M, conv, ssm, tok, logits, decisions, stream);
+    if (rc) return rc;
     s->T += M;
     return SM_OK;
 }
@@ -601,17 +628,82 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
 extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
     SM_REQUIRE(s && frames && M >= 1 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, max_frames_per_call=%d]", M, s ? s->m->Bmax : 0);
     // one ViT batch, then the connector+gate in frame order, at most 32 frames (16 with fp8 weights) per weight pass
-    int rc = sm_vit_encode(s->m, frames, M, s->pooled.as<float>(), nullptr, nullptr, stream);
+    int rc = sm_vit_encode(s->m, frames, M, s->w.pooled.as<float>(), nullptr, nullptr, stream);
     if (rc) return rc;
     const int cap = s->m->c.weights_fp8 ? 16 : 32;
     const int parts = cdiv(M, cap), per = cdiv(M, parts);
     for (int i = 0; i < M; i += per) {
         const int n = M - i < per ? M - i : per;
-        rc = sm_stream_push_pooled(s, s->pooled.as<float>() + (size_t)i * s->m->c.conn_mm_hidden, n, logits ? logits + 2 * i : nullptr,
+        rc = sm_stream_push_pooled(s, s->w.pooled.as<float>() + (size_t)i * s->m->c.conn_mm_hidden, n, logits ? logits + 2 * i : nullptr,
                                    decisions ? decisions + i : nullptr, stream);
         if (rc) return rc;
     }
     return SM_OK;
+}
+
+// ---- stream group: one tick of S streams through ONE ViT batch and ONE connector + gate weight pass per <= 32 rows.
+// The reference serves one stream per model object, one frame per call (eval/video_score_stream_demo.py:283-299; "only
+// support batch size 1", eval/inference_video_score_stream_ddp.py:325): at one frame per call the ViT GEMMs run at M = 577 and
+// the gate streams 1.6 GB of weights per frame.  Batching ACROSS streams keeps the per-frame decision latency of one frame
+// while the kernels see S x 577 rows -- results per stream are those of S independent one-frame calls.
+struct sm_stream_group {
+    sm_model* m;
+    std::vector<sm_stream*> streams;
+    ConnScratch w;
+};
+
+extern "C" int sm_group_create(sm_stream** streams, int S, sm_stream_group** out) {
+    SM_REQUIRE(streams && out && S >= 1, "sm_group_create: bad args");
+    for (int i = 0; i < S; ++i) {
+        SM_REQUIRE(streams[i] && streams[i]->m == streams[0]->m, "sm_group_create: stream %d is null or belongs to another model", i);
+        for (int j = 0; j < i; ++j) SM_REQUIRE(streams[i] != streams[j], "sm_group_create: stream %d listed twice", i);
+    }
+    sm_stream_group* g = new sm_stream_group();
+    g->m = streams[0]->m;
+    g->streams.assign(streams, streams + S);
+    int rc = g->w.alloc(g->m);
+    if (rc) { delete g; return rc; }
+    *out = g;
+    return SM_OK;
+}
+extern "C" void sm_group_destroy(sm_stream_group* g) { delete g; }
+extern "C" int sm_group_size(sm_stream_group* g) { return g ? (int)g->streams.size() : -1; }
+
+// pooled [S][F][mm_hidden] (stream-major) -> logits [S][F][2], decisions [S][F]
+extern "C" int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int F, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(g && pooled && F >= 1, "sm_group_push_pooled: bad args");
+    sm_model* m = g->m;
+    const int S = (int)g->streams.size(), d = m->c.conn_d_model;
+    const int cap = m->c.weights_fp8 ? 16 : 32;
+    SM_REQUIRE(F <= cap, "sm_group_push_pooled: %d frames per stream exceed one weight pass (%d rows)", F, cap);
+    for (int i = 0; i < S; ++i)
+        SM_REQUIRE(g->streams[i]->T + F <= g->streams[i]->max_frames, "sm_group_push_pooled: token store of stream %d full (%d + %d > %d)", i,
+                   g->streams[i]->T, F, g->streams[i]->max_frames);
+    const int per = cap / F;                       // whole streams per weight pass
+    for (int s0 = 0; s0 < S; s0 += per) {
+        const int n = S - s0 < per ? S - s0 : per;
+        SmSegStates conv, ssm, tok;
+        for (int i = 0; i < n; ++i) {
+            sm_stream* st = g->streams[s0 + i];
+            conv.p[i] = st->conv_state.as<float>(); ssm.p[i] = st->ssm_state.as<float>();
+            tok.p[i] = st->tokens.as<float>() + (size_t)st->T * d;
+        }
+        int rc = conn_gate_pass(m, g->w, pooled + (size_t)s0 * F * m->c.conn_mm_hidden, n, F, conv, ssm, tok,
+                                logits ? logits + (size_t)2 * s0 * F : nullptr, decisions ? decisions + (size_t)s0 * F : nullptr, stream);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) g->streams[s0 + i]->T += F;
+    }
+    return SM_OK;
+}
+
+// frames u8 [S][F][H][W][3] (stream-major: the F new frames of stream 0, then of stream 1, ...)
+extern "C" int sm_group_push_frames(sm_stream_group* g, const uint8_t* frames, int F, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(g && frames && F >= 1, "sm_group_push_frames: bad args");
+    const int S = (int)g->streams.size();
+    SM_REQUIRE(S * F <= g->m->Bmax, "sm_group_push_frames: %d streams x %d frames exceed max_frames_per_call=%d", S, F, g->m->Bmax);
+    int rc = sm_vit_encode(g->m, frames, S * F, g->w.pooled.as<float>(), nullptr, nullptr, stream);
+    if (rc) return rc;
+    return sm_group_push_pooled(g, g->w.pooled.as<float>(), F, logits, decisions, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ LLM

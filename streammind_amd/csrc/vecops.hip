@@ -5,7 +5,7 @@
 
 thread_local char g_sm_err[512] = {0};
 extern "C" const char* sm_last_error(void) { return g_sm_err; }
-extern "C" int sm_abi_version(void) { return 1; }
+extern "C" int sm_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------------------ profiling hooks
 #include <vector>
@@ -395,41 +395,53 @@ extern "C" int sm_pool_patches(const float* x, int B, int S, int D, float* poole
 }
 
 // ------------------------------------------------------------------------------------------------ mamba step
-__global__ void mamba_conv_kernel(const float* __restrict__ xz, int M, int di, int dc, float* __restrict__ cs,
+// rows are S segments (streams) of F consecutive frames each: blockIdx.y = segment, its recurrent state st.p[segment]
+__global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, int dc, SmSegStates st,
                                   const float* __restrict__ cw, const float* __restrict__ cb, float* __restrict__ xc) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= di) return;
-    float st[8], w[8];
-    for (int j = 0; j < dc; ++j) { st[j] = cs[(size_t)d * dc + j]; w[j] = cw[(size_t)d * dc + j]; }
+    float* __restrict__ cs = st.p[blockIdx.y];
+    const int m0 = blockIdx.y * F;
+    float stt[8], w[8];
+    for (int j = 0; j < dc; ++j) { stt[j] = cs[(size_t)d * dc + j]; w[j] = cw[(size_t)d * dc + j]; }
     const float bias = cb[d];
-    for (int m = 0; m < M; ++m) {
-        for (int j = 0; j + 1 < dc; ++j) st[j] = st[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
-        st[dc - 1] = xz[(size_t)m * 2 * di + d];
+    for (int m = m0; m < m0 + F; ++m) {
+        for (int j = 0; j + 1 < dc; ++j) stt[j] = stt[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
+        stt[dc - 1] = xz[(size_t)m * 2 * di + d];
         float a = 0.f;
-        for (int j = 0; j < dc; ++j) a += st[j] * w[j];
+        for (int j = 0; j < dc; ++j) a += stt[j] * w[j];
         xc[(size_t)m * di + d] = siluf_(a + bias);
     }
-    for (int j = 0; j < dc; ++j) cs[(size_t)d * dc + j] = st[j];
+    for (int j = 0; j < dc; ++j) cs[(size_t)d * dc + j] = stt[j];
 }
-extern "C" int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, float* conv_state, const float* conv_w,
-                                  const float* conv_b, float* xc, void* stream) {
-    SM_REQUIRE(xz && conv_state && conv_w && conv_b && xc && M > 0 && d_conv <= 8, "sm_mamba_conv_step: bad args");
-    mamba_conv_kernel<<<cdiv(di, 256), 256, 0, (hipStream_t)stream>>>(xz, M, di, d_conv, conv_state, conv_w, conv_b, xc);
+int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,
+                           const float* conv_b, float* xc, void* stream) {
+    SM_REQUIRE(xz && conv_w && conv_b && xc && S > 0 && S <= SM_MAX_SEG && F > 0 && d_conv <= 8, "sm_mamba_conv_step: bad args");
+    mamba_conv_kernel<<<dim3(cdiv(di, 256), S), 256, 0, (hipStream_t)stream>>>(xz, F, di, d_conv, st, conv_w, conv_b, xc);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
+extern "C" int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, float* conv_state, const float* conv_w,
+                                  const float* conv_b, float* xc, void* stream) {
+    SM_REQUIRE(conv_state, "sm_mamba_conv_step: null state");
+    SmSegStates st;
+    st.p[0] = conv_state;
+    return sm_mamba_conv_step_seg(xz, 1, M, di, d_conv, st, conv_w, conv_b, xc, stream);
+}
 
-// thread per channel d, d_state (<= 32) state elements in registers
+// thread per channel d, d_state (<= 32) state elements in registers; segments as in mamba_conv_kernel
 __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __restrict__ delta,
-                                 const float* __restrict__ xdbl, int ldx, int R, const float* __restrict__ xz, int M, int di,
+                                 const float* __restrict__ xdbl, int ldx, int R, const float* __restrict__ xz, int F, int di,
                                  int ds, const float* __restrict__ Alog, const float* __restrict__ Dp,
-                                 float* __restrict__ hst, float* __restrict__ y) {
+                                 SmSegStates st, float* __restrict__ y) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= di) return;
+    float* __restrict__ hst = st.p[blockIdx.y];
+    const int m0 = blockIdx.y * F;
     float h[32], A[32];
     for (int n = 0; n < ds; ++n) { h[n] = hst[(size_t)d * ds + n]; A[n] = -__expf(Alog[(size_t)d * ds + n]); }
     const float Dd = Dp[d];
-    for (int m = 0; m < M; ++m) {
+    for (int m = m0; m < m0 + F; ++m) {
         const float dt = delta[(size_t)m * di + d];
         const float xv = xc[(size_t)m * di + d];
         const float* Bm = xdbl + (size_t)m * ldx + R;
@@ -444,13 +456,34 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
     }
     for (int n = 0; n < ds; ++n) hst[(size_t)d * ds + n] = h[n];
 }
+int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank, const float* xz, int S,
+                          int F, int di, int d_state, const float* A_log, const float* Dp, const SmSegStates& st, float* y,
+                          void* stream) {
+    SM_REQUIRE(xc && delta && x_dbl && xz && A_log && Dp && y, "sm_mamba_ssm_step: null arg");
+    SM_REQUIRE(S > 0 && S <= SM_MAX_SEG && F > 0 && d_state <= 32, "sm_mamba_ssm_step: d_state <= 32, segments <= %d", SM_MAX_SEG);
+    mamba_ssm_kernel<<<dim3(cdiv(di, 128), S), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, F, di, d_state,
+                                                                              A_log, Dp, st, y);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
 extern "C" int sm_mamba_ssm_step(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank,
                                  const float* xz, int M, int di, int d_state, const float* A_log, const float* Dp,
                                  float* ssm_state, float* y, void* stream) {
-    SM_REQUIRE(xc && delta && x_dbl && xz && A_log && Dp && ssm_state && y, "sm_mamba_ssm_step: null arg");
-    SM_REQUIRE(M > 0 && d_state <= 32, "sm_mamba_ssm_step: d_state <= 32");
-    mamba_ssm_kernel<<<cdiv(di, 128), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, M, di, d_state,
-                                                                     A_log, Dp, ssm_state, y);
+    SM_REQUIRE(ssm_state, "sm_mamba_ssm_step: null state");
+    SmSegStates st;
+    st.p[0] = ssm_state;
+    return sm_mamba_ssm_step_seg(xc, delta, x_dbl, ldx, dt_rank, xz, 1, M, di, d_state, A_log, Dp, st, y, stream);
+}
+
+// rows [S][F][d] -> per-segment destinations dst.p[s] + f*d  (per-stream token stores)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int F, int d, SmSegStates dst) {
+    const int row = blockIdx.x, s = row / F, f = row - s * F;
+    float* __restrict__ o = dst.p[s] + (size_t)f * d;
+    for (int c = threadIdx.x * 4; c < d; c += blockDim.x * 4) *(f32x4*)(o + c) = *(const f32x4*)(src + (size_t)row * d + c);
+}
+int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& dst, void* stream) {
+    SM_REQUIRE(src && S > 0 && S <= SM_MAX_SEG && F > 0 && (d & 3) == 0, "sm_scatter_rows: bad args");
+    scatter_rows_kernel<<<S * F, 256, 0, (hipStream_t)stream>>>(src, F, d, dst);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

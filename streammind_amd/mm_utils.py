@@ -22,6 +22,20 @@ def frame_sample(duration: int, mode: str = "uniform", num_frames: int = NUM_FRA
     raise ImportError(f"Unsupported frame sampling mode: {mode}")
 
 
+def _crop_side(processor) -> int:
+    """side of the processor's centre crop: `crop_size` is a dict in transformers 4.x, a SizeDict object (attribute AND item
+    access, not a dict subclass) in 5.x, an int in very old versions; 336 (CLIP-L/14-336) when there is no processor"""
+    size = getattr(processor, "crop_size", None)
+    if size is None:
+        return 336
+    if isinstance(size, int):
+        return size
+    try:
+        return int(size["height"])
+    except (TypeError, KeyError):
+        return int(getattr(size, "height"))
+
+
 def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NUM_FRAMES, image_grid: bool = False,
                   sample_scheme: str = "uniform") -> torch.Tensor:
     """list of PIL images / HWC arrays (or an [n,H,W,3] uint8 array) -> uint8 frames tensor [n,S,S,3], S = the
@@ -44,8 +58,7 @@ def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NU
         frames = np.stack([np.asarray(x) for x in video])
     assert len(frames) == num_frames, (len(frames), num_frames)
     assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.shape[-1] == 3
-    size = getattr(processor, "crop_size", None)
-    S = size["height"] if isinstance(size, dict) else 336
+    S = _crop_side(processor)
     if frames.shape[1] == S and frames.shape[2] == S:
         return torch.from_numpy(np.ascontiguousarray(frames))
     from . import native

