@@ -502,8 +502,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt_local = dt
+    gemm_prof = None
     if prof:
         lib.sm_prof_enable(0)
+        cnt, ms = C.c_int(), C.c_float()
+        _lib.check(lib.sm_prof_read(0, C.byref(cnt), C.byref(ms)))       # synchronises the recorded events; later passes reset them
+        gemm_prof = (cnt.value, ms.value)
     per_rank = None
     if dist is not None:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
@@ -585,9 +589,11 @@ def main():
             more_roof["error"] = repr(e)[:200]
 
     roof = None
-    if prof:
-        cnt, ms = C.c_int(), C.c_float()
-        _lib.check(lib.sm_prof_read(0, C.byref(cnt), C.byref(ms)))
+    if gemm_prof is not None:
+        class _V:
+            pass
+        cnt, ms = _V(), _V()
+        cnt.value, ms.value = gemm_prof
         if cnt.value:
             flops_per_launch = vit_linear_flops_per_frame(cfg) * B * prof_steps / cnt.value
             avg_s = ms.value * 1e-3 / cnt.value

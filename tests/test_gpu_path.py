@@ -241,7 +241,7 @@ def test_feature_cache_bulk_encode(tiny, tmp_path):
     m, Wv, _, _ = tiny
     frames = O.synthetic_frames(7, TV.image_size, seed=3, scene_len=2)
     paths = fc.encode_video_features(m, frames, str(tmp_path / "features_video_encode_ddp" / "v0"), "v0")
-    assert [p.split("/")[-1] for p in paths] == ["v0_encode_feature_frame_0_7.pt"]
+    assert [p.split("/")[-1] for p in paths] == ["v0_encode_feature_frame_0_500.pt"]      # the name says start + 500 (golden g13)
     f = torch.load(paths[0])
     assert tuple(f.shape) == (1, 7, TV.n_patches, TV.hidden) and f.dtype == torch.bfloat16
     ref = O.vit_features(O.preprocess_frames(frames, TV.image_size), Wv, TV, O.MIXED)
