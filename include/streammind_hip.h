@@ -275,6 +275,10 @@ int sm_cross_entropy(const float* logits, int n, int V, int ld, const int32_t* l
 /* a12 decode: n_steps greedy steps continuing from the last prefill/decode; out_ids_dev[n_steps] int32 device.
  * Step j emits the token predicted after the previous one, feeds it back, appends its KV.             */
 int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids_dev, void* stream);
+/* replace the pending token (the greedy argmax a prefill / decode step left) by the caller's choice, e.g. one SAMPLED from
+ * sm_stream_logits (HF generate with do_sample=True: serve/model_worker.py:247-282 passes temperature / top_p); the next
+ * sm_llm_decode step emits and feeds back THIS token */
+int sm_stream_set_next_token(sm_stream* s, const int32_t* tok_dev, void* stream);
 /* last-position logits of the most recent prefill/decode step: device fp32 [vocab] */
 const float* sm_stream_logits(sm_stream* s);
 /* async device-to-device copies out of the stream's own storage (tokens [t0, t0+n) x d_model fp32; vocabulary

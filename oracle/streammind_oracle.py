@@ -965,6 +965,31 @@ def feature_cache_chunks(video_path: str, duration: int, chunk: int = 500) -> Li
 
 
 # ----------------------------------------------------------------------------------------------
+# f2  which frames are fed (eval/video_score_stream_demo.py:212-225; mm_utils.py:378-407,420-430)
+# ----------------------------------------------------------------------------------------------
+
+def stream_frame_indices(n_frames: int, video_fps: float, cur_fps: float = 2) -> "np.ndarray":
+    """read_video_stream: arange(0, n - 1, int(video_fps / cur_fps)) -- the last frame is never sampled"""
+    import numpy as np
+    return np.arange(0, n_frames - 1, int(video_fps / cur_fps), dtype=int)
+
+
+def clip_frame_indices(duration: int, local_fps: float, num_frames: int, scheme: str = "uniform", gif: bool = False,
+                       max_frames: int = 320000) -> List[int]:
+    """process_video's frame_sample (+ the MAX_FRAMES cap, + the .gif branch's once-per-index rule)"""
+    import numpy as np
+    if scheme == "uniform":
+        seg = float(duration - 1) / num_frames
+        ids = [(int(np.round(seg * i)) + int(np.round(seg * (i + 1)))) // 2 for i in range(num_frames)]
+    else:
+        seg_len = min(local_fps // 1, duration)
+        ids = np.arange(seg_len // 2, duration, seg_len, dtype=int).tolist()
+    if len(ids) > max_frames:
+        ids = np.linspace(0, duration - 1, max_frames, dtype=int).tolist()
+    return sorted(set(int(i) for i in ids)) if gif else [int(i) for i in ids]
+
+
+# ----------------------------------------------------------------------------------------------
 # seeded synthetic weights / frames (shared by tests, smoke and bench -- plain torch CPU generator)
 # ----------------------------------------------------------------------------------------------
 

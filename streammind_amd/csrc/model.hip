@@ -811,6 +811,13 @@ extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, fl
     return sm_argmax(s->lmlog.as<float>(), V, s->next_tok.as<int32_t>(), stream);
 }
 
+extern "C" int sm_stream_set_next_token(sm_stream* s, const int32_t* tok_dev, void* stream) {
+    SM_REQUIRE(s && tok_dev && s->m->c.llm_layers > 0, "sm_stream_set_next_token: bad args / perception-only model");
+    copy_i32_kernel<<<1, 1, 0, (hipStream_t)stream>>>(tok_dev, s->next_tok.as<int32_t>());
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* stream) {
     SM_REQUIRE(s && out_ids && n_steps > 0 && s->m->c.llm_layers > 0, "sm_llm_decode: bad args");
     SM_REQUIRE(s->kv_len + n_steps <= s->max_seq, "sm_llm_decode: context %d + %d exceeds max_seq %d", s->kv_len, n_steps, s->max_seq);

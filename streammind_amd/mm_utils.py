@@ -7,7 +7,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-from .constants import IMAGE_TOKEN_INDEX, MMODAL_INDEX_TOKEN, NUM_FRAMES, NUM_FRAMES_PER_SECOND
+from .constants import IMAGE_TOKEN_INDEX, MAX_FRAMES, MMODAL_INDEX_TOKEN, NUM_FRAMES, NUM_FRAMES_PER_SECOND
 
 
 def frame_sample(duration: int, mode: str = "uniform", num_frames: int = NUM_FRAMES, local_fps=None) -> List[int]:
@@ -46,10 +46,22 @@ def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NU
     host->device copy is 4x smaller.  Frames that already are S x S pass through on the host (resize and crop are
     identities); any other size goes through the device ingest front-end (`sm_ingest_frames`:
     expand2square with int(image_mean * 255) when aspect_ratio == "pad", PIL-exact bicubic shortest-edge resize, centre
-    crop) and comes back as a CUDA tensor.  Decoding a file path (decord / imageio / moviepy) stays outside this build:
-    decode with the tool of your choice, pick frames with `frame_sample`, and pass the arrays."""
+    crop) and comes back as a CUDA tensor.  A path goes through `video_io.open_video` (decoder adaptor) and the reference's
+    frame sampling first."""
     if isinstance(video, str):
-        raise NotImplementedError("video decoding (decord) is outside this build: pass decoded frames (see frame_sample)")
+        # mm_utils.py:399-435: open, sample `num_frames` ids ("uniform") or one per second ("fps"), cap at MAX_FRAMES, fetch.
+        # The decoder is an adaptor (video_io.open_video): .gif at the reference's constant 10 fps, other containers through
+        # whichever decoder the deployment has; this image ships none, see video_io.
+        from .video_io import open_video
+        vr = open_video(video)
+        duration, local_fps = len(vr), float(vr.get_avg_fps())
+        ids = frame_sample(duration, mode=sample_scheme, num_frames=num_frames, local_fps=local_fps)
+        if len(ids) > MAX_FRAMES:
+            ids = np.linspace(0, duration - 1, MAX_FRAMES, dtype=int).tolist()
+        if video.lower().endswith(".gif"):
+            ids = sorted(set(int(i) for i in ids))          # mm_utils.py:407 keeps each sampled index once, in file order
+        video = np.asarray(vr.get_batch(ids).asnumpy())
+        num_frames = len(ids)
     if image_grid:
         raise NotImplementedError("image_grid=True (photo grid prepended, mm_utils.py:447-450) is not on the streaming path")
     if isinstance(video, np.ndarray):

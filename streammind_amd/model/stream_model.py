@@ -244,9 +244,24 @@ class Videollama2MistralForCausalLM:
                 seq.append(int(t))
         return seq
 
-    # ---- a12: greedy generate from the spliced context with KV prefix reuse
+    # ---- a12: generate from the spliced context with KV prefix reuse (greedy; or sampled, serve/model_worker.py:247-282)
+    def _sample(self, temperature: float, top_p: float, generator=None) -> torch.Tensor:
+        """HF's sampling rule on the pending position's logits (TemperatureLogitsWarper, then TopPLogitsWarper, then
+        multinomial): plain torch on the [vocab] logits vector -- token choice, not a kernel of the path."""
+        lg, _ = self.stream.logits()
+        lg = lg / max(float(temperature), 1e-6)
+        if top_p < 1.0:
+            srt, idx = torch.sort(lg, descending=False)
+            cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
+            drop = cum <= (1.0 - top_p)
+            drop[-1] = False                                  # min_tokens_to_keep = 1
+            lg = lg.masked_fill(torch.zeros_like(drop).scatter(0, idx, drop), float("-inf"))
+        return torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).to(torch.int32)
+
     @torch.no_grad()
-    def _generate(self, seq: List[int], max_new_tokens: int, stopping_criteria=None) -> List[int]:
+    def _generate_iter(self, seq: List[int], max_new_tokens: int, stopping_criteria=None, do_sample: bool = False,
+                       temperature: float = 1.0, top_p: float = 1.0, generator=None):
+        """yields the new ids in chunks (what a TextIteratorStreamer consumer sees); the concatenation is `_generate`'s list"""
         if len(seq) + max_new_tokens > self.max_seq:
             max_new_tokens = self.max_seq - len(seq)
             if max_new_tokens <= 0:
@@ -263,10 +278,16 @@ class Videollama2MistralForCausalLM:
         out: List[int] = []
         done = False
         while not done and len(out) < max_new_tokens:
-            n = min(self.decode_chunk, max_new_tokens - len(out))
+            if do_sample:                                     # one step at a time: the choice needs this position's logits
+                self.stream.set_next_token(self._sample(temperature, top_p, generator))
+                n = 1
+            else:
+                n = min(self.decode_chunk, max_new_tokens - len(out))
             ids = self.stream.decode(n).cpu().tolist()          # n speculative greedy steps, one host sync
+            fresh: List[int] = []
             for j, tok in enumerate(ids):
                 out.append(tok)
+                fresh.append(tok)
                 self._kv_ids.append(tok)
                 if self.eos_token_id is not None and tok == self.eos_token_id:
                     done = True
@@ -279,7 +300,10 @@ class Videollama2MistralForCausalLM:
                     self._kv_ids = self._kv_ids[:len(seq) + len(out)]
                     self.stream.set_kv_len(len(self._kv_ids))
                     break
-        return out
+            yield fresh
+
+    def _generate(self, seq: List[int], max_new_tokens: int, stopping_criteria=None, **sample_kw) -> List[int]:
+        return [t for chunk in self._generate_iter(seq, max_new_tokens, stopping_criteria, **sample_kw) for t in chunk]
 
     # ---- f1: teacher-forced evaluation forward (videollama2_mistral.py:173-259, videollama2_arch.py:613-753), batch 1
     @torch.no_grad()
@@ -379,18 +403,28 @@ class Videollama2MistralForCausalLM:
             raise NotImplementedError("`inputs_embeds` is not supported")
         if kwargs.pop("score_video", None):
             raise NotImplementedError("score_video=True (pre-extracted feature files, prepare_inputs_labels_for_multimodal_score) is not built")
-        if kwargs.get("do_sample", False):
-            raise NotImplementedError("only greedy decoding (do_sample=False)")
         if inputs.dim() != 2 or inputs.shape[0] != 1:
             raise NotImplementedError("generate: batch size 1")
         if self.native.cfg.llm_layers == 0:
             raise RuntimeError("perception-only model: no LLM loaded")
         ids = inputs[0].tolist()
-        if images_or_videos is not None:
+        if images_or_videos is not None and len(images_or_videos):
             seq, _, _, _ = self._splice_clips(ids, images_or_videos, modal_list or ["video"])
         else:
             seq = [int(t) for t in ids]
-        new_ids = self._generate(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"))
+        do_sample = bool(kwargs.get("do_sample", False))
+        sample_kw = dict(do_sample=do_sample, temperature=float(kwargs.get("temperature") or 1.0), top_p=float(kwargs.get("top_p") or 1.0),
+                         generator=kwargs.get("generator")) if do_sample else {}
+        streamer = kwargs.get("streamer")                 # HF streamer protocol: put(ids) per step, end() -- model_worker.py:263
+        new_ids: List[int] = []
+        if streamer is not None:                          # HF hands the (here empty: the inputs are embeddings) prompt ids over first
+            streamer.put(torch.empty(1, 0, dtype=torch.long))
+        for chunk in self._generate_iter(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"), **sample_kw):
+            new_ids.extend(chunk)
+            if streamer is not None and chunk:
+                streamer.put(torch.tensor(chunk, dtype=torch.long))
+        if streamer is not None:
+            streamer.end()
         return torch.tensor([new_ids], dtype=torch.long)
 
     @torch.no_grad()
@@ -411,9 +445,9 @@ class Videollama2MistralForCausalLM:
             raise RuntimeError("perception-only model: no LLM loaded")
         ids = inputs[0].tolist() if inputs.dim() == 2 else inputs.tolist()
         seq = self._expand(ids)
-        if kwargs.get("do_sample", False):
-            raise NotImplementedError("only greedy decoding (do_sample=False) is on the streaming path")
-        new_ids = self._generate(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"))
+        sample_kw = dict(do_sample=True, temperature=float(kwargs.get("temperature") or 1.0), top_p=float(kwargs.get("top_p") or 1.0),
+                         generator=kwargs.get("generator")) if kwargs.get("do_sample", False) else {}
+        new_ids = self._generate(seq, int(kwargs.get("max_new_tokens", 1024)), kwargs.get("stopping_criteria"), **sample_kw)
         self.last_new_ids = new_ids
         output = tokenizer.batch_decode([new_ids], skip_special_tokens=True)[0].strip()
         return output, cls_pred

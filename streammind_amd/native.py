@@ -242,6 +242,11 @@ class NativeStream:
         check(self.lib.sm_llm_decode(self.h, n_steps, out.data_ptr(), _stream()), "sm_llm_decode")
         return out
 
+    def set_next_token(self, tok: torch.Tensor) -> None:
+        """tok: int32 [1] on the GPU -- replaces the pending greedy token (sampling)"""
+        assert tok.dtype == torch.int32 and tok.is_cuda and tok.numel() == 1
+        check(self.lib.sm_stream_set_next_token(self.h, tok.data_ptr(), _stream()), "sm_stream_set_next_token")
+
     def logits(self) -> Tuple[torch.Tensor, torch.Tensor]:
         lg = torch.empty(self.model.cfg.llm_vocab, dtype=torch.float32, device=self.dev)
         nt = torch.empty(1, dtype=torch.int32, device=self.dev)

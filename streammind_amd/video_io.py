@@ -1,0 +1,199 @@
+"""Video ingest on the host side: frame sources with the decord `VideoReader` surface the reference's
+callers use, and the streaming sampler `read_video_stream` (eval/video_score_stream_demo.py:212-225).
+
+The reference decodes on the CPU with decord (one thread, video_score_stream_demo.py:218; mm_utils.py:419), imageio (.gif,
+mm_utils.py:400-407) or moviepy (.webm, :409-418).  None of them -- nor ffmpeg, OpenCV, PyAV, rocDecode -- exists in this
+image, so the codec is an ADAPTOR: `open_video` serves what can be decoded with what is here (frame arrays, .npy / .npz,
+directories of still images, multi-frame .gif / .tiff / .webp through PIL) and hands every other container to whichever of
+decord / cv2 / imageio the deployment has installed.  Everything after the decoder (sampling, expand2square, PIL-exact
+resize, centre crop, normalisation) is this build's own and runs on the GPU (`mm_utils.process_video`, `sm_ingest_frames`).
+
+A source offers: len(src), src.get_avg_fps(), src[i].asnumpy() -> HWC uint8, src.get_batch(ids).asnumpy() -> [n,H,W,3]."""
+from __future__ import annotations
+
+import os
+from typing import Iterator, List, Sequence, Tuple
+
+import numpy as np
+
+IMAGE_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".webp", ".ppm")
+
+
+class _Frames:
+    """what decord returns from __getitem__ / get_batch: an array-like with .asnumpy() (and .numpy(), mm_utils.py:432-435)"""
+
+    def __init__(self, arr: np.ndarray):
+        self._a = arr
+
+    def asnumpy(self) -> np.ndarray:
+        return self._a
+
+    numpy = asnumpy
+
+    def __array__(self, dtype=None, copy=None):
+        return self._a if dtype is None else self._a.astype(dtype)
+
+    @property
+    def shape(self):
+        return self._a.shape
+
+
+class ArrayVideo:
+    """frames already in memory: [n, H, W, 3] uint8 (also the .npy / .npz source)"""
+
+    def __init__(self, frames: np.ndarray, fps: float = 30.0):
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[-1] != 3:
+            raise ValueError(f"ArrayVideo: expected [n, H, W, 3] uint8 frames, got {frames.dtype} {frames.shape}")
+        self.frames, self.fps = frames, float(fps)
+
+    def __len__(self) -> int:
+        return len(self.frames)
+
+    def get_avg_fps(self) -> float:
+        return self.fps
+
+    def __getitem__(self, i) -> _Frames:
+        return _Frames(self.frames[int(i)])
+
+    def get_batch(self, ids: Sequence[int]) -> _Frames:
+        return _Frames(self.frames[np.asarray(ids, dtype=np.int64)])
+
+
+class ImageSequenceVideo:
+    """a directory of still images in name order (decoded lazily with PIL); fps from `fps.txt` in the directory, else 30"""
+
+    def __init__(self, directory: str, fps: float | None = None):
+        self.files = sorted(os.path.join(directory, f) for f in os.listdir(directory) if f.lower().endswith(IMAGE_EXT))
+        if not self.files:
+            raise FileNotFoundError(f"no still images under {directory}")
+        fp = os.path.join(directory, "fps.txt")
+        self.fps = float(fps if fps is not None else (open(fp).read().strip() if os.path.exists(fp) else 30.0))
+
+    def __len__(self) -> int:
+        return len(self.files)
+
+    def get_avg_fps(self) -> float:
+        return self.fps
+
+    def _load(self, i: int) -> np.ndarray:
+        from PIL import Image
+        with Image.open(self.files[int(i)]) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def __getitem__(self, i) -> _Frames:
+        return _Frames(self._load(i))
+
+    def get_batch(self, ids: Sequence[int]) -> _Frames:
+        return _Frames(np.stack([self._load(i) for i in ids]))
+
+
+class PilMultiFrameVideo(ArrayVideo):
+    """animated .gif / multi-page .tiff / animated .webp: all frames through PIL.  fps: 10 for .gif, the reference's constant
+    (mm_utils.py:402), else from the container's frame duration when it states one"""
+
+    def __init__(self, path: str):
+        from PIL import Image, ImageSequence
+        with Image.open(path) as im:
+            frames = np.stack([np.asarray(f.convert("RGB")) for f in ImageSequence.Iterator(im)])
+            dur = im.info.get("duration")
+        fps = 10.0 if path.lower().endswith(".gif") else (1000.0 / dur if dur else 30.0)
+        super().__init__(frames, fps)
+
+
+class _DecordVideo:
+    def __init__(self, path: str):
+        from decord import VideoReader, cpu
+        self.vr = VideoReader(uri=path, ctx=cpu(0), num_threads=1)       # mm_utils.py:419 (one thread: no fork deadlock)
+
+    def __len__(self):
+        return len(self.vr)
+
+    def get_avg_fps(self):
+        return float(self.vr.get_avg_fps())
+
+    def __getitem__(self, i):
+        return self.vr[int(i)]
+
+    def get_batch(self, ids):
+        return self.vr.get_batch(list(ids))
+
+
+class _Cv2Video(ArrayVideo):
+    def __init__(self, path: str):
+        import cv2
+        cap = cv2.VideoCapture(path)
+        if not cap.isOpened():
+            raise IOError(f"cv2 cannot open {path}")
+        fps, frames = cap.get(cv2.CAP_PROP_FPS) or 30.0, []
+        while True:
+            ok, bgr = cap.read()
+            if not ok:
+                break
+            frames.append(bgr[:, :, ::-1])
+        cap.release()
+        super().__init__(np.ascontiguousarray(np.stack(frames)), fps)
+
+
+class _ImageioVideo(ArrayVideo):
+    def __init__(self, path: str):
+        import imageio
+        rd = imageio.get_reader(path)
+        fps = float(rd.get_meta_data().get("fps", 30.0))
+        super().__init__(np.stack([np.asarray(f)[..., :3] for f in rd]), fps)
+
+
+def open_video(src, fps: float | None = None):
+    """path / directory / array -> a frame source (see the module docstring)."""
+    if isinstance(src, np.ndarray):
+        return ArrayVideo(src, 30.0 if fps is None else fps)
+    if hasattr(src, "get_avg_fps") and hasattr(src, "__len__"):
+        return src                                          # already a reader (decord.VideoReader or one of the above)
+    if not isinstance(src, str):
+        raise TypeError(f"open_video: unsupported source {type(src)}")
+    if os.path.isdir(src):
+        return ImageSequenceVideo(src, fps)
+    if not os.path.exists(src):
+        raise FileNotFoundError(src)
+    low = src.lower()
+    if low.endswith(".npy"):
+        return ArrayVideo(np.load(src), 30.0 if fps is None else fps)
+    if low.endswith(".npz"):
+        z = np.load(src)
+        return ArrayVideo(z["frames"], float(z["fps"]) if "fps" in z.files and fps is None else (fps or 30.0))
+    if low.endswith((".gif", ".tif", ".tiff", ".webp")):
+        return PilMultiFrameVideo(src)
+    errors: List[str] = []
+    for name, cls in (("decord", _DecordVideo), ("cv2", _Cv2Video), ("imageio", _ImageioVideo)):
+        try:
+            return cls(src)
+        except ImportError:
+            errors.append(f"{name}: not installed")
+        except Exception as e:                                    # installed but cannot read this file: try the next decoder
+            errors.append(f"{name}: {e!r}")
+    raise ImportError(f"no decoder for {src}: " + "; ".join(errors) + ". This image ships no video codec (no decord / OpenCV / imageio / "
+                      "ffmpeg / rocDecode): install one of decord, opencv-python, imageio[ffmpeg], or pass decoded frames / a .npy file / "
+                      "a directory of stills.")
+
+
+def get_index_stream(start_frame: int, end_frame: int, vidoe_fps: float, cur_fps: float = 2) -> np.ndarray:
+    """eval/video_score_stream_demo.py:212-215: every int(video_fps / cur_fps)-th frame of [start, end)"""
+    seg_size = int(vidoe_fps / cur_fps)
+    return np.arange(start_frame, end_frame, seg_size, dtype=int)
+
+
+def read_video_stream(video_path, cur_fps: float) -> Tuple[np.ndarray, object]:
+    """eval/video_score_stream_demo.py:217-225: (frame indices at `cur_fps`, the open reader); the LAST frame is never sampled
+    (end = len - 1, exclusive)."""
+    vr = open_video(video_path)
+    max_frame = len(vr) - 1
+    video_fps = float(vr.get_avg_fps())
+    return get_index_stream(start_frame=0, end_frame=max_frame, vidoe_fps=video_fps, cur_fps=cur_fps), vr
+
+
+def stream_frames(video_path, cur_fps: float) -> Iterator[Tuple[int, np.ndarray]]:
+    """(frame id, HWC uint8 frame) in stream order: what the demo loop feeds one by one (video_score_stream_demo.py:283-287),
+    and what `StreamingSession.run` takes as its frame iterator (the pinned ring buffer sits behind it)."""
+    ids, vr = read_video_stream(video_path, cur_fps)
+    for fid in ids:
+        yield int(fid), np.asarray(vr[int(fid)].asnumpy())

@@ -47,11 +47,8 @@ def test_process_video_keeps_u8_frames():
     fr = [np.full((336, 336, 3), i, dtype=np.uint8) for i in range(3)]
     out = mm_utils.process_video(fr, None, aspect_ratio=None, num_frames=3)
     assert out.dtype == torch.uint8 and tuple(out.shape) == (3, 336, 336, 3) and out[2, 0, 0, 0] == 2
-    try:
+    with pytest.raises(FileNotFoundError):
         mm_utils.process_video("/some/video.mp4", None)
-        raise AssertionError
-    except NotImplementedError:
-        pass
 
 
 def test_sentinel_expansion_and_errors():
@@ -144,3 +141,53 @@ def test_checkpoint_config_to_path_dims(gold):
     assert c2.llm_rope_theta == 5e5 and (c2.gate_heads, c2.gate_kv_heads, c2.gate_mlp, c2.gate_layers) == (2, 1, 512, 4)
     with pytest.raises(ValueError, match="select feature"):
         path_config_from_checkpoint(dict(cfgj, mm_vision_select_feature="cls_patch"), vj)
+
+
+def _marked_frames(n, side=336):
+    return np.stack([np.full((side, side, 3), i % 256, np.uint8) for i in range(n)])
+
+
+def test_read_video_stream_and_process_video_paths_vs_reference_golden(tmp_path, gold):
+    """f2 host side against golden g14 (the reference's own read_video_stream / process_video path branch run with stub
+    readers): the drop-in samples the same frame ids for the streaming loop and for offline clips ("uniform" / "fps", .gif
+    rule), from every source the decoder adaptor serves in this image (.npy, .npz with fps, a directory of stills, .gif)."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from streammind_amd import video_io
+    from streammind_amd.mm_utils import process_video
+    g = gold("g14_video_sampling")
+    for i, (n, fps, cur) in enumerate(g["stream_cases"]):
+        n = int(n)
+        p = tmp_path / f"s{i}.npz"
+        np.savez(p, frames=_marked_frames(n, 8), fps=fps)
+        ids, vr = video_io.read_video_stream(str(p), cur)
+        assert ids.tolist() == g[f"stream_ids{i}"].tolist() and len(vr) == n and vr.get_avg_fps() == fps
+        if len(ids):
+            assert int(vr[ids[-1]].asnumpy()[0, 0, 0]) == int(ids[-1]) % 256
+    got = [(fid, int(fr[0, 0, 0])) for fid, fr in video_io.stream_frames(str(tmp_path / "s3.npz"), 30)]
+    assert [a for a, _ in got] == g["stream_ids3"].tolist() and all(a % 256 == b for a, b in got)
+    proc = SimpleNamespace(crop_size={"height": 336, "width": 336}, image_mean=[0.5, 0.5, 0.5])
+    for i, (n, fps, nf, sc) in enumerate(g["clip_cases"]):
+        n, nf = int(n), int(nf)
+        d = tmp_path / f"clip{i}"
+        d.mkdir()
+        (d / "fps.txt").write_text(str(fps))
+        for j in range(n):
+            Image.fromarray(np.full((336, 336, 3), j, np.uint8)).save(d / f"f{j:05d}.png")
+        out = process_video(str(d), proc, aspect_ratio=None, num_frames=nf, sample_scheme="uniform" if sc == 0 else "fps")
+        assert out.dtype == torch.uint8 and out[:, 0, 0, 0].tolist() == g[f"clip_ids{i}"].tolist()
+    gif = tmp_path / "a.gif"
+    fr = [Image.fromarray(np.full((336, 336, 3), (j, 255 - j, j), np.uint8)) for j in range(int(g["gif_n"]))]
+    fr[0].save(gif, save_all=True, append_images=fr[1:], duration=100, loop=0)
+    assert len(video_io.open_video(str(gif))) == int(g["gif_n"]) and video_io.open_video(str(gif)).get_avg_fps() == 10.0
+    from oracle import streammind_oracle as O
+    for i, (nf, sc) in enumerate(g["gif_cases"]):
+        out = process_video(str(gif), proc, aspect_ratio=None, num_frames=int(nf), sample_scheme="uniform" if sc == 0 else "fps")
+        want = g[f"gif_ids{i}"].tolist()
+        assert out.shape[0] == len(want) == len(O.clip_frame_indices(int(g["gif_n"]), 10, int(nf), "uniform" if sc == 0 else "fps", gif=True))
+    npy = tmp_path / "v.npy"
+    np.save(npy, _marked_frames(40))
+    assert process_video(str(npy), proc, num_frames=8)[:, 0, 0, 0].tolist() == O.clip_frame_indices(40, 30, 8)
+    (tmp_path / "movie.mp4").write_bytes(b"not a video")
+    with pytest.raises(ImportError, match="no decoder"):
+        video_io.open_video(str(tmp_path / "movie.mp4"))
