@@ -231,6 +231,28 @@ class Videollama2MistralForCausalLM:
         self._tick_logits = torch.cat(tick_logits)
         return logits[-1], int(dec[-1].item())        # the per-tick device->host read (videollama2_arch.py:941 .item())
 
+    @torch.no_grad()
+    def _perceive_features(self, feats: torch.Tensor) -> None:
+        """pre-extracted tower features [t, P, C] (the on-disk cache of row a15, or CLIPVisionTower.forward output): patch-mean
+        -> connector + gate, appended to this stream like frames would be (mamba_encode_images_or_videos_score,
+        videollama2_arch.py:206-207 -> temporal_aggregator)"""
+        nat, cfg = self.native, self.native.cfg
+        if feats.dim() == 4 and feats.shape[0] == 1:
+            feats = feats[0]
+        if feats.dim() != 3 or feats.shape[-1] != cfg.vit_hidden:
+            raise ValueError(f"expected features [t, patches, {cfg.vit_hidden}], got {tuple(feats.shape)}")
+        x = feats.to(self.device)
+        if x.dtype not in _DT:
+            x = x.float()
+        x = x.contiguous()
+        t, P, Cw = x.shape
+        pooled = torch.empty(t, Cw, dtype=torch.float32, device=self.device)
+        check(nat.lib.sm_pool_rows(x.data_ptr(), _DT[x.dtype], t, P, Cw, pooled.data_ptr(), _stream()), "sm_pool_rows")
+        cap = 16 if cfg.weights_fp8 else 32
+        logits = [self.stream.push_pooled(pooled[i:i + cap].contiguous())[0] for i in range(0, t, cap)]
+        self._tick_logits = torch.cat(logits)
+        self.last_gate_logits = self._tick_logits[-1]
+
     # ---- a10: sentinel expansion (videollama2_arch.py:948-984)
     def _expand(self, input_ids: Sequence[int]) -> List[int]:
         starts = [0] + self.interval_id_list[:-1]
@@ -358,15 +380,20 @@ class Videollama2MistralForCausalLM:
     __call__ = forward
 
     # ---- f4: offline generate (videollama2_mistral.py:261-318, non-score branch), greedy
-    def _splice_clips(self, ids: Sequence[int], clips, keys, sample_type: str = "all", sample_per: float = 0.5):
+    def _splice_clips(self, ids: Sequence[int], clips, keys, sample_type: str = "all", sample_per: float = 0.5, features: bool = False):
         """all clips -> ViT -> one connector pass (stream reset first); sentinels -> (optionally sub-sampled) frame indices.
         -> (sequence of ids with frame positions as -(index+1), per-position 'is frame' flags, gate logits of every frame)."""
         self.frame_feature = None
         counts, all_logits = [], []
         for clip in clips:
-            if clip.shape[0] > 600:
+            if clip.shape[0] > 600 and not features:
                 clip = clip[-600:]                                        # videollama2_arch.py:150-151
-            self._perceive(clip)
+            if features:
+                self._perceive_features(clip)
+                if clip.dim() == 4:
+                    clip = clip[0]
+            else:
+                self._perceive(clip)
             all_logits.append(self._tick_logits)
             counts.append(int(clip.shape[0]))
         feature_idx = [sum(counts[:i + 1]) for i in range(len(counts))]
@@ -401,15 +428,18 @@ class Videollama2MistralForCausalLM:
         kwargs.pop("attention_mask", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")
-        if kwargs.pop("score_video", None):
-            raise NotImplementedError("score_video=True (pre-extracted feature files, prepare_inputs_labels_for_multimodal_score) is not built")
+        # score_video=True: the reference routes to prepare_inputs_labels_for_multimodal_score (videollama2_mistral.py:276-289),
+        # whose `encode_images_or_videos_score` does not exist in the tree (videollama2_arch.py:502: AttributeError on every
+        # call).  The evident intent -- clips given as PRE-EXTRACTED tower features [t, 576, 1024] (the feature cache of row
+        # a15), connector only (mamba_encode_images_or_videos_score, :206-207) -- is what this build does for that flag.
+        score_video = bool(kwargs.pop("score_video", None))
         if inputs.dim() != 2 or inputs.shape[0] != 1:
             raise NotImplementedError("generate: batch size 1")
         if self.native.cfg.llm_layers == 0:
             raise RuntimeError("perception-only model: no LLM loaded")
         ids = inputs[0].tolist()
         if images_or_videos is not None and len(images_or_videos):
-            seq, _, _, _ = self._splice_clips(ids, images_or_videos, modal_list or ["video"])
+            seq, _, _, _ = self._splice_clips(ids, images_or_videos, modal_list or ["video"], features=score_video)
         else:
             seq = [int(t) for t in ids]
         do_sample = bool(kwargs.get("do_sample", False))

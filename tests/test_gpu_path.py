@@ -590,8 +590,17 @@ def test_offline_generate_vs_reference_golden(tiny, gold, tiny_tokenizer):
     # u8 frames through the same path (the drop-in keeps frames as uint8) and the package-level API
     text = streammind_amd.infer_offline(model, frames, "a b", tiny_tokenizer, version="mistral_instruct", max_new_tokens=4)
     assert isinstance(text, str)
-    with pytest.raises(NotImplementedError):
-        model.generate(ids, images_or_videos=[pix], do_sample=True)
+    # score_video=True: the same clip handed over as PRE-EXTRACTED tower features (feature-cache path) gives the same reply
+    feats = model.get_vision_tower()(pix)
+    out_f = model.generate(ids, images_or_videos=[feats], modal_list=["video"], do_sample=False, max_new_tokens=int(g["max_new"]), score_video=True)
+    tok_f = model.stream.tokens().cpu()
+    out_p = model.generate(ids, images_or_videos=[pix], modal_list=["video"], do_sample=False, max_new_tokens=int(g["max_new"]))
+    tok_p = model.stream.tokens().cpu()
+    assert tok_f.shape == tok_p.shape and maxdiff(tok_f, tok_p) < 2e-2 * max(1.0, tok_p.abs().max().item())    # features went through one bf16 rounding
+    assert out_f.shape[1] >= 1
+    # sampling runs and stays inside the vocabulary (serve/model_worker.py passes temperature / top_p)
+    smp = model.generate(ids, images_or_videos=[pix], do_sample=True, temperature=0.8, top_p=0.9, max_new_tokens=5, generator=torch.Generator(device="cuda").manual_seed(3))
+    assert smp.shape[0] == 1 and 0 < smp.shape[1] <= 5 and int(smp.max()) < TL.vocab
 
 
 def test_streaming_session_with_native_size_frames(tiny, tiny_tokenizer):
