@@ -653,14 +653,25 @@ def test_stream_group_equals_independent_streams_and_oracle(tiny, S, F, ticks):
     for s in range(S):
         solo = m.open_stream(max_frames=32, max_seq=64)
         lg_s = torch.cat([solo.push_frames(frames[s, t * F:(t + 1) * F].contiguous().cuda())[0].cpu() for t in range(ticks)])
-        assert maxdiff(lg_g[s], lg_s) < 2e-5 * max(1.0, lg_s.abs().max().item())
-        assert maxdiff(streams[s].tokens(), solo.tokens()) < 2e-5 * max(1.0, solo.tokens().abs().max().item())
+        # through the ViT the batch size picks other GEMM kernels (other fp32 summation order -> a few bf16 roundings flip): 1e-3
+        assert maxdiff(lg_g[s], lg_s) < 1e-3 * max(1.0, lg_s.abs().max().item())
+        assert maxdiff(streams[s].tokens(), solo.tokens()) < 1e-3 * max(1.0, solo.tokens().abs().max().item())
         pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[s], TV.image_size), Wv, TV, O.MIXED))
         ref = O.gate_logits_shortcut(O.connector_scan(pooled, Wc, TC), Wc, TG)
         assert maxdiff(lg_g[s], ref) < 5e-3
         for j in range(F * ticks):
             if abs(float(ref[j, 1] - ref[j, 0])) > 1e-2:
                 assert int(dc_g[s, j]) == O.gate_decision(ref[j])
+    # connector + gate alone (identical pooled features in): the group pass equals S independent passes to fp32 summation order
+    pooled = torch.randn(S, F * ticks, TC.mm_hidden, generator=torch.Generator().manual_seed(S * 10 + F)).cuda()
+    st2 = [m.open_stream(max_frames=32, max_seq=64) for _ in range(S)]
+    g2 = m.open_group(st2)
+    lg_p = torch.cat([g2.push_pooled(pooled[:, t * F:(t + 1) * F].contiguous())[0] for t in range(ticks)], dim=1).cpu()
+    for s in range(S):
+        solo = m.open_stream(max_frames=32, max_seq=64)
+        lg_s = torch.cat([solo.push_pooled(pooled[s, t * F:(t + 1) * F].contiguous())[0] for t in range(ticks)]).cpu()
+        assert maxdiff(lg_p[s], lg_s) < 2e-5 * max(1.0, lg_s.abs().max().item())
+        assert maxdiff(st2[s].tokens(), solo.tokens()) < 2e-5 * max(1.0, solo.tokens().abs().max().item())
     # the group borrows the streams: a member keeps working on its own afterwards
     lg1, _ = streams[0].push_frames(frames[0, :1].contiguous().cuda())
     assert lg1.shape == (1, 2) and streams[0].num_frames == F * ticks + 1
