@@ -396,6 +396,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=28, help="frames per step (28 x 577 tokens = 63.1 tiles of 256 rows: every "
                                                            "ViT GEMM is a whole number of 256-CU rounds)")
+    ap.add_argument("--vit-fp16", action="store_true", help="vision-tower operands in IEEE fp16 (the reference demo's precision, "
+                                                            "model/builder.py:54) instead of BASELINE configs[1]'s bf16")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (perception + scheduled replies) leg")
     ap.add_argument("--no-fp8", action="store_true", help="skip the opt-in fp8-weight decode leg (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -432,7 +434,7 @@ def main():
     from streammind_amd.native import NativeModel, PathConfig
     lib = _lib.load()
     B = a.batch
-    cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B)
+    cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B, vit_fp16=a.vit_fp16)
     model = NativeModel(cfg, f"cuda:{local}")
     random_weights_into(model, cfg, seed=1234)
     if not a.no_decode:
@@ -638,7 +640,7 @@ def main():
             "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate); Mistral-7B decode tokens/sec in `decode`", "value": round(total_frames / dt, 2),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp16 tower operands (fp32 accumulate / residual), bf16 connector + gate + LLM" if a.vit_fp16 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
                                    f"4-layer Mistral event gate, synthetic 336x336 30 fps stream ({n_pool}-frame pool = {n_pool / 30:.1f} s, "
                                    f"{a.steps * B} frames timed), {B} frames per step, one stream per GPU, random-init weights of the true shapes",

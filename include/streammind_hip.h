@@ -36,6 +36,8 @@ extern "C" {
 #define SM_X_F32 1
 #define SM_W_BF16 0
 #define SM_W_FP8 1
+#define SM_OP_BF16 0  /* 16-bit operands (packed weights, x, 16-bit outputs) are bfloat16 */
+#define SM_OP_F16 1   /* ... IEEE half: tiled GEMM only (the ViT's optional fp16 mode = the reference demo's precision, builder.py:54) */
 #define SM_TILE_AUTO 0
 #define SM_TILE_128 128
 #define SM_TILE_256 256
@@ -101,6 +103,9 @@ typedef struct sm_linear_t {
      * 128x128), SM_TILE_128 / SM_TILE_256 / SM_TILE_256x128 force one kernel.  A tuning and test knob: results are the
      * same up to fp32 summation order. */
     int tile_hint;
+    /* SM_OP_BF16 (default) or SM_OP_F16: w is then the packed image of fp16 values (sm_pack_weight is type-agnostic: it moves
+     * 16-bit words), x and out_bf16 hold fp16.  Same MFMA rate, fp32 accumulation either way. */
+    int op_dtype;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 
@@ -111,13 +116,16 @@ int sm_linear(const sm_linear_t* args, void* stream);
  * result; writes fp32 and/or bf16.  Replaces nn.LayerNorm (CLIP, mamba Block, norm_fn) and MistralRMSNorm. */
 int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
             int post_act, float* out_f32, void* out_bf16, int ldo, void* stream);
+/* the same with the 16-bit output written as SM_OP_F16 (IEEE half) or SM_OP_BF16 */
+int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
+               int post_act, float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);
 
 /* a1 (mm_utils.py:449-464 + video_score_stream_demo.py:86): u8 HWC frames [B][H][W][3] -> bf16 patch
  * matrix [B*(H/p)*(W/p)][ldp], column c*p*p + i*p + j, value (u8/255 - mean[c]) / std[c]; columns
  * >= 3*p*p zero-filled up to ldp.  Optionally also the CHW fp32 pixel tensor (pixel_values).        */
 int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch, const float* mean3_host,
                           const float* std3_host, void* patches_bf16, int ldp, float* pixel_values_opt,
-                          void* stream);
+                          int op_dtype, void* stream);      /* op_dtype: 16-bit type of the patch matrix (SM_OP_BF16 / SM_OP_F16) */
 /* same patch matrix from ALREADY-normalised pixel_values [B][3][H][W] (dtype SM_DT_BF16 / SM_DT_F32 / SM_DT_F16): the
  * reference-convention input of CLIPVisionTower.forward (clip_encoder.py:41-53; video_score_stream_demo.py:86) */
 /* f2 ingest front-end (mm_utils.py:257-268 expand2square; 452-464 -> HF CLIPImageProcessor bicubic shortest-edge resize +
@@ -129,7 +137,7 @@ size_t sm_ingest_tmp_bytes(int B, int H, int W, int pad_square, int out_size);
 int sm_ingest_frames(const uint8_t* frames, int B, int H, int W, int pad_square, const uint8_t* pad_rgb_host, int out_size,
                      uint8_t* out_frames, uint8_t* tmp, void* stream);
 int sm_patchify_pixels(const void* pixel_values, int dtype, int B, int H, int W, int patch, void* patches_bf16,
-                       int ldp, void* stream);
+                       int ldp, int op_dtype, void* stream);
 /* builder.py:405 on caller-held features: feats [T][P][C] (bf16/f32/f16) -> pooled fp32 [T][C] = mean over P */
 int sm_pool_rows(const void* feats, int dtype, int T, int P, int C, float* pooled, void* stream);
 /* CLS row: x[b*S + 0][:] = class_embedding + pos[0]  (HF CLIPVisionEmbeddings) */
@@ -137,8 +145,8 @@ int sm_vit_cls_rows(float* x, int B, int S, int D, const float* cls, const float
 /* non-causal MHA over bf16 qkv [B*S][3*H*dh] (Q|K|V); ctx bf16 [B*S][H*dh].  V is taken row-major from qkv and
  * transposed while it is staged in LDS (vt == NULL), or read from a pre-transposed vt[B][H][dh][vt_ld].
  * Replaces HF CLIPAttention (eager / SDPA).                                                          */
-int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
-                     void* stream);
+int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld, int op_dtype,
+                     void* stream);     /* op_dtype SM_OP_F16: qkv / ctx hold fp16 (vt == NULL, dh == 64 only) */
 /* builder.py:405 mean over the P patch tokens (CLS row skipped): x fp32 [B*S][D] -> pooled fp32 [B][D];
  * optionally the raw patch features as bf16 [B][P][D] (CLIPVisionTower.forward's return value).      */
 int sm_pool_patches(const float* x, int B, int S, int D, float* pooled, void* feats_bf16_opt, void* stream);
@@ -213,6 +221,9 @@ typedef struct sm_config_t {
     int weights_fp8;         /* 1: gate + LLM linear weights are quantised to fp8 (per-row scale) at load time and every  */
                              /*    decode/gate product streams them as fp8 (prefill chunks expand them to bf16 per call); */
                              /*    BASELINE config 5, opt-in: numerics differ from the bf16 checkpoint                     */
+    int vit_fp16;            /* 1: the vision tower's GEMM / attention operands (weights + activations) are IEEE fp16 instead */
+                             /*    of bf16 -- the precision the reference's demo loads the model in (model/builder.py:54:      */
+                             /*    torch_dtype=float16); same MFMA rate, fp32 accumulation and fp32 residual stream as before */
 } sm_config_t;
 
 typedef struct sm_model sm_model;

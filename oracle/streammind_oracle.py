@@ -110,19 +110,20 @@ class LmCfg:                        # Mistral decoder (gate: MistralConfig() def
 
 
 class Prec:
-    def __init__(self, mode: str = "fp32"):
+    def __init__(self, mode: str = "fp32", dtype=torch.bfloat16):
         assert mode in ("fp32", "mixed")
-        self.mode = mode
+        self.mode, self.dtype = mode, dtype
 
     def act(self, x: Tensor) -> Tensor:
-        """activation that the HIP path stores as ONE bf16 (operand of a bf16 MFMA GEMM)."""
+        """activation that the HIP path stores as ONE 16-bit value (operand of an MFMA GEMM): bf16, or fp16 in vit_fp16 mode."""
         if self.mode == "mixed":
-            return x.to(torch.bfloat16).to(F32)
+            return x.to(self.dtype).to(F32)
         return x
 
 
 FP32 = Prec("fp32")
 MIXED = Prec("mixed")
+MIXED_F16 = Prec("mixed", torch.float16)      # the ViT's optional fp16-operand mode (the reference demo's precision)
 
 
 def bf16_round(x: Tensor) -> Tensor:

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("STREAMMIND_HIP_LIB", LIB_PATH)
 SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
 SM_X_BF16, SM_X_F32 = 0, 1
 SM_W_BF16, SM_W_FP8 = 0, 1
+SM_OP_BF16, SM_OP_F16 = 0, 1
 SM_DT_BF16, SM_DT_F32, SM_DT_F16 = 0, 1, 2
 
 vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -30,7 +31,7 @@ class sm_linear_t(C.Structure):
         ("remap_in", i32), ("remap_out", i32), ("remap_off", i32),
         ("vt", vp), ("vt_n0", i32), ("vt_S", i32), ("vt_dh", i32), ("vt_ld", i32),
         ("w_dtype", i32), ("w_scale", vp), ("w2_scale", vp),
-        ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32),
+        ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32), ("op_dtype", i32),
     ]
 
 
@@ -44,7 +45,7 @@ class sm_config_t(C.Structure):
         ("gate_eps", f32),
         ("llm_hidden", i32), ("llm_layers", i32), ("llm_heads", i32), ("llm_kv_heads", i32), ("llm_mlp", i32),
         ("llm_vocab", i32), ("llm_eps", f32), ("llm_rope_theta", f32),
-        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32),
+        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32),
     ]
 
 
@@ -58,13 +59,14 @@ SIGNATURES = {
     "sm_quant_pack_weight_fp8": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sm_linear": (i32, [C.POINTER(sm_linear_t), vp]),
     "sm_norm": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, vp]),
-    "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, vp]),
+    "sm_norm_ex": (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, vp, i32, i32, vp]),
+    "sm_preprocess_patches": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, i32, vp, i32, vp]),
     "sm_ingest_tmp_bytes": (sz, [i32, i32, i32, i32, i32]),
     "sm_ingest_frames": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, vp]),
-    "sm_patchify_pixels": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "sm_patchify_pixels": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "sm_pool_rows": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sm_vit_cls_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
-    "sm_vit_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sm_vit_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sm_pool_patches": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sm_mamba_conv_step": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "sm_mamba_ssm_step": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -346,6 +346,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 //   V LDS image: byte(key, d) = key*128 + (((d >> 4) ^ h(key)) * 32) + (d & 15)*2, h = ((key >> 1) & 1) | (((key >> 3) & 1) << 1):
 //   the 8 rows x 32 B that one 32-lane phase of the transpose read touches land on 8 different 32-byte bank groups.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <bool F16>
+__device__ __forceinline__ bf16x8 make8(const float (&e)[8]) {
+    const u32x4 u = {pack16<F16>(e[0], e[1]), pack16<F16>(e[2], e[3]), pack16<F16>(e[4], e[5]), pack16<F16>(e[6], e[7])};
+    return __builtin_bit_cast(bf16x8, u);
+}
+template <bool F16>      // F16: q / k / v / P / ctx are IEEE fp16 (the ViT's optional fp16 mode), else bf16
 __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
     constexpr int DH = 64, KROW = 128, TILE_BYTES = 16384;
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
@@ -376,9 +382,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
         for (int df = 0; df < 4; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
     float m_run[2] = {-INFINITY, -INFINITY};
     f32x4 lsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    const float one8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    const bf16x8 ones = make8<F16>(one8);
     const bool active = q0 < p.nq;
     const int nk = p.nk;
 
@@ -451,8 +456,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 kf = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & 7)) * 16));
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], a1, 0, 0, 0);
+                    a0 = mfma16<F16>(kf, qf[0][ks], a0);
+                    a1 = mfma16<F16>(kf, qf[1][ks], a1);
                 }
                 s[0][kb][f] = a0;
                 s[1][kb][f] = a1;
@@ -488,11 +493,11 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
             const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                bf16x8 pv;
+                float pe[8];
                 if (PART && kb == 1 && half) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = (__bf16)0.0f;
-                    pf[qb][1] = pv;
+                    for (int e = 0; e < 8; ++e) pe[e] = 0.0f;
+                    pf[qb][1] = make8<F16>(pe);
                     continue;
                 }
 #pragma unroll
@@ -500,10 +505,10 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;
-                        pv[f * 4 + r] = (__bf16)__builtin_amdgcn_exp2f(t[0]);
-                        pv[f * 4 + r + 1] = (__bf16)__builtin_amdgcn_exp2f(t[1]);
+                        pe[f * 4 + r] = __builtin_amdgcn_exp2f(t[0]);
+                        pe[f * 4 + r + 1] = __builtin_amdgcn_exp2f(t[1]);
                     }
-                pf[qb][kb] = pv;
+                pf[qb][kb] = make8<F16>(pe);
             }
             if (__builtin_amdgcn_ballot_w64(moved) != 0) {
 #pragma unroll
@@ -515,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (PART && kb == 1 && half) continue;
-            lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][kb], lsum[0], 0, 0, 0);
-            lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][kb], lsum[1], 0, 0, 0);
+            lsum[0] = mfma16<F16>(ones, pf[0][kb], lsum[0]);
+            lsum[1] = mfma16<F16>(ones, pf[1][kb], lsum[1]);
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
                 union { bf16x8 v; s16x4 hlf[2]; } vf;
@@ -527,8 +532,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
                     vf.hlf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(Vl + key * 128 + ((df ^ hk) * 32) + (i & 3) * 8));
                 }
-                o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[0][kb], o[0][df], 0, 0, 0);
-                o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[1][kb], o[1][df], 0, 0, 0);
+                o[0][df] = mfma16<F16>(vf.v, pf[0][kb], o[0][df]);
+                o[1][df] = mfma16<F16>(vf.v, pf[1][kb], o[1][df]);
             }
         }
     };
@@ -545,8 +550,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
                 f32x4 v = o[qb][df] * inv;
-                bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *(bf16x4*)(dst + df * 16) = w;
+                *(u32x2*)(dst + df * 16) = u32x2{pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3])};
             }
         }
     }
@@ -581,14 +585,16 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
     }
 }
 
-static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
+static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
     dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
     SmProfScope prof(SM_PROF_ATTN, st);
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
+    SM_REQUIRE(!f16 || (p.v && dh == 64), "attention: fp16 operands only on the ViT fast path (row-major V, head_dim 64)");
     if (p.v) {
-        if (dh == 64) vit_attn_kernel<<<grid, 256, 0, st>>>(p);
+        if (dh == 64 && f16) vit_attn_kernel<true><<<grid, 256, 0, st>>>(p);
+        else if (dh == 64) vit_attn_kernel<false><<<grid, 256, 0, st>>>(p);
         else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
     } else if (p.causal) {
         if (dh == 64) attn_kernel<64, false, false, true><<<grid, 256, 0, st>>>(p);
@@ -601,7 +607,7 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st) {
     return SM_OK;
 }
 
-extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld,
+extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int B, int S, int H, int dh, int vt_ld, int op_dtype,
                                 void* stream) {
     SM_REQUIRE(qkv && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
     SM_REQUIRE(!vt || (vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64), "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
@@ -615,7 +621,7 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
-    return launch_attn(p, B, dh, (hipStream_t)stream);
+    return launch_attn(p, B, dh, (hipStream_t)stream, op_dtype == SM_OP_F16);
 }
 
 extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,

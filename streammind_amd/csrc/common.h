@@ -26,6 +26,26 @@ __device__ __forceinline__ uint32_t f2bf(float f) { return __builtin_bit_cast(ui
 __device__ __forceinline__ float bf2f(uint32_t b) { return __uint_as_float(b << 16); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return __builtin_bit_cast(uint32_t, bf16x2{(__bf16)lo, (__bf16)hi}); }
 
+// ---- 16-bit operand type of the MFMA products: bf16 (default everywhere) or IEEE fp16 (opt-in for the ViT: the reference's own
+// demo precision, model/builder.py:54 -- same MFMA rate, 3 more mantissa bits on every activation, fp16 range suffices for the
+// tower's LayerNorm outputs / attention context / MLP activations).  Storage stays raw uint16 / `bf16x8`-typed 16-byte
+// fragments (LDS-DMA, layouts and swizzles are type-agnostic); only the MFMA opcode and the fp32 <-> 16-bit conversions differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round to nearest even
+__device__ __forceinline__ float h2f(uint32_t b) { return (float)__builtin_bit_cast(_Float16, (uint16_t)b); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return __builtin_bit_cast(uint32_t, f16x2{(_Float16)lo, (_Float16)hi}); }
+template <bool F16> __device__ __forceinline__ uint32_t cvt16(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+template <bool F16> __device__ __forceinline__ uint32_t pack16(float lo, float hi) { if constexpr (F16) return pack2h(lo, hi); else return pack2bf(lo, hi); }
+template <bool F16> __device__ __forceinline__ float up16(uint32_t b) { if constexpr (F16) return h2f(b); else return bf2f(b); }
+__device__ __forceinline__ uint32_t cvt16_rt(float f, int f16) { return f16 ? f2h(f) : f2bf(f); }
+__device__ __forceinline__ uint32_t pack16_rt(float lo, float hi, int f16) { return f16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+
 // cross-row exchanges on the VALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of ds_bpermute's LDS round trip:
 // swapping x with itself leaves {row0,row0,row2,row2} / {row1,row1,row3,row3} (resp. the two 32-lane halves) in the pair
 __device__ __forceinline__ float xor16_max(float x) {

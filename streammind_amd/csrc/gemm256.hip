@@ -31,7 +31,7 @@ __device__ long long* g_gemm_timeline;
 #define TL(k) do {} while (0)
 #endif
 
-template <int ACT, int CPR, int RPP>     // CPR: 16-byte chunks per staged row; RPP: rows covered by one pass of the block
+template <int ACT, int CPR, int RPP, bool F16>     // CPR: 16-byte chunks per staged row; RPP: rows covered by one pass of the block
 __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
                                                    const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
                                                    int ldo, bf16_t* __restrict__ out_bf16, int ldob, int m0, int n0, int M,
@@ -62,12 +62,12 @@ __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem
                 o[j] = t + r[u][j];
             }
             if (out_f32) store16_wt(out_f32 + (size_t)m * ldo + n, __builtin_bit_cast(u32x4, o));
-            if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
         }
     }
 }
 
-template <int ACT, int WN>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves
+template <int ACT, int WN, bool F16>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves; F16: fp16 operands / outputs
 __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n) {
     constexpr int BN = 128 * WN;
     constexpr int NW = 4 * WN;                       // waves
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             for (int nf = 0; nf < 8; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                    acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
             PH(2);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                 const bf16x8 wf = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[mf], acc[nf][mf], 0, 0, 0);
+                    acc[nf][mf] = mfma16<F16>(wf, xf[mf], acc[nf][mf]);
             }
             slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                         if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
                         o[j] = t;
                     }
-                    *(u32x2*)(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) * 16) + (nl & 4) * 2) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *(u32x2*)(smem + ml * 512 + (((nl >> 3) ^ (ml & 31)) * 16) + (nl & 4) * 2) = u32x2{pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
                 }
             }
             __syncthreads();
@@ -346,12 +346,12 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                     if (m < a.M) {
                         float v = *(const float*)(smem + ml * ROWB + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
                         const int b = m / a.vt_S, sidx = m - b * a.vt_S;
-                        a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act_rt(v, a.act));
+                        a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)cvt16<F16>(apply_act_rt(v, a.act));
                     }
                 }
             }
         } else if (fast) {
-            half_rows_epilogue<ACT, CPR, RPP>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, m0,
+            half_rows_epilogue<ACT, CPR, RPP, F16>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, m0,
                                               tile_n * BN, a.M, tid);
         } else {
             for (int pass = 0; pass < 128 / RPP; ++pass) {
@@ -365,22 +365,22 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     TL(4);
 }
 
-template <int WN>
+template <int WN, bool F16>
 static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
     constexpr int BN = 128 * WN;
     constexpr int LDS = WN == 2 ? 4 * 32768 : 3 * (BN * 64 + 16384);
     const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const dim3 grid(tiles_m * tiles_n);
-    if (act == SM_ACT_NONE) gemm256_kernel<0, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
-    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
-    else gemm256_kernel<-1, WN><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    if (act == SM_ACT_NONE) gemm256_kernel<0, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    else gemm256_kernel<-1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -388,5 +388,6 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
 // bn = 256: one 8-wave block per CU; bn = 128: two independent 4-wave blocks per CU (their phases drift apart, so one
 // block's barriers / epilogue overlap the other's MFMAs)
 int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st) {
-    return bn == 128 ? launch_wn<1>(a, act, st) : launch_wn<2>(a, act, st);
+    if (a.f16) return bn == 128 ? launch_wn<1, true>(a, act, st) : launch_wn<2, true>(a, act, st);
+    return bn == 128 ? launch_wn<1, false>(a, act, st) : launch_wn<2, false>(a, act, st);
 }

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
 // passes on the store round trip (measured: 25 us of a 34 us QKV GEMM).  In-place residual is still safe: the
 // same lane reads an element before it writes it, and different passes touch different rows.  ACT is a
 // compile-time activation so the 64 inlined element epilogues stay small (I-cache).
-template <int ACT, int THREADS>
+template <int ACT, int THREADS, bool F16>
 __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem, const float* __restrict__ bias,
                                                    const float* __restrict__ residual, int ldr, float* __restrict__ out_f32,
                                                    int ldo, bf16_t* __restrict__ out_bf16, int ldob, int m0, int n0,
@@ -556,7 +556,7 @@ __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem
                 o[j] = t + r[u][j];
             }
             if (out_f32) *(f32x4*)(out_f32 + (size_t)m * ldo + n) = o;
-            if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (out_bf16) *(u32x2*)(out_bf16 + (size_t)m * ldob + n) = u32x2{pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
         }
     }
 }
@@ -564,7 +564,7 @@ __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem
 // WV = 8: the same tile on 8 waves (4(n) x 2(m), each 2x4 fragments): with one block per CU a 4-wave block leaves ONE wave
 // per SIMD, whose DMA issues, fragment reads and MFMAs then run strictly one after the other (~0.75 us per k-tile against
 // 0.27 us of MFMA issue); two waves per SIMD overlap each other.
-template <int ACT, int WV = 4>   // ACT: compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
+template <int ACT, int WV = 4, bool F16 = false>   // ACT: compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NF = 16 / WV;                // 16-row weight fragments per wave: 4 (2 x 2 waves) or 2 (4 x 2 waves)
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], xf[mf], acc[nf][mf], 0, 0, 0);
+                    acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -685,13 +685,13 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
                 if (m < a.M) {
                     float v = *(const float*)(smem + ml * 512 + (((nl >> 2) ^ (ml & 31)) * 16) + (nl & 3) * 4) + bv;
                     const int b = m / a.vt_S, sidx = m - b * a.vt_S;
-                    a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)f2bf(apply_act_rt(v, a.act));
+                    a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + sidx] = (bf16_t)cvt16<F16>(apply_act_rt(v, a.act));
                 }
             }
         }
     } else if (ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * GEMM_BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
                (a.ldr & 3) == 0) {
-        tile_rows_epilogue<ACT, WV * 64>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16,
+        tile_rows_epilogue<ACT, WV * 64, F16>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16,
                                 tile_m * GEMM_BM, tile_n * GEMM_BN, a.M, tid);
     } else {
         for (int pass = 0; pass < 128 / (WV * 2); ++pass) {
@@ -981,6 +981,10 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     const bool w8 = p->w_dtype == SM_W_FP8;
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
+    a.f16 = p->op_dtype == SM_OP_F16;
+    SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
+    SM_REQUIRE(!a.f16 || (p->x_dtype == SM_X_BF16 && !p->w2 && !w8 && !p->norm_gamma && !p->vt),
+               "sm_linear: fp16 operands run on the tiled GEMM only (16-bit x, single bf16-layout weight image, no fused norm / vt)");
     SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
                "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
@@ -1001,7 +1005,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         a.wscale = a.wscale2 = nullptr;
     }
     const bool w8k = w8 && p->M <= 16;            // fp8 kernels in use
-    if (p->M <= 32) {
+    if (p->M <= 32 && !a.f16) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
         const bool split = xf32 && p->precise;
@@ -1074,6 +1078,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<ACT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES))
         GEMM_ATTR(0); GEMM_ATTR(1); GEMM_ATTR(-1);
 #undef GEMM_ATTR
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         attr_set = true;
     }
     // Few tiles (a single frame through the ViT: 40-160 tiles; LLM prefill chunks): split-K so that ~256 blocks exist, but
@@ -1093,7 +1100,8 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SmProfScope prof(SM_PROF_GEMM, st);
 #define GEMM_LAUNCH(ACT, ARGS, GRID)                                                                                         \
     do {                                                                                                                     \
-        if (wv8) gemm_kernel<ACT, 8><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                       \
+        if (a.f16) gemm_kernel<ACT, 8, true><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);               \
+        else if (wv8) gemm_kernel<ACT, 8><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                  \
         else gemm_kernel<ACT, 4><<<GRID, 256, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                           \
     } while (0)
     if (S > 1) {

@@ -24,6 +24,7 @@ struct LinArgs {
     const float* wscale2;       //   ... of the second (dual) weight
     const float* ngamma;        // fused RMSNorm of the activations (weight-streaming path): gamma [K], or nullptr
     float neps;
+    int f16;                    // 16-bit operands AND 16-bit outputs are IEEE fp16 instead of bf16 (tiled GEMM path only)
 };
 
 static __device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
@@ -68,17 +69,17 @@ static __device__ __forceinline__ void store4(const LinArgs& a, int m, int n0, f
             int c = n0 + r - a.vt_n0;
             if (n0 + r < a.N) {
                 int h = c / a.vt_dh, d = c - h * a.vt_dh;
-                a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + s] = (bf16_t)f2bf(o[r]);
+                a.vt[((size_t)(b * nh + h) * a.vt_dh + d) * a.vt_ld + s] = (bf16_t)cvt16_rt(o[r], a.f16);
             }
         }
     } else if (a.out_bf16) {
         bf16_t* p = a.out_bf16 + (size_t)orow * a.ldo_bf16 + n0;
         if (full && ((a.ldo_bf16 & 3) == 0)) {
-            *(u32x2*)p = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            *(u32x2*)p = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (n0 + r < a.N) p[r] = (bf16_t)f2bf(o[r]);
+                if (n0 + r < a.N) p[r] = (bf16_t)cvt16_rt(o[r], a.f16);
         }
     }
 }
@@ -92,4 +93,4 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
-int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);     // gemm256.hip (256 x bn tile)
+int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);     // gemm256.hip (256 x bn tile; a.f16 selects the fp16 build)

@@ -29,6 +29,14 @@ __global__ void f16_to_bf16_kernel(const _Float16* in, bf16_t* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (bf16_t)f2bf((float)in[i]);
 }
+__global__ void bf16_to_f16_kernel(const bf16_t* in, bf16_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16_t)f2h(bf2f(in[i]));          // exact inside fp16's normal range (10 > 7 mantissa bits)
+}
+__global__ void f32_to_f16_kernel(const float* in, bf16_t* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16_t)f2h(in[i]);
+}
 __global__ void f16_to_f32_kernel(const _Float16* in, float* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
@@ -65,6 +73,7 @@ struct Slot {            // one tensor the path reads
     bool complete() const { return loaded == (parts >= 32 ? 0xffffffffu : (1u << parts) - 1u); }
     int Klogical = 0;    // > 0: checkpoint K (the packed image pads it to K); patch embedding only
     bool fp8 = false;    // packed as fp8 + per-row scales (weights_fp8 mode, gate + LLM linears)
+    bool f16 = false;    // packed image holds IEEE fp16 instead of bf16 (vit_fp16 mode, ViT linears)
     DevBuf scale;        // fp32 [N]
 };
 
@@ -116,6 +125,7 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     SM_REQUIRE(c.gate_hidden == c.conn_d_model, "gate width must equal the connector width");
     SM_REQUIRE(c.gate_hidden % 32 == 0 && c.gate_mlp % 32 == 0 && c.gate_heads % c.gate_kv_heads == 0, "gate dims");
     SM_REQUIRE(c.max_frames_per_call >= 1, "max_frames_per_call >= 1");
+    SM_REQUIRE(!c.vit_fp16 || c.vit_hidden / c.vit_heads == 64, "vit_fp16 needs head_dim 64 (the ViT attention fast path)");
     if (c.llm_layers > 0) {
         SM_REQUIRE(c.llm_hidden == c.conn_d_model, "LLM width must equal the connector width");
         SM_REQUIRE(c.llm_hidden % 64 == 0 && c.llm_mlp % 64 == 0, "LLM dims must be multiples of 64");
@@ -201,6 +211,9 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
         add_f32(m, "llm.model.norm.weight", ld);
         add_linear(m, "llm.lm_head", c.llm_vocab, ld, {"llm.lm_head.weight"}, c.llm_vocab);
     }
+    if (c.vit_fp16)
+        for (auto& kv : m->slots)
+            if (kv.second.kind == 1 && kv.first.rfind("vit.", 0) == 0) kv.second.f16 = true;
     if (c.weights_fp8)
         for (auto& kv : m->slots)
             if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head"))
@@ -249,11 +262,20 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
                    name_c, (long long)rows, (long long)cols, it->second.rows, s.Klogical ? s.Klogical : s.K);
         DevBuf tmp;
         const bf16_t* src = (const bf16_t*)data;
-        if (dtype != SM_DT_BF16) {      // fp32 / fp16 (the reference loads fp16, model/builder.py:54) -> bf16, round to nearest even
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        if (s.kind == 1 && s.f16) {     // fp16 image (vit_fp16): an fp16 checkpoint tensor goes in AS IS (builder.py:54 loads fp16)
+            if (dtype != SM_DT_F16) {
+                int rc = tmp.alloc(n * 2);
+                if (rc) return rc;
+                if (dtype == SM_DT_F32) f32_to_f16_kernel<<<nb, 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
+                else bf16_to_f16_kernel<<<nb, 256, 0, st>>>((const bf16_t*)data, tmp.as<bf16_t>(), n);
+                src = tmp.as<bf16_t>();
+            }
+        } else if (dtype != SM_DT_BF16) {      // fp32 / fp16 (the reference loads fp16, model/builder.py:54) -> bf16, round to nearest even
             int rc = tmp.alloc(n * 2);
             if (rc) return rc;
-            if (dtype == SM_DT_F32) f32_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
-            else f16_to_bf16_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>((const _Float16*)data, tmp.as<bf16_t>(), n);
+            if (dtype == SM_DT_F32) f32_to_bf16_kernel<<<nb, 256, 0, st>>>((const float*)data, tmp.as<bf16_t>(), n);
+            else f16_to_bf16_kernel<<<nb, 256, 0, st>>>((const _Float16*)data, tmp.as<bf16_t>(), n);
             src = tmp.as<bf16_t>();
         }
         if (s.kind == 1 && s.fp8) {
@@ -328,10 +350,13 @@ static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dt
     memset(&a, 0, sizeof(a));
     a.w = w.buf.p; a.N = w.N; a.K = w.K; a.x = x; a.x_dtype = x_dtype; a.M = M; a.ldx = ldx;
     if (w.fp8) { a.w_dtype = SM_W_FP8; a.w_scale = w.scale.as<float>(); }
+    if (w.f16) a.op_dtype = SM_OP_F16;
     return a;
 }
 
-extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, void* stream);
+extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, int op_dtype, void* stream);
+extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
+                          float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);
 static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream);
 
 extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats, float* pix, void* stream) {
@@ -339,7 +364,7 @@ extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* p
     SM_REQUIRE(frames && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode: B=%d outside [1, %d]", B, m->Bmax);
     const sm_config_t& c = m->c;
     // a1: u8 ring buffer -> normalised bf16 patch matrix
-    int rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, m->patches.p, m->Kpe, pix, stream);
+    int rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, m->patches.p, m->Kpe, pix, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, stream);
     if (rc) return rc;
     return vit_body(m, B, pooled, feats, stream);
 }
@@ -348,7 +373,7 @@ extern "C" int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int d
     SM_REQUIRE(m && m->finalized, "sm_vit_encode_pixels: model not finalized");
     SM_REQUIRE(pixel_values && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode_pixels: B=%d outside [1, %d]", B, m->Bmax);
     const sm_config_t& c = m->c;
-    int rc = sm_patchify_pixels(pixel_values, dtype, B, c.vit_image, c.vit_image, c.vit_patch, m->patches.p, m->Kpe, stream);
+    int rc = sm_patchify_pixels(pixel_values, dtype, B, c.vit_image, c.vit_image, c.vit_patch, m->patches.p, m->Kpe, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, stream);
     if (rc) return rc;
     return vit_body(m, B, pooled, feats, stream);
 }
@@ -357,6 +382,7 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
     const sm_config_t& c = m->c;
     const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P, M = B * S;
     int rc;
+    const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
     float* x = m->x.as<float>();
     bf16_t* xn = m->xn.as<bf16_t>();
     // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
@@ -371,7 +397,7 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
     if ((rc = sm_norm(x, M, D, D, m->ptr<float>("vit.pre_layrnorm.weight"), m->ptr<float>("vit.pre_layrnorm.bias"), c.vit_eps, 0, x, nullptr, D, stream))) return rc;
     for (int l = 0; l < c.vit_layers_run; ++l) {
         const std::string p = "vit.encoder.layers." + std::to_string(l) + ".";
-        if ((rc = sm_norm(x, M, D, D, m->ptr<float>(p + "layer_norm1.weight"), m->ptr<float>(p + "layer_norm1.bias"), c.vit_eps, 0, nullptr, xn, D, stream))) return rc;
+        if ((rc = sm_norm_ex(x, M, D, D, m->ptr<float>(p + "layer_norm1.weight"), m->ptr<float>(p + "layer_norm1.bias"), c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
         {
             sm_linear_t a = lin(m, m->slots.at(p + "qkv"), xn, SM_X_BF16, M, D);
             a.bias = m->ptr<float>(p + "qkv.bias");
@@ -380,14 +406,14 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
         }
         // V is transposed inside the attention kernel's LDS staging (a V^T side output of the QKV GEMM cost ~50 us of
         // scalar 2-byte stores per layer at 28 frames)
-        if ((rc = sm_vit_attention(m->qkv.p, nullptr, m->ctx.p, B, S, H, dh, 0, stream))) return rc;
+        if ((rc = sm_vit_attention(m->qkv.p, nullptr, m->ctx.p, B, S, H, dh, 0, od, stream))) return rc;
         {
             sm_linear_t a = lin(m, m->slots.at(p + "out"), m->ctx.p, SM_X_BF16, M, D);
             a.bias = m->ptr<float>(p + "self_attn.out_proj.bias");
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
-        if ((rc = sm_norm(x, M, D, D, m->ptr<float>(p + "layer_norm2.weight"), m->ptr<float>(p + "layer_norm2.bias"), c.vit_eps, 0, nullptr, xn, D, stream))) return rc;
+        if ((rc = sm_norm_ex(x, M, D, D, m->ptr<float>(p + "layer_norm2.weight"), m->ptr<float>(p + "layer_norm2.bias"), c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
         {
             sm_linear_t a = lin(m, m->slots.at(p + "fc1"), xn, SM_X_BF16, M, D);
             a.bias = m->ptr<float>(p + "mlp.fc1.bias"); a.act = SM_ACT_QUICK_GELU;

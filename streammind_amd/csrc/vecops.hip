@@ -44,7 +44,7 @@ template <bool LN>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, int M, int D, int ldx,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    float eps, int post_act, float* __restrict__ of, bf16_t* __restrict__ ob,
-                                                   int ldo) {
+                                                   int ldo, int f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
             o[j] = apply_act(y, post_act);
         }
         if (of) *(f32x4*)(of + (size_t)row * ldo + v * 4) = f32x4{o[0], o[1], o[2], o[3]};
-        if (ob) *(u32x2*)(ob + (size_t)row * ldo + v * 4) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + v * 4) = u32x2{pack16_rt(o[0], o[1], f16), pack16_rt(o[2], o[3], f16)};
     }
 }
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
 template <bool LN, int NV>
 __global__ __launch_bounds__(256) void norm_wave_fixed_kernel(const float* __restrict__ x, int M, int ldx,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float eps, float* __restrict__ of, bf16_t* __restrict__ ob, int ldo) {
+                                                              float eps, float* __restrict__ of, bf16_t* __restrict__ ob, int ldo, int f16) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void norm_wave_fixed_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = LN ? (v[j][e] - mu) * rstd * gm[e] + bt[e] : gm[e] * (v[j][e] * rstd);
         if (of) *(f32x4*)(of + (size_t)row * ldo + c) = o;
-        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c) = u32x2{pack16_rt(o[0], o[1], f16), pack16_rt(o[2], o[3], f16)};
     }
 }
 
@@ -137,7 +137,7 @@ template <bool LN>
 __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __restrict__ x, int D, int ldx,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int post_act, float* __restrict__ of,
-                                                             bf16_t* __restrict__ ob, int ldo) {
+                                                             bf16_t* __restrict__ ob, int ldo, int f16) {
     __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* xr = x + (size_t)row * ldx;
@@ -191,37 +191,43 @@ __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __rest
             o[e] = apply_act(y, post_act);
         }
         if (of) *(f32x4*)(of + (size_t)row * ldo + c * 4) = f32x4{o[0], o[1], o[2], o[3]};
-        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c * 4) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        if (ob) *(u32x2*)(ob + (size_t)row * ldo + c * 4) = u32x2{pack16_rt(o[0], o[1], f16), pack16_rt(o[2], o[3], f16)};
     }
 }
 
-extern "C" int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
-                       int post_act, float* out_f32, void* out_bf16, int ldo, void* stream) {
+extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
+                          int post_act, float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream) {
     SM_REQUIRE(x && gamma && (out_f32 || out_bf16), "sm_norm: null arg");
+    const int f16 = op_dtype == SM_OP_F16;
     SM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "sm_norm: D, ldx, ldo must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
     if (M <= 64 && D <= 8192) {
-        if (beta) norm_row_block_kernel<true><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
-        else norm_row_block_kernel<false><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+        if (beta) norm_row_block_kernel<true><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
+        else norm_row_block_kernel<false><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
     if (post_act == 0 && (D == 1024 || D == 4096)) {
         const bf16_t* dummy = nullptr; (void)dummy;
         if (D == 1024) {
-            if (beta) norm_wave_fixed_kernel<true, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
-            else norm_wave_fixed_kernel<false, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+            if (beta) norm_wave_fixed_kernel<true, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo, f16);
+            else norm_wave_fixed_kernel<false, 4><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo, f16);
         } else {
-            if (beta) norm_wave_fixed_kernel<true, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
-            else norm_wave_fixed_kernel<false, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo);
+            if (beta) norm_wave_fixed_kernel<true, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo, f16);
+            else norm_wave_fixed_kernel<false, 16><<<cdiv(M, 4), 256, 0, st>>>(x, M, ldx, gamma, beta, eps, out_f32, (bf16_t*)out_bf16, ldo, f16);
         }
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
-    if (beta) norm_kernel<true><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
-    else norm_kernel<false><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo);
+    if (beta) norm_kernel<true><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
+    else norm_kernel<false><<<cdiv(M, 4), 256, 0, st>>>(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
+}
+
+extern "C" int sm_norm(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
+                       int post_act, float* out_f32, void* out_bf16, int ldo, void* stream) {
+    return sm_norm_ex(x, M, D, ldx, gamma, beta, eps, post_act, out_f32, out_bf16, ldo, SM_OP_BF16, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ preprocess
@@ -229,7 +235,7 @@ struct Norm3 { float mean[3], istd[3]; };
 
 // one thread per (patch row, 8 output columns).  u8 reads hit L2 (a frame is 338 KB); writes are 16 B/lane.
 __global__ void preprocess_kernel(const uint8_t* __restrict__ fr, int B, int H, int W, int p, Norm3 nm,
-                                  bf16_t* __restrict__ out, int ldp, float* __restrict__ pix) {
+                                  bf16_t* __restrict__ out, int ldp, float* __restrict__ pix, int f16) {
     const int gx = W / p, gy = H / p;
     const int cols8 = ldp >> 3;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -258,12 +264,13 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ fr, int B, int H, 
         v[j] = val;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack2bf(v[2 * j], v[2 * j + 1]);
+    for (int j = 0; j < 4; ++j) o[j] = pack16_rt(v[2 * j], v[2 * j + 1], f16);
     *(u32x4*)(out + prow * ldp + c8 * 8) = u32x4{o[0], o[1], o[2], o[3]};
 }
 
 extern "C" int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W, int patch, const float* mean3,
-                                     const float* std3, void* patches, int ldp, float* pix, void* stream) {
+                                     const float* std3, void* patches, int ldp, float* pix, int op_dtype, void* stream) {
+    const int f16 = op_dtype == SM_OP_F16;
     SM_REQUIRE(frames && patches && mean3 && std3, "sm_preprocess_patches: null arg");
     SM_REQUIRE(B > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "sm_preprocess_patches: H, W must be multiples of patch");
     SM_REQUIRE(ldp % 8 == 0 && ldp >= 3 * patch * patch, "sm_preprocess_patches: ldp must be a multiple of 8 and >= 3*p*p");
@@ -271,7 +278,7 @@ extern "C" int sm_preprocess_patches(const uint8_t* frames, int B, int H, int W,
     for (int c = 0; c < 3; ++c) { nm.mean[c] = mean3[c]; nm.istd[c] = 1.0f / std3[c]; }
     size_t total = (size_t)B * (H / patch) * (W / patch) * (ldp / 8);
     preprocess_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(frames, B, H, W, patch, nm,
-                                                                                       (bf16_t*)patches, ldp, pix);
+                                                                                       (bf16_t*)patches, ldp, pix, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -285,7 +292,7 @@ __device__ __forceinline__ float load_pix(const void* p, size_t i) {
     return (float)((const _Float16*)p)[i];
 }
 template <int DT>
-__global__ void patchify_pixels_kernel(const void* __restrict__ pix, int B, int H, int W, int p, bf16_t* __restrict__ out, int ldp) {
+__global__ void patchify_pixels_kernel(const void* __restrict__ pix, int B, int H, int W, int p, bf16_t* __restrict__ out, int ldp, int f16) {
     const int gx = W / p, gy = H / p, cols8 = ldp >> 3, pp = p * p;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)B * gx * gy * cols8;
@@ -305,17 +312,19 @@ __global__ void patchify_pixels_kernel(const void* __restrict__ pix, int B, int 
         }
         v[j] = val;
     }
-    *(u32x4*)(out + prow * ldp + c8 * 8) = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    *(u32x4*)(out + prow * ldp + c8 * 8) = u32x4{pack16_rt(v[0], v[1], f16), pack16_rt(v[2], v[3], f16), pack16_rt(v[4], v[5], f16), pack16_rt(v[6], v[7], f16)};
 }
-extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, void* stream) {
+extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int W, int patch, void* patches, int ldp, int op_dtype,
+                                  void* stream) {
+    const int f16 = op_dtype == SM_OP_F16;
     SM_REQUIRE(pix && patches && B > 0 && patch > 0 && H % patch == 0 && W % patch == 0, "sm_patchify_pixels: bad args");
     SM_REQUIRE(ldp % 8 == 0 && ldp >= 3 * patch * patch && dtype >= 0 && dtype <= 2, "sm_patchify_pixels: ldp / dtype");
     size_t total = (size_t)B * (H / patch) * (W / patch) * (ldp / 8);
     unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 1) patchify_pixels_kernel<1><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
-    else if (dtype == 0) patchify_pixels_kernel<0><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
-    else patchify_pixels_kernel<2><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp);
+    if (dtype == 1) patchify_pixels_kernel<1><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp, f16);
+    else if (dtype == 0) patchify_pixels_kernel<0><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp, f16);
+    else patchify_pixels_kernel<2><<<blocks, 256, 0, st>>>(pix, B, H, W, patch, (bf16_t*)patches, ldp, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

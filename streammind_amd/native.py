@@ -58,6 +58,7 @@ class PathConfig:
     max_frames_per_call: int = 8
     gate_precise: bool = True
     weights_fp8: bool = False      # opt-in BASELINE config 5: fp8 gate + LLM weights (weight-streaming path only)
+    vit_fp16: bool = False         # vision-tower operands in IEEE fp16 (the reference demo's precision) instead of bf16
 
     @property
     def vit_layers_run(self) -> int:
@@ -89,6 +90,7 @@ class PathConfig:
         c.llm_eps, c.llm_rope_theta = self.llm_eps, self.llm_rope_theta
         c.max_frames_per_call, c.gate_precise = self.max_frames_per_call, int(self.gate_precise)
         c.weights_fp8 = int(self.weights_fp8)
+        c.vit_fp16 = int(self.vit_fp16)
         return c
 
 
@@ -319,9 +321,9 @@ class NativeStreamGroup:
 def pack_weight(w: torch.Tensor) -> torch.Tensor:
     """[N,K] bf16 (GPU) -> packed fragment-major image (flat bf16 tensor)."""
     lib = _lib.load()
-    assert w.dtype == torch.bfloat16 and w.is_cuda and w.dim() == 2 and w.is_contiguous()
+    assert w.dtype in (torch.bfloat16, torch.float16) and w.is_cuda and w.dim() == 2 and w.is_contiguous()
     N, K = w.shape
-    out = torch.empty(lib.sm_packed_elems(N, K), dtype=torch.bfloat16, device=w.device)
+    out = torch.empty(lib.sm_packed_elems(N, K), dtype=w.dtype, device=w.device)
     check(lib.sm_pack_weight(w.data_ptr(), N, K, K, out.data_ptr(), _stream()), "sm_pack_weight")
     return out
 
@@ -375,7 +377,13 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front."""
     lib = _lib.load()
-    assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32)
+    assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32, torch.float16)
+    if x.dtype == torch.float16:       # fp16 operands: `wp` must be the packed image of fp16 weights (pack_weight moves 16-bit words)
+        a_f16 = True
+        if out is None and out_dtype == torch.bfloat16:
+            out_dtype = torch.float16
+    else:
+        a_f16 = False
     M = x.shape[0]
     a = sm_linear_t()
     a.w, a.w2, a.N, a.K = wp.data_ptr(), _p(w2p), N, K
@@ -389,6 +397,7 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     if norm_gamma is not None:
         a.norm_gamma, a.norm_eps = norm_gamma.data_ptr(), float(norm_eps)
     a.tile_hint = tile_hint
+    a.op_dtype = _lib.SM_OP_F16 if a_f16 else _lib.SM_OP_BF16
     if remap is not None:       # (remap_in, remap_out, remap_off): patch-embed row scatter + broadcast residual rows
         a.remap_in, a.remap_out, a.remap_off = remap
         assert out is not None, "a remapped product writes into a caller-provided [rows][N] buffer"

@@ -138,7 +138,7 @@ def test_vit_attention_28_frames(nat):
     qkv = O.bf16_round(rnd((B * S, 3 * D), 31))
     qg = qkv.cuda().bfloat16()
     ctx = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
-    check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, torch.cuda.current_stream().cuda_stream))
+    check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, 0, torch.cuda.current_stream().cuda_stream))
     q = qkv[:, :D].reshape(B, S, H, dh).transpose(1, 2)
     k = qkv[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
     v = qkv[:, 2 * D:].reshape(B, S, H, dh).transpose(1, 2)
@@ -146,3 +146,46 @@ def test_vit_attention_28_frames(nat):
     e = torch.exp(s - s.max(-1, keepdim=True).values)
     ref = ((O.bf16_round(e) @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * S, D)
     assert relerr(ctx, ref) < 8e-3
+
+
+@pytest.mark.parametrize("tile", [0, SM_TILE_256, SM_TILE_256x128, SM_TILE_128])
+@pytest.mark.parametrize("M,N,K,act,use_res,out16", [(VIT_M, 3072, 1024, 0, False, True), (VIT_M, 1024, 4096, 0, True, False), (VIT_M, 4096, 1024, 1, False, True),
+                                                   (577, 1024, 1024, 1, True, True), (300, 200, 256, 2, True, False), (16, 128, 640, 0, True, False)])
+def test_gemm_fp16_operands_vs_fp64(nat, tile, M, N, K, act, use_res, out16):
+    """vit_fp16 mode (IEEE half operands, the reference demo's precision -- model/builder.py:54): the same tile kernels built
+    with v_mfma_f32_16x16x32_f16.  fp64 reference on the SAME fp16 operands; fp32 outputs 1e-5, fp16 outputs 2^-11 (6e-4)."""
+    w = rnd((N, K), 41, K ** -0.5).half()
+    x = rnd((M, K), 42).half()
+    bias = rnd((N,), 43, 0.1)
+    res = rnd((M, N), 44) if use_res else None
+    wp = nat.pack_weight(w.cuda())
+    assert wp.dtype == torch.float16
+    kw = dict(bias=bias.cuda(), act=act, tile_hint=tile)
+    if out16:
+        y = nat.linear(x.cuda(), wp, N, K, residual=None if res is None else res.cuda(), out_dtype=torch.float16, **kw)
+        assert y.dtype == torch.float16
+    else:
+        y = nat.linear(x.cuda(), wp, N, K, residual=None if res is None else res.cuda(), out_dtype=torch.float32, **kw)
+    ref = ref_linear(x.float(), w.float(), bias, act, res)
+    assert relerr(y, ref) < (6e-4 if out16 else 1e-5)
+
+
+def test_vit_attention_fp16_28_frames(nat):
+    """vit_attn_kernel<fp16> at the bench's batch against the oracle's mixed statement with fp16 roundings (P rounded to fp16 for
+    PV): output fp16, one ulp-ish (1e-3 of max)."""
+    from streammind_amd._lib import load, check, SM_OP_F16
+    lib = load()
+    B, S, H, dh = 28, 577, 16, 64
+    D = H * dh
+    qkv = rnd((B * S, 3 * D), 31).half()
+    qg = qkv.cuda()
+    ctx = torch.empty(B * S, D, device="cuda", dtype=torch.float16)
+    check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, SM_OP_F16, torch.cuda.current_stream().cuda_stream))
+    f = qkv.float()
+    q = f[:, :D].reshape(B, S, H, dh).transpose(1, 2)
+    k = f[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
+    v = f[:, 2 * D:].reshape(B, S, H, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    e = torch.exp(s - s.max(-1, keepdim=True).values)
+    ref = ((e.half().float() @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * S, D)
+    assert relerr(ctx, ref) < 1e-3

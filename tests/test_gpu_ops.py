@@ -123,9 +123,9 @@ def test_vit_attention(nat, B, S, H, dh, vmode):
     qg, vg = qkv.cuda().bfloat16(), vt.cuda().bfloat16()
     ctx = torch.empty(B * S, D, device="cuda", dtype=torch.bfloat16)
     if vmode == "row_major_v":
-        check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, torch.cuda.current_stream().cuda_stream))
+        check(lib.sm_vit_attention(qg.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, 0, torch.cuda.current_stream().cuda_stream))
     else:
-        check(lib.sm_vit_attention(qg.data_ptr(), vg.data_ptr(), ctx.data_ptr(), B, S, H, dh, Spad, torch.cuda.current_stream().cuda_stream))
+        check(lib.sm_vit_attention(qg.data_ptr(), vg.data_ptr(), ctx.data_ptr(), B, S, H, dh, Spad, 0, torch.cuda.current_stream().cuda_stream))
     q = qkv[:, :D].reshape(B, S, H, dh).transpose(1, 2)
     k = qkv[:, D:2 * D].reshape(B, S, H, dh).transpose(1, 2)
     vv = v.transpose(1, 2)
@@ -148,7 +148,7 @@ def test_preprocess_matches_oracle_and_golden(nat, gold):
     pix = torch.empty(2, 3, 336, 336, device="cuda")
     mean = (C.c_float * 3)(*O.CLIP_MEAN)
     std = (C.c_float * 3)(*O.CLIP_STD)
-    check(lib.sm_preprocess_patches(fg.data_ptr(), 2, 336, 336, 14, mean, std, patches.data_ptr(), ldp, pix.data_ptr(),
+    check(lib.sm_preprocess_patches(fg.data_ptr(), 2, 336, 336, 14, mean, std, patches.data_ptr(), ldp, pix.data_ptr(), 0,
                                     torch.cuda.current_stream().cuda_stream))
     ref = O.preprocess_frames(frames)
     assert (pix.cpu() - ref).abs().max().item() < 1e-6

@@ -31,7 +31,7 @@ qkv = (torch.randn(B * S, 3 * H * dh, device="cuda") * 0.5).bfloat16()
 ctx = torch.empty(B * S, H * dh, device="cuda", dtype=torch.bfloat16)
 st = torch.cuda.current_stream().cuda_stream
 def run_attn():
-    _lib.check(lib.sm_vit_attention(qkv.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, st))
+    _lib.check(lib.sm_vit_attention(qkv.data_ptr(), None, ctx.data_ptr(), B, S, H, dh, 0, 0, st))
     return ctx
 ref_attn = run_attn().clone()
 from streammind_amd.native import NativeModel, PathConfig
