@@ -564,6 +564,29 @@ def main():
             lat_leg = latency_leg(model, frames)
         except Exception as e:
             lat_leg = {"error": repr(e)[:200]}
+    fp16_tower_leg = None
+    if world == 1 and not a.no_aux and not a.vit_fp16:
+        # the same step with the tower's operands in IEEE fp16 (vit_fp16: the reference demo's precision, model/builder.py:54;
+        # gate logits 1.3e-4 from the fp32 oracle at this batch instead of bf16's 2.3e-3 -- tests/test_gpu_path.py)
+        try:
+            cfg16 = PathConfig(llm_layers=0, max_frames_per_call=B, vit_fp16=True)
+            m16 = NativeModel(cfg16, f"cuda:{local}")
+            random_weights_into(m16, cfg16, seed=1234)
+            m16.finalize()
+            s16 = m16.open_stream(max_frames=B * 24, max_seq=64)
+            for i in range(3):
+                s16.push_frames(frames[i * B:(i + 1) * B])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(16):
+                s16.push_frames(frames[(i * B) % (n_pool - B + 1):][:B])
+            torch.cuda.synchronize()
+            d16 = (time.perf_counter() - t1) / 16
+            fp16_tower_leg = {"frames_per_s": round(B / d16, 1), "ms_per_step": round(d16 * 1e3, 3),
+                              "note": "vit_fp16=1: tower GEMM / attention operands in IEEE fp16 (same MFMA rate), everything else as the headline run"}
+            s16.close(); m16.close()
+        except Exception as e:
+            fp16_tower_leg = {"error": repr(e)[:200]}
     streams_leg = None
     if world == 1 and not a.no_aux:
         try:
@@ -653,6 +676,7 @@ def main():
             "ingest_frontend": ing_leg,
             "per_call_latency": lat_leg,
             "streams_x1": streams_leg,
+            "fp16_tower": fp16_tower_leg,
             "rooflines_other": more_roof or None,
             "decode_fp8_weights": fp8_leg,
         }

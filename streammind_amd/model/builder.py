@@ -84,7 +84,8 @@ def path_config_from_checkpoint(cfgj: dict, vision_cfg: dict, **overrides) -> Pa
 def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7B", load_8bit=False, load_4bit=False,
                           device_map="auto", device="cuda", use_flash_attn=False, **kwargs):
     """-> (tokenizer, model, image_processor, context_len).  Extra keyword arguments of this build: max_frames_per_call
-    (ViT batch capacity, default 8), max_seq (KV capacity per stream), max_frames (token store), weights_fp8."""
+    (ViT batch capacity, default 8), max_seq (KV capacity per stream), max_frames (token store), weights_fp8, torch_dtype
+    (torch.float16 = the reference's loading precision, default; torch.bfloat16 = its evaluation precision)."""
     if load_8bit or load_4bit:
         raise NotImplementedError("bitsandbytes quantisation is not part of the MI355X path")
     if model_base is not None or "lora" in model_name.lower():
@@ -99,7 +100,15 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     if not tower_dir or not os.path.isdir(tower_dir):
         raise FileNotFoundError(f"config.mm_vision_tower={tower_dir!r} is not a local directory (hub ids cannot be resolved here)")
     vj = json.load(open(os.path.join(tower_dir, "config.json")))
-    over = dict(max_frames_per_call=kwargs.pop("max_frames_per_call", 8), weights_fp8=bool(kwargs.pop("weights_fp8", False)))
+    # precision of the vision tower's operands: the reference loads EVERYTHING as fp16 (builder.py:54, tower :201) and its
+    # teacher-forced evaluation casts to bf16 (eval/inference_video_ego4d_stream_parallel_new.py:160).  fp16 is the default here
+    # too (gate logits 1e-4 from fp32 at full size); torch_dtype=torch.bfloat16 selects the bf16 tower.  The connector / gate /
+    # LLM weights are stored bf16 either way (fp32-class activations in the connector + gate, bf16 in the LLM).
+    tdt = kwargs.pop("torch_dtype", torch.float16)
+    if tdt not in (torch.float16, torch.bfloat16):
+        raise ValueError(f"torch_dtype must be torch.float16 or torch.bfloat16, got {tdt}")
+    over = dict(max_frames_per_call=kwargs.pop("max_frames_per_call", 8), weights_fp8=bool(kwargs.pop("weights_fp8", False)),
+                vit_fp16=(tdt == torch.float16 and vj.get("vision_config", vj)["hidden_size"] // vj.get("vision_config", vj)["num_attention_heads"] == 64))
     ppath = os.path.join(tower_dir, "preprocessor_config.json")
     if os.path.exists(ppath):                               # the normalisation constants belong to the tower checkpoint
         pj = json.load(open(ppath))
