@@ -90,6 +90,19 @@ struct sm_model {
     // RoPE tables for the LLM
     DevBuf rope_cos, rope_sin;
     int rope_len = 0;
+    // every tensor the hot calls touch, resolved ONCE at finalize (no string building / hashing per launch; element
+    // addresses of an unordered_map are stable)
+    struct LayerW { const Slot *qkv = nullptr, *out = nullptr, *fc1 = nullptr, *fc2 = nullptr, *v = nullptr, *o = nullptr, *gu = nullptr, *down = nullptr;
+                    const float *qkv_b = nullptr, *out_b = nullptr, *fc1_b = nullptr, *fc2_b = nullptr, *ln1_w = nullptr, *ln1_b = nullptr,
+                                *ln2_w = nullptr, *ln2_b = nullptr; };
+    struct Resolved {
+        const Slot *patch = nullptr, *pre = nullptr, *in_proj = nullptr, *x_proj = nullptr, *dt_proj = nullptr, *out_proj = nullptr, *post = nullptr,
+                   *gate_head = nullptr, *lm_head = nullptr, *embed = nullptr;
+        const float *cls = nullptr, *pos = nullptr, *pre_ln_w = nullptr, *pre_ln_b = nullptr;
+        const float *pre_b = nullptr, *cn_w = nullptr, *cn_b = nullptr, *conv_w = nullptr, *conv_b = nullptr, *dt_b = nullptr, *A_log = nullptr, *Dp = nullptr,
+                    *nf_w = nullptr, *nf_b = nullptr, *post_b = nullptr, *gate_norm = nullptr, *llm_norm = nullptr;
+        std::vector<LayerW> vit, gate, llm;
+    } R;
 
     Slot* get(const std::string& n) {
         auto it = slots.find(n);
@@ -338,6 +351,44 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
     if ((rc = m->qkv.alloc(rows * 3 * D * 2))) return rc;
     if ((rc = m->ctx.alloc(rows * D * 2))) return rc;
     if ((rc = m->hmid.alloc(rows * c.vit_mlp * 2))) return rc;
+    {   // resolve the names once
+        auto S = [&](const std::string& n) { return (const Slot*)&m->slots.at(n); };
+        auto F = [&](const std::string& n) { return (const float*)m->slots.at(n).buf.p; };
+        sm_model::Resolved& R = m->R;
+        R.patch = S("vit.patch_embed"); R.cls = F("vit.embeddings.class_embedding"); R.pos = F("vit.embeddings.position_embedding.weight");
+        R.pre_ln_w = F("vit.pre_layrnorm.weight"); R.pre_ln_b = F("vit.pre_layrnorm.bias");
+        R.vit.resize(c.vit_layers_run);
+        for (int l = 0; l < c.vit_layers_run; ++l) {
+            const std::string p = "vit.encoder.layers." + std::to_string(l) + ".";
+            sm_model::LayerW& w = R.vit[l];
+            w.qkv = S(p + "qkv"); w.out = S(p + "out"); w.fc1 = S(p + "fc1"); w.fc2 = S(p + "fc2");
+            w.qkv_b = F(p + "qkv.bias"); w.out_b = F(p + "self_attn.out_proj.bias"); w.fc1_b = F(p + "mlp.fc1.bias"); w.fc2_b = F(p + "mlp.fc2.bias");
+            w.ln1_w = F(p + "layer_norm1.weight"); w.ln1_b = F(p + "layer_norm1.bias"); w.ln2_w = F(p + "layer_norm2.weight"); w.ln2_b = F(p + "layer_norm2.bias");
+        }
+        const std::string sp = "proj.mamba_model.ssms.0.";
+        R.pre = S("proj.pre"); R.pre_b = F("proj.pre_net.fc3.bias"); R.cn_w = F(sp + "norm.weight"); R.cn_b = F(sp + "norm.bias");
+        R.in_proj = S("proj.in_proj"); R.conv_w = F(sp + "mixer.conv1d.weight"); R.conv_b = F(sp + "mixer.conv1d.bias");
+        R.x_proj = S("proj.x_proj"); R.dt_proj = S("proj.dt_proj"); R.dt_b = F(sp + "mixer.dt_proj.bias");
+        R.A_log = F(sp + "mixer.A_log"); R.Dp = F(sp + "mixer.D"); R.out_proj = S("proj.out_proj");
+        R.nf_w = F("proj.mamba_model.norm_fn.weight"); R.nf_b = F("proj.mamba_model.norm_fn.bias");
+        R.post = S("proj.post"); R.post_b = F("proj.post_net.fc3.bias");
+        R.gate.resize(c.gate_layers);
+        for (int l = 0; l < c.gate_layers; ++l) {
+            const std::string p = "proj.cls_net.cls_model.model.layers." + std::to_string(l) + ".";
+            sm_model::LayerW& w = R.gate[l];
+            w.v = S(p + "v"); w.o = S(p + "o"); w.gu = S(p + "gu"); w.down = S(p + "down");
+            w.ln1_w = F(p + "input_layernorm.weight"); w.ln2_w = F(p + "post_attention_layernorm.weight");
+        }
+        R.gate_norm = F("proj.cls_net.cls_model.model.norm.weight"); R.gate_head = S("proj.gate_head");
+        R.llm.resize(c.llm_layers);
+        for (int l = 0; l < c.llm_layers; ++l) {
+            const std::string p = "llm.model.layers." + std::to_string(l) + ".";
+            sm_model::LayerW& w = R.llm[l];
+            w.qkv = S(p + "qkv"); w.o = S(p + "o"); w.gu = S(p + "gu"); w.down = S(p + "down");
+            w.ln1_w = F(p + "input_layernorm.weight"); w.ln2_w = F(p + "post_attention_layernorm.weight");
+        }
+        if (c.llm_layers > 0) { R.llm_norm = F("llm.model.norm.weight"); R.lm_head = S("llm.lm_head"); R.embed = S("llm.embed"); }
+    }
     m->finalized = true;
     return SM_OK;
 }
@@ -380,6 +431,7 @@ extern "C" int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int d
 
 static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream) {
     const sm_config_t& c = m->c;
+    const sm_model::Resolved& R = m->R;
     const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P, M = B * S;
     int rc;
     const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
@@ -387,20 +439,20 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
     bf16_t* xn = m->xn.as<bf16_t>();
     // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
     {
-        sm_linear_t a = lin(m, m->slots.at("vit.patch_embed"), m->patches.p, SM_X_BF16, B * P, m->Kpe);
+        sm_linear_t a = lin(m, *R.patch, m->patches.p, SM_X_BF16, B * P, m->Kpe);
         a.out_f32 = x; a.ldo = D;
-        a.residual = m->ptr<float>("vit.embeddings.position_embedding.weight"); a.ldr = D;
+        a.residual = R.pos; a.ldr = D;
         a.remap_in = P; a.remap_out = S; a.remap_off = 1;
         if ((rc = sm_linear(&a, stream))) return rc;
     }
-    if ((rc = sm_vit_cls_rows(x, B, S, D, m->ptr<float>("vit.embeddings.class_embedding"), m->ptr<float>("vit.embeddings.position_embedding.weight"), stream))) return rc;
-    if ((rc = sm_norm(x, M, D, D, m->ptr<float>("vit.pre_layrnorm.weight"), m->ptr<float>("vit.pre_layrnorm.bias"), c.vit_eps, 0, x, nullptr, D, stream))) return rc;
+    if ((rc = sm_vit_cls_rows(x, B, S, D, R.cls, R.pos, stream))) return rc;
+    if ((rc = sm_norm(x, M, D, D, R.pre_ln_w, R.pre_ln_b, c.vit_eps, 0, x, nullptr, D, stream))) return rc;
     for (int l = 0; l < c.vit_layers_run; ++l) {
-        const std::string p = "vit.encoder.layers." + std::to_string(l) + ".";
-        if ((rc = sm_norm_ex(x, M, D, D, m->ptr<float>(p + "layer_norm1.weight"), m->ptr<float>(p + "layer_norm1.bias"), c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
+        const sm_model::LayerW& w = R.vit[l];
+        if ((rc = sm_norm_ex(x, M, D, D, w.ln1_w, w.ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
         {
-            sm_linear_t a = lin(m, m->slots.at(p + "qkv"), xn, SM_X_BF16, M, D);
-            a.bias = m->ptr<float>(p + "qkv.bias");
+            sm_linear_t a = lin(m, *w.qkv, xn, SM_X_BF16, M, D);
+            a.bias = w.qkv_b;
             a.out_bf16 = m->qkv.p; a.ldo_bf16 = 3 * D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
@@ -408,21 +460,21 @@ static int vit_body(sm_model* m, int B, float* pooled, void* feats, void* stream
         // scalar 2-byte stores per layer at 28 frames)
         if ((rc = sm_vit_attention(m->qkv.p, nullptr, m->ctx.p, B, S, H, dh, 0, od, stream))) return rc;
         {
-            sm_linear_t a = lin(m, m->slots.at(p + "out"), m->ctx.p, SM_X_BF16, M, D);
-            a.bias = m->ptr<float>(p + "self_attn.out_proj.bias");
+            sm_linear_t a = lin(m, *w.out, m->ctx.p, SM_X_BF16, M, D);
+            a.bias = w.out_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
-        if ((rc = sm_norm_ex(x, M, D, D, m->ptr<float>(p + "layer_norm2.weight"), m->ptr<float>(p + "layer_norm2.bias"), c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
+        if ((rc = sm_norm_ex(x, M, D, D, w.ln2_w, w.ln2_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
         {
-            sm_linear_t a = lin(m, m->slots.at(p + "fc1"), xn, SM_X_BF16, M, D);
-            a.bias = m->ptr<float>(p + "mlp.fc1.bias"); a.act = SM_ACT_QUICK_GELU;
+            sm_linear_t a = lin(m, *w.fc1, xn, SM_X_BF16, M, D);
+            a.bias = w.fc1_b; a.act = SM_ACT_QUICK_GELU;
             a.out_bf16 = m->hmid.p; a.ldo_bf16 = c.vit_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         {
-            sm_linear_t a = lin(m, m->slots.at(p + "fc2"), m->hmid.p, SM_X_BF16, M, c.vit_mlp);
-            a.bias = m->ptr<float>(p + "mlp.fc2.bias");
+            sm_linear_t a = lin(m, *w.fc2, m->hmid.p, SM_X_BF16, M, c.vit_mlp);
+            a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
@@ -566,74 +618,74 @@ extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_tok
 // a5-a9 for S streams x F new frames each (rows stream-major, M = S*F <= 32: ONE pass over the connector + gate weights):
 // PreNet -> LN -> Mamba step on each stream's own conv / ssm state -> +res -> LN_f -> PostNet -> frame tokens (appended to
 // each stream's store) -> 4-layer gate (V/O shortcut) on every token independently -> logits [M][2], decisions [M]
-static int conn_gate_pass(sm_model* m, ConnScratch& w, const float* pooled, int S, int F, const SmSegStates& conv, const SmSegStates& ssm,
+static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int S, int F, const SmSegStates& conv, const SmSegStates& ssm,
                           const SmSegStates& tokdst, float* logits, int32_t* decisions, void* stream) {
     const sm_config_t& c = m->c;
     const int M = S * F;
     const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
     const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;
     const int pr = c.gate_precise;
-    const std::string sp = "proj.mamba_model.ssms.0.";
+    const sm_model::Resolved& W = m->R;
     int rc;
-    auto L = [&](const std::string& slot, const float* x, int ldx) {
-        sm_linear_t a = lin(m, m->slots.at(slot), x, SM_X_F32, M, ldx);
+    auto L = [&](const Slot* slot, const float* x, int ldx) {
+        sm_linear_t a = lin(m, *slot, x, SM_X_F32, M, ldx);
         a.precise = pr;
         return a;
     };
-    float* tok = S == 1 ? tokdst.p[0] : w.tokrows.as<float>();     // one stream: PostNet writes straight into its token store
+    float* tok = S == 1 ? tokdst.p[0] : ws.tokrows.as<float>();     // one stream: PostNet writes straight into its token store
     {   // PreNet: leaky_relu(W x + b)                                         builder.py:166-170
-        sm_linear_t a = L("proj.pre", pooled, c.conn_mm_hidden);
-        a.bias = m->ptr<float>("proj.pre_net.fc3.bias"); a.act = SM_ACT_LEAKY_RELU; a.out_f32 = w.t0.as<float>(); a.ldo = d;
+        sm_linear_t a = L(W.pre, pooled, c.conn_mm_hidden);
+        a.bias = W.pre_b; a.act = SM_ACT_LEAKY_RELU; a.out_f32 = ws.t0.as<float>(); a.ldo = d;
         if ((rc = sm_linear(&a, stream))) return rc;
     }
     // Block: hidden = Mamba(LN(residual)), residual = t0                      block.py:51-67
-    if ((rc = sm_norm(w.t0.as<float>(), M, d, d, m->ptr<float>(sp + "norm.weight"), m->ptr<float>(sp + "norm.bias"), c.conn_eps, 0, w.u.as<float>(), nullptr, d, stream))) return rc;
-    {   sm_linear_t a = L("proj.in_proj", w.u.as<float>(), d); a.out_f32 = w.xz.as<float>(); a.ldo = 2 * di;
+    if ((rc = sm_norm(ws.t0.as<float>(), M, d, d, W.cn_w, W.cn_b, c.conn_eps, 0, ws.u.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L(W.in_proj, ws.u.as<float>(), d); a.out_f32 = ws.xz.as<float>(); a.ldo = 2 * di;
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_mamba_conv_step_seg(w.xz.as<float>(), S, F, di, c.conn_d_conv, conv, m->ptr<float>(sp + "mixer.conv1d.weight"), m->ptr<float>(sp + "mixer.conv1d.bias"), w.xc.as<float>(), stream))) return rc;
-    {   sm_linear_t a = L("proj.x_proj", w.xc.as<float>(), di); a.out_f32 = w.xdbl.as<float>(); a.ldo = xd;
+    if ((rc = sm_mamba_conv_step_seg(ws.xz.as<float>(), S, F, di, c.conn_d_conv, conv, W.conv_w, W.conv_b, ws.xc.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L(W.x_proj, ws.xc.as<float>(), di); a.out_f32 = ws.xdbl.as<float>(); a.ldo = xd;
         if ((rc = sm_linear(&a, stream))) return rc; }
     {   // dt = softplus(W_dt dt_r + b): K = dt_rank is padded to 32 inside the packed weight (zeros), x_dbl rows are xd wide
-        sm_linear_t a = L("proj.dt_proj", w.xdbl.as<float>(), xd);
-        a.bias = m->ptr<float>(sp + "mixer.dt_proj.bias"); a.act = SM_ACT_SOFTPLUS; a.out_f32 = w.delta.as<float>(); a.ldo = di;
+        sm_linear_t a = L(W.dt_proj, ws.xdbl.as<float>(), xd);
+        a.bias = W.dt_b; a.act = SM_ACT_SOFTPLUS; a.out_f32 = ws.delta.as<float>(); a.ldo = di;
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_mamba_ssm_step_seg(w.xc.as<float>(), w.delta.as<float>(), w.xdbl.as<float>(), xd, R, w.xz.as<float>(), S, F, di, ds, m->ptr<float>(sp + "mixer.A_log"), m->ptr<float>(sp + "mixer.D"), ssm, w.y.as<float>(), stream))) return rc;
-    {   sm_linear_t a = L("proj.out_proj", w.y.as<float>(), di);
-        a.residual = w.t0.as<float>(); a.ldr = d; a.out_f32 = w.r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
+    if ((rc = sm_mamba_ssm_step_seg(ws.xc.as<float>(), ws.delta.as<float>(), ws.xdbl.as<float>(), xd, R, ws.xz.as<float>(), S, F, di, ds, W.A_log, W.Dp, ssm, ws.y.as<float>(), stream))) return rc;
+    {   sm_linear_t a = L(W.out_proj, ws.y.as<float>(), di);
+        a.residual = ws.t0.as<float>(); a.ldr = d; a.out_f32 = ws.r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_norm(w.r.as<float>(), M, d, d, m->ptr<float>("proj.mamba_model.norm_fn.weight"), m->ptr<float>("proj.mamba_model.norm_fn.bias"), c.conn_eps, SM_ACT_LEAKY_RELU, w.lnf.as<float>(), nullptr, d, stream))) return rc;
-    {   sm_linear_t a = L("proj.post", w.lnf.as<float>(), d);
-        a.bias = m->ptr<float>("proj.post_net.fc3.bias"); a.out_f32 = tok; a.ldo = d;
+    if ((rc = sm_norm(ws.r.as<float>(), M, d, d, W.nf_w, W.nf_b, c.conn_eps, SM_ACT_LEAKY_RELU, ws.lnf.as<float>(), nullptr, d, stream))) return rc;
+    {   sm_linear_t a = L(W.post, ws.lnf.as<float>(), d);
+        a.bias = W.post_b; a.out_f32 = tok; a.ldo = d;
         if ((rc = sm_linear(&a, stream))) return rc; }
     if (S > 1 && (rc = sm_scatter_rows(tok, S, F, d, tokdst, stream))) return rc;
     // ---- gate on each of the M tokens independently (seq-len 1 each; builder.py:553-562)
     const int gdh = c.gate_hidden / c.gate_heads, kvn = c.gate_kv_heads * gdh, qn = c.gate_heads * gdh;
-    const float* hcur = tok;       // layer 0 reads the token, writes w.h
+    const float* hcur = tok;       // layer 0 reads the token, writes ws.h
     for (int l = 0; l < c.gate_layers; ++l) {
-        const std::string p = "proj.cls_net.cls_model.model.layers." + std::to_string(l) + ".";
-        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.gate_eps, 0, w.hn.as<float>(), nullptr, d, stream))) return rc;
-        {   sm_linear_t a = L(p + "v", w.hn.as<float>(), d); a.out_f32 = w.v.as<float>(); a.ldo = kvn;
+        const sm_model::LayerW& w = W.gate[l];
+        if ((rc = sm_norm(hcur, M, d, d, w.ln1_w, nullptr, c.gate_eps, 0, ws.hn.as<float>(), nullptr, d, stream))) return rc;
+        {   sm_linear_t a = L(w.v, ws.hn.as<float>(), d); a.out_f32 = ws.v.as<float>(); a.ldo = kvn;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_repeat_kv(w.v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, w.vrep.as<float>(), stream))) return rc;
-        {   sm_linear_t a = L(p + "o", w.vrep.as<float>(), qn);
-            a.residual = hcur; a.ldr = d; a.out_f32 = w.h.as<float>(); a.ldo = d;
+        if ((rc = sm_repeat_kv(ws.v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, ws.vrep.as<float>(), stream))) return rc;
+        {   sm_linear_t a = L(w.o, ws.vrep.as<float>(), qn);
+            a.residual = hcur; a.ldr = d; a.out_f32 = ws.h.as<float>(); a.ldo = d;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        hcur = w.h.as<float>();
-        if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.gate_eps, 0, w.hn.as<float>(), nullptr, d, stream))) return rc;
-        {   const Slot& gu = m->slots.at(p + "gu");
-            sm_linear_t a = L(p + "gu", w.hn.as<float>(), d);
+        hcur = ws.h.as<float>();
+        if ((rc = sm_norm(hcur, M, d, d, w.ln2_w, nullptr, c.gate_eps, 0, ws.hn.as<float>(), nullptr, d, stream))) return rc;
+        {   const Slot& gu = *w.gu;
+            sm_linear_t a = L(w.gu, ws.hn.as<float>(), d);
             a.N = c.gate_mlp;
             if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.gate_mlp / 16) * ((((d + 31) / 32) + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.gate_mlp; }
             else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.gate_mlp / 16) * ((d + 31) / 32) * 512;
-            a.out_f32 = w.act.as<float>(); a.ldo = c.gate_mlp;
+            a.out_f32 = ws.act.as<float>(); a.ldo = c.gate_mlp;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        {   sm_linear_t a = L(p + "down", w.act.as<float>(), c.gate_mlp);
-            a.residual = hcur; a.ldr = d; a.out_f32 = w.h.as<float>(); a.ldo = d;
+        {   sm_linear_t a = L(w.down, ws.act.as<float>(), c.gate_mlp);
+            a.residual = hcur; a.ldr = d; a.out_f32 = ws.h.as<float>(); a.ldo = d;
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
-    if ((rc = sm_norm(hcur, M, d, d, m->ptr<float>("proj.cls_net.cls_model.model.norm.weight"), nullptr, c.gate_eps, 0, w.hfin.as<float>(), nullptr, d, stream))) return rc;
-    float* lg = logits ? logits : w.logits2.as<float>();
-    {   sm_linear_t a = L("proj.gate_head", w.hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
+    if ((rc = sm_norm(hcur, M, d, d, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>(), nullptr, d, stream))) return rc;
+    float* lg = logits ? logits : ws.logits2.as<float>();
+    {   sm_linear_t a = L(W.gate_head, ws.hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
         if ((rc = sm_linear(&a, stream))) return rc; }
     if (decisions && (rc = sm_gate_decide(lg, M, decisions, stream))) return rc;
     return SM_OK;
@@ -744,38 +796,38 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
     float* x = s->emb.as<float>();
     int rc;
     for (int l = 0; l < c.llm_layers; ++l) {
-        const std::string p = "llm.model.layers." + std::to_string(l) + ".";
+        const sm_model::LayerW& w = m->R.llm[l];
         // decode (one row): both RMSNorms ride inside the weight-streaming products that consume them
         const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
-        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "input_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-        {   sm_linear_t a = fuse_norm ? lin(m, m->slots.at(p + "qkv"), x, SM_X_F32, n, ld) : lin(m, m->slots.at(p + "qkv"), s->xnb.p, SM_X_BF16, n, ld);
-            if (fuse_norm) { a.norm_gamma = m->ptr<float>(p + "input_layernorm.weight"); a.norm_eps = c.llm_eps; }
+        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, n, ld) : lin(m, *w.qkv, s->xnb.p, SM_X_BF16, n, ld);
+            if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
             a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
             if ((rc = sm_linear(&a, stream))) return rc; }
         if ((rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
         if (n == 1) {
             if ((rc = sm_llm_decode_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, stream))) return rc;
         } else if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;
-        {   sm_linear_t a = lin(m, m->slots.at(p + "o"), s->ctxb.p, SM_X_BF16, n, qn);
+        {   sm_linear_t a = lin(m, *w.o, s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, m->ptr<float>(p + "post_attention_layernorm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
         if (n <= 32) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel
-            const Slot& gu = m->slots.at(p + "gu");
+            const Slot& gu = *w.gu;
             sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, n, ld) : lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
-            if (fuse_norm) { a.norm_gamma = m->ptr<float>(p + "post_attention_layernorm.weight"); a.norm_eps = c.llm_eps; }
+            if (fuse_norm) { a.norm_gamma = w.ln2_w; a.norm_eps = c.llm_eps; }
             a.N = c.llm_mlp;
             if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
             else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
             a.out_bf16 = s->actb.p; a.ldo_bf16 = c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         } else {
-            sm_linear_t a = lin(m, m->slots.at(p + "gu"), s->xnb.p, SM_X_BF16, n, ld);
+            sm_linear_t a = lin(m, *w.gu, s->xnb.p, SM_X_BF16, n, ld);
             a.out_f32 = s->guf.as<float>(); a.ldo = 2 * c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
             if ((rc = sm_swiglu(s->guf.as<float>(), n, c.llm_mlp, s->actb.p, stream))) return rc;
         }
-        {   sm_linear_t a = lin(m, m->slots.at(p + "down"), s->actb.p, SM_X_BF16, n, c.llm_mlp);
+        {   sm_linear_t a = lin(m, *w.down, s->actb.p, SM_X_BF16, n, c.llm_mlp);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
@@ -790,10 +842,10 @@ static int llm_head(sm_stream* s, int row, void* stream) {
     const int ld = c.llm_hidden;
     int rc;
     const bool fuse_norm = (ld & 31) == 0 && !g_no_fused_norm;
-    if (!fuse_norm && (rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-    sm_linear_t a = fuse_norm ? lin(m, m->slots.at("llm.lm_head"), s->emb.as<float>() + (size_t)row * ld, SM_X_F32, 1, ld)
-                              : lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, 1, ld);
-    if (fuse_norm) { a.norm_gamma = m->ptr<float>("llm.model.norm.weight"); a.norm_eps = c.llm_eps; }
+    if (!fuse_norm && (rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+    sm_linear_t a = fuse_norm ? lin(m, *m->R.lm_head, s->emb.as<float>() + (size_t)row * ld, SM_X_F32, 1, ld)
+                              : lin(m, *m->R.lm_head, s->xnb.p, SM_X_BF16, 1, ld);
+    if (fuse_norm) { a.norm_gamma = m->R.llm_norm; a.norm_eps = c.llm_eps; }
     a.out_f32 = s->lmlog.as<float>(); a.ldo = c.llm_vocab;
     if ((rc = sm_linear(&a, stream))) return rc;
     return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);
@@ -807,7 +859,7 @@ extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* str
     int rc, done = 0, last_rows = 0;
     while (done < n) {
         int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice(ids + done, cur, m->slots.at("llm.embed").buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = sm_embed_splice(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         done += cur; last_rows = cur;
     }
@@ -823,11 +875,11 @@ extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, fl
     int rc, done = 0;
     while (done < n) {
         const int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice(ids + done, cur, m->slots.at("llm.embed").buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = sm_embed_splice(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         // final norm + lm_head on all `cur` rows of this chunk (llm_head does the last row only)
-        if ((rc = sm_norm(s->emb.as<float>(), cur, ld, ld, m->ptr<float>("llm.model.norm.weight"), nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
-        sm_linear_t a = lin(m, m->slots.at("llm.lm_head"), s->xnb.p, SM_X_BF16, cur, ld);
+        if ((rc = sm_norm(s->emb.as<float>(), cur, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        sm_linear_t a = lin(m, *m->R.lm_head, s->xnb.p, SM_X_BF16, cur, ld);
         a.out_f32 = logits + (size_t)done * V; a.ldo = V;
         if ((rc = sm_linear(&a, stream))) return rc;
         done += cur;
@@ -853,7 +905,7 @@ extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* 
     for (int j = 0; j < n_steps; ++j) {
         // emit the pending greedy token, then feed it back (its KV is appended, the next token becomes pending)
         copy_i32_kernel<<<1, 1, 0, st>>>(s->next_tok.as<int32_t>(), out_ids + j);
-        embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->slots.at("llm.embed").buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
+        embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->R.embed->buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
         SM_LAUNCH_CHECK();
         if ((rc = llm_layers(s, 1, stream))) return rc;
         if ((rc = llm_head(s, 0, stream))) return rc;
