@@ -137,17 +137,14 @@ extern "C" int sm_quant_pack_weight_fp8(const void* w, int N, int K, int ldw, vo
     return SM_OK;
 }
 
-// 8 fp8 (two dwords) -> 8 bf16: v_cvt_pk_f32_fp8 then keep the high halves (every e4m3 value is exact in bf16)
+// 8 fp8 (two dwords) -> 8 bf16 with v_cvt_scalef32_pk_bf16_fp8 (gfx950): ONE instruction per pair (scale 1: every e4m3 value is
+// exact in bf16) instead of v_cvt_pk_f32_fp8 + v_perm_b32 -- the conversion is what bounds the fp8 weight-streaming kernels
 __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t lo, uint32_t hi) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-    union { bf16x8 v; uint32_t u[4]; } r;
-    // v_perm_b32: result = {hi16(second), hi16(first)}  (selector bytes 4-7 index the first source, 0-3 the second)
-    r.u[0] = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x07060302u);
-    r.u[1] = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x07060302u);
-    r.u[2] = __builtin_amdgcn_perm(__float_as_uint(c[1]), __float_as_uint(c[0]), 0x07060302u);
-    r.u[3] = __builtin_amdgcn_perm(__float_as_uint(d[1]), __float_as_uint(d[0]), 0x07060302u);
+    union { bf16x8 v; bf16x2 p[4]; } r;
+    r.p[0] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false);
+    r.p[1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    r.p[2] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false);
+    r.p[3] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
     return r.v;
 }
 
