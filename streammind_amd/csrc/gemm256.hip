@@ -68,7 +68,7 @@ __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem
 }
 
 template <int ACT, int WN, bool F16>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves; F16: fp16 operands / outputs
-__global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n, int cb) {
     constexpr int BN = 128 * WN;
     constexpr int NW = 4 * WN;                       // waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +83,18 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    if (cb > 0) {
+        // blocked walk inside the XCD's band (rows_x row tiles x tiles_n column tiles): column groups of `cb` tiles, all rows of
+        // the band inside a group -- the ~32 tiles an XCD runs at once then share cb/tiles_n of W and the band's X rows, so W
+        // crosses the fabric once per XCD instead of once per round (profiles/r02_gemm_traffic.json)
+        const int q = nblk >> 3, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int rows_x = q / tiles_n;
+        const int cg = idx / (rows_x * cb), rem = idx - cg * rows_x * cb;
+        const int r = rem / cb;
+        tile_m = xcd * rows_x + r;
+        tile_n = cg * cb + (rem - r * cb);
+    }
 
     TL(0);
 #ifdef SM_GEMM_TIMELINE
@@ -378,9 +389,20 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
         attr_set = true;
     }
     const dim3 grid(tiles_m * tiles_n);
-    if (act == SM_ACT_NONE) gemm256_kernel<0, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
-    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
-    else gemm256_kernel<-1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n);
+    // blocked tile walk: the XCD's band is walked in SM_GEMM_CG column groups (0 = plain row-major walk; default 3, or the next smaller count that divides the column tiles); needs whole
+    // bands per XCD and a group count that divides the column tiles
+    static int cg_env = -1;
+    if (cg_env < 0) { const char* e = getenv("SM_GEMM_CG"); cg_env = e ? atoi(e) : 3; }
+    const int nblk = tiles_m * tiles_n;
+    int cb = 0;
+    if (cg_env > 1 && (nblk & 7) == 0 && (nblk >> 3) % tiles_n == 0) {
+        int g = cg_env;
+        while (g > 1 && tiles_n % g) --g;
+        if (g > 1) cb = tiles_n / g;
+    }
+    if (act == SM_ACT_NONE) gemm256_kernel<0, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
+    else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
+    else gemm256_kernel<-1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

@@ -77,3 +77,21 @@ def test_no_gpu_means_loud_failure_not_fallback():
         raise AssertionError("expected failure without a GPU")
     except StreamMindHipError as e:
         assert "no HIP device" in str(e)
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """the C ABI re-exposed as torch.ops.streammind_hip.* (PyTorch-ROCm custom ops); shape inference through the fake
+    kernels works without a GPU (the real kernels need one)."""
+    import torch
+    import streammind_amd.torch_ops as T
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in T.OPS:
+        assert hasattr(torch.ops.streammind_hip, name), name
+    with FakeTensorMode():
+        x = torch.empty(577, 1024, dtype=torch.bfloat16)
+        y = torch.ops.streammind_hip.linear(x, torch.empty(8, dtype=torch.bfloat16), 3072, 1024, None, 1, None, torch.bfloat16)
+        assert tuple(y.shape) == (577, 3072) and y.dtype == torch.bfloat16
+        lg, dc = torch.ops.streammind_hip.stream_push_frames(0, torch.empty(4, 336, 336, 3, dtype=torch.uint8))
+        assert tuple(lg.shape) == (4, 2) and dc.dtype == torch.int32
+        assert tuple(torch.ops.streammind_hip.vit_attention(torch.empty(2 * 577, 3072, dtype=torch.float16), 2, 577, 16, 64).shape) == (1154, 1024)
+        assert tuple(torch.ops.streammind_hip.pool_rows(torch.empty(5, 576, 1024)).shape) == (5, 1024)

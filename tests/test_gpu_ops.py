@@ -348,3 +348,33 @@ def test_ingest_frames_bit_exact(nat, H, W, pad):
     got = nat.ingest_frames(torch.from_numpy(frames).cuda(), pad_square=pad, image_size=336)
     want = O.ingest_frames(list(frames), "pad" if pad else None, 336)
     assert torch.equal(got.cpu(), want)
+
+
+def test_torch_library_ops_call_the_native_kernels(nat):
+    """torch.ops.streammind_hip.* are the same kernels as the ctypes path (bit-identical outputs), incl. the handle-taking ops."""
+    import streammind_amd.torch_ops  # noqa: F401
+    from tests.util_models import build_native, conn_gate_weights
+    ops = torch.ops.streammind_hip
+    w = O.bf16_round(rnd((384, 256), 1, 256 ** -0.5)).cuda().bfloat16()
+    x = O.bf16_round(rnd((300, 256), 2)).cuda().bfloat16()
+    bias = rnd((384,), 3, 0.1).cuda()
+    wp = ops.pack_weight(w)
+    assert torch.equal(wp, nat.pack_weight(w))
+    y = ops.linear(x, wp, 384, 256, bias, 1, None, torch.bfloat16)
+    assert torch.equal(y, nat.linear(x, wp, 384, 256, bias=bias, act=1, out_dtype=torch.bfloat16))
+    xf = rnd((37, 1024), 4).cuda()
+    g, b = (1 + rnd((1024,), 5, 0.1)).cuda(), rnd((1024,), 6, 0.1).cuda()
+    ln = ops.norm(xf, g, b, 1e-5, torch.float32)
+    assert relerr(ln, O.layer_norm(xf.cpu(), g.cpu(), b.cpu(), 1e-5)) < 1e-5
+    assert ops.norm(xf, g, None, 1e-5, torch.float16).dtype == torch.float16
+    TVc = O.VitCfg(image_size=56, patch=14, hidden=128, heads=2, mlp=256, layers=3)
+    TCc, TGc = O.ConnCfg(mm_hidden=128, d_model=256), O.LmCfg.gate(hidden=256, heads=2, kv_heads=1, mlp=512)
+    m = build_native(TVc, TCc, TGc, O.make_vit_weights(TVc, 41), conn_gate_weights(TCc, TGc, 86), max_frames_per_call=4)
+    fr = O.synthetic_frames(3, 56, seed=5).cuda()
+    assert torch.equal(ops.vit_encode(m.h.value, fr, 128), m.vit_encode(fr))
+    s1, s2 = m.open_stream(16, 64), m.open_stream(16, 64)
+    lg, dc = ops.stream_push_frames(s1.h.value, fr)
+    lg2, dc2 = s2.push_frames(fr)
+    assert torch.equal(lg, lg2) and torch.equal(dc, dc2) and s1.num_frames == 3
+    pooled = ops.pool_rows(torch.randn(3, 16, 128, device="cuda"))
+    assert pooled.shape == (3, 128)
