@@ -587,6 +587,31 @@ def main():
             s16.close(); m16.close()
         except Exception as e:
             fp16_tower_leg = {"error": repr(e)[:200]}
+    two_leg = None
+    if world == 1 and not a.no_aux:
+        # two independent 28-frame streams of the SAME model on two HIP streams: each stream's kernels fill the other's launch
+        # gaps and tails (the tower's workspaces are per HIP stream); aggregate frames/s of the GPU
+        try:
+            hs = [torch.cuda.Stream(), torch.cuda.Stream()]
+            ss = [model.open_stream(max_frames=B * 20, max_seq=64) for _ in hs]
+            def both(i):
+                for k in range(2):
+                    with torch.cuda.stream(hs[k]):
+                        ss[k].push_frames(frames[((2 * i + k) * B) % (n_pool - B + 1):][:B])
+            for i in range(2):
+                both(i)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for i in range(12):
+                both(i)
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t2) / 12
+            two_leg = {"streams": 2, "frames_per_step_per_stream": B, "frames_per_s": round(2 * B / d2, 1), "ms_per_round": round(d2 * 1e3, 3),
+                       "note": "two sm_streams of one sm_model driven on two HIP streams"}
+            for st_ in ss:
+                st_.close()
+        except Exception as e:
+            two_leg = {"error": repr(e)[:200]}
     streams_leg = None
     if world == 1 and not a.no_aux:
         try:
@@ -691,6 +716,7 @@ def main():
             "per_call_latency": lat_leg,
             "streams_x1": streams_leg,
             "fp16_tower": fp16_tower_leg,
+            "two_streams_per_gpu": two_leg,
             "rooflines_other": more_roof or None,
             "decode_fp8_weights": fp8_leg,
         }

@@ -199,10 +199,10 @@ int sm_argmax(const float* logits, int V, int32_t* out, void* stream);
  *   sm_stream <- the per-stream fields the reference keeps ON the model object
  *                (frame_feature, interval_id_list: language_model/videollama2_mistral.py:159-162) plus what
  *                the reference recomputes every frame: Mamba conv/ssm state, per-frame tokens, LLM KV cache.
- * One host thread per stream handle.  The LLM calls (prefill / decode / forward_logits) and sm_stream_push_pooled of
- * DIFFERENT streams of one model may run concurrently on different HIP streams (all their scratch is per stream); the calls
- * that run the vision tower (sm_vit_encode*, sm_stream_push_frames, sm_group_push_frames) share the model's ViT workspaces and
- * must be issued on ONE HIP stream at a time per model -- batch frames of several streams through a stream group instead.
+ * One host thread per stream handle.  Different streams of one model may be driven concurrently on DIFFERENT HIP streams: all
+ * per-call scratch is per sm_stream, and the vision tower's workspaces are kept per HIP stream (allocated on the first call a HIP
+ * stream makes, never afterwards).  Two streams driven on two HIP streams fill each other's launch gaps and kernel tails
+ * (measured +7 % aggregate frames/s at 28 frames per call each); calls issued on ONE HIP stream are ordered as usual.
  * A stream's token store (max_frames) and KV cache (max_seq) are fixed-size: a full store is an error, never a silent drop;
  * long-running deployments size them for the session (4096 tokens = 34 min at 2 fps, 0.5 GB of KV) or reset the stream
  * (sm_stream_reset; the reference's own callers reset by `model.frame_feature = None` between videos).

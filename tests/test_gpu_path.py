@@ -722,3 +722,30 @@ def test_stream_group_equals_independent_streams_and_oracle(tiny, S, F, ticks):
         m.open_group([streams[0], streams[0]])
     with pytest.raises(ValueError):
         grp.push_frames(torch.zeros(S + 1, 1, TV.image_size, TV.image_size, 3, dtype=torch.uint8, device="cuda"))
+
+
+def test_two_streams_of_one_model_on_two_hip_streams(tiny):
+    """the tower's workspaces are per HIP stream: two streams of ONE model driven concurrently on two HIP streams give exactly
+    the results each gives alone (round-1 advisor finding: they used to share one workspace and could corrupt each other)."""
+    m, *_ = tiny
+    fa = O.synthetic_frames(24, TV.image_size, seed=401, scene_len=3).cuda()
+    fb = O.synthetic_frames(24, TV.image_size, seed=402, scene_len=3).cuda()
+    ref = []
+    for f in (fa, fb):
+        s = m.open_stream(max_frames=32, max_seq=64)
+        ref.append(torch.cat([s.push_frames(f[i:i + 6].contiguous())[0] for i in range(0, 24, 6)]).cpu())
+    hs = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ss = [m.open_stream(max_frames=32, max_seq=64) for _ in hs]
+    out = [[], []]
+    torch.cuda.synchronize()
+    for rep in range(3):                                   # several interleaved rounds: the launches of the two streams overlap
+        for k in range(2):
+            ss[k].reset()
+        out = [[], []]
+        for i in range(0, 24, 6):
+            for k, f in enumerate((fa, fb)):
+                with torch.cuda.stream(hs[k]):
+                    out[k].append(ss[k].push_frames(f[i:i + 6].contiguous())[0])
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(torch.cat(out[k]).cpu(), ref[k])

@@ -1,4 +1,5 @@
-"""Experiment: two independent video streams (two sm_model replicas) driven on two HIP streams of ONE GPU, to see
+"""Experiment: independent video streams of ONE sm_model (NMODELS=1, default; the tower's workspaces are per HIP stream) or of
+separate replicas (NMODELS=0: one model per stream, the round-1 form) driven on different HIP streams of ONE GPU, to see
 whether the hardware overlaps one stream's HBM-bound phases (epilogues, LayerNorm, gate GEMVs) with the other's
 MFMA-bound GEMM main loops.   python tools/two_stream_bench.py [batch] [steps]"""
 import os, sys, time
@@ -12,8 +13,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 NS = int(os.environ.get("NSTREAMS", "2"))
 cfg = PathConfig(llm_layers=0, max_frames_per_call=B)
 models, streams, hs = [], [], []
+ONE = os.environ.get("NMODELS", "1") == "1"
 for i in range(NS):
-    m = NativeModel(cfg); bench.random_weights_into(m, cfg, 1 + i); m.finalize()
+    if i == 0 or not ONE:
+        m = NativeModel(cfg); bench.random_weights_into(m, cfg, 1 + i); m.finalize()
     models.append(m); streams.append(m.open_stream(max_frames=B * (steps + 4) + 16, max_seq=64)); hs.append(torch.cuda.Stream())
 frames = bench.synthetic_frames_gpu(B * 4, 336, 1, 0)
 torch.cuda.synchronize()
