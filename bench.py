@@ -398,6 +398,8 @@ def main():
                                                            "ViT GEMM is a whole number of 256-CU rounds)")
     ap.add_argument("--vit-fp16", action="store_true", help="vision-tower operands in IEEE fp16 (the reference demo's precision, "
                                                             "model/builder.py:54) instead of BASELINE configs[1]'s bf16")
+    ap.add_argument("--no-pipeline", action="store_true", help="issue each step with sm_stream_push_frames (connector + gate pass on the "
+                    "caller's stream) instead of the pipelined form (pass on a side stream, overlapping the next step's tower)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (perception + scheduled replies) leg")
     ap.add_argument("--no-fp8", action="store_true", help="skip the opt-in fp8-weight decode leg (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -447,7 +449,9 @@ def main():
 
     def step(i):
         off = (i * B) % (n_pool - B + 1)
-        return stream.push_frames(frames[off:off + B])
+        if a.no_pipeline:
+            return stream.push_frames(frames[off:off + B])
+        return stream.push_frames_pipelined(frames[off:off + B])      # same results; the gate pass of step i overlaps the tower of step i+1
 
     # N > 1 (BASELINE configs[3]): every step is one exchange tick.  Ranks "fire" on DIFFERENT, rank-specific steps (the random
     # gate's own decisions are not a workload): on its fire steps a rank contributes the frame tokens of the segment since its
@@ -494,6 +498,7 @@ def main():
         logits, dec = step(a.warmup + i)
         if ex is not None:
             exchange(a.warmup + i)
+    stream.join()                        # the last step's connector + gate pass is inside the timed region
     if ex is not None:
         last = ex.flush()
         if last is not None:
@@ -706,7 +711,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
                                    f"4-layer Mistral event gate, synthetic 336x336 30 fps stream ({n_pool}-frame pool = {n_pool / 30:.1f} s, "
                                    f"{a.steps * B} frames timed), {B} frames per step, one stream per GPU, random-init weights of the true shapes",
-                       "frames_per_step": B, "streams_per_gpu": 1, "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
+                       "frames_per_step": B, "streams_per_gpu": 1, "pipelined_gate_pass": not a.no_pipeline, "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,

@@ -272,6 +272,13 @@ void sm_stream_close(sm_stream* s);
 int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream);
 /* convenience = sm_vit_encode + sm_stream_push_pooled (the per-frame "gate step") */
 int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream);
+/* pipelined form: the tower runs on `stream`, the connector + gate pass on the stream's own side HIP stream (behind the tower,
+ * behind the previous call's pass), so `stream` can start the next call's tower at once and the memory-bound pass fills the
+ * gaps of the next tower's MFMA kernels (~4 % more frames/s at 28 frames per call).  Same results.  logits / decisions are
+ * complete for work enqueued on `stream` after sm_stream_join(s, stream); every other sm_stream_* / sm_llm_* / sm_group_* call
+ * on the stream joins by itself. */
+int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream);
+int sm_stream_join(sm_stream* s, void* stream);
 int sm_stream_num_frames(sm_stream* s);
 const float* sm_stream_tokens(sm_stream* s);             /* device fp32 [num_frames][d_model]          */
 int sm_stream_kv_len(sm_stream* s);

@@ -90,6 +90,8 @@ SIGNATURES = {
     "sm_stream_close": (None, [vp]),
     "sm_stream_push_pooled": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_stream_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_stream_push_frames_pipelined": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_stream_join": (i32, [vp, vp]),
     "sm_stream_num_frames": (i32, [vp]),
     "sm_stream_tokens": (vp, [vp]),
     "sm_stream_kv_len": (i32, [vp]),

@@ -546,7 +546,28 @@ struct sm_stream {
     std::vector<DevBuf> kc, vtc;
     DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok, attn_ws;
     int chunk = 0;
+    // pipelined perception (sm_stream_push_frames_pipelined): the connector + gate pass of call i runs on this stream's own
+    // side HIP stream while the caller's stream already runs the tower of call i+1
+    hipStream_t side = nullptr;
+    hipEvent_t ev_vit = nullptr, ev_pass[2] = {nullptr, nullptr};
+    DevBuf pooled_pp[2];
+    int flip = 0, last = -1;           // last: index of the event of the newest pass not yet joined by the caller's stream (-1: none)
+    ~sm_stream() {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (ev_vit) (void)hipEventDestroy(ev_vit);
+        for (auto e : ev_pass) if (e) (void)hipEventDestroy(e);
+    }
 };
+
+// every entry point that reads or writes a stream's state on the caller's HIP stream first orders that stream behind the
+// pipelined passes still running on the side stream (a no-op when none is pending)
+static int auto_join(sm_stream* s, void* stream) {
+    if (s && s->last >= 0) {
+        SM_HIP(hipStreamWaitEvent((hipStream_t)stream, s->ev_pass[s->last], 0));
+        s->last = -1;
+    }
+    return SM_OK;
+}
 
 extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_stream** out) {
     SM_REQUIRE(m && m->finalized && out && max_frames > 0, "sm_stream_open: bad args / model not finalized");
@@ -605,6 +626,7 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
 
 extern "C" int sm_stream_reset(sm_stream* s, void* stream) {
     SM_REQUIRE(s, "sm_stream_reset: null");
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     hipStream_t st = (hipStream_t)stream;
     SM_HIP(hipMemsetAsync(s->conv_state.p, 0, s->conv_state.bytes, st));
     SM_HIP(hipMemsetAsync(s->ssm_state.p, 0, s->ssm_state.bytes, st));
@@ -623,6 +645,7 @@ extern "C" int sm_stream_set_kv_len(sm_stream* s, int n) {
 extern "C" const float* sm_stream_logits(sm_stream* s) { return s ? s->lmlog.as<float>() : nullptr; }
 extern "C" int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, void* stream) {
     SM_REQUIRE(s && out && t0 >= 0 && n >= 0 && t0 + n <= s->T, "sm_stream_read_tokens: [%d, %d) outside [0, %d)", t0, t0 + n, s ? s->T : 0);
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     if (n == 0) return SM_OK;
     const int d = s->m->c.conn_d_model;
     SM_HIP(hipMemcpyAsync(out, s->tokens.as<float>() + (size_t)t0 * d, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -630,6 +653,7 @@ extern "C" int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, vo
 }
 extern "C" int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream) {
     SM_REQUIRE(s && src && t0 >= 0 && n > 0 && t0 <= s->T && t0 + n <= s->max_frames, "sm_stream_write_tokens: [%d, %d) not appendable (T=%d, cap=%d)", t0, t0 + n, s ? s->T : 0, s ? s->max_frames : 0);
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     const int d = s->m->c.conn_d_model;
     SM_HIP(hipMemcpyAsync(s->tokens.as<float>() + (size_t)t0 * d, src, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (t0 + n > s->T) s->T = t0 + n;
@@ -721,6 +745,7 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
 extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, float* logits, int32_t* decisions, void* stream) {
     SM_REQUIRE(s && pooled && M >= 1 && M <= 32, "sm_stream_push_pooled: M=%d outside [1,32]", M);
     SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_pooled: token store full (%d + %d > %d)", s->T, M, s->max_frames);
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     SmSegStates conv, ssm, tok;
     conv.p[0] = s->conv_state.as<float>(); ssm.p[0] = s->ssm_state.as<float>();
     tok.p[0] = s->tokens.as<float>() + (size_t)s->T * s->m->c.conn_d_model;
@@ -744,6 +769,57 @@ extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M,
         if (rc) return rc;
     }
     return SM_OK;
+}
+
+// Pipelined form of sm_stream_push_frames.  The tower of this call runs on the caller's stream; its connector + gate pass runs on
+// the stream's side HIP stream, ordered behind the tower by an event and behind the previous call's pass by stream order.  The
+// caller's stream is free to start the next call's tower at once: the weight-streaming pass (memory-bound, ~5 % of a 28-frame
+// step) then runs in the launch gaps and tails of the next tower's MFMA kernels.  Results are identical; `logits` / `decisions`
+// are complete for the caller's stream after sm_stream_join (every other sm_stream_* call joins by itself).
+extern "C" int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(s && frames && M >= 1 && M <= s->m->Bmax, "sm_stream_push_frames_pipelined: M=%d outside [1, max_frames_per_call=%d]", M, s ? s->m->Bmax : 0);
+    SM_REQUIRE(s->T + M <= s->max_frames, "sm_stream_push_frames_pipelined: token store full (%d + %d > %d)", s->T, M, s->max_frames);
+    sm_model* m = s->m;
+    hipStream_t st = (hipStream_t)stream;
+    if (!s->side) {
+        SM_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        SM_HIP(hipEventCreateWithFlags(&s->ev_vit, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            SM_HIP(hipEventCreateWithFlags(&s->ev_pass[i], hipEventDisableTiming));
+            int rc = s->pooled_pp[i].alloc((size_t)m->Bmax * m->c.conn_mm_hidden * 4);
+            if (rc) return rc;
+        }
+    }
+    const int f = s->flip;
+    // pooled_pp[f] was last read by the pass issued two calls ago: the tower must not overwrite it earlier
+    SM_HIP(hipStreamWaitEvent(st, s->ev_pass[f], 0));      // (an event that was never recorded counts as complete: no wait)
+    float* pooled = s->pooled_pp[f].as<float>();
+    int rc = sm_vit_encode(m, frames, M, pooled, nullptr, nullptr, stream);
+    if (rc) return rc;
+    SM_HIP(hipEventRecord(s->ev_vit, st));
+    SM_HIP(hipStreamWaitEvent(s->side, s->ev_vit, 0));
+    const int cap = m->c.weights_fp8 ? 16 : 32;
+    const int parts = cdiv(M, cap), per = cdiv(M, parts);
+    const int d = m->c.conn_d_model;
+    for (int i = 0; i < M; i += per) {
+        const int n = M - i < per ? M - i : per;
+        SmSegStates conv, ssm, tok;
+        conv.p[0] = s->conv_state.as<float>(); ssm.p[0] = s->ssm_state.as<float>();
+        tok.p[0] = s->tokens.as<float>() + (size_t)s->T * d;
+        rc = conn_gate_pass(m, s->w, pooled + (size_t)i * m->c.conn_mm_hidden, 1, n, conv, ssm, tok, logits ? logits + 2 * i : nullptr,
+                            decisions ? decisions + i : nullptr, (void*)s->side);
+        if (rc) return rc;
+        s->T += n;
+    }
+    SM_HIP(hipEventRecord(s->ev_pass[f], s->side));
+    s->last = f;
+    s->flip ^= 1;
+    return SM_OK;
+}
+
+extern "C" int sm_stream_join(sm_stream* s, void* stream) {
+    SM_REQUIRE(s, "sm_stream_join: null");
+    return auto_join(s, stream);
 }
 
 // ---- stream group: one tick of S streams through ONE ViT batch and ONE connector + gate weight pass per <= 32 rows.
@@ -784,6 +860,7 @@ extern "C" int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int
     for (int i = 0; i < S; ++i)
         SM_REQUIRE(g->streams[i]->T + F <= g->streams[i]->max_frames, "sm_group_push_pooled: token store of stream %d full (%d + %d > %d)", i,
                    g->streams[i]->T, F, g->streams[i]->max_frames);
+    for (int i = 0; i < S; ++i) { int jrc = auto_join(g->streams[i], stream); if (jrc) return jrc; }
     const int per = cap / F;                       // whole streams per weight pass
     for (int s0 = 0; s0 < S; s0 += per) {
         const int n = S - s0 < per ? S - s0 : per;
@@ -881,6 +958,7 @@ static int llm_head(sm_stream* s, int row, void* stream) {
 extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* stream) {
     SM_REQUIRE(s && ids && n > 0 && s->m->c.llm_layers > 0, "sm_llm_prefill: bad args / perception-only model");
     SM_REQUIRE(s->kv_len + n <= s->max_seq, "sm_llm_prefill: context %d + %d exceeds max_seq %d", s->kv_len, n, s->max_seq);
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     sm_model* m = s->m;
     const int ld = m->c.llm_hidden;
     int rc, done = 0, last_rows = 0;
@@ -896,6 +974,7 @@ extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* str
 extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, float* logits, void* stream) {
     SM_REQUIRE(s && ids && logits && n > 0 && s->m->c.llm_layers > 0, "sm_llm_forward_logits: bad args / perception-only model");
     SM_REQUIRE(s->kv_len + n <= s->max_seq, "sm_llm_forward_logits: context %d + %d exceeds max_seq %d", s->kv_len, n, s->max_seq);
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     sm_model* m = s->m;
     const sm_config_t& c = m->c;
     const int ld = c.llm_hidden, V = c.llm_vocab;

@@ -217,6 +217,25 @@ class NativeStream:
         check(self.lib.sm_stream_push_frames(self.h, frames_u8.data_ptr(), M, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_stream_push_frames")
         return logits, dec
 
+    def push_frames_pipelined(self, frames_u8: torch.Tensor):
+        """push_frames with the connector + gate pass on the stream's side HIP stream (overlaps the next call's tower).  The
+        returned tensors are complete after `join()` (or any other call on this stream object)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        side = self.model.cfg.vit_image
+        if tuple(frames_u8.shape[1:]) != (side, side, 3):
+            raise ValueError(f"push_frames: frames must be [n, {side}, {side}, 3] uint8, got {tuple(frames_u8.shape)}")
+        M = frames_u8.shape[0]
+        logits = torch.empty(M, 2, dtype=torch.float32, device=self.dev)
+        dec = torch.empty(M, dtype=torch.int32, device=self.dev)
+        check(self.lib.sm_stream_push_frames_pipelined(self.h, frames_u8.data_ptr(), M, logits.data_ptr(), dec.data_ptr(), _stream()),
+              "sm_stream_push_frames_pipelined")
+        # the side stream is unknown to torch's caching allocator: keep the outputs (and the frames) alive until joined
+        self._inflight = getattr(self, "_inflight", [])[-4:] + [(logits, dec, frames_u8)]
+        return logits, dec
+
+    def join(self) -> None:
+        check(self.lib.sm_stream_join(self.h, _stream()), "sm_stream_join")
+
     def tokens(self, t0: int = 0, n: Optional[int] = None) -> torch.Tensor:
         n = self.num_frames - t0 if n is None else n
         out = torch.empty(n, self.model.cfg.conn_d_model, dtype=torch.float32, device=self.dev)

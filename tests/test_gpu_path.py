@@ -749,3 +749,32 @@ def test_two_streams_of_one_model_on_two_hip_streams(tiny):
         torch.cuda.synchronize()
         for k in range(2):
             assert torch.equal(torch.cat(out[k]).cpu(), ref[k])
+
+
+def test_pipelined_push_frames_equals_plain(tiny, tiny_tokenizer):
+    """sm_stream_push_frames_pipelined (connector + gate pass on the stream's side HIP stream, overlapping the next call's tower)
+    gives bit-identical logits / decisions / tokens / Mamba state evolution to the plain call, over many back-to-back calls, and
+    the calls that follow on the stream (token reads, LLM prefill) see the finished passes without an explicit join."""
+    m, *_ = tiny
+    frames = O.synthetic_frames(36, TV.image_size, seed=77, scene_len=4).cuda()
+    a, b = m.open_stream(max_frames=64, max_seq=128), m.open_stream(max_frames=64, max_seq=128)
+    ref = [a.push_frames(frames[i:i + 6].contiguous()) for i in range(0, 36, 6)]
+    got = [b.push_frames_pipelined(frames[i:i + 6].contiguous()) for i in range(0, 36, 6)]     # issued back to back, no sync in between
+    assert b.num_frames == 36
+    tok_b = b.tokens()                                        # auto-joins
+    b.join()
+    for (lr, dr), (lg, dg) in zip(ref, got):
+        assert torch.equal(lr, lg) and torch.equal(dr, dg)
+    assert torch.equal(tok_b, a.tokens())
+    # mixed use: a plain call after pipelined ones, then the LLM on the spliced tokens
+    l1, _ = a.push_frames(frames[:2].contiguous())
+    l2, _ = b.push_frames(frames[:2].contiguous())
+    assert torch.equal(l1, l2)
+    ids = torch.cat([torch.tensor([1, 5]), -(torch.arange(38) + 1), torch.tensor([9])]).to(torch.int32).cuda()
+    a.prefill(ids); b.push_frames_pipelined(frames[2:4].contiguous()); b.set_kv_len(0)
+    b2 = m.open_stream(max_frames=64, max_seq=128)
+    for i in range(0, 36, 6):
+        b2.push_frames_pipelined(frames[i:i + 6].contiguous())
+    b2.push_frames_pipelined(frames[:2].contiguous())
+    b2.prefill(ids)                                           # no join: prefill orders itself behind the pending passes
+    assert torch.equal(a.logits()[0], b2.logits()[0])
