@@ -103,8 +103,8 @@ class StreamingSession:
         self.prompt += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
         return StreamEvent(upto_frame, text, new_ids)
 
-    def feed(self, frames: torch.Tensor) -> List[StreamEvent]:
-        """frames: u8 [n,H,W,3] on the HOST (n <= batch_frames).  Returns the replies fired by these frames, in order."""
+    def _issue(self, frames: torch.Tensor, pipelined: bool):
+        """stage one batch and enqueue its perception; returns what `_collect` needs (no host sync here)"""
         if self.prompt is None:
             self.prompt = self._initial_prompt()
         dev_frames, ready, slot = self.ring.push(frames)
@@ -113,9 +113,17 @@ class StreamingSession:
         if self.src_hw != (self.image, self.image):
             from . import native
             dev_frames = native.ingest_frames(dev_frames.contiguous(), self.pad_square, self.image, self.pad_rgb)
-        logits, dec = self.model.stream.push_frames(dev_frames)
+        push = self.model.stream.push_frames_pipelined if pipelined else self.model.stream.push_frames
+        logits, dec = push(dev_frames)
         self.ring.release(slot)
-        dec_host = dec.cpu().tolist()                   # the one host sync of this batch
+        return logits, dec, base, pipelined
+
+    def _collect(self, handle) -> List[StreamEvent]:
+        """the one host sync of a batch (its decisions), then the replies its frames fired, in order"""
+        logits, dec, base, pipelined = handle
+        if pipelined:
+            self.model.stream.join()                    # the caller's stream waits for that batch's side-stream pass
+        dec_host = dec.cpu().tolist()
         if self.keep_logits:
             self.stats.gate_logits.append(logits.cpu())
         self.stats.frames += len(dec_host)
@@ -126,13 +134,33 @@ class StreamingSession:
                 events.append(self._reply(base + j + 1))
         return events
 
+    def feed(self, frames: torch.Tensor) -> List[StreamEvent]:
+        """frames: u8 [n,H,W,3] on the HOST (n <= batch_frames).  Returns the replies fired by these frames, in order."""
+        return self._collect(self._issue(frames, pipelined=False))
+
     def run(self, frames: Iterable[torch.Tensor]) -> Iterator[StreamEvent]:
-        """frames: iterable of u8 [H,W,3] host tensors (the decoded stream).  Yields replies as they fire."""
+        """frames: iterable of u8 [H,W,3] host tensors (the decoded stream).  Yields replies as they fire.
+
+        One batch of look-ahead: batch i+1 is staged and its tower enqueued BEFORE the decisions of batch i are read back, and
+        the connector + gate pass of every batch runs on the stream's side HIP stream (sm_stream_push_frames_pipelined) -- the GPU
+        never idles on the host's decision read, and the memory-bound pass overlaps the next tower.  A reply for a fire in batch i
+        is generated from the tokens [0, t] of its own frame: frames perceived ahead change nothing but latency."""
         buf: List[torch.Tensor] = []
-        for f in frames:
-            buf.append(f)
-            if len(buf) == self.batch:
-                yield from self.feed(torch.stack(buf))
-                buf = []
-        if buf:
-            yield from self.feed(torch.stack(buf))
+        pending = None
+
+        def batches():
+            nonlocal buf
+            for f in frames:
+                buf.append(f)
+                if len(buf) == self.batch:
+                    yield torch.stack(buf)
+                    buf = []
+            if buf:
+                yield torch.stack(buf)
+        for b in batches():
+            handle = self._issue(b, pipelined=True)
+            if pending is not None:
+                yield from self._collect(pending)
+            pending = handle
+        if pending is not None:
+            yield from self._collect(pending)
