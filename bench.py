@@ -593,6 +593,34 @@ def main():
             s16.close(); m16.close()
         except Exception as e:
             fp16_tower_leg = {"error": repr(e)[:200]}
+    host_leg = None
+    if world == 1 and not a.no_aux:
+        # frames handed over as HOST buffers (what the reference's boundary does: `.half().cuda()` per frame,
+        # eval/video_score_stream_demo.py:86): pinned ring -> async H2D on a copy stream -> the same step.  338 688 B per frame.
+        try:
+            from streammind_amd.stream import FrameRing
+            ring = FrameRing(3, B, 336, 336, torch.device("cuda", local))
+            host_frames = frames[:4 * B].cpu()
+            sh = model.open_stream(max_frames=B * 24, max_seq=64)
+
+            def hstep(i):
+                dev, ready, slot = ring.push(host_frames[(i % 4) * B:(i % 4 + 1) * B])
+                torch.cuda.current_stream().wait_event(ready)
+                sh.push_frames(dev)
+                ring.release(slot)
+            for i in range(3):
+                hstep(i)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for i in range(16):
+                hstep(i)
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - t4) / 16
+            host_leg = {"frames_per_s": round(B / d4, 1), "ms_per_step": round(d4 * 1e3, 3), "h2d_bytes_per_frame": 336 * 336 * 3,
+                        "note": "PCIe-inclusive: u8 frames start in pinned host memory every step (3-slot ring, copy stream); never the headline value"}
+            sh.close()
+        except Exception as e:
+            host_leg = {"error": repr(e)[:200]}
     pipe_leg = None
     if world == 1 and not a.no_aux and not a.pipeline:
         try:       # the same steps with the connector + gate pass of step i on a side stream under the tower of step i+1
@@ -739,6 +767,7 @@ def main():
             "per_call_latency": lat_leg,
             "streams_x1": streams_leg,
             "fp16_tower": fp16_tower_leg,
+            "host_staged_frames": host_leg,
             "pipelined": pipe_leg,
             "two_streams_per_gpu": two_leg,
             "rooflines_other": more_roof or None,

@@ -778,3 +778,24 @@ def test_pipelined_push_frames_equals_plain(tiny, tiny_tokenizer):
     b2.push_frames_pipelined(frames[:2].contiguous())
     b2.prefill(ids)                                           # no join: prefill orders itself behind the pending passes
     assert torch.equal(a.logits()[0], b2.logits()[0])
+
+
+def test_fp8_gate_full_size_vs_its_oracle_definition():
+    """BASELINE configs[4] at FULL size: the 872 M-parameter gate with fp8 (e4m3, per-row scale) weights, 28 rows per pass (two
+    16-row fp8 passes), against the oracle run on the dequantised weights -- the mode's own definition: gate logits 1e-3,
+    decisions equal outside a 2e-3 margin; and the quantisation itself moves the logits by more than that (it is a different
+    model, reported separately by the bench)."""
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate()
+    Wc = conn_gate_weights(ccfg, gcfg, 102)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), Wc, weights_fp8=True, max_frames_per_call=28)
+    Wc8 = {k: (O.fp8_quantize_rows(v)[0] if (k.startswith("cls_net.") and v.dim() == 2 and "embed_tokens" not in k) else v) for k, v in Wc.items()}
+    pooled = torch.randn(28, 1024, generator=torch.Generator().manual_seed(8)) * 3
+    s = m.open_stream(max_frames=32, max_seq=64)
+    lg = torch.cat([s.push_pooled(pooled[i:i + 14].cuda().contiguous())[0] for i in (0, 14)]).cpu()
+    tok = O.connector_scan(pooled, Wc8, ccfg)
+    ref = O.gate_logits_shortcut(tok, Wc8, gcfg)
+    assert maxdiff(lg, ref) < 1e-3
+    assert maxdiff(s.tokens(), tok) < 1e-4 * max(1.0, tok.abs().max().item())
+    ref_bf16 = O.gate_logits_shortcut(tok, Wc, gcfg)
+    assert maxdiff(lg, ref_bf16) > 2e-3
