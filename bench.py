@@ -154,6 +154,38 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
                          "bytes_per_token": weight_bytes + kv_bytes}}
 
 
+def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32), n_ctx=328, n_new=48):
+    """Batched greedy decode across streams (sm_group_llm_decode): S streams, each with its OWN KV cache and a 328-token context,
+    advance together -- one pass over the 14.2 GB of Mistral-7B weights per step for all of them.  Aggregate tokens/s; HBM
+    roofline per step = weights once + every stream's KV."""
+    d = cfg.conn_d_model
+    g = torch.Generator(device="cuda").manual_seed(17)
+    out = {"context_tokens": n_ctx, "new_tokens_per_stream": n_new, "streams": [], "tokens_per_s": [], "ms_per_step": [], "hbm_frac": []}
+    weight_bytes = 2.0 * (cfg.llm_layers * (d * d * 2 + 2 * d * (cfg.llm_kv_heads * (d // cfg.llm_heads)) + 3 * d * cfg.llm_mlp) + cfg.llm_vocab * d)
+    streams = []
+    for S in sizes:
+        while len(streams) < S:
+            st = model.open_stream(max_frames=8, max_seq=1024)
+            st.prefill(torch.randint(3, cfg.llm_vocab, (n_ctx,), generator=g, device="cuda", dtype=torch.int32))
+            streams.append(st)
+        for st in streams:
+            st.set_kv_len(n_ctx)                      # every size starts from the same context length
+        grp = model.open_group(streams[:S])
+        grp.decode(8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        grp.decode(n_new)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_new
+        kv_bytes = S * 2.0 * 2 * cfg.llm_layers * cfg.llm_kv_heads * (d // cfg.llm_heads) * (n_ctx + 8 + n_new // 2)
+        out["streams"].append(S); out["tokens_per_s"].append(round(S / dt, 1)); out["ms_per_step"].append(round(dt * 1e3, 3))
+        out["hbm_frac"].append(round((weight_bytes + kv_bytes) / dt / 1e9 / HBM_PEAK_GBS, 4))
+        grp.close()
+    for st in streams:
+        st.close()
+    return out
+
+
 def teacher_forced_leg(model, stream, cfg, n_text=128, n_frames=384):
     """ONE teacher-forced Mistral-7B forward over a spliced context (text + per-frame tokens) with the
     logits of every position (sm_llm_forward_logits) and the shifted cross-entropy (sm_cross_entropy) -- the unit of the
@@ -553,6 +585,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
+    gdec_leg = None
+    if not a.no_decode and world == 1 and not a.no_aux:
+        try:
+            gdec_leg = group_decode_leg(model, cfg)
+        except Exception as e:
+            gdec_leg = {"error": repr(e)[:200]}
     tf_leg = None
     if not a.no_decode and world == 1 and not a.no_aux:
         try:
@@ -761,6 +799,7 @@ def main():
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,
+            "group_decode": gdec_leg,
             "end_to_end": e2e,
             "teacher_forced_eval": tf_leg,
             "ingest_frontend": ing_leg,

@@ -110,6 +110,7 @@ SIGNATURES = {
     "sm_group_size": (i32, [vp]),
     "sm_group_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_group_push_pooled": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_group_llm_decode": (i32, [vp, C.POINTER(C.c_int32), i32, vp, vp]),
     "sm_prof_enable": (i32, [i32]),
     "sm_prof_reset": (i32, []),
     "sm_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f32)]),

@@ -30,6 +30,10 @@ struct AttnP {
     float* part_o;                           // [splits][H][nq][DH] fp32
     float* part_ml;                          // [splits][H][nq][2]  (running max in scaled-log2 domain source units, l)
     int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
+    // batched decode (GROUPQ, blockIdx.x = stream): per-stream caches and key counts; nseg == 0: single stream (k / vt / nk above)
+    int nseg;
+    long part_bs, ml_bs;                     // per-stream strides of part_o / part_ml (floats)
+    SmDecodeSeg seg;
 };
 
 template <int DH, bool GROUPQ = false, bool VROW = false, bool CAUSAL = false>
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // measured without it, each of the 5 q-tiles of a ViT head fetched its K/V through a different L2 (FETCH_SIZE 5x).
     int h, b, qtile;
     if (GROUPQ) {
-        h = blockIdx.y; b = 0; qtile = 0;
+        h = blockIdx.y; b = blockIdx.x; qtile = 0;          // b: stream index of a batched decode (grid.x == 1 otherwise)
     } else {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const int grp = (j / p.nqt) * 8 + xcd;
@@ -62,13 +66,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     }
     const int kvh = h / (p.H / p.KV);
     const int q0 = qtile * 128 + wave * 32;
+    const bool segm = GROUPQ && p.nseg > 0;
+    const int nk = segm ? p.seg.pos[b] + 1 : p.nk;
 
     bf16x8 qf[2][KSQ];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         int qr = q0 + qb * 16 + i;
         if (qr >= p.nq) qr = p.nq - 1;
-        const bf16_t* src = GROUPQ ? p.q + ((long)h * p.nq + qr) * DH + g * 8
+        const bf16_t* src = GROUPQ ? p.q + b * p.q_bs + ((long)h * p.nq + qr) * DH + g * 8
                                    : p.q + b * p.q_bs + (long)qr * p.q_rs + h * DH + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks) qf[qb][ks] = *(const bf16x8*)(src + ks * 32);
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
     const bool active = q0 < p.nq;
 
-    int k_end = p.nk, k_begin = 0;
+    int k_end = nk, k_begin = 0;
     if (CAUSAL) {
         int last = p.pos0 + min(qtile * 128 + 127, p.nq - 1) + 1;
         k_end = min(k_end, last);
@@ -96,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         k_begin = blockIdx.z * p.split_len;
         k_end = min(k_end, k_begin + p.split_len);
     }
-    const bf16_t* kbase = p.k + b * p.k_bs + kvh * DH;
-    const bf16_t* vbase = VROW ? nullptr : p.vt + b * p.vt_bs + kvh * p.vt_hs;
+    const bf16_t* kbase = (segm ? (const bf16_t*)p.seg.kc[b] : p.k + b * p.k_bs) + kvh * DH;
+    const bf16_t* vbase = VROW ? nullptr : (segm ? (const bf16_t*)p.seg.vtc[b] : p.vt + b * p.vt_bs) + kvh * p.vt_hs;
 
     // K / V^T tiles go HBM/L2 -> registers -> LDS: the loads of tile t+1 are issued before tile t is multiplied (their
     // latency hides under the MFMAs) and written to the OTHER LDS buffer at the top of the next iteration, so there is
@@ -131,15 +137,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     }
     const long kstep = 64 * p.k_rs, vstep = VROW ? 64 * p.v_rs : 64;
     auto fetch = [&](int kt0) {
-        if (kt0 + 64 <= p.nk || !VROW) {
-            if (kt0 + 64 <= p.nk) {
+        if (kt0 + 64 <= nk || !VROW) {
+            if (kt0 + 64 <= nk) {
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) kreg[j] = *(const u32x4*)kptr[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < KJ; ++j) {
                     const int key = (tid + 256 * j) / KCH;
-                    kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (p.nk - 1), 0) * p.k_rs);
+                    kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (nk - 1), 0) * p.k_rs);
                 }
             }
 #pragma unroll
@@ -148,13 +154,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const int key = (tid + 256 * j) / KCH;
-                kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (p.nk - 1), 0) * p.k_rs);
+                kreg[j] = *(const u32x4*)(kptr[j] - (long)max(kt0 + key - (nk - 1), 0) * p.k_rs);
             }
 #pragma unroll
             for (int j = 0; j < VPJ; ++j) {
                 const int kp = (tid + 256 * j) & 31;
-                vreg[2 * j] = *(const u32x4*)(vptr[2 * j] - (long)max(kt0 + 2 * kp - (p.nk - 1), 0) * p.v_rs);
-                vreg[2 * j + 1] = *(const u32x4*)(vptr[2 * j + 1] - (long)max(kt0 + 2 * kp + 1 - (p.nk - 1), 0) * p.v_rs);
+                vreg[2 * j] = *(const u32x4*)(vptr[2 * j] - (long)max(kt0 + 2 * kp - (nk - 1), 0) * p.v_rs);
+                vreg[2 * j + 1] = *(const u32x4*)(vptr[2 * j + 1] - (long)max(kt0 + 2 * kp + 1 - (nk - 1), 0) * p.v_rs);
             }
         }
 #pragma unroll
@@ -229,11 +235,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 s[1][kb][f] = a1;
             }
         // ---- mask + online softmax (lane-local query = lane & 15)
-        if (CAUSAL || kt0 + 64 > p.nk) {
+        if (CAUSAL || kt0 + 64 > nk) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int qpos = p.pos0 + q0 + qb * 16 + i;
-                const int lim = CAUSAL ? min(p.nk - 1, qpos) : p.nk - 1;       // last visible key of this lane's query
+                const int lim = CAUSAL ? min(nk - 1, qpos) : nk - 1;       // last visible key of this lane's query
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -315,10 +321,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         if (p.split_len) {
             if (qr < p.nq) {
                 const size_t row = ((size_t)blockIdx.z * p.H + h) * p.nq + qr;
-                float* dst = p.part_o + row * DH + g * 4;
+                float* dst = p.part_o + (segm ? b * p.part_bs : 0) + row * DH + g * 4;
 #pragma unroll
                 for (int df = 0; df < DF; ++df) *(f32x4*)(dst + df * 16) = o[qb][df];
-                if (g == 0) { p.part_ml[row * 2] = m_run[qb]; p.part_ml[row * 2 + 1] = l; }
+                if (g == 0) { float* ml = p.part_ml + (segm ? b * p.ml_bs : 0); ml[row * 2] = m_run[qb]; ml[row * 2 + 1] = l; }
             }
             continue;
         }
@@ -559,8 +565,10 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 // merge the key splits of flash-decoding: out[h][d] = sum_p w_p o_p / sum_p w_p l_p, w_p = exp2((m_p - M) c).
 // One block per head; the (m, l) pairs of all splits are read with one load per lane, then each lane owns two d's.
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                          int splits, int rows, int dh, float c, bf16_t* __restrict__ out) {
+                                                          int splits, int rows, int dh, float c, bf16_t* __restrict__ out,
+                                                          long part_bs, long ml_bs) {
     const int row = blockIdx.x, lane = threadIdx.x;
+    part_o += blockIdx.y * part_bs; part_ml += blockIdx.y * ml_bs; out += (size_t)blockIdx.y * rows * dh;     // blockIdx.y: stream of a batched decode
     float m = -INFINITY, l = 0.f;
     if (lane < splits) {
         m = part_ml[((size_t)lane * rows + row) * 2];
@@ -612,6 +620,7 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     SM_REQUIRE(qkv && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
     SM_REQUIRE(!vt || (vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64), "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
     AttnP p;
+    p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     const long ld = 3L * H * dh;
     p.q = (const bf16_t*)qkv; p.q_bs = (long)S * ld; p.q_rs = ld;
     p.k = (const bf16_t*)qkv + (long)H * dh; p.k_bs = (long)S * ld; p.k_rs = ld;
@@ -629,6 +638,7 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
     SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
     AttnP p;
+    p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = (long)H * dh;
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
@@ -654,6 +664,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
     splits = cdiv(nk, split_len);
     AttnP p;
+    p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
@@ -675,7 +686,50 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
         else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
         SM_LAUNCH_CHECK();
     }
-    attn_combine_kernel<<<H, 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx);
+    attn_combine_kernel<<<H, 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, 0, 0);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// single-token decode attention of S streams in ONE launch pair: stream t's query row block q[t] (H heads) against ITS cache
+// [0, pos[t]]; the key range is cut into the same number of splits for every stream (sized for the longest context; a split
+// that lies beyond a shorter stream's cache contributes weight 0 to the merge)
+int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
+                                int splits_max, void* ctx, void* stream) {
+    SM_REQUIRE(q && ctx && workspace && S > 0 && S <= SM_MAX_SEG, "sm_llm_decode_attention_seg: bad args");
+    SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && (dh == 64 || dh == 128), "sm_llm_decode_attention_seg: dims");
+    const int rep = H / KV;
+    int nk = 1;
+    for (int t = 0; t < S; ++t) {
+        SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg: stream %d: bad position / cache", t);
+        nk = seg.pos[t] + 1 > nk ? seg.pos[t] + 1 : nk;
+    }
+    int splits = cdiv(nk, 64);
+    if (splits > splits_max) splits = splits_max;
+    const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
+    splits = cdiv(nk, split_len);
+    AttnP p;
+    p.q = (const bf16_t*)q; p.q_bs = (long)H * dh; p.q_rs = dh;
+    p.k = nullptr; p.k_bs = 0; p.k_rs = (long)KV * dh;
+    p.vt = nullptr; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
+    p.v = nullptr; p.v_bs = 0; p.v_rs = 0;
+    p.o = nullptr; p.o_bs = 0; p.o_rs = 0;
+    p.nq = rep; p.nk = nk; p.H = KV; p.KV = KV; p.causal = 0; p.pos0 = 0;
+    p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    p.split_len = split_len;
+    p.nseg = S; p.seg = seg;
+    p.part_bs = (long)splits_max * H * (dh + 2); p.ml_bs = p.part_bs;
+    p.part_o = workspace; p.part_ml = workspace + (size_t)splits_max * H * dh;
+    p.nqt = 1; p.nbatch = 1;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        SmProfScope prof(SM_PROF_ATTN, st);
+        dim3 grid(S, KV, splits);
+        if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
+        else attn_kernel<128, true><<<grid, 256, 0, st>>>(p);
+        SM_LAUNCH_CHECK();
+    }
+    attn_combine_kernel<<<dim3(H, S), 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, p.part_bs, p.ml_bs);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

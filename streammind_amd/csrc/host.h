@@ -39,6 +39,17 @@ int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_db
                           void* stream);
 int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& dst, void* stream);
 
+// batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
+struct SmDecodeSeg { void* kc[SM_MAX_SEG]; void* vtc[SM_MAX_SEG]; int pos[SM_MAX_SEG]; };
+struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
+int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
+                          const SmDecodeSeg& seg, int S_max, void* stream);                                       // vecops.hip
+int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
+                                int splits_max, void* ctx_bf16, void* stream);                                    // attention.hip
+int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
+                        void* stream);
+int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);
+
 // Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that
 // class is bracketed by HIP events recorded ON THE LAUNCH STREAM; sm_prof_read() synchronises and sums.
 enum { SM_PROF_GEMM = 0, SM_PROF_SKINNY = 1, SM_PROF_ATTN = 2, SM_PROF_NCLS = 3 };

@@ -831,6 +831,9 @@ struct sm_stream_group {
     sm_model* m;
     std::vector<sm_stream*> streams;
     ConnScratch w;
+    // batched decode scratch (rows = streams), allocated by the first sm_group_llm_decode
+    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
+    bool d_ready = false;
 };
 
 extern "C" int sm_group_create(sm_stream** streams, int S, sm_stream_group** out) {
@@ -1016,5 +1019,85 @@ extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* 
         if ((rc = llm_layers(s, 1, stream))) return rc;
         if ((rc = llm_head(s, 0, stream))) return rc;
     }
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batched decode
+// n_steps greedy steps of the ACTIVE streams of a group at once: the weight-streaming products run with one row per stream, so
+// the 14.2 GB of Mistral-7B weights are read once per step for all of them (batch-1 decode is HBM-bound: S streams decode at
+// nearly S times the aggregate tokens/s until the GEMVs turn compute-bound).  Each stream keeps its own KV cache, position and
+// pending token; RoPE / append, the flash-decoding attention + merge, the token gather and the arg-max run once per step over
+// all streams (per-stream pointers by value).  The reference decodes one stream per model object (HF generate, batch 1:
+// videollama2_mistral.py:426-431); per stream the arithmetic is that of sm_llm_decode (same bf16 rounding points; the RMSNorm
+// runs as its own launch here, and the fp32 summation order of the skinny products depends on the row count).
+extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_host, int n_steps, int32_t* out_ids, void* stream) {
+    SM_REQUIRE(g && out_ids && n_steps > 0 && g->m->c.llm_layers > 0, "sm_group_llm_decode: bad args / perception-only model");
+    sm_model* m = g->m;
+    const sm_config_t& c = m->c;
+    std::vector<sm_stream*> act;
+    std::vector<int> idx;
+    for (size_t i = 0; i < g->streams.size(); ++i)
+        if (!active_host || active_host[i]) { act.push_back(g->streams[i]); idx.push_back((int)i); }
+    const int S = (int)act.size();
+    SM_REQUIRE(S >= 1, "sm_group_llm_decode: no active stream");
+    SM_REQUIRE(S <= (c.weights_fp8 ? 16 : SM_MAX_SEG), "sm_group_llm_decode: %d active streams exceed one weight pass", S);
+    const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh, V = c.llm_vocab;
+    int S_max = act[0]->max_seq;
+    for (sm_stream* s : act) {
+        SM_REQUIRE(s->max_seq == S_max, "sm_group_llm_decode: the streams of a batched decode need equal max_seq (%d vs %d)", s->max_seq, S_max);
+        SM_REQUIRE(s->kv_len >= 1 && s->kv_len + n_steps <= s->max_seq, "sm_group_llm_decode: a stream has no context or would exceed max_seq (%d + %d > %d)", s->kv_len, n_steps, s->max_seq);
+        int jrc = auto_join(s, stream); if (jrc) return jrc;
+    }
+    int rc = 0;
+    if (!g->d_ready) {
+        const size_t R = SM_MAX_SEG;
+#define A(buf, bytes) if (!rc) rc = g->buf.alloc(bytes)
+        A(d_emb, R * ld * 4); A(d_xnb, R * ld * 2); A(d_qkvf, R * (qn + 2 * kn) * 4); A(d_qb, R * qn * 2); A(d_ctxb, R * qn * 2);
+        A(d_actb, R * c.llm_mlp * 2); A(d_log, R * V * 4); A(d_ws, R * SM_DECODE_SPLITS * H * (dh + 2) * 4);
+#undef A
+        if (rc) return rc;
+        g->d_ready = true;
+    }
+    float* x = g->d_emb.as<float>();
+    SmTokPtrs tok, rows;
+    for (int t = 0; t < S; ++t) { tok.p[t] = act[t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[t] * n_steps; }
+    for (int j = 0; j < n_steps; ++j) {
+        // emit the pending token of every stream (out_ids[stream][j], rows of inactive streams untouched) and feed it back
+        if ((rc = sm_embed_tokens_seg(tok, S, m->R.embed->buf.p, ld, x, rows, j, stream))) return rc;
+        for (int l = 0; l < c.llm_layers; ++l) {
+            const sm_model::LayerW& w = m->R.llm[l];
+            if ((rc = sm_norm(x, S, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+            {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
+                a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
+                if ((rc = sm_linear(&a, stream))) return rc; }
+            SmDecodeSeg seg;
+            for (int t = 0; t < S; ++t) { seg.kc[t] = act[t]->kc[l].p; seg.vtc[t] = act[t]->vtc[l].p; seg.pos[t] = act[t]->kv_len; }
+            if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, seg, S_max, stream))) return rc;
+            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, stream))) return rc;
+            {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
+                a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+                if ((rc = sm_linear(&a, stream))) return rc; }
+            if ((rc = sm_norm(x, S, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+            {   const Slot& gu = *w.gu;
+                sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
+                a.N = c.llm_mlp;
+                if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
+                else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
+                a.out_bf16 = g->d_actb.p; a.ldo_bf16 = c.llm_mlp;
+                if ((rc = sm_linear(&a, stream))) return rc; }
+            {   sm_linear_t a = lin(m, *w.down, g->d_actb.p, SM_X_BF16, S, c.llm_mlp);
+                a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+                if ((rc = sm_linear(&a, stream))) return rc; }
+        }
+        for (sm_stream* s : act) s->kv_len += 1;
+        if ((rc = sm_norm(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+        {   sm_linear_t a = lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
+            a.out_f32 = g->d_log.as<float>(); a.ldo = V;
+            if ((rc = sm_linear(&a, stream))) return rc; }
+        if ((rc = sm_argmax_rows_seg(g->d_log.as<float>(), S, V, V, tok, stream))) return rc;
+    }
+    // each stream's own "last logits" as sm_llm_decode would have left them
+    for (int t = 0; t < S; ++t)
+        SM_HIP(hipMemcpyAsync(act[t]->lmlog.p, g->d_log.as<float>() + (size_t)t * V, (size_t)V * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SM_OK;
 }

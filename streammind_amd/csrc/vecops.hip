@@ -570,6 +570,54 @@ extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int K
     return SM_OK;
 }
 
+// the same for S streams x one token each: row t = stream t at ITS position, appended to ITS caches
+__global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict__ qkv, int H, int KV, int dh,
+                                                         const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                         bf16_t* __restrict__ q, SmDecodeSeg seg, int S_max) {
+    const int t = blockIdx.x, hd = blockIdx.y;
+    const int pos = seg.pos[t];
+    bf16_t* __restrict__ kc = (bf16_t*)seg.kc[t];
+    bf16_t* __restrict__ vtc = (bf16_t*)seg.vtc[t];
+    const int half = dh >> 1;
+    const float* x = qkv + (size_t)t * (H + 2 * KV) * dh + (size_t)hd * dh;
+    if (hd < H + KV) {
+        for (int j = threadIdx.x; j < half; j += 64) {
+            const float c = cos_tab[(size_t)pos * half + j], s = sin_tab[(size_t)pos * half + j];
+            const float a = x[j], b = x[j + half];
+            const float o0 = a * c - b * s, o1 = b * c + a * s;
+            bf16_t* dst = hd < H ? q + ((size_t)t * H + hd) * dh : kc + ((size_t)pos * KV + (hd - H)) * dh;
+            dst[j] = (bf16_t)f2bf(o0);
+            dst[j + half] = (bf16_t)f2bf(o1);
+        }
+    } else {
+        const int kh = hd - H - KV;
+        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)f2bf(x[e]);
+    }
+}
+int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
+                          const SmDecodeSeg& seg, int S_max, void* stream) {
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_MAX_SEG, "sm_rope_kv_append_seg: bad args");
+    rope_kv_seg_kernel<<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// row t: emit stream t's pending token (out_rows.p[t][col]) and gather its embedding
+__global__ void embed_tokens_seg_kernel(SmTokPtrs tok, const bf16_t* __restrict__ table, int D, float* __restrict__ out,
+                                        SmTokPtrs out_rows, int col) {
+    const int t = blockIdx.x;
+    const int id = *tok.p[t];
+    if (threadIdx.x == 0) out_rows.p[t][col] = id;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[(size_t)t * D + c] = bf2f(table[(size_t)id * D + c]);
+}
+int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table, int D, float* out, const SmTokPtrs& out_rows, int col,
+                        void* stream) {
+    SM_REQUIRE(table && out && S > 0 && S <= SM_MAX_SEG, "sm_embed_tokens_seg: bad args");
+    embed_tokens_seg_kernel<<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 __global__ void swiglu_kernel(const float* __restrict__ gu, int M, int F, bf16_t* __restrict__ out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t tot = (size_t)M * (F >> 2);
@@ -657,6 +705,39 @@ extern "C" int sm_cross_entropy(const float* logits, int n, int V, int ld, const
                                 int32_t* argmax, void* stream) {
     SM_REQUIRE(logits && n > 0 && V > 0 && ld >= V && (nll || argmax) && (!nll || labels), "sm_cross_entropy: bad args");
     cross_entropy_kernel<<<n, 256, 0, (hipStream_t)stream>>>(logits, V, ld, labels, ignore_index, nll, argmax);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// one block per row: greedy token of row t into stream t's own pending-token word
+__global__ __launch_bounds__(1024) void argmax_rows_seg_kernel(const float* __restrict__ lg, int V, int ld, SmTokPtrs out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const float* row = lg + (size_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        float t = row[v];
+        if (t > best) { best = t; idx = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(idx, o, 64);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
+        *out.p[blockIdx.x] = idx;
+    }
+}
+int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream) {
+    SM_REQUIRE(logits && S > 0 && S <= SM_MAX_SEG && V > 0, "sm_argmax_rows_seg: bad args");
+    argmax_rows_seg_kernel<<<S, 1024, 0, (hipStream_t)stream>>>(logits, V, ld, out);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

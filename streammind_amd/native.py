@@ -324,6 +324,14 @@ class NativeStreamGroup:
         check(self.lib.sm_group_push_pooled(self.h, pooled.data_ptr(), F, logits.data_ptr(), dec.data_ptr(), _stream()), "sm_group_push_pooled")
         return logits, dec
 
+    def decode(self, n_steps: int, active: Optional[Sequence[bool]] = None) -> torch.Tensor:
+        """batched greedy decode of the (active) streams: int32 [S, n_steps]; rows of inactive streams are -1"""
+        S = len(self.streams)
+        out = torch.full((S, n_steps), -1, dtype=torch.int32, device=self.dev)
+        mask = None if active is None else (C.c_int32 * S)(*[int(bool(a)) for a in active])
+        check(self.lib.sm_group_llm_decode(self.h, mask, n_steps, out.data_ptr(), _stream()), "sm_group_llm_decode")
+        return out
+
     def close(self) -> None:
         if getattr(self, "h", None):
             self.lib.sm_group_destroy(self.h)

