@@ -280,10 +280,8 @@ class Videollama2MistralForCausalLM:
             lg = lg.masked_fill(torch.zeros_like(drop).scatter(0, idx, drop), float("-inf"))
         return torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).to(torch.int32)
 
-    @torch.no_grad()
-    def _generate_iter(self, seq: List[int], max_new_tokens: int, stopping_criteria=None, do_sample: bool = False,
-                       temperature: float = 1.0, top_p: float = 1.0, generator=None):
-        """yields the new ids in chunks (what a TextIteratorStreamer consumer sees); the concatenation is `_generate`'s list"""
+    def _begin_generate(self, seq: List[int], max_new_tokens: int) -> int:
+        """prefill `seq` behind the longest cached prefix (KV prefix reuse); returns the number of new tokens that still fit"""
         if len(seq) + max_new_tokens > self.max_seq:
             max_new_tokens = self.max_seq - len(seq)
             if max_new_tokens <= 0:
@@ -297,6 +295,31 @@ class Videollama2MistralForCausalLM:
         self.stream.set_kv_len(lcp)
         self.stream.prefill(torch.tensor(seq[lcp:], dtype=torch.int32, device=self.device))
         self._kv_ids = list(seq)
+        return max_new_tokens
+
+    def _accept_tokens(self, out: List[int], ids: Sequence[int], seq_len: int, stopping_criteria=None) -> Tuple[List[int], bool]:
+        """take the freshly decoded `ids` one by one up to the first stop (EOS / stopping criteria): the accepted ones join
+        `out`; the K/V of speculative tokens after a stop is dropped.  -> (accepted ids, stopped?)"""
+        fresh: List[int] = []
+        for tok in ids:
+            out.append(tok)
+            fresh.append(tok)
+            self._kv_ids.append(tok)
+            done = self.eos_token_id is not None and tok == self.eos_token_id
+            if not done and stopping_criteria is not None:
+                t = torch.tensor([out], dtype=torch.long)
+                done = all(c(t, None) for c in stopping_criteria)
+            if done:
+                self._kv_ids = self._kv_ids[:seq_len + len(out)]
+                self.stream.set_kv_len(len(self._kv_ids))
+                return fresh, True
+        return fresh, False
+
+    @torch.no_grad()
+    def _generate_iter(self, seq: List[int], max_new_tokens: int, stopping_criteria=None, do_sample: bool = False,
+                       temperature: float = 1.0, top_p: float = 1.0, generator=None):
+        """yields the new ids in chunks (what a TextIteratorStreamer consumer sees); the concatenation is `_generate`'s list"""
+        max_new_tokens = self._begin_generate(seq, max_new_tokens)
         out: List[int] = []
         done = False
         while not done and len(out) < max_new_tokens:
@@ -306,22 +329,7 @@ class Videollama2MistralForCausalLM:
             else:
                 n = min(self.decode_chunk, max_new_tokens - len(out))
             ids = self.stream.decode(n).cpu().tolist()          # n speculative greedy steps, one host sync
-            fresh: List[int] = []
-            for j, tok in enumerate(ids):
-                out.append(tok)
-                fresh.append(tok)
-                self._kv_ids.append(tok)
-                if self.eos_token_id is not None and tok == self.eos_token_id:
-                    done = True
-                elif stopping_criteria is not None:
-                    t = torch.tensor([out], dtype=torch.long)
-                    if all(c(t, None) for c in stopping_criteria):
-                        done = True
-                if done:
-                    # tokens after the stop were speculative: their K/V is dropped
-                    self._kv_ids = self._kv_ids[:len(seq) + len(out)]
-                    self.stream.set_kv_len(len(self._kv_ids))
-                    break
+            fresh, done = self._accept_tokens(out, ids, len(seq), stopping_criteria)
             yield fresh
 
     def _generate(self, seq: List[int], max_new_tokens: int, stopping_criteria=None, **sample_kw) -> List[int]:

@@ -164,3 +164,76 @@ class StreamingSession:
             pending = handle
         if pending is not None:
             yield from self._collect(pending)
+
+
+class MultiStreamSession:
+    """S concurrent video streams on one GPU, one frame per stream per tick -- the reference's per-frame loop
+    (eval/video_score_stream_demo.py:283-299) for MANY streams at once.
+
+        tick(frames[S]) : ONE ViT batch + one connector / gate weight pass for all streams (sm_group_push_frames), one device->host
+                          read of the S decisions; the streams whose gate fired get their replies TOGETHER: each prefills its own
+                          grown prompt (KV prefix reuse), then all of them decode in lock step through sm_group_llm_decode -- one
+                          pass over the LLM weights per step -- until each hits its own stop.
+
+    Per stream the results are those of its own `streammind_amd.infer` loop (same gate decisions, same prompt growth; the
+    reply ids are the greedy ids of the same logits up to fp32 summation order).  `models`: one
+    Videollama2MistralForCausalLM per stream, all built on the SAME NativeModel."""
+
+    def __init__(self, models, tokenizer, max_new_tokens: int = 1024, decode_chunk: int = 16):
+        assert len(models) >= 1 and all(m.native is models[0].native for m in models), "the streams must share one NativeModel"
+        self.models, self.tok = list(models), tokenizer
+        self.native = models[0].native
+        self.group = self.native.open_group([m.stream for m in models])
+        self.max_new, self.chunk = max_new_tokens, decode_chunk
+        self.prompts: List[Optional[str]] = [None] * len(models)
+        self.stats = StreamStats()
+
+    def _initial_prompt(self) -> str:
+        from .conversation import conv_templates
+        conv = conv_templates["mistral_instruct"].copy()
+        conv.append_message(conv.roles[0], "<video>\n")
+        conv.append_message(conv.roles[1], None)
+        return conv.get_prompt()
+
+    def tick(self, frames: torch.Tensor) -> List[Tuple[int, StreamEvent]]:
+        """frames: u8 [S, H, W, 3] (host or device), frame t of every stream.  -> [(stream index, reply event)] of this tick."""
+        S = len(self.models)
+        assert frames.shape[0] == S
+        logits, dec = self.group.push_frames(frames.to(self.native.device).contiguous())
+        dec_host = dec[:, 0].cpu().tolist()               # the one host sync of the tick
+        self.last_gate_logits = logits[:, 0]
+        self.stats.frames += S
+        fired = [i for i, d in enumerate(dec_host) if d == 1]
+        if not fired:
+            return []
+        self.stats.fires += len(fired)
+        # ---- every fired stream: its own splice + prefill (prompt growth and KV prefix reuse as in the single-stream loop)
+        state = {}
+        for i in fired:
+            m = self.models[i]
+            if self.prompts[i] is None:
+                self.prompts[i] = self._initial_prompt()
+            upto = m.stream.num_frames
+            m.interval_id_list.append(upto)
+            input_ids = tokenizer_MMODAL_token(self.prompts[i], self.tok, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
+            seq = m._expand(input_ids[0].tolist())
+            budget = m._begin_generate(seq, self.max_new)
+            state[i] = {"seq_len": len(seq), "budget": budget, "out": [], "crit": [KeywordsStoppingCriteria(["</s>"], self.tok, input_ids)],
+                        "upto": upto}
+        # ---- all of them decode together
+        active = set(fired)
+        while active:
+            n = min([self.chunk] + [state[i]["budget"] - len(state[i]["out"]) for i in active])
+            ids = self.group.decode(n, active=[i in active for i in range(S)]).cpu().tolist()
+            for i in list(active):
+                st = state[i]
+                _, done = self.models[i]._accept_tokens(st["out"], ids[i], st["seq_len"], st["crit"])
+                if done or len(st["out"]) >= st["budget"]:
+                    active.discard(i)
+        events = []
+        for i in fired:
+            st = state[i]
+            text = self.tok.batch_decode([st["out"]], skip_special_tokens=True)[0].strip()
+            self.prompts[i] += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
+            events.append((i, StreamEvent(st["upto"], text, st["out"])))
+        return events

@@ -844,3 +844,36 @@ def test_group_batched_decode_equals_solo_decode(tiny):
     from streammind_amd._lib import StreamMindHipError
     with pytest.raises(StreamMindHipError, match="no context"):
         m.open_group([m.open_stream(max_frames=8, max_seq=128)]).decode(2)
+
+
+def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenizer):
+    """MultiStreamSession (group perception + batched decode of the fired streams) against S independent reference-shaped
+    loops (`streammind_amd.infer`, one frame per call): per stream the same fire positions, the same prompt growth and the same
+    replies."""
+    import streammind_amd
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd.stream import MultiStreamSession
+    m, *_ = tiny
+    S, T = 4, 10
+    frames = torch.stack([O.synthetic_frames(T, TV.image_size, seed=500 + s, scene_len=3) for s in range(S)])     # [S, T, H, W, 3]
+    ref_events, ref_prompts = [], []
+    for s in range(S):
+        a = Videollama2MistralForCausalLM(m, max_frames=32, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
+        prompt, ev = None, []
+        for t in range(T):
+            text, prompt = streammind_amd.infer(a, frames[s, t:t + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=6)
+            if text is not None:
+                ev.append((t + 1, text))
+        ref_events.append(ev); ref_prompts.append(prompt)
+    models = [Videollama2MistralForCausalLM(m, max_frames=32, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id) for _ in range(S)]
+    sess = MultiStreamSession(models, tiny_tokenizer, max_new_tokens=6, decode_chunk=4)
+    got = [[] for _ in range(S)]
+    for t in range(T):
+        for i, e in sess.tick(frames[:, t]):
+            got[i].append((e.frame_index, e.text))
+    assert sum(len(g) for g in got) >= 3                          # the seeded gate fires on several streams
+    for s in range(S):
+        assert [g[0] for g in got[s]] == [r[0] for r in ref_events[s]]
+        assert got[s] == ref_events[s]
+        assert (sess.prompts[s] or O.initial_prompt()) == (ref_prompts[s] or O.initial_prompt()) or sess.prompts[s] is None
+    assert sess.stats.frames == S * T
