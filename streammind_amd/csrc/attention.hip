@@ -9,6 +9,7 @@
 //   so that the S^T accumulators of fragments f = 0,1 are, register for register, the 8 consecutive keys the
 //   PV MFMA wants in its B operand: no transpose, no LDS round trip, no cross-lane traffic for P.
 //   V is consumed as V^T ([d][keys]); the producers (QKV GEMM epilogue / KV-append kernel) write it that way.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "host.h"
@@ -650,6 +651,160 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
     return launch_attn(p, 1, dh, (hipStream_t)stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------ decode, one launch
+// Single-token decode attention with the key-split merge INSIDE the block (no partials in HBM, no merge kernel): one 8-wave
+// block per (stream, KV group); wave w owns the 32-key blocks w, w + 8, ... of the cache and every fragment it needs is a
+// direct 16-byte global load in MFMA operand layout (nothing is staged through LDS):
+//   S^T = K . Q^T : A = K rows (lane (i, g) reads dims ks*32 + g*8.. of key key0 + (i>>2)*8 + a*4 + (i&3): the row permutation
+//                   that makes the two accumulators a = 0, 1 the PV B operand register for register), B = the group's query heads;
+//   O^T = V^T . P^T: A = V^T rows (lane (i, g) reads positions key0 + g*8.. of dim df*16 + i: contiguous in the d-major cache).
+// All K and V loads of a round (two key blocks per wave = 512 keys per block) are issued before anything is consumed: one memory
+// round trip per round.  The 8 per-wave partial softmaxes meet in LDS (fp32, 16 KiB) and 512 threads write the merged bf16
+// context.  Same arithmetic as attn_kernel + attn_combine_kernel (scores in the scaled log2 domain, P rounded to bf16 before
+// both the PV product and the row sum); used while the context is short enough for one CU per KV group (the launcher decides).
+struct DecAttnP {
+    const bf16_t* q; bf16_t* ctx;      // [S][H*128]
+    const bf16_t* k; const bf16_t* vt; // single stream (nseg == 0)
+    int nk, H, KV, S_max, nseg;
+    float c;
+    SmDecodeSeg seg;
+};
+__global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
+    constexpr int DH = 128;
+    __shared__ float osh[8][16][DH + 4];
+    __shared__ float msh[8][16], lsh[8][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int rep = p.H / p.KV;
+    const bool segm = p.nseg > 0;
+    const int nk = segm ? p.seg.pos[b] + 1 : p.nk;
+    const bf16_t* kc = (segm ? (const bf16_t*)p.seg.kc[b] : p.k) + kvh * DH;
+    const bf16_t* vt = (segm ? (const bf16_t*)p.seg.vtc[b] : p.vt) + (size_t)kvh * DH * p.S_max;
+    const long k_rs = (long)p.KV * DH;
+    bf16x8 qf[4];
+    {
+        union { bf16x8 v; u32x4 u; } z;
+        z.u = u32x4{0, 0, 0, 0};
+        const bf16_t* src = p.q + ((size_t)b * p.H + kvh * rep + (i < rep ? i : 0)) * DH + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = i < rep ? *(const bf16x8*)(src + ks * 32) : z.v;
+    }
+    f32x4 o[8];
+#pragma unroll
+    for (int df = 0; df < 8; ++df) o[df] = f32x4{0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int NB = (nk + 31) >> 5;
+    for (int blk0 = wave; blk0 < NB; blk0 += 16) {
+        const bool two = blk0 + 8 < NB;
+        bf16x8 kf[2][2][4], vf[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int key0 = (blk0 + 8 * u) * 32;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                int key = key0 + (i >> 2) * 8 + a * 4 + (i & 3);
+                key = key < nk ? key : nk - 1;
+                const bf16_t* src = kc + (long)key * k_rs + g * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[u][a][ks] = *(const bf16x8*)(src + ks * 32);
+            }
+#pragma unroll
+            for (int df = 0; df < 8; ++df) vf[u][df] = *(const bf16x8*)(vt + (size_t)(df * 16 + i) * p.S_max + key0 + g * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int key0 = (blk0 + 8 * u) * 32;
+            f32x4 sc[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][a][ks], qf[ks], acc, 0, 0, 0);
+                sc[a] = acc;
+            }
+            const bool part = key0 + 32 > nk;        // only the last block of the cache carries masked keys
+            if (part) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + g * 8 + a * 4 + r >= nk) sc[a][r] = -INFINITY;
+                // positions past the cache end may hold anything (a caller-owned cache need not be zeroed): 0 * garbage must stay 0
+#pragma unroll
+                for (int df = 0; df < 8; ++df) {
+                    union { bf16x8 v; uint16_t h[8]; } t;
+                    t.v = vf[u][df];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + g * 8 + e >= nk) t.h[e] = 0;
+                    vf[u][df] = t.v;
+                }
+            }
+            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])), fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+            mx = xor32_max(xor16_max(mx));
+            const float m_new = fmaxf(m_run, mx);            // finite: the block holds at least one real key
+            const float mc = m_new * p.c;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run, p.c, -mc));
+            m_run = m_new;
+            float pe[8], psum = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[a][r], p.c, -mc));
+                    const float er = bf2f(f2bf(e));            // the row sum adds the SAME rounded P the PV product multiplies
+                    pe[a * 4 + r] = er;
+                    psum += er;
+                }
+            const bf16x8 pf = make8<false>(pe);
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int df = 0; df < 8; ++df) {
+                o[df] *= alpha;
+                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u][df], pf, o[df], 0, 0, 0);
+            }
+        }
+    }
+    // per-wave partial -> LDS (lane (i, g): query i, dims df*16 + g*4 + r; l still split over the four g's)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (i < rep) {
+#pragma unroll
+        for (int df = 0; df < 8; ++df) *(f32x4*)&osh[wave][i][df * 16 + g * 4] = o[df];
+        if (g == 0) { msh[wave][i] = m_run; lsh[wave][i] = l_run; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rep * DH; idx += 512) {
+        const int qi = idx >> 7, d = idx & (DH - 1);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) M = fmaxf(M, msh[w][qi]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float mw = msh[w][qi];
+            const float wt = mw == -INFINITY ? 0.f : exp2f((mw - M) * p.c);
+            num += wt * osh[w][qi][d];
+            den += wt * lsh[w][qi];
+        }
+        p.ctx[((size_t)b * p.H + kvh * rep + qi) * DH + d] = (bf16_t)f2bf(num / den);
+    }
+}
+// SM_DECODE_ATTN_FUSED=0: keep the split + merge launch pair for every context length (A/B switch); the one-launch kernel is
+// used up to SM_DECODE_ATTN_FUSED_MAXK keys (default 2048: beyond that one CU per KV group streams too much)
+static bool decode_attn_fused_ok(int nk, int dh) {
+    static int on = -1, maxk = 0;
+    if (on < 0) {
+        const char* e = getenv("SM_DECODE_ATTN_FUSED"); on = e ? atoi(e) : 1;
+        const char* k = getenv("SM_DECODE_ATTN_FUSED_MAXK"); maxk = k ? atoi(k) : 2048;
+    }
+    return on && dh == 128 && nk <= maxk;
+}
+
 // Single-token decode ("flash-decoding"): the H/KV query heads of one KV group play the role of the query rows of the
 // tile kernel (so K/V of a group are streamed once for all its heads), the keys are split across gridDim.z blocks so
 // that every CU streams part of the cache, and a tiny kernel merges the partial softmaxes.
@@ -659,6 +814,15 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
+    if (decode_attn_fused_ok(nk, dh)) {
+        DecAttnP d;
+        d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = (const bf16_t*)kcache; d.vt = (const bf16_t*)vtcache;
+        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = 0; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+        SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
+        decode_attn_kernel<<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
     int splits = cdiv(nk, 64);            // one 64-key tile per block while the cache is short: the kernel is a latency chain per tile
     if (splits > splits_max) splits = splits_max;
     const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
@@ -703,6 +867,15 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
     for (int t = 0; t < S; ++t) {
         SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg: stream %d: bad position / cache", t);
         nk = seg.pos[t] + 1 > nk ? seg.pos[t] + 1 : nk;
+    }
+    if (decode_attn_fused_ok(nk, dh)) {
+        DecAttnP d;
+        d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
+        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+        SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
+        decode_attn_kernel<<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
     }
     int splits = cdiv(nk, 64);
     if (splits > splits_max) splits = splits_max;

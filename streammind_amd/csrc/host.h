@@ -42,6 +42,11 @@ int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& ds
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
 struct SmDecodeSeg { void* kc[SM_MAX_SEG]; void* vtc[SM_MAX_SEG]; int pos[SM_MAX_SEG]; };
 struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
+// epilogue of the decode-step q/k/v product with RoPE + KV append fused in (linear.hip sm_linear_qkv_rope): row i of the
+// activations is stream i's token at seg.pos[i]; q goes out rotated as bf16 [M][H*dh], k rotated into seg.kc[i], v transposed
+// into seg.vtc[i] -- the arithmetic of rope_kv_kernel on the fp32 accumulators, without the fp32 round trip and its launch
+struct SmRopeEpi { const float* cos_tab; const float* sin_tab; void* q; int H, KV, S_max; SmDecodeSeg seg; };
+int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream);                                  // linear.hip
 int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
                           const SmDecodeSeg& seg, int S_max, void* stream);                                       // vecops.hip
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,

@@ -332,21 +332,53 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
     store4(a, i, rg * 16 + g * 4, acc, DUAL ? &acc2 : nullptr);
 }
 
+// one lane's share of the fused RoPE / KV-append epilogue: row `row` (= stream), head slot hs (q heads, then k heads, then v
+// heads), dims d0..d0+3 in `lo` and d0+64..d0+67 in `hi` of a 128-wide head.  Same arithmetic as rope_kv_kernel (vecops.hip).
+static __device__ __forceinline__ void rope_store(const SmRopeEpi& re, int row, int hs, int d0, f32x4 lo, f32x4 hi) {
+    const int pos = re.seg.pos[row];
+    if (hs < re.H + re.KV) {
+        const f32x4 c = *(const f32x4*)(re.cos_tab + (size_t)pos * 64 + d0), s = *(const f32x4*)(re.sin_tab + (size_t)pos * 64 + d0);
+        float o0[4], o1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0[r] = lo[r] * c[r] - hi[r] * s[r];
+            o1[r] = hi[r] * c[r] + lo[r] * s[r];
+        }
+        bf16_t* dst = hs < re.H ? (bf16_t*)re.q + ((size_t)row * re.H + hs) * 128 + d0
+                                : (bf16_t*)re.seg.kc[row] + ((size_t)pos * re.KV + (hs - re.H)) * 128 + d0;
+        *(u32x2*)dst = u32x2{pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3])};
+        *(u32x2*)(dst + 64) = u32x2{pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
+    } else {
+        bf16_t* vt = (bf16_t*)re.seg.vtc[row] + ((size_t)(hs - re.H - re.KV) * 128 + d0) * re.S_max + pos;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vt[(size_t)r * re.S_max] = (bf16_t)f2bf(lo[r]);
+            vt[(size_t)(64 + r) * re.S_max] = (bf16_t)f2bf(hi[r]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ skinny (M <= 16)
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
 // reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
 // NORM: RMSNorm of the activations fused in front (norm_issue / norm_finish above; decode q/k/v, gate/up, lm_head at one row)
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false>   // MB: 16-row activation blocks (M <= 16 * MB)
-__global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
+struct NoRope {};
+// ROPE: the fused q/k/v product of a decode step (head_dim 128).  Block b streams row groups rg = (b / 4) * 8 + b % 4 and
+// rg + 4 of the SAME weight image (the DUAL machinery: two accumulators over one activation fragment), i.e. dims d and d + 64
+// of one head land in the same lane, and the epilogue applies rotate_half RoPE and writes q / the K cache / the V^T cache
+// directly (rope_store).
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false, bool ROPE = false>   // MB: 16-row activation blocks (M <= 16 * MB)
+__global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::conditional_t<ROPE, SmRopeEpi, NoRope> re) {
     static_assert(!NORM || (XF32 && !SPLIT && MB == 1), "fused RMSNorm: fp32 activations, one rounding, <= 16 rows");
+    static_assert(!ROPE || (DUAL && MB == 1), "fused RoPE: the two halves of a head ride the dual accumulators");
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = blockIdx.x;
+    const int rg = ROPE ? (int)((blockIdx.x >> 2) * 8 + (blockIdx.x & 3)) : (int)blockIdx.x;
     const int KS = a.KS;
     const int i = lane & 15, g = lane >> 4;
     const bf16x8* wp = a.w + (size_t)rg * KS * 64 + lane;
-    const bf16x8* wp2 = DUAL ? a.w2 + (size_t)rg * KS * 64 + lane : nullptr;
+    const bf16x8* wp2 = ROPE ? a.w + (size_t)(rg + 4) * KS * 64 + lane : DUAL ? a.w2 + (size_t)rg * KS * 64 + lane : nullptr;
     bool valid[MB];
     const char* xrow[MB];
 #pragma unroll
@@ -491,6 +523,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a) {
                 acc[mb][r] = s;
                 if (DUAL) acc2[mb][r] = s2;
             }
+    }
+    if constexpr (ROPE) {
+        // rows walked with a wave-uniform index: the per-stream position / cache pointers are scalar loads from the argument block
+        for (int row = 0; row < a.M; ++row)
+            if (i == row) rope_store(re, row, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3) * 16 + g * 4, acc[0], acc2[0]);
+        return;
     }
     if (pre_res) {
         LinArgs b = a;
@@ -933,7 +971,7 @@ template <int WAVES, int MB = 1>
 static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
     dim3 grid(a.NRG), block(WAVES * 64);
     size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * MB * 64 * sizeof(float) : 0;
-#define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB><<<grid, block, sh, st>>>(a)
+#define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB><<<grid, block, sh, st>>>(a, NoRope{})
     if (xf32) {
         if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
         else       { if (dual) SK(true, false, true); else SK(true, false, false); }
@@ -952,17 +990,13 @@ static int launch_skinny_norm(const LinArgs& a, bool dual, bool fp8, hipStream_t
     if (fp8) {
         if (dual) skinny_fp8_kernel<WAVES, true, false, true, true><<<grid, block, sh, st>>>(a);
         else skinny_fp8_kernel<WAVES, true, false, false, true><<<grid, block, sh, st>>>(a);
-    } else if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a);
-    else skinny_kernel<WAVES, true, false, false, 1, true><<<grid, block, sh, st>>>(a);
+    } else if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a, NoRope{});
+    else skinny_kernel<WAVES, true, false, false, 1, true><<<grid, block, sh, st>>>(a, NoRope{});
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
 
-extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
-    SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
-    SM_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "sm_linear: bad dims M=%d N=%d K=%d", p->M, p->N, p->K);
-    SM_REQUIRE(p->out_f32 || p->out_bf16 || p->vt, "sm_linear: no output");
-    LinArgs a;
+static void fill_args(const sm_linear_t* p, LinArgs& a) {
     a.w = (const bf16x8*)p->w;
     a.w2 = (const bf16x8*)p->w2;
     a.N = p->N; a.K = p->K;
@@ -979,6 +1013,42 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
     a.f16 = p->op_dtype == SM_OP_F16;
+}
+
+// the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): bf16 weights, head_dim 128,
+// M <= 16 rows of fp32 activations, RMSNorm fused in front when p->norm_gamma is set
+int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) {
+    SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && p->w_dtype != SM_W_FP8 && !p->vt &&
+               p->remap_in == 0 && p->op_dtype == SM_OP_BF16, "sm_linear_qkv_rope: plain bf16 q/k/v weights only");
+    SM_REQUIRE(p->M > 0 && p->M <= 16 && p->M <= SM_MAX_SEG && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0 &&
+               p->N == (re.H + 2 * re.KV) * 128, "sm_linear_qkv_rope: M <= 16 fp32 rows, K %% 32 == 0, N = (H + 2 KV) * 128 (M=%d N=%d K=%d)", p->M, p->N, p->K);
+    SM_REQUIRE(!p->norm_gamma || (long)p->M * p->K <= 16384, "sm_linear_qkv_rope: fused RMSNorm needs M*K <= 16384");
+    SM_REQUIRE(re.cos_tab && re.sin_tab && re.q, "sm_linear_qkv_rope: null tables / q");
+    LinArgs a;
+    fill_args(p, a);
+    hipStream_t st = (hipStream_t)stream;
+    SmProfScope prof(SM_PROF_SKINNY, st);
+    constexpr int WAVES = 8;
+    SM_REQUIRE(a.KS >= WAVES * 4, "sm_linear_qkv_rope: K too small");
+    const dim3 grid((re.H + 2 * re.KV) * 4), block(WAVES * 64);
+    if (p->norm_gamma) {
+        const size_t sh = ((size_t)WAVES * 8 * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
+        skinny_kernel<WAVES, true, false, true, 1, true, true><<<grid, block, sh, st>>>(a, re);
+    } else {
+        const size_t sh = (size_t)WAVES * 8 * 64 * sizeof(float);
+        skinny_kernel<WAVES, true, false, true, 1, false, true><<<grid, block, sh, st>>>(a, re);
+    }
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
+    SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
+    SM_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "sm_linear: bad dims M=%d N=%d K=%d", p->M, p->N, p->K);
+    SM_REQUIRE(p->out_f32 || p->out_bf16 || p->vt, "sm_linear: no output");
+    LinArgs a;
+    fill_args(p, a);
+    const bool w8 = p->w_dtype == SM_W_FP8;
     SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
     SM_REQUIRE(!a.f16 || (p->x_dtype == SM_X_BF16 && !p->w2 && !w8 && !p->norm_gamma && !p->vt),
                "sm_linear: fp16 operands run on the tiled GEMM only (16-bit x, single bf16-layout weight image, no fused norm / vt)");

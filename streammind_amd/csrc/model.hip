@@ -894,6 +894,8 @@ extern "C" int sm_group_push_frames(sm_stream_group* g, const uint8_t* frames, i
 // ------------------------------------------------------------------------------------------------ LLM
 // SM_NO_FUSED_NORM=1: keep the separate RMSNorm launches on the decode path (A/B tuning switch)
 static const bool g_no_fused_norm = [] { const char* e = getenv("SM_NO_FUSED_NORM"); return e && atoi(e) != 0; }();
+// SM_NO_FUSED_ROPE=1: separate rope_kv_kernel launch behind the q/k/v product of a decode step (A/B tuning switch)
+static const bool g_no_fused_rope = [] { const char* e = getenv("SM_NO_FUSED_ROPE"); return e && atoi(e) != 0; }();
 
 // one pass of the decoder over n rows of s->emb (fp32 residual stream) at positions kv_len..kv_len+n-1
 static int llm_layers(sm_stream* s, int n, void* stream) {
@@ -907,11 +909,22 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         // decode (one row): both RMSNorms ride inside the weight-streaming products that consume them
         const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
         if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        // decode: RoPE + KV append ride in the epilogue of the q/k/v product (no fp32 q/k/v round trip, one launch less per layer)
+        const bool fuse_rope = fuse_norm && dh == 128 && ld >= 1024 && !w.qkv->fp8 && !g_no_fused_rope;
         {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, n, ld) : lin(m, *w.qkv, s->xnb.p, SM_X_BF16, n, ld);
             if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
-            a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
-            if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
+            if (fuse_rope) {
+                SmRopeEpi re;
+                re.cos_tab = m->rope_cos.as<float>(); re.sin_tab = m->rope_sin.as<float>(); re.q = s->qb.p;
+                re.H = H; re.KV = KV; re.S_max = s->max_seq;
+                re.seg.kc[0] = s->kc[l].p; re.seg.vtc[0] = s->vtc[l].p; re.seg.pos[0] = s->kv_len;
+                if ((rc = sm_linear_qkv_rope(&a, re, stream))) return rc;
+            } else {
+                a.out_f32 = s->qkvf.as<float>(); a.ldo = qn + 2 * kn;
+                if ((rc = sm_linear(&a, stream))) return rc;
+            }
+        }
+        if (!fuse_rope && (rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
         if (n == 1) {
             if ((rc = sm_llm_decode_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, stream))) return rc;
         } else if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;

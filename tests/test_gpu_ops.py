@@ -216,9 +216,12 @@ def test_gate_decide_and_argmax(nat):
     assert out.item() == 123 == int(torch.argmax(v))
 
 
-@pytest.mark.parametrize("pos,H,KV,dh", [(0, 32, 8, 128), (37, 32, 8, 128), (1000, 32, 8, 128), (4095, 32, 8, 128), (200, 2, 1, 128), (77, 4, 4, 64)])
+@pytest.mark.parametrize("pos,H,KV,dh", [(0, 32, 8, 128), (37, 32, 8, 128), (1000, 32, 8, 128), (4095, 32, 8, 128), (200, 2, 1, 128), (77, 4, 4, 64),
+                                         (30, 32, 8, 128), (31, 32, 8, 128), (32, 32, 8, 128), (255, 32, 8, 128), (256, 32, 8, 128), (511, 32, 8, 128),
+                                         (513, 32, 8, 128), (2047, 32, 8, 128), (2048, 32, 8, 128), (300, 16, 1, 128)])
 def test_decode_attention_split_keys(nat, pos, H, KV, dh):
-    """flash-decoding (key-split + merge) vs plain softmax attention over the cache: bf16 output, 8e-3 of max."""
+    """single-token decode attention vs plain softmax attention over the cache: bf16 output, 8e-3 of max.  Up to 2048 keys at
+    head_dim 128 this is the one-launch kernel (in-block merge of the 8 per-wave partials), beyond that key-split + merge."""
     from streammind_amd._lib import load, check
     lib = load()
     S_max = 4096
@@ -239,6 +242,13 @@ def test_decode_attention_split_keys(nat, pos, H, KV, dh):
     s = torch.einsum("hd,khd->hk", q, kk) * dh ** -0.5
     ref = torch.einsum("hk,khd->hd", torch.softmax(s, -1), vv)
     assert relerr(ctx, ref) < 8e-3
+    if dh == 128 and pos < 2048:
+        # a caller-owned cache need not be clean behind the last key: NaN there must not reach the output
+        kg[pos + 1:] = float("nan"); vt[:, :, pos + 1:] = float("nan")
+        ctx2 = torch.empty_like(ctx)
+        check(lib.sm_llm_decode_attention(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), pos, H, KV, dh, S_max, ws.data_ptr(), 32,
+                                          ctx2.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(ctx2, ctx)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 96), (8, 4096, 4096), (1, 4096, 14336), (16, 288, 8192), (2, 2, 4096)])

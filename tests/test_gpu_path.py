@@ -438,6 +438,9 @@ def test_full_width_llm_two_layers_prefill_and_decode():
             break
     lg2, _ = s.logits()
     assert torch.isfinite(lg2).all() and s.kv_len == 96
+    if got == ref_ids[:6]:
+        # the decode steps ran the fused q/k/v + RoPE + KV-append epilogue (head_dim 128): logits after six of them
+        assert maxdiff(lg2, trace[6]) < 3e-2
 
 
 def test_fp8_weights_mode_gate_and_llm(gold):
