@@ -130,6 +130,7 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
     ids = torch.cat([torch.randint(3, cfg.llm_vocab, (n_ctx_text,), generator=g, device="cuda", dtype=torch.int32),
                      -(torch.arange(base, base + n_ctx_frames, device="cuda", dtype=torch.int32) + 1),
                      torch.randint(3, cfg.llm_vocab, (8,), generator=g, device="cuda", dtype=torch.int32)])
+    stream.set_kv_len(0)                 # the context named below is the whole cache (earlier legs leave theirs behind)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stream.prefill(ids.contiguous())
@@ -424,15 +425,16 @@ def cpu_baseline(n_frames: int = 12) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed steps; 64 x 28 frames + warm-up = the 1800-frame (60 s x 30 fps) stream")
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; 32 x 56 frames + warm-up = the 1800-frame (60 s x 30 fps) stream")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=28, help="frames per step (28 x 577 tokens = 63.1 tiles of 256 rows: every "
-                                                           "ViT GEMM is a whole number of 256-CU rounds)")
+    ap.add_argument("--batch", type=int, default=56, help="frames per step.  >= 48: the tower runs as two concurrent half batches (two lanes, "
+                                                           "sm_vit_encode); a 28-frame lane is 28 x 577 tokens = 63.1 tiles of 256 rows, so every ViT "
+                                                           "GEMM is a whole number of 256-CU rounds.  --batch 28 --no-pipeline = the round-1 configuration")
     ap.add_argument("--vit-fp16", action="store_true", help="vision-tower operands in IEEE fp16 (the reference demo's precision, "
                                                             "model/builder.py:54) instead of BASELINE configs[1]'s bf16")
-    ap.add_argument("--pipeline", action="store_true", help="issue each timed step with sm_stream_push_frames_pipelined (connector + gate pass "
-                    "on a side stream, overlapping the next step's tower: +2.4 %% frames/s, but the concurrent pass stretches the GEMM "
-                    "launches the roofline is measured on) instead of the plain call; the default run reports it as the `pipelined` leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="issue each timed step with the plain sm_stream_push_frames instead of "
+                    "sm_stream_push_frames_pipelined (connector + gate pass of step i on a side stream under the tower of step i+1; identical results)")
+    ap.add_argument("--pipeline", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (perception + scheduled replies) leg")
     ap.add_argument("--no-fp8", action="store_true", help="skip the opt-in fp8-weight decode leg (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -469,6 +471,10 @@ def main():
     from streammind_amd.native import NativeModel, PathConfig
     lib = _lib.load()
     B = a.batch
+    a.pipeline = not a.no_pipeline
+    lanes = 2 if (B >= 48 and os.environ.get("SM_VIT_LANES", "2") != "1") else 1
+    LB = (B + 1) // 2 if lanes == 2 else B            # frames per tower lane: the batch of the single-lane legs and of the roofline segment
+    concurrent = lanes == 2 or a.pipeline             # kernels of independent work share the chip during the timed steps
     cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B, vit_fp16=a.vit_fp16)
     model = NativeModel(cfg, f"cuda:{local}")
     random_weights_into(model, cfg, seed=1234)
@@ -477,7 +483,7 @@ def main():
     model.finalize()
     n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
     frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
-    stream = model.open_stream(max_frames=B * (a.steps + a.warmup + 16) + 16 + 256, max_seq=2048)
+    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 4096, max_seq=2048)
     torch.cuda.synchronize()
 
     def step(i):
@@ -520,13 +526,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events around every tiled-GEMM launch break the back-to-back dispatch of the stream (~5.5 us per boundary, 4.4 % of
-    # a step when every launch is bracketed), so only the LAST prof_steps of the timed region carry them
+    # a step when every launch is bracketed), so only the LAST prof_steps of the timed region carry them.  With two tower lanes /
+    # the pipelined gate pass two kernels share the chip, and the time between a launch's two events is no longer that kernel's
+    # time (a 256x256 GEMM block owns its CU: concurrent GEMMs interleave at block granularity and each looks up to 2x longer):
+    # then the dominant kernel is measured on prof_steps single-lane plain steps of the same lane batch RIGHT AFTER the timed region.
     prof_steps = max(1, a.steps // 5) if prof else 0
+    prof_in_timed = prof and not concurrent
     if prof:
         lib.sm_prof_reset()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        if prof and i == a.steps - prof_steps:
+        if prof_in_timed and i == a.steps - prof_steps:
             lib.sm_prof_enable(1)
         logits, dec = step(a.warmup + i)
         if ex is not None:
@@ -543,6 +553,16 @@ def main():
     dt = time.perf_counter() - t0
     dt_local = dt
     gemm_prof = None
+    if prof and not prof_in_timed:
+        prof_steps = 12
+        for i in range(2):
+            stream.push_frames(frames[i * LB:(i + 1) * LB])
+        torch.cuda.synchronize()
+        lib.sm_prof_reset()
+        lib.sm_prof_enable(1)
+        for i in range(prof_steps):
+            stream.push_frames(frames[(i * LB) % (n_pool - LB + 1):][:LB])
+        torch.cuda.synchronize()
     if prof:
         lib.sm_prof_enable(0)
         cnt, ms = C.c_int(), C.c_float()
@@ -613,21 +633,21 @@ def main():
         # the same step with the tower's operands in IEEE fp16 (vit_fp16: the reference demo's precision, model/builder.py:54;
         # gate logits 1.3e-4 from the fp32 oracle at this batch instead of bf16's 2.3e-3 -- tests/test_gpu_path.py)
         try:
-            cfg16 = PathConfig(llm_layers=0, max_frames_per_call=B, vit_fp16=True)
+            cfg16 = PathConfig(llm_layers=0, max_frames_per_call=LB, vit_fp16=True)
             m16 = NativeModel(cfg16, f"cuda:{local}")
             random_weights_into(m16, cfg16, seed=1234)
             m16.finalize()
-            s16 = m16.open_stream(max_frames=B * 24, max_seq=64)
+            s16 = m16.open_stream(max_frames=LB * 24, max_seq=64)
             for i in range(3):
-                s16.push_frames(frames[i * B:(i + 1) * B])
+                s16.push_frames(frames[i * LB:(i + 1) * LB])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(16):
-                s16.push_frames(frames[(i * B) % (n_pool - B + 1):][:B])
+                s16.push_frames(frames[(i * LB) % (n_pool - LB + 1):][:LB])
             torch.cuda.synchronize()
             d16 = (time.perf_counter() - t1) / 16
-            fp16_tower_leg = {"frames_per_s": round(B / d16, 1), "ms_per_step": round(d16 * 1e3, 3),
-                              "note": "vit_fp16=1: tower GEMM / attention operands in IEEE fp16 (same MFMA rate), everything else as the headline run"}
+            fp16_tower_leg = {"frames_per_s": round(LB / d16, 1), "frames_per_step": LB, "ms_per_step": round(d16 * 1e3, 3),
+                              "note": "vit_fp16=1: tower GEMM / attention operands in IEEE fp16 (same MFMA rate), everything else as the `single_lane_plain` row of `pipelined`"}
             s16.close(); m16.close()
         except Exception as e:
             fp16_tower_leg = {"error": repr(e)[:200]}
@@ -637,12 +657,12 @@ def main():
         # eval/video_score_stream_demo.py:86): pinned ring -> async H2D on a copy stream -> the same step.  338 688 B per frame.
         try:
             from streammind_amd.stream import FrameRing
-            ring = FrameRing(3, B, 336, 336, torch.device("cuda", local))
-            host_frames = frames[:4 * B].cpu()
-            sh = model.open_stream(max_frames=B * 24, max_seq=64)
+            ring = FrameRing(3, LB, 336, 336, torch.device("cuda", local))
+            host_frames = frames[:4 * LB].cpu()
+            sh = model.open_stream(max_frames=LB * 24, max_seq=64)
 
             def hstep(i):
-                dev, ready, slot = ring.push(host_frames[(i % 4) * B:(i % 4 + 1) * B])
+                dev, ready, slot = ring.push(host_frames[(i % 4) * LB:(i % 4 + 1) * LB])
                 torch.cuda.current_stream().wait_event(ready)
                 sh.push_frames(dev)
                 ring.release(slot)
@@ -654,25 +674,38 @@ def main():
                 hstep(i)
             torch.cuda.synchronize()
             d4 = (time.perf_counter() - t4) / 16
-            host_leg = {"frames_per_s": round(B / d4, 1), "ms_per_step": round(d4 * 1e3, 3), "h2d_bytes_per_frame": 336 * 336 * 3,
+            host_leg = {"frames_per_s": round(LB / d4, 1), "frames_per_step": LB, "ms_per_step": round(d4 * 1e3, 3), "h2d_bytes_per_frame": 336 * 336 * 3,
                         "note": "PCIe-inclusive: u8 frames start in pinned host memory every step (3-slot ring, copy stream); never the headline value"}
             sh.close()
         except Exception as e:
             host_leg = {"error": repr(e)[:200]}
     pipe_leg = None
-    if world == 1 and not a.no_aux and not a.pipeline:
-        try:       # the same steps with the connector + gate pass of step i on a side stream under the tower of step i+1
-            sp = model.open_stream(max_frames=B * 24, max_seq=64)
-            for i in range(3):
-                sp.push_frames_pipelined(frames[i * B:(i + 1) * B])
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for i in range(16):
-                sp.push_frames_pipelined(frames[(i * B) % (n_pool - B + 1):][:B])
-            sp.join()
-            torch.cuda.synchronize()
-            d3 = (time.perf_counter() - t3) / 16
-            pipe_leg = {"frames_per_s": round(B / d3, 1), "ms_per_step": round(d3 * 1e3, 3), "note": "sm_stream_push_frames_pipelined, identical results"}
+    if world == 1 and not a.no_aux:
+        # the schedule ladder on this box, same frames: plain single-lane call (the round-1 configuration) -> + pipelined gate pass
+        # -> two tower lanes (plain) -> two lanes + pipelined (the headline schedule)
+        try:
+            sp = model.open_stream(max_frames=2 * LB * 24 + 64, max_seq=64)
+
+            def ladder(nb, piped):
+                sp.reset()
+                call = sp.push_frames_pipelined if piped else sp.push_frames
+                for i in range(2):
+                    call(frames[i * nb:(i + 1) * nb])
+                sp.join()
+                torch.cuda.synchronize()
+                n_it = 16 if nb <= 32 else 8
+                t3 = time.perf_counter()
+                for i in range(n_it):
+                    call(frames[(i * nb) % (n_pool - nb + 1):][:nb])
+                sp.join()
+                torch.cuda.synchronize()
+                d3 = (time.perf_counter() - t3) / n_it
+                return {"frames_per_step": nb, "frames_per_s": round(nb / d3, 1), "ms_per_step": round(d3 * 1e3, 3)}
+            pipe_leg = {"single_lane_plain": ladder(LB, False), "single_lane_pipelined": ladder(LB, True)}
+            if lanes == 2:
+                pipe_leg["two_lanes_plain"] = ladder(B, False)
+                pipe_leg["two_lanes_pipelined"] = ladder(B, True)
+            pipe_leg["note"] = "identical results in every row (tests/test_gpu_path.py); single_lane_plain is the round-1 bench configuration"
             sp.close()
         except Exception as e:
             pipe_leg = {"error": repr(e)[:200]}
@@ -682,11 +715,11 @@ def main():
         # gaps and tails (the tower's workspaces are per HIP stream); aggregate frames/s of the GPU
         try:
             hs = [torch.cuda.Stream(), torch.cuda.Stream()]
-            ss = [model.open_stream(max_frames=B * 20, max_seq=64) for _ in hs]
+            ss = [model.open_stream(max_frames=LB * 20, max_seq=64) for _ in hs]
             def both(i):
                 for k in range(2):
                     with torch.cuda.stream(hs[k]):
-                        ss[k].push_frames(frames[((2 * i + k) * B) % (n_pool - B + 1):][:B])
+                        ss[k].push_frames(frames[((2 * i + k) * LB) % (n_pool - LB + 1):][:LB])
             for i in range(2):
                 both(i)
             torch.cuda.synchronize()
@@ -695,7 +728,7 @@ def main():
                 both(i)
             torch.cuda.synchronize()
             d2 = (time.perf_counter() - t2) / 12
-            two_leg = {"streams": 2, "frames_per_step_per_stream": B, "frames_per_s": round(2 * B / d2, 1), "ms_per_round": round(d2 * 1e3, 3),
+            two_leg = {"streams": 2, "frames_per_step_per_stream": LB, "frames_per_s": round(2 * LB / d2, 1), "ms_per_round": round(d2 * 1e3, 3),
                        "note": "two sm_streams of one sm_model driven on two HIP streams"}
             for st_ in ss:
                 st_.close()
@@ -704,7 +737,7 @@ def main():
     streams_leg = None
     if world == 1 and not a.no_aux:
         try:
-            streams_leg = streams_x1_leg(model, frames, B)
+            streams_leg = streams_x1_leg(model, frames, LB)
         except Exception as e:
             streams_leg = {"error": repr(e)[:200]}
     # rooflines of the other kernels of a step, each from its own HIP-event pass over a few steps (bracketing a class breaks the
@@ -714,16 +747,17 @@ def main():
         try:
             S_tok = cfg.n_patches + 1
             attn_flops = cfg.vit_layers_run * 4.0 * S_tok * S_tok * cfg.vit_hidden            # per frame: QK^T + PV
+            plain3 = lambda: [stream.push_frames(frames[j * LB:(j + 1) * LB]) for j in range(3)]      # single-lane plain steps: undisturbed kernel times
             more_roof["vit_attention"] = class_roofline(
-                lib, 2, lambda: [step(j) for j in range(3)], 3 * B, attn_flops, "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                lib, 2, plain3, 3 * LB, attn_flops, "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
                 "vit_attn_kernel (non-causal flash-style attention, S = 577, 16 heads x 64)")
             d, di = cfg.conn_d_model, cfg.conn_expand * cfg.conn_d_model
             gdh = d // cfg.gate_heads
             conn_bytes = 2.0 * (cfg.vit_hidden * d + d * 2 * di + di * (cfg.conn_dt_rank + 2 * cfg.conn_d_state) + cfg.conn_dt_rank * di + di * d + d * d)
             gate_bytes = 2.0 * (cfg.gate_layers * (d * cfg.gate_kv_heads * gdh + d * d + 3 * d * cfg.gate_mlp) + 2 * d)
             more_roof["connector_gate_pass"] = class_roofline(
-                lib, 1, lambda: [step(j) for j in range(3)], 3, conn_bytes + gate_bytes, "hbm", HBM_PEAK_GBS, "GB/s",
-                f"skinny_lds_kernel + split-K reduce (weight-streaming linears of the connector + V/O-only gate, {B} rows per pass)")
+                lib, 1, plain3, 3, conn_bytes + gate_bytes, "hbm", HBM_PEAK_GBS, "GB/s",
+                f"skinny_lds_kernel + split-K reduce (weight-streaming linears of the connector + V/O-only gate, {LB} rows per pass)")
         except Exception as e:
             more_roof["error"] = repr(e)[:200]
 
@@ -734,7 +768,8 @@ def main():
         cnt, ms = _V(), _V()
         cnt.value, ms.value = gemm_prof
         if cnt.value:
-            flops_per_launch = vit_linear_flops_per_frame(cfg) * B * prof_steps / cnt.value
+            PB = B if prof_in_timed else LB            # frames per profiled step
+            flops_per_launch = vit_linear_flops_per_frame(cfg) * PB * prof_steps / cnt.value
             avg_s = ms.value * 1e-3 / cnt.value
             ach = flops_per_launch / avg_s / 1e12
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
@@ -745,12 +780,15 @@ def main():
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
                     break
-            big = B * (cfg.n_patches + 1) >= 192 * 64
+            big = PB * (cfg.n_patches + 1) >= 192 * 64
             roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups)" if big else
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 8 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "flops_per_launch": flops_per_launch}
+                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB,
+                    "measured_on": "the last fifth of the timed steps" if prof_in_timed else
+                                   f"{prof_steps} single-lane plain steps of {PB} frames right after the timed region (during the timed steps two kernels share "
+                                   "the chip -- tower lanes / pipelined gate pass -- and the time between a launch's events is not that kernel's time)"}
     fp8_leg = None
     if not a.no_decode and not a.no_fp8 and world == 1:
         # BASELINE config 5 (reported separately, never the headline: reduced-precision weights): a second replica whose gate
@@ -794,8 +832,10 @@ def main():
             "vs_baseline": None, "dtype": "fp16 tower operands (fp32 accumulate / residual), bf16 connector + gate + LLM" if a.vit_fp16 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
                                    f"4-layer Mistral event gate, synthetic 336x336 30 fps stream ({n_pool}-frame pool = {n_pool / 30:.1f} s, "
-                                   f"{a.steps * B} frames timed), {B} frames per step, one stream per GPU, random-init weights of the true shapes",
-                       "frames_per_step": B, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
+                                   f"{a.steps * B} frames timed), {B} frames per step" + (f" (two concurrent tower lanes of {LB})" if lanes == 2 else "") +
+                                   (", connector + gate pass of step i under the tower of step i+1" if a.pipeline else "") +
+                                   ", one stream per GPU, random-init weights of the true shapes",
+                       "frames_per_step": B, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,

@@ -794,17 +794,16 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
         p.ctx[((size_t)b * p.H + kvh * rep + qi) * DH + d] = (bf16_t)f2bf(num / den);
     }
 }
-// SM_DECODE_ATTN_FUSED=0: keep the split + merge launch pair for every context length (A/B switch); the one-launch kernel is
-// used up to SM_DECODE_ATTN_FUSED_MAXK keys (default 2048: beyond that one CU per KV group streams too much)
-static bool decode_attn_fused_ok(int nk, int dh) {
-    static int on = -1, maxk = 0;
-    if (on < 0) {
-        const char* e = getenv("SM_DECODE_ATTN_FUSED"); on = e ? atoi(e) : 1;
-        const char* k = getenv("SM_DECODE_ATTN_FUSED_MAXK"); maxk = k ? atoi(k) : 2048;
-    }
-    return on && dh == 128 && nk <= maxk;
+// SM_DECODE_ATTN_FUSED=0: keep the split + merge launch pair for every context length (A/B switch).  The one-launch kernel gives
+// ONE CU per (stream, KV group): measured at Mistral-7B shapes it equals the launch pair at 328 keys for a single stream and
+// loses beyond ~512 (1024 keys: 301 vs 322 tokens/s) -- but with 16+ streams its S x KV blocks fill the chip by themselves and
+// it wins (32 streams at 328 keys: 7026 vs 6674 tokens/s aggregate).
+static bool decode_attn_fused_ok(int nk, int dh, int S, int KV) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SM_DECODE_ATTN_FUSED"); on = e ? atoi(e) : 1; }
+    if (!on || dh != 128) return false;
+    return nk <= 384 || (S * KV >= 128 && nk <= 2048);
 }
-
 // Single-token decode ("flash-decoding"): the H/KV query heads of one KV group play the role of the query rows of the
 // tile kernel (so K/V of a group are streamed once for all its heads), the keys are split across gridDim.z blocks so
 // that every CU streams part of the cache, and a tiny kernel merges the partial softmaxes.
@@ -814,7 +813,7 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
-    if (decode_attn_fused_ok(nk, dh)) {
+    if (decode_attn_fused_ok(nk, dh, 1, KV)) {
         DecAttnP d;
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = (const bf16_t*)kcache; d.vt = (const bf16_t*)vtcache;
         d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = 0; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
@@ -868,7 +867,7 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
         SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg: stream %d: bad position / cache", t);
         nk = seg.pos[t] + 1 > nk ? seg.pos[t] + 1 : nk;
     }
-    if (decode_attn_fused_ok(nk, dh)) {
+    if (decode_attn_fused_ok(nk, dh, S, KV)) {
         DecAttnP d;
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
         d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;

@@ -113,6 +113,27 @@ struct sm_model {
         *out = e.get();
         return SM_OK;
     }
+    // second tower lane of a caller stream (sm_vit_encode with >= SM_VIT_LANE_MIN frames): a side HIP stream + fork / join events
+    struct Lane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    std::map<void*, Lane> lanes;
+    int lane_of(void* stream, Lane** out) {
+        std::lock_guard<std::mutex> lk(ws_mu);
+        Lane& L = lanes[stream];
+        if (!L.side) {
+            SM_HIP(hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking));
+            SM_HIP(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
+            SM_HIP(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
+        }
+        *out = &L;
+        return SM_OK;
+    }
+    ~sm_model() {
+        for (auto& kv : lanes) {
+            if (kv.second.side) { (void)hipStreamSynchronize(kv.second.side); (void)hipStreamDestroy(kv.second.side); }
+            if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+            if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+        }
+    }
     // RoPE tables for the LLM
     DevBuf rope_cos, rope_sin;
     int rope_len = 0;
@@ -430,83 +451,135 @@ extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int 
 extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
                           float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);
 static int vit_body(sm_model* m, sm_model::VitWs* ws, int B, float* pooled, void* feats, void* stream);
+struct VitLaneArgs { sm_model::VitWs* ws; int B; float* pooled; void* feats; void* stream; };
+static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl);
+
+// Two tower lanes: a call with >= SM_VIT_LANE_MIN frames (default 48; SM_VIT_LANES=1 disables) is cut in two halves that run the
+// whole tower CONCURRENTLY, the first on the caller's stream, the second on a side stream of that caller stream (own
+// workspaces; fork / join by events, nothing for the caller to do).  The tower alternates MFMA-bound GEMM main loops with
+// HBM-bound phases (fp32-residual epilogues, LayerNorm, pooling) and a 256x256 GEMM block leaves no room for a second resident
+// block, so a single batch runs them strictly one after the other; two independent half batches fill each other's epilogues,
+// kernel tails and launch gaps (+8 % frames/s at 2 x 28 frames, tools/two_stream_bench.py).  Results are those of two calls.
+static int vit_lane_count(int B) {
+    static int lanes = -1, min_b = 48;
+    if (lanes < 0) {
+        const char* e = getenv("SM_VIT_LANES"); lanes = e ? atoi(e) : 2;
+        const char* mb = getenv("SM_VIT_LANE_MIN"); if (mb) min_b = atoi(mb);
+    }
+    return lanes >= 2 && B >= min_b ? 2 : 1;
+}
+template <class Front>      // front(ws, first frame, frames, stream): fills ws->patches for `frames` frames starting at `first frame`
+static int vit_encode_lanes(sm_model* m, int B, float* pooled, void* feats, void* stream, Front front) {
+    const sm_config_t& c = m->c;
+    sm_model::VitWs* ws;
+    int rc = m->vit_workspace(stream, &ws);
+    if (rc) return rc;
+    if (vit_lane_count(B) == 1) {
+        if ((rc = front(ws, 0, B, stream))) return rc;
+        return vit_body(m, ws, B, pooled, feats, stream);
+    }
+    sm_model::Lane* L;
+    sm_model::VitWs* ws1;
+    if ((rc = m->lane_of(stream, &L))) return rc;
+    if ((rc = m->vit_workspace((void*)L->side, &ws1))) return rc;
+    const int B0 = (B + 1) / 2, B1 = B - B0;
+    SM_HIP(hipEventRecord(L->fork, (hipStream_t)stream));            // the frames (and the output buffers' previous readers) are in stream order
+    SM_HIP(hipStreamWaitEvent(L->side, L->fork, 0));
+    if ((rc = front(ws, 0, B0, stream))) return rc;
+    if ((rc = front(ws1, B0, B1, (void*)L->side))) return rc;
+    const VitLaneArgs two[2] = {{ws, B0, pooled, feats, stream},
+                                {ws1, B1, pooled + (size_t)B0 * c.vit_hidden, feats ? (char*)feats + (size_t)B0 * m->P * c.vit_hidden * 2 : nullptr, (void*)L->side}};
+    if ((rc = vit_body_lanes(m, two, 2))) return rc;
+    SM_HIP(hipEventRecord(L->join, L->side));
+    SM_HIP(hipStreamWaitEvent((hipStream_t)stream, L->join, 0));
+    return SM_OK;
+}
 
 extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats, float* pix, void* stream) {
     SM_REQUIRE(m && m->finalized, "sm_vit_encode: model not finalized");
     SM_REQUIRE(frames && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode: B=%d outside [1, %d]", B, m->Bmax);
     const sm_config_t& c = m->c;
+    const size_t fpx = (size_t)c.vit_image * c.vit_image * 3;
     // a1: u8 ring buffer -> normalised bf16 patch matrix
-    sm_model::VitWs* ws;
-    int rc = m->vit_workspace(stream, &ws);
-    if (rc) return rc;
-    rc = sm_preprocess_patches(frames, B, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, ws->patches.p, m->Kpe, pix, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, stream);
-    if (rc) return rc;
-    return vit_body(m, ws, B, pooled, feats, stream);
+    return vit_encode_lanes(m, B, pooled, feats, stream, [&](sm_model::VitWs* ws, int f0, int nf, void* st) {
+        return sm_preprocess_patches(frames + (size_t)f0 * fpx, nf, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, ws->patches.p, m->Kpe,
+                                     pix ? pix + (size_t)f0 * fpx : nullptr, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, st);
+    });
 }
 
 extern "C" int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int dtype, int B, float* pooled, void* feats, void* stream) {
     SM_REQUIRE(m && m->finalized, "sm_vit_encode_pixels: model not finalized");
     SM_REQUIRE(pixel_values && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode_pixels: B=%d outside [1, %d]", B, m->Bmax);
     const sm_config_t& c = m->c;
-    sm_model::VitWs* ws;
-    int rc = m->vit_workspace(stream, &ws);
-    if (rc) return rc;
-    rc = sm_patchify_pixels(pixel_values, dtype, B, c.vit_image, c.vit_image, c.vit_patch, ws->patches.p, m->Kpe, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, stream);
-    if (rc) return rc;
-    return vit_body(m, ws, B, pooled, feats, stream);
+    const size_t fpx = (size_t)c.vit_image * c.vit_image * 3 * (dtype == SM_DT_F32 ? 4 : 2);
+    return vit_encode_lanes(m, B, pooled, feats, stream, [&](sm_model::VitWs* ws, int f0, int nf, void* st) {
+        return sm_patchify_pixels((const char*)pixel_values + (size_t)f0 * fpx, dtype, nf, c.vit_image, c.vit_image, c.vit_patch, ws->patches.p, m->Kpe,
+                                  c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, st);
+    });
 }
 
-static int vit_body(sm_model* m, sm_model::VitWs* ws, int B, float* pooled, void* feats, void* stream) {
+// the tower over `nl` independent half batches, issued INTERLEAVED (every step for lane 0, then the same step for lane 1): both
+// lanes start together and stay a step apart instead of one running ~2 ms (the host's issue time of a whole lane) behind the other
+static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
     const sm_config_t& c = m->c;
     const sm_model::Resolved& R = m->R;
-    const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P, M = B * S;
+    const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P;
     int rc;
     const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
-    float* x = ws->x.as<float>();
-    bf16_t* xn = ws->xn.as<bf16_t>();
+#define LANES for (int li = 0; li < nl; ++li)
+#define LV const VitLaneArgs& L = lanes[li]; float* x = L.ws->x.as<float>(); bf16_t* xn = L.ws->xn.as<bf16_t>(); const int M = L.B * S; void* stream = L.stream; (void)x; (void)xn; (void)M
     // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
-    {
-        sm_linear_t a = lin(m, *R.patch, ws->patches.p, SM_X_BF16, B * P, m->Kpe);
+    LANES { LV;
+        sm_linear_t a = lin(m, *R.patch, L.ws->patches.p, SM_X_BF16, L.B * P, m->Kpe);
         a.out_f32 = x; a.ldo = D;
         a.residual = R.pos; a.ldr = D;
         a.remap_in = P; a.remap_out = S; a.remap_off = 1;
         if ((rc = sm_linear(&a, stream))) return rc;
+        if ((rc = sm_vit_cls_rows(x, L.B, S, D, R.cls, R.pos, stream))) return rc;
+        if ((rc = sm_norm(x, M, D, D, R.pre_ln_w, R.pre_ln_b, c.vit_eps, 0, x, nullptr, D, stream))) return rc;
     }
-    if ((rc = sm_vit_cls_rows(x, B, S, D, R.cls, R.pos, stream))) return rc;
-    if ((rc = sm_norm(x, M, D, D, R.pre_ln_w, R.pre_ln_b, c.vit_eps, 0, x, nullptr, D, stream))) return rc;
     for (int l = 0; l < c.vit_layers_run; ++l) {
         const sm_model::LayerW& w = R.vit[l];
-        if ((rc = sm_norm_ex(x, M, D, D, w.ln1_w, w.ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
-        {
+        LANES { LV;
+            if ((rc = sm_norm_ex(x, M, D, D, w.ln1_w, w.ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.qkv, xn, SM_X_BF16, M, D);
             a.bias = w.qkv_b;
-            a.out_bf16 = ws->qkv.p; a.ldo_bf16 = 3 * D;
+            a.out_bf16 = L.ws->qkv.p; a.ldo_bf16 = 3 * D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         // V is transposed inside the attention kernel's LDS staging (a V^T side output of the QKV GEMM cost ~50 us of
         // scalar 2-byte stores per layer at 28 frames)
-        if ((rc = sm_vit_attention(ws->qkv.p, nullptr, ws->ctx.p, B, S, H, dh, 0, od, stream))) return rc;
-        {
-            sm_linear_t a = lin(m, *w.out, ws->ctx.p, SM_X_BF16, M, D);
+        LANES { LV;
+            if ((rc = sm_vit_attention(L.ws->qkv.p, nullptr, L.ws->ctx.p, L.B, S, H, dh, 0, od, stream))) return rc;
+            sm_linear_t a = lin(m, *w.out, L.ws->ctx.p, SM_X_BF16, M, D);
             a.bias = w.out_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
-        if ((rc = sm_norm_ex(x, M, D, D, w.ln2_w, w.ln2_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
-        {
+        LANES { LV;
+            if ((rc = sm_norm_ex(x, M, D, D, w.ln2_w, w.ln2_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.fc1, xn, SM_X_BF16, M, D);
             a.bias = w.fc1_b; a.act = SM_ACT_QUICK_GELU;
-            a.out_bf16 = ws->hmid.p; a.ldo_bf16 = c.vit_mlp;
+            a.out_bf16 = L.ws->hmid.p; a.ldo_bf16 = c.vit_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
-        {
-            sm_linear_t a = lin(m, *w.fc2, ws->hmid.p, SM_X_BF16, M, c.vit_mlp);
+        LANES { LV;
+            sm_linear_t a = lin(m, *w.fc2, L.ws->hmid.p, SM_X_BF16, M, c.vit_mlp);
             a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
     }
-    return sm_pool_patches(x, B, S, D, pooled, feats, stream);
+    LANES { LV;
+        if ((rc = sm_pool_patches(x, L.B, S, D, L.pooled, L.feats, stream))) return rc;
+    }
+#undef LANES
+#undef LV
+    return SM_OK;
+}
+static int vit_body(sm_model* m, sm_model::VitWs* ws, int B, float* pooled, void* feats, void* stream) {
+    const VitLaneArgs one = {ws, B, pooled, feats, stream};
+    return vit_body_lanes(m, &one, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ stream

@@ -10,5 +10,8 @@ model = NativeModel(cfg)
 bench.random_weights_into(model, cfg, 1)
 bench.random_llm_weights_into(model, cfg, 2)
 model.finalize()
-s = model.open_stream(max_frames=512, max_seq=int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
-print(bench.decode_leg(model, s, cfg, n_new=int(sys.argv[1]) if len(sys.argv) > 1 else 64))
+s = model.open_stream(max_frames=16384, max_seq=int(sys.argv[2]) if len(sys.argv) > 2 else 1024)
+nctx = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256]        # frame tokens of the context (+ 72 text tokens)
+for n in nctx:
+    r = bench.decode_leg(model, s, cfg, n_ctx_frames=n, n_new=int(sys.argv[1]) if len(sys.argv) > 1 else 64)
+    print(r if len(nctx) == 1 else {k: r[k] for k in ("context_tokens", "tokens_per_s", "ms_per_token")})

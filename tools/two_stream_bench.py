@@ -14,6 +14,7 @@ NS = int(os.environ.get("NSTREAMS", "2"))
 cfg = PathConfig(llm_layers=0, max_frames_per_call=B)
 models, streams, hs = [], [], []
 ONE = os.environ.get("NMODELS", "1") == "1"
+PIPE = os.environ.get("PIPE", "0") == "1"          # sm_stream_push_frames_pipelined (gate pass of call i under the tower of call i+1)
 for i in range(NS):
     if i == 0 or not ONE:
         m = NativeModel(cfg); bench.random_weights_into(m, cfg, 1 + i); m.finalize()
@@ -23,11 +24,13 @@ torch.cuda.synchronize()
 def step(i):
     for k in range(NS):
         with torch.cuda.stream(hs[k]):
-            streams[k].push_frames(frames[(i % 4) * B:(i % 4) * B + B])
+            (streams[k].push_frames_pipelined if PIPE else streams[k].push_frames)(frames[(i % 4) * B:(i % 4) * B + B])
 for i in range(2): step(i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps): step(i)
+if PIPE:
+    for st in streams: st.join()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"NSTREAMS={NS} B={B}: {NS * B * steps / dt:.1f} frames/s aggregate, {dt / steps * 1e3:.2f} ms per round")
