@@ -358,6 +358,11 @@ __device__ __forceinline__ bf16x8 make8(const float (&e)[8]) {
     const u32x4 u = {pack16<F16>(e[0], e[1]), pack16<F16>(e[2], e[3]), pack16<F16>(e[4], e[5]), pack16<F16>(e[6], e[7])};
     return __builtin_bit_cast(bf16x8, u);
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <bool F16>      // F16: q / k / v / P / ctx are IEEE fp16 (the ViT's optional fp16 mode), else bf16
 __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
     constexpr int DH = 64, KROW = 128, TILE_BYTES = 16384;
@@ -482,15 +487,21 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
                             s[qb][kb][f][r] = key >= nk ? -INFINITY : s[qb][kb][f][r];
                         }
         }
+        // vmax3 is inline asm: the hazard recogniser does not know that it reads registers an MFMA has just written (a VALU read of
+        // an XDL result needs up to 19 wait states, which hipcc only inserts in front of instructions it can see) -- without this pad
+        // the fp16 build returned NaN at 28 frames.  Nothing is scheduled across it.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            // two independent max chains per query block (a single chain is 32 dependent v_max)
-            float mxa = fmaxf(fmaxf(s[qb][0][0][0], s[qb][0][0][1]), fmaxf(s[qb][0][0][2], s[qb][0][0][3]));
-            float mxb = fmaxf(fmaxf(s[qb][0][1][0], s[qb][0][1][1]), fmaxf(s[qb][0][1][2], s[qb][0][1][3]));
-            float mxc = fmaxf(fmaxf(s[qb][1][0][0], s[qb][1][0][1]), fmaxf(s[qb][1][0][2], s[qb][1][0][3]));
-            float mxd = fmaxf(fmaxf(s[qb][1][1][0], s[qb][1][1][1]), fmaxf(s[qb][1][1][2], s[qb][1][1][3]));
-            float mx = fmaxf(fmaxf(mxa, mxb), fmaxf(mxc, mxd));
+            // 16 scores per lane -> 8 v_max3_f32 in three independent chains (plain fmaxf compiles to a canonicalising
+            // v_max_f32 x, x, x per operand in front of every max: 24 instructions for the same reduction)
+            const float mxa = vmax3(vmax3(s[qb][0][0][0], s[qb][0][0][1], s[qb][0][0][2]), s[qb][0][0][3], s[qb][0][1][0]);
+            const float mxb = vmax3(vmax3(s[qb][0][1][1], s[qb][0][1][2], s[qb][0][1][3]), s[qb][1][0][0], s[qb][1][0][1]);
+            const float mxc = vmax3(vmax3(s[qb][1][0][2], s[qb][1][0][3], s[qb][1][1][0]), s[qb][1][1][1], s[qb][1][1][2]);
+            float mx = vmax3(vmax3(mxa, mxb, mxc), s[qb][1][1][3], s[qb][1][1][3]);
             mx = xor32_max(xor16_max(mx));
             const float m_new = fmaxf(m_run[qb], mx);         // finite: every tile holds at least one real key
             const float mc = m_new * p.c;
