@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     constexpr int BN = 128 * WN;
     constexpr int NW = 4 * WN;                       // waves
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: LDS-DMA destinations (M0) and source bases stay scalar
     const int i = lane & 15, g = lane >> 4;
     const int wn = wave >> 2, wm = wave & 3;
 
@@ -127,25 +128,38 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         //        the barrier group 1 reaches from its R(t) with that wait behind it.
         constexpr int STAGE = 32768;
         const int KS = a.KS;
-        const char* wsrc[2];
-        const char* xsrc[2];
+        // Staging sources as a wave-uniform 64-bit base (scalar registers, advanced on the scalar unit) plus a 32-bit per-lane
+        // offset that is fixed for the whole tile: no vector arithmetic per DMA piece.  VALU instructions of the wave that is
+        // in its R interval are not free for the OTHER wave of the SIMD: on gfx950 they do not overlap with its MFMAs
+        // (tools/experiments/mfma_valu_coexec2.hip), so the ~15 address / readfirstlane instructions per k-step the per-lane
+        // pointers cost came straight out of the M interval (32 MFMAs measured at ~20 clk each instead of 16-17).
+        const char* wbase[2];
+        const uint32_t woff = lane * 16;
+        const char* const xbase = (const char*)a.x + (size_t)tile_m * G2_BM * a.ldx * 2;
+        uint32_t xoff[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int rgg = tile_n * 16 + wave * 2 + j;
             if (rgg >= a.NRG) rgg = a.NRG - 1;
-            wsrc[j] = (const char*)a.w + (size_t)rgg * KS * 1024 + lane * 16;
+            wbase[j] = (const char*)a.w + (size_t)rgg * KS * 1024;
             const int row = (wave * 2 + j) * 16 + (lane >> 2);
-            int mg = tile_m * G2_BM + row;
-            if (mg >= a.M) mg = a.M - 1;
+            int rl = row;
+            if (tile_m * G2_BM + row >= a.M) rl = a.M - 1 - tile_m * G2_BM;
             const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
-            xsrc[j] = (const char*)a.x + ((size_t)mg * a.ldx + chunk * 8) * 2;
+            xoff[j] = (uint32_t)(rl * a.ldx + chunk * 8) * 2;
         }
+        // global_load_lds in its scalar-base form (s[base] + v offset), written out: the builtin takes a per-lane 64-bit pointer and
+        // hipcc rebuilds one with two v_lshl_add_u64 per piece even from a uniform base.  Waits are counted by hand below anyway.
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+        auto dma = [&](const char* sbase, uint32_t voff, uint32_t dst) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+        };
         auto stage = [&](int ks, int slot) {
-            char* sb = smem + slot * STAGE;
+            const uint32_t sb = lds0 + slot * STAGE + wave * 2048;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(wsrc[j] + (size_t)ks * 1024, sb + (wave * 2 + j) * 1024);
+            for (int j = 0; j < 2; ++j) dma(wbase[j] + (size_t)ks * 1024, woff, sb + j * 1024);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(xsrc[j] + (size_t)ks * 64, sb + 16384 + (wave * 2 + j) * 1024);
+            for (int j = 0; j < 2; ++j) dma(xbase + (size_t)ks * 64, xoff[j], sb + 16384 + j * 1024);
         };
         stage(0, 0);
         if (KS > 1) stage(1, 1);
@@ -202,6 +216,13 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             PH(3);
         };
         int ks = 0;
+        // four k-steps per trip with compile-time ring slots: the fragment reads take immediate offsets (no per-step address adds)
+        for (; ks + 6 < KS; ks += 4) {
+            kstep(ks, std::integral_constant<int, 0>{}, 0);
+            kstep(ks + 1, std::integral_constant<int, 0>{}, 1);
+            kstep(ks + 2, std::integral_constant<int, 0>{}, 2);
+            kstep(ks + 3, std::integral_constant<int, 0>{}, 3);
+        }
         for (; ks + 3 < KS; ++ks) kstep(ks, std::integral_constant<int, 0>{}, ks & 3);
         if (ks + 2 < KS) { kstep(ks, std::integral_constant<int, 1>{}, ks & 3); ++ks; }
         for (; ks < KS; ++ks) kstep(ks, std::integral_constant<int, 2>{}, ks & 3);
