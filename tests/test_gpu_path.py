@@ -941,3 +941,24 @@ def test_group_decode_full_width_16_streams_one_launch_attention():
             j = next(k for k in range(n_new) if out[t][k] != solo_ids[t][k])
             assert j > 0 or float(torch.topk(solo_first[t], 2).values.diff().abs()) < 6e-2, (t, out[t], solo_ids[t])
     assert same >= S - 2, (same, out, solo_ids)
+
+
+def test_full_size_two_lanes_of_28_frames_equal_two_calls():
+    """The bench's step: 56 FULL-SIZE frames in one call = two concurrent 28-frame tower lanes (256x256 GEMMs, split-K reduces,
+    attention and norms of two batches in flight on two HIP streams of one model).  Pooled features must be bit-identical to two
+    separate 28-frame calls, repeatedly (any cross-lane sharing of scratch would show as a difference), and the pipelined push
+    must give the plain push's logits."""
+    vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 101), conn_gate_weights(ccfg, gcfg, 102), max_frames_per_call=56)
+    frames = O.synthetic_frames(56, 336, seed=91, scene_len=4).cuda()
+    ref = torch.cat([m.vit_encode(frames[:28]), m.vit_encode(frames[28:])])
+    for _ in range(4):
+        assert torch.equal(m.vit_encode(frames), ref)
+    a, b = m.open_stream(max_frames=128, max_seq=64), m.open_stream(max_frames=128, max_seq=64)
+    lg_a0, _ = a.push_frames(frames)
+    lg_a1, _ = a.push_frames(frames.flip(0).contiguous())
+    lg_b0, _ = b.push_frames_pipelined(frames)
+    lg_b1, _ = b.push_frames_pipelined(frames.flip(0).contiguous())     # its tower runs over the first call's connector + gate pass
+    b.join()
+    assert torch.equal(lg_b0, lg_a0) and torch.equal(lg_b1, lg_a1)
+    assert torch.equal(b.tokens(0, 112), a.tokens(0, 112))
