@@ -6,19 +6,25 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round; mkdir -p $O
 timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log > $O/bench_default.json; cut -c1-400 $O/bench_default.json
-# kernel stats of the BENCH STEPS ONLY (no decode / end-to-end / auxiliary legs, no HIP-event bracketing): the dominant kernel's
-# in-bench average can be read straight from this file
+# kernel stats of the BENCH STEPS ONLY (no decode / end-to-end / auxiliary legs, no HIP-event bracketing).  Two runs:
+#  (a) the default schedule (56 frames per step, two tower lanes + pipelined gate pass): two kernels share the chip, so a kernel's
+#      duration here includes the time its blocks waited for CUs the other lane's kernel held;
+#  (b) --batch 28 --no-pipeline (one lane, plain call = the schedule bench.py's `roofline` segment runs): the dominant kernel's
+#      undisturbed average can be read straight from this file and must agree with roofline.avg_launch_us
 rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-decode --no-aux --no-e2e --no-prof > $O/bench_profiled.log 2>&1
 grep '^{"metric"' $O/bench_profiled.log > $O/bench_profiled.json
-cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_steps.csv
+cp "$(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_steps_default.csv
+rm -rf /tmp/prof_stats1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats1 -- python bench.py --batch 28 --no-pipeline --steps 20 --warmup 2 --no-cpu-baseline --no-decode --no-aux --no-e2e --no-prof > $O/bench_profiled_single_lane.log 2>&1
+grep '^{"metric"' $O/bench_profiled_single_lane.log > $O/bench_profiled_single_lane.json
+cp "$(find /tmp/prof_stats1 -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_steps.csv
 # the decode step on its own (Mistral-7B, 64 tokens after a 328-token prefill)
 rm -rf /tmp/prof_dec; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -- python tools/decode_bench.py 64 1024 > $O/decode_profiled.log 2>&1
 cp "$(find /tmp/prof_dec -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_decode.csv
 rm -rf /tmp/pmc_f /tmp/pmc_w
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
 rm -rf /tmp/pmc_m
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_mfma_summary.py /tmp/pmc_m $O/mfma_util.json
-head -12 $O/kernel_stats_steps.csv | cut -c1-160; head -8 $O/kernel_stats_decode.csv | cut -c1-160
+head -8 $O/kernel_stats_steps_default.csv | cut -c1-160; head -12 $O/kernel_stats_steps.csv | cut -c1-160; head -8 $O/kernel_stats_decode.csv | cut -c1-160
