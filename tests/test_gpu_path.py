@@ -962,3 +962,37 @@ def test_full_size_two_lanes_of_28_frames_equal_two_calls():
     b.join()
     assert torch.equal(lg_b0, lg_a0) and torch.equal(lg_b1, lg_a1)
     assert torch.equal(b.tokens(0, 112), a.tokens(0, 112))
+
+
+def test_full_depth_32_layers_prefill_and_decode():
+    """Mistral-7B at its FULL depth and widths (32 layers x 4096 / 32 q heads / 8 kv heads x 128 / MLP 14336; small vocab): a 72-token
+    prefill and 5 greedy decode steps (fused RMSNorm + q/k/v + RoPE + KV-append kernel, one-launch decode attention) against the
+    oracle in mixed precision.  The 32 layers reuse the seeded tensors of 4 distinct layers (the test is about 32 layers of
+    accumulation through the native pipeline, not about 7 G distinct random numbers)."""
+    lcfg = O.LmCfg(hidden=4096, layers=32, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
+    base = O.make_lm_weights(O.LmCfg(hidden=4096, layers=4, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6), 79)
+    Wl = {k: v for k, v in base.items() if ".layers." not in k}
+    for i in range(32):
+        for k, v in base.items():
+            if f".layers.{i % 4}." in k:
+                Wl[k.replace(f".layers.{i % 4}.", f".layers.{i}.")] = v
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl)
+    g = torch.Generator().manual_seed(19)
+    text = torch.randint(3, lcfg.vocab, (72,), generator=g)
+    s = m.open_stream(max_frames=8, max_seq=128)
+    s.prefill(text.to(torch.int32).cuda())
+    lg, _ = s.logits()
+    torch.set_num_threads(max(16, torch.get_num_threads()))
+    ref_ids, trace = O.greedy_generate(Wl["model.embed_tokens.weight"][text], Wl, lcfg, 6, eos_token_id=None, prec=O.MIXED, return_logits=True)
+    scale = float(trace[0].abs().max())
+    assert maxdiff(lg, trace[0]) < 2e-2 * max(1.0, scale), (maxdiff(lg, trace[0]), scale)
+    got = s.decode(5).cpu().tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 4e-2 * max(1.0, scale), (j, got, ref_ids)
+            break
+    else:
+        assert maxdiff(s.logits()[0], trace[5]) < 2e-2 * max(1.0, scale)
+    assert s.kv_len == 77
