@@ -9,7 +9,8 @@ from streammind_amd import native
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 precise = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 xdt = torch.bfloat16 if (len(sys.argv) > 3 and sys.argv[3] == "bf16") else torch.float32
-shapes = [("v", 1024, 4096, False), ("o", 4096, 4096, False), ("gate_up", 14336, 4096, True), ("down", 4096, 14336, False)]
+shapes = [("v", 1024, 4096, False), ("o", 4096, 4096, False), ("qkv", 6144, 4096, False), ("gate_up", 14336, 4096, True), ("down", 4096, 14336, False),
+          ("lm_head", 32000, 4096, False)]
 for name, N, K, dual in shapes:
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     wp = native.pack_weight(w)
@@ -29,4 +30,4 @@ for name, N, K, dual in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     mb = N * K * 2 * (2 if dual else 1) / 1e6
-    print(f"{name:8s} M={M} N={N} K={K} dual={dual}: {us:7.1f} us  {mb / us / 1e6 * 1e6:7.1f} GB/s ... {mb/us*1e-3:.2f} TB/s", flush=True)
+    print(f"{name:8s} M={M} N={N} K={K} dual={dual}: {us:7.1f} us  {mb / us:.2f} TB/s of weights (launch pair where the K slices are summed by a second kernel)", flush=True)
