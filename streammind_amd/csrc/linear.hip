@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
     const bool valid = i < a.M;
     const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
     f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    constexpr int U = DUAL ? 2 : 4;
+    constexpr int U = DUAL ? 2 : 4;          // 16-byte weight loads in flight per wave (8 measured slower: 378 vs 437 tokens/s, short K loops fall into the tail loop)
     int kp = wave;
     bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);     // NORM: normalised bf16 rows [M][K]
     auto body = [&](u32x4 q, u32x4 q2, int kpi) {
@@ -1084,6 +1084,11 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
             return launch_skinny_norm<1>(a, dual, w8k, st);
         }
         if (w8k) {
+            static int f8w = -1;                      // SM_FP8_WAVES=4|8|16: tuning override for the fp8 weight-streaming kernels
+            if (f8w < 0) { const char* e = getenv("SM_FP8_WAVES"); f8w = e ? atoi(e) : 0; }
+            if (f8w == 4 && a.KS >= 8) return launch_skinny_fp8<4>(a, xf32, split, dual, st);
+            if (f8w == 8 && a.KS >= 32) return launch_skinny_fp8<8>(a, xf32, split, dual, st);
+            if (f8w == 16 && a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);
             if (a.KS >= 64 && !dual) return launch_skinny_fp8<16>(a, xf32, split, dual, st);
             if (a.KS >= 32) return launch_skinny_fp8<8>(a, xf32, split, dual, st);
             if (a.KS >= 8) return launch_skinny_fp8<4>(a, xf32, split, dual, st);
