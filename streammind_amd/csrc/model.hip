@@ -49,6 +49,43 @@ __global__ void embed_last_kernel(const int32_t* tok, const bf16_t* table, int D
     for (int c = threadIdx.x; c < D; c += blockDim.x) out[c] = bf2f(table[(size_t)id * D + c]);
 }
 __global__ void copy_i32_kernel(const int32_t* src, int32_t* dst) { *dst = *src; }
+// the tail of a decode step in ONE launch: greedy argmax of the logits (lowest index wins ties, as torch.argmax) -> pending token;
+// emitted as the next step's output id and its embedding row gathered for the next step's first kernel (both optional).  Was
+// argmax + copy + gather: three latency-only launches per token.
+__global__ __launch_bounds__(1024) void argmax_emit_embed_kernel(const float* __restrict__ lg, int V, int32_t* __restrict__ next_tok,
+                                                                 int32_t* __restrict__ emit, const bf16_t* __restrict__ table, int D,
+                                                                 float* __restrict__ emb) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ int winner;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const float t = lg[v];
+        if (t > best) { best = t; idx = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
+        *next_tok = idx;
+        if (emit) *emit = idx;
+        winner = idx;
+    }
+    __syncthreads();
+    if (emb) {
+        const int id = winner;
+        for (int c = threadIdx.x; c < D; c += blockDim.x) emb[c] = bf2f(table[(size_t)id * D + c]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ storage
 struct DevBuf {
@@ -1028,8 +1065,9 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
     return SM_OK;
 }
 
-// final norm + lm_head on row `row` of the residual stream, greedy argmax into next_tok
-static int llm_head(sm_stream* s, int row, void* stream) {
+// final norm + lm_head on row `row` of the residual stream, greedy argmax into next_tok; decode steps pass where the NEXT step's
+// output id goes and ask for its embedding row in s->emb (row 0) -- nullptr / false after a prefill and on the last step
+static int llm_head(sm_stream* s, int row, void* stream, int32_t* emit_next = nullptr, bool embed_next = false) {
     sm_model* m = s->m;
     const sm_config_t& c = m->c;
     const int ld = c.llm_hidden;
@@ -1041,7 +1079,11 @@ static int llm_head(sm_stream* s, int row, void* stream) {
     if (fuse_norm) { a.norm_gamma = m->R.llm_norm; a.norm_eps = c.llm_eps; }
     a.out_f32 = s->lmlog.as<float>(); a.ldo = c.llm_vocab;
     if ((rc = sm_linear(&a, stream))) return rc;
-    return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);
+    if (!emit_next && !embed_next) return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);
+    argmax_emit_embed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), emit_next,
+                                                                 m->R.embed->buf.as<bf16_t>(), ld, embed_next ? s->emb.as<float>() : nullptr);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
 }
 
 extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* stream) {
@@ -1097,13 +1139,15 @@ extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* 
     sm_model* m = s->m;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    // emit the pending greedy token and feed it back (its KV is appended, the next token becomes pending); from the second step on
+    // the emit + embedding gather ride in the previous step's argmax launch
+    copy_i32_kernel<<<1, 1, 0, st>>>(s->next_tok.as<int32_t>(), out_ids);
+    embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->R.embed->buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
+    SM_LAUNCH_CHECK();
     for (int j = 0; j < n_steps; ++j) {
-        // emit the pending greedy token, then feed it back (its KV is appended, the next token becomes pending)
-        copy_i32_kernel<<<1, 1, 0, st>>>(s->next_tok.as<int32_t>(), out_ids + j);
-        embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->R.embed->buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
-        SM_LAUNCH_CHECK();
+        const bool more = j + 1 < n_steps;
         if ((rc = llm_layers(s, 1, stream))) return rc;
-        if ((rc = llm_head(s, 0, stream))) return rc;
+        if ((rc = llm_head(s, 0, stream, more ? out_ids + j + 1 : nullptr, more))) return rc;
     }
     return SM_OK;
 }
