@@ -5,12 +5,16 @@ event gate), BASELINE.json configs[1]; one stream per GPU, `--gpus N` ranks are 
 (the path shards by stream with no data-path collective) -> weak scaling.
 
 A "step" = one batch of `--batch` consecutive frames of the synthetic 336x336 stream pushed through
-sm_stream_push_frames (ViT batch, then the connector scanned in frame order and the gate applied to every frame:
-results identical to frame-at-a-time).  Frames are resident in HBM before the timed region.
+sm_stream_push_frames[_pipelined] (ViT batch, then the connector scanned in frame order and the gate applied to every
+frame: results identical to frame-at-a-time).  Default: 56 frames per step -- the library runs the tower of
+such a call as two concurrent 28-frame lanes -- with the connector + gate pass of step i issued under the tower of step i+1
+(identical results; `--batch 28 --no-pipeline` is the plain one-lane schedule of round 1, also printed as a leg of every run).
+Frames are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the tiled MFMA GEMM; durations from
-HIP events recorded on the launch stream inside the timed region) and `cpu_baseline` (the oracle -- a plain-torch
-CPU port of the reference arithmetic -- timed on this host on a bounded sample; rank 0, N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the tiled MFMA GEMM; HIP events recorded on the
+launch stream: inside the timed region for the one-lane schedule, on one-lane plain steps right after it when the timed steps run
+two kernels at a time -- `roofline.measured_on`) and `cpu_baseline` (the oracle -- a plain-torch CPU port of the reference
+arithmetic -- timed on this host on a bounded sample; rank 0, N=1 only).
 """
 from __future__ import annotations
 
