@@ -528,6 +528,10 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+        try:                                  # every rank: push RCCL's init-time banner out of the C stdio buffer NOW, not at exit behind the JSON line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
     torch.cuda.synchronize()
     # HIP events around every tiled-GEMM launch break the back-to-back dispatch of the stream (~5.5 us per boundary, 4.4 % of
     # a step when every launch is bracketed), so only the LAST prof_steps of the timed region carry them.  With two tower lanes /
@@ -863,9 +867,16 @@ def main():
                                            "fire_schedule": "rank r fires on steps i with i % 9 == r % 9 (never two ranks of one node together)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when stdout is a
+    # pipe or a file: its buffer is only flushed at exit), so the communicator is torn down and C stdio flushed first
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
