@@ -230,6 +230,9 @@ typedef struct sm_config_t {
     int vit_fp16;            /* 1: the vision tower's GEMM / attention operands (weights + activations) are IEEE fp16 instead */
                              /*    of bf16 -- the precision the reference's demo loads the model in (model/builder.py:54:      */
                              /*    torch_dtype=float16); same MFMA rate, fp32 accumulation and fp32 residual stream as before */
+    int llm_fp16;            /* 1: the same for the LLM: linear weights, embedding table, activations, q / KV caches and the   */
+                             /*    attention's P in IEEE fp16 (an fp16 checkpoint goes in bit for bit; bf16 storage would drop */
+                             /*    3 of its mantissa bits and flip greedy token ids at near-ties).  Excludes weights_fp8.      */
 } sm_config_t;
 
 typedef struct sm_model sm_model;

@@ -37,7 +37,7 @@ struct AttnP {
     SmDecodeSeg seg;
 };
 
-template <int DH, bool GROUPQ = false, bool VROW = false, bool CAUSAL = false>
+template <int DH, bool GROUPQ = false, bool VROW = false, bool CAUSAL = false, bool F16 = false>       // F16: q / K / V^T / P / ctx are IEEE fp16 (llm_fp16)
 // GROUPQ: decode mode (query row r of kv-group h is head h*nq + r); VROW: V is row-major [key][d] and is transposed while
 // it is staged; CAUSAL is compile-time so that the mask is a handful of v_cmp/v_cndmask under ONE wave-uniform branch (as
 // a runtime flag it compiled to two scalar branches per score: 64 per key tile)
@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // bf16-rounded P the numerator uses) in every row -> no VALU adds per score and no cross-lane reduction at the end
     f32x4 lsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    {
+        const uint32_t one2 = pack16<F16>(1.0f, 1.0f);
+        ones = __builtin_bit_cast(bf16x8, u32x4{one2, one2, one2, one2});
+    }
     const bool active = q0 < p.nq;
 
     int k_end = nk, k_begin = 0;
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
                 for (int ks = 0; ks < KSQ; ++ks) {
                     bf16x8 kf = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & KMASK)) * 16));
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], a1, 0, 0, 0);
+                    a0 = mfma16<F16>(kf, qf[0][ks], a0);
+                    a1 = mfma16<F16>(kf, qf[1][ks], a1);
                 }
                 s[0][kb][f] = a0;
                 s[1][kb][f] = a1;
@@ -273,11 +275,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                bf16x8 pv;
+                u32x4 pv;
                 if (kb == 1 && half) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pv[e] = (__bf16)0.0f;
-                    pf[qb][1] = pv;
+                    pf[qb][1] = __builtin_bit_cast(bf16x8, u32x4{0, 0, 0, 0});
                     continue;
                 }
 #pragma unroll
@@ -286,10 +286,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                     for (int r = 0; r < 4; r += 2) {
                         const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;      // v_pk_fma_f32
                         const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                        pv[f * 4 + r] = (__bf16)e[0];
-                        pv[f * 4 + r + 1] = (__bf16)e[1];
+                        pv[f * 2 + (r >> 1)] = pack16<F16>(e[0], e[1]);
                     }
-                pf[qb][kb] = pv;
+                pf[qb][kb] = __builtin_bit_cast(bf16x8, pv);
             }
             // rescale the accumulators only when some lane's max moved (multiplying by alpha == 1 is exact, so skipping it
             // is bit-identical); after the first few key tiles the maxima are stable and the 16 multiplies disappear
@@ -303,14 +302,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && half) continue;
-            lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[0][kb], lsum[0], 0, 0, 0);
-            lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[1][kb], lsum[1], 0, 0, 0);
+            lsum[0] = mfma16<F16>(ones, pf[0][kb], lsum[0]);
+            lsum[1] = mfma16<F16>(ones, pf[1][kb], lsum[1]);
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 const int d = df * 16 + i;
                 bf16x8 vf = *(const bf16x8*)(Vl + d * 128 + (((kb * 4 + g) ^ (d & 7)) * 16));
-                o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][kb], o[0][df], 0, 0, 0);
-                o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][kb], o[1][df], 0, 0, 0);
+                o[0][df] = mfma16<F16>(vf, pf[0][kb], o[0][df]);
+                o[1][df] = mfma16<F16>(vf, pf[1][kb], o[1][df]);
             }
         }
     }
@@ -335,8 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
             for (int df = 0; df < DF; ++df) {
                 f32x4 v = o[qb][df] * inv;
-                bf16x4 w = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                *(bf16x4*)(dst + df * 16) = w;
+                *(u32x2*)(dst + df * 16) = u32x2{pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3])};
             }
         }
     }
@@ -578,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
 // One block per head; the (m, l) pairs of all splits are read with one load per lane, then each lane owns two d's.
 __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                           int splits, int rows, int dh, float c, bf16_t* __restrict__ out,
-                                                          long part_bs, long ml_bs) {
+                                                          long part_bs, long ml_bs, int f16) {
     const int row = blockIdx.x, lane = threadIdx.x;
     part_o += blockIdx.y * part_bs; part_ml += blockIdx.y * ml_bs; out += (size_t)blockIdx.y * rows * dh;     // blockIdx.y: stream of a batched decode
     float m = -INFINITY, l = 0.f;
@@ -601,7 +599,7 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
             for (int u = 0; u < 8; ++u)
                 if (s0 + u < splits) num += __shfl(w, s0 + u, 64) * po[u];
         }
-        out[(size_t)row * dh + d] = (bf16_t)f2bf(num / den);
+        out[(size_t)row * dh + d] = (bf16_t)cvt16_rt(num / den, f16);
     }
 }
 
@@ -611,13 +609,16 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false
     SmProfScope prof(SM_PROF_ATTN, st);
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
-    SM_REQUIRE(!f16 || (p.v && dh == 64), "attention: fp16 operands only on the ViT fast path (row-major V, head_dim 64)");
+    SM_REQUIRE(!f16 || (p.v && dh == 64) || p.causal, "attention: fp16 operands on the ViT fast path (row-major V, head_dim 64) and the causal LLM path");
     if (p.v) {
         if (dh == 64 && f16) vit_attn_kernel<true><<<grid, 256, 0, st>>>(p);
         else if (dh == 64) vit_attn_kernel<false><<<grid, 256, 0, st>>>(p);
         else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
     } else if (p.causal) {
-        if (dh == 64) attn_kernel<64, false, false, true><<<grid, 256, 0, st>>>(p);
+        if (f16) {
+            if (dh == 64) attn_kernel<64, false, false, true, true><<<grid, 256, 0, st>>>(p);
+            else attn_kernel<128, false, false, true, true><<<grid, 256, 0, st>>>(p);
+        } else if (dh == 64) attn_kernel<64, false, false, true><<<grid, 256, 0, st>>>(p);
         else attn_kernel<128, false, false, true><<<grid, 256, 0, st>>>(p);
     } else {
         if (dh == 64) attn_kernel<64, false><<<grid, 256, 0, st>>>(p);
@@ -645,8 +646,8 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     return launch_attn(p, B, dh, (hipStream_t)stream, op_dtype == SM_OP_F16);
 }
 
-extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
-                                int dh, int S_max, void* ctx, void* stream) {
+int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
+                        int dh, int S_max, void* ctx, int f16, void* stream) {
     SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
     AttnP p;
@@ -659,7 +660,11 @@ extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* v
     p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
-    return launch_attn(p, 1, dh, (hipStream_t)stream);
+    return launch_attn(p, 1, dh, (hipStream_t)stream, f16 != 0);
+}
+extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
+                                int dh, int S_max, void* ctx, void* stream) {
+    return sm_llm_attention_ex(q, kcache, vtcache, n, pos0, H, KV, dh, S_max, ctx, 0, stream);
 }
 
 
@@ -681,6 +686,7 @@ struct DecAttnP {
     float c;
     SmDecodeSeg seg;
 };
+template <bool F16>
 __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
     constexpr int DH = 128;
     __shared__ float osh[8][16][DH + 4];
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
             for (int a = 0; a < 2; ++a) {
                 f32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][a][ks], qf[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) acc = mfma16<F16>(kf[u][a][ks], qf[ks], acc);
                 sc[a] = acc;
             }
             const bool part = key0 + 32 > nk;        // only the last block of the cache carries masked keys
@@ -767,16 +773,16 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(sc[a][r], p.c, -mc));
-                    const float er = bf2f(f2bf(e));            // the row sum adds the SAME rounded P the PV product multiplies
+                    const float er = up16<F16>(cvt16<F16>(e));            // the row sum adds the SAME rounded P the PV product multiplies
                     pe[a * 4 + r] = er;
                     psum += er;
                 }
-            const bf16x8 pf = make8<false>(pe);
+            const bf16x8 pf = make8<F16>(pe);
             l_run = l_run * alpha + psum;
 #pragma unroll
             for (int df = 0; df < 8; ++df) {
                 o[df] *= alpha;
-                o[df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u][df], pf, o[df], 0, 0, 0);
+                o[df] = mfma16<F16>(vf[u][df], pf, o[df]);
             }
         }
     }
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
             num += wt * osh[w][qi][d];
             den += wt * lsh[w][qi];
         }
-        p.ctx[((size_t)b * p.H + kvh * rep + qi) * DH + d] = (bf16_t)f2bf(num / den);
+        p.ctx[((size_t)b * p.H + kvh * rep + qi) * DH + d] = (bf16_t)cvt16<F16>(num / den);
     }
 }
 // SM_DECODE_ATTN_FUSED=0: keep the split + merge launch pair for every context length (A/B switch).  The one-launch kernel gives
@@ -819,8 +825,8 @@ static bool decode_attn_fused_ok(int nk, int dh, int S, int KV) {
 // tile kernel (so K/V of a group are streamed once for all its heads), the keys are split across gridDim.z blocks so
 // that every CU streams part of the cache, and a tiny kernel merges the partial softmaxes.
 // workspace: fp32 [splits_max * H * (dh + 2)]
-extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
-                                       int S_max, float* workspace, int splits_max, void* ctx, void* stream) {
+int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
+                               int S_max, float* workspace, int splits_max, void* ctx, int f16, void* stream) {
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
@@ -829,7 +835,8 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = (const bf16_t*)kcache; d.vt = (const bf16_t*)vtcache;
         d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = 0; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
         SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
-        decode_attn_kernel<<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
+        if (f16) decode_attn_kernel<true><<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
+        else decode_attn_kernel<false><<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
@@ -855,21 +862,28 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
     {
         SmProfScope prof(SM_PROF_ATTN, st);
         dim3 grid(1, KV, splits);
-        if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
-        else if (dh == 128) attn_kernel<128, true><<<grid, 256, 0, st>>>(p);
-        else SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
+        if (dh != 64 && dh != 128) SM_FAIL(SM_EINVAL, "attention: head_dim %d not supported (64 or 128)", dh);
+        if (f16) {
+            if (dh == 64) attn_kernel<64, true, false, false, true><<<grid, 256, 0, st>>>(p);
+            else attn_kernel<128, true, false, false, true><<<grid, 256, 0, st>>>(p);
+        } else if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
+        else attn_kernel<128, true><<<grid, 256, 0, st>>>(p);
         SM_LAUNCH_CHECK();
     }
-    attn_combine_kernel<<<H, 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, 0, 0);
+    attn_combine_kernel<<<H, 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, 0, 0, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
+}
+extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
+                                       int S_max, float* workspace, int splits_max, void* ctx, void* stream) {
+    return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream);
 }
 
 // single-token decode attention of S streams in ONE launch pair: stream t's query row block q[t] (H heads) against ITS cache
 // [0, pos[t]]; the key range is cut into the same number of splits for every stream (sized for the longest context; a split
 // that lies beyond a shorter stream's cache contributes weight 0 to the merge)
 int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
-                                int splits_max, void* ctx, void* stream) {
+                                int splits_max, void* ctx, int f16, void* stream) {
     SM_REQUIRE(q && ctx && workspace && S > 0 && S <= SM_MAX_SEG, "sm_llm_decode_attention_seg: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && (dh == 64 || dh == 128), "sm_llm_decode_attention_seg: dims");
     const int rep = H / KV;
@@ -883,7 +897,8 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
         d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
         SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
-        decode_attn_kernel<<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+        if (f16) decode_attn_kernel<true><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+        else decode_attn_kernel<false><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
@@ -908,11 +923,14 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
     {
         SmProfScope prof(SM_PROF_ATTN, st);
         dim3 grid(S, KV, splits);
-        if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
+        if (f16) {
+            if (dh == 64) attn_kernel<64, true, false, false, true><<<grid, 256, 0, st>>>(p);
+            else attn_kernel<128, true, false, false, true><<<grid, 256, 0, st>>>(p);
+        } else if (dh == 64) attn_kernel<64, true><<<grid, 256, 0, st>>>(p);
         else attn_kernel<128, true><<<grid, 256, 0, st>>>(p);
         SM_LAUNCH_CHECK();
     }
-    attn_combine_kernel<<<dim3(H, S), 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, p.part_bs, p.ml_bs);
+    attn_combine_kernel<<<dim3(H, S), 64, 0, st>>>(p.part_o, p.part_ml, splits, H, dh, p.c, (bf16_t*)ctx, p.part_bs, p.ml_bs, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

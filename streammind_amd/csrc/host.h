@@ -48,11 +48,20 @@ struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
 struct SmRopeEpi { const float* cos_tab; const float* sin_tab; void* q; int H, KV, S_max; SmDecodeSeg seg; };
 int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream);                                  // linear.hip
 int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
-                          const SmDecodeSeg& seg, int S_max, void* stream);                                       // vecops.hip
+                          const SmDecodeSeg& seg, int S_max, int f16, void* stream);                              // vecops.hip
+// fp16-aware forms of C-ABI glue ops (f16 != 0: the 16-bit tables / outputs are IEEE fp16, llm_fp16 mode); the extern "C" names keep bf16
+int sm_rope_kv_append_ex(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
+                         void* kcache, void* vtcache, int S_max, int f16, void* stream);
+int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, void* stream);
+int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
-                                int splits_max, void* ctx_bf16, void* stream);                                    // attention.hip
+                                int splits_max, void* ctx_bf16, int f16, void* stream);                           // attention.hip
+int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max,
+                        void* ctx, int f16, void* stream);
+int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh, int S_max,
+                               float* workspace, int splits_max, void* ctx, int f16, void* stream);
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
-                        void* stream);
+                        int f16, void* stream);
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);
 
 // Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that

@@ -52,9 +52,21 @@ extern "C" int sm_pack_weight(const void* w, int N, int K, int ldw, void* out, v
 }
 
 // fp32 -> bf16 hi (+ lo = bf16(x - hi), the next 8 mantissa bits) with the hardware RNE conversion (v_cvt_pk_bf16_f32)
-template <bool SPLIT>
+template <bool SPLIT, bool F16 = false>
 __device__ __forceinline__ void split_x(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo) {
     const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if constexpr (F16) {                                   // IEEE fp16 operands (llm_fp16 / vit_fp16): same storage, other rounding
+        f16x8 Hh, Lh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 h = (_Float16)f[j];
+            Hh[j] = h;
+            if (SPLIT) Lh[j] = (_Float16)(f[j] - (float)h);
+        }
+        hi = __builtin_bit_cast(bf16x8, Hh);
+        if (SPLIT) lo = __builtin_bit_cast(bf16x8, Lh);
+        return;
+    }
     bf16x8 H, L;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -67,7 +79,7 @@ __device__ __forceinline__ void split_x(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo
 }
 
 // x fragment of the skinny kernels: 8 consecutive k of row m, as bf16 (hi) and optionally the bf16 residual (lo)
-template <bool XF32, bool SPLIT>
+template <bool XF32, bool SPLIT, bool F16 = false>
 __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16x8& hi, bf16x8& lo) {
     if (XF32) {
         f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
@@ -75,7 +87,7 @@ __device__ __forceinline__ void load_x(const char* xrow, int k, bool valid, bf16
             a = *(const f32x4*)(xrow + (size_t)k * 4);
             b = *(const f32x4*)(xrow + (size_t)k * 4 + 16);
         }
-        split_x<SPLIT>(a, b, hi, lo);
+        split_x<SPLIT, F16>(a, b, hi, lo);
     } else {
         union { bf16x8 v; u32x4 u; } H;
         H.u = u32x4{0, 0, 0, 0};
@@ -191,7 +203,7 @@ __device__ __forceinline__ void norm_issue(const LinArgs& a, int wave, int lane,
         gm[u] = c < nv ? *(const f32x4*)(a.ngamma + (size_t)c * 4) : f32x4{0, 0, 0, 0};
     }
 }
-template <int WAVES>
+template <int WAVES, bool F16 = false>
 __device__ __forceinline__ void norm_finish(const LinArgs& a, float* nsum, bf16_t* xs, int wave, int lane, f32x4 (&t)[4], const f32x4 (&gm)[4]) {
     const int nv = a.K >> 2;
     const float* xr = (const float*)a.x;
@@ -223,12 +235,12 @@ __device__ __forceinline__ void norm_finish(const LinArgs& a, float* nsum, bf16_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = (u * WAVES + wave) * 64 + lane;
-            if (c < nv) *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gm[u][0] * (t[u][0] * rs), gm[u][1] * (t[u][1] * rs)),
-                                                               pack2bf(gm[u][2] * (t[u][2] * rs), gm[u][3] * (t[u][3] * rs))};
+            if (c < nv) *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack16<F16>(gm[u][0] * (t[u][0] * rs), gm[u][1] * (t[u][1] * rs)),
+                                                               pack16<F16>(gm[u][2] * (t[u][2] * rs), gm[u][3] * (t[u][3] * rs))};
         }
         for (int c = (4 * WAVES + wave) * 64 + lane; c < nv; c += WAVES * 64) {
             const f32x4 q = *(const f32x4*)(xm + (size_t)c * 4), gq = *(const f32x4*)(a.ngamma + (size_t)c * 4);
-            *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack2bf(gq[0] * (q[0] * rs), gq[1] * (q[1] * rs)), pack2bf(gq[2] * (q[2] * rs), gq[3] * (q[3] * rs))};
+            *(u32x2*)(xo + (size_t)c * 4) = u32x2{pack16<F16>(gq[0] * (q[0] * rs), gq[1] * (q[1] * rs)), pack16<F16>(gq[2] * (q[2] * rs), gq[3] * (q[3] * rs))};
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
 
 // one lane's share of the fused RoPE / KV-append epilogue: row `row` (= stream), head slot hs (q heads, then k heads, then v
 // heads), dims d0..d0+3 in `lo` and d0+64..d0+67 in `hi` of a 128-wide head.  Same arithmetic as rope_kv_kernel (vecops.hip).
+template <bool F16 = false>
 static __device__ __forceinline__ void rope_store(const SmRopeEpi& re, int row, int hs, int d0, f32x4 lo, f32x4 hi) {
     const int pos = re.seg.pos[row];
     if (hs < re.H + re.KV) {
@@ -346,14 +359,14 @@ static __device__ __forceinline__ void rope_store(const SmRopeEpi& re, int row, 
         }
         bf16_t* dst = hs < re.H ? (bf16_t*)re.q + ((size_t)row * re.H + hs) * 128 + d0
                                 : (bf16_t*)re.seg.kc[row] + ((size_t)pos * re.KV + (hs - re.H)) * 128 + d0;
-        *(u32x2*)dst = u32x2{pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3])};
-        *(u32x2*)(dst + 64) = u32x2{pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
+        *(u32x2*)dst = u32x2{pack16<F16>(o0[0], o0[1]), pack16<F16>(o0[2], o0[3])};
+        *(u32x2*)(dst + 64) = u32x2{pack16<F16>(o1[0], o1[1]), pack16<F16>(o1[2], o1[3])};
     } else {
         bf16_t* vt = (bf16_t*)re.seg.vtc[row] + ((size_t)(hs - re.H - re.KV) * 128 + d0) * re.S_max + pos;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            vt[(size_t)r * re.S_max] = (bf16_t)f2bf(lo[r]);
-            vt[(size_t)(64 + r) * re.S_max] = (bf16_t)f2bf(hi[r]);
+            vt[(size_t)r * re.S_max] = (bf16_t)cvt16<F16>(lo[r]);
+            vt[(size_t)(64 + r) * re.S_max] = (bf16_t)cvt16<F16>(hi[r]);
         }
     }
 }
@@ -368,7 +381,7 @@ struct NoRope {};
 // rg + 4 of the SAME weight image (the DUAL machinery: two accumulators over one activation fragment), i.e. dims d and d + 64
 // of one head land in the same lane, and the epilogue applies rotate_half RoPE and writes q / the K cache / the V^T cache
 // directly (rope_store).
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false, bool ROPE = false>   // MB: 16-row activation blocks (M <= 16 * MB)
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, int MB, bool NORM = false, bool ROPE = false, bool F16 = false>   // MB: 16-row activation blocks (M <= 16 * MB); F16: IEEE fp16 operands
 __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::conditional_t<ROPE, SmRopeEpi, NoRope> re) {
     static_assert(!NORM || (XF32 && !SPLIT && MB == 1), "fused RMSNorm: fp32 activations, one rounding, <= 16 rows");
     static_assert(!ROPE || (DUAL && MB == 1), "fused RoPE: the two halves of a head ride the dual accumulators");
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             if (valid[0]) r.u = *(const u32x4*)(xs + (size_t)i * a.K + kk * 32 + g * 8);
             xh = r.v;
         } else {
-            load_x<XF32, SPLIT>(xrow[mb], kk * 32 + g * 8, valid[mb], xh, xl);
+            load_x<XF32, SPLIT, F16>(xrow[mb], kk * 32 + g * 8, valid[mb], xh, xl);
         }
     };
     auto mfmas = [&](const bf16x8 (&wa)[U], const bf16x8 (&wb)[U], int k0) {
@@ -421,8 +434,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
                 for (int u = 0; u < 2; ++u) xfrag(0, k0 + (u0 + u) * WAVES, xh[u], xl[u]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u0 + u], xh[u], acc[0], 0, 0, 0);
-                    if (DUAL) acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u0 + u], xh[u], acc2[0], 0, 0, 0);
+                    acc[0] = mfma16<F16>(wa[u0 + u], xh[u], acc[0]);
+                    if (DUAL) acc2[0] = mfma16<F16>(wb[u0 + u], xh[u], acc2[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -435,11 +448,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             for (int u = 0; u < U; ++u) xfrag(mb, k0 + u * WAVES, xh[u], xl[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc[mb], 0, 0, 0);
-                if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc[mb], 0, 0, 0);
+                acc[mb] = mfma16<F16>(wa[u], xh[u], acc[mb]);
+                if (SPLIT) acc[mb] = mfma16<F16>(wa[u], xl[u], acc[mb]);
                 if (DUAL) {
-                    acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2[mb], 0, 0, 0);
-                    if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2[mb], 0, 0, 0);
+                    acc2[mb] = mfma16<F16>(wb[u], xh[u], acc2[mb]);
+                    if (SPLIT) acc2[mb] = mfma16<F16>(wb[u], xl[u], acc2[mb]);
                 }
             }
         }
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
                 if (DUAL) wb0[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
             }
         }
-        norm_finish<WAVES>(a, nsum, xs, wave, lane, t, gm);
+        norm_finish<WAVES, F16>(a, nsum, xs, wave, lane, t, gm);
         if (have0) { mfmas(wa0, wb0, ks); ks += U * WAVES; }
     }
     for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
@@ -472,14 +485,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
         for (int mb = 0; mb < MB; ++mb) {
             bf16x8 xh[U], xl[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) load_x<XF32, SPLIT>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
+            for (int u = 0; u < U; ++u) load_x<XF32, SPLIT, F16>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xh[u], acc[mb], 0, 0, 0);
-                if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[u], xl[u], acc[mb], 0, 0, 0);
+                acc[mb] = mfma16<F16>(wa[u], xh[u], acc[mb]);
+                if (SPLIT) acc[mb] = mfma16<F16>(wa[u], xl[u], acc[mb]);
                 if (DUAL) {
-                    acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xh[u], acc2[mb], 0, 0, 0);
-                    if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[u], xl[u], acc2[mb], 0, 0, 0);
+                    acc2[mb] = mfma16<F16>(wb[u], xh[u], acc2[mb]);
+                    if (SPLIT) acc2[mb] = mfma16<F16>(wb[u], xl[u], acc2[mb]);
                 }
             }
         }
@@ -491,11 +504,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
         for (int mb = 0; mb < MB; ++mb) {
             bf16x8 xh, xl;
             xfrag(mb, ks, xh, xl);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xh, acc[mb], 0, 0, 0);
-            if (SPLIT) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xl, acc[mb], 0, 0, 0);
+            acc[mb] = mfma16<F16>(wa, xh, acc[mb]);
+            if (SPLIT) acc[mb] = mfma16<F16>(wa, xl, acc[mb]);
             if (DUAL) {
-                acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xh, acc2[mb], 0, 0, 0);
-                if (SPLIT) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xl, acc2[mb], 0, 0, 0);
+                acc2[mb] = mfma16<F16>(wb, xh, acc2[mb]);
+                if (SPLIT) acc2[mb] = mfma16<F16>(wb, xl, acc2[mb]);
             }
         }
     }
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
     if constexpr (ROPE) {
         // rows walked with a wave-uniform index: the per-stream position / cache pointers are scalar loads from the argument block
         for (int row = 0; row < a.M; ++row)
-            if (i == row) rope_store(re, row, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3) * 16 + g * 4, acc[0], acc2[0]);
+            if (i == row) rope_store<F16>(re, row, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3) * 16 + g * 4, acc[0], acc2[0]);
         return;
     }
     if (pre_res) {
@@ -832,7 +845,7 @@ static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual,
 // K slice: the x chunk (8 k-steps = 256 k, both 16-row column blocks) is converted once per block into B-fragment order in
 // LDS (hi and, in precise mode, lo) and every wave multiplies it with its own weight rows; the K slices of the grid's second
 // dimension are summed by splitk_reduce_kernel (fixed order), which also applies the epilogue.
-template <bool XF32, bool SPLIT, bool DUAL>
+template <bool XF32, bool SPLIT, bool DUAL, bool F16 = false>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __restrict__ ws, float* __restrict__ ws2, int ks_per_split) {
     constexpr int KC = 8;                                   // k-steps per staged chunk
     __shared__ __attribute__((aligned(16))) bf16x8 xs[2][SPLIT ? 2 : 1][KC * 2 * 64];      // [buf][hi/lo][(ks, mb, lane)]
@@ -873,7 +886,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
         for (int it = 0; it < NIT; ++it) {
             const int item = tid + it * 512;
             bf16x8 hi, lo;
-            if (XF32) split_x<SPLIT>(xa[it], xb[it], hi, lo);
+            if (XF32) split_x<SPLIT, F16>(xa[it], xb[it], hi, lo);
             else hi = __builtin_bit_cast(bf16x8, xa[it]);
             xs[buf][0][item] = hi;
             if (SPLIT) xs[buf][SPLIT ? 1 : 0][item] = lo;
@@ -897,12 +910,12 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const bf16x8 xh = xs[buf][0][(u * 2 + mb) * 64 + lane];
-                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[set][u], xh, acc[mb], 0, 0, 0);
-                if (DUAL) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[set][u], xh, acc2[mb], 0, 0, 0);
+                acc[mb] = mfma16<F16>(wa[set][u], xh, acc[mb]);
+                if (DUAL) acc2[mb] = mfma16<F16>(wb[set][u], xh, acc2[mb]);
                 if (SPLIT) {
                     const bf16x8 xl = xs[buf][SPLIT ? 1 : 0][(u * 2 + mb) * 64 + lane];
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[set][u], xl, acc[mb], 0, 0, 0);
-                    if (DUAL) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[set][u], xl, acc2[mb], 0, 0, 0);
+                    acc[mb] = mfma16<F16>(wa[set][u], xl, acc[mb]);
+                    if (DUAL) acc2[mb] = mfma16<F16>(wb[set][u], xl, acc2[mb]);
                 }
             }
         }
@@ -953,7 +966,10 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
     float* ws2 = dual ? ws + slab : nullptr;
     const dim3 grid(nb, S);
 #define SL(XF, SP, DU) skinny_lds_kernel<XF, SP, DU><<<grid, 512, 0, st>>>(a, ws, ws2, per)
-    if (xf32) {
+    if (a.f16) {           // fp16 operands: single rounding only (the hi/lo split is the bf16 paths' way to fp32-like activations)
+        if (xf32) { if (dual) skinny_lds_kernel<true, false, true, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<true, false, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+        else { if (dual) skinny_lds_kernel<false, false, true, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<false, false, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+    } else if (xf32) {
         if (split) { if (dual) SL(true, true, true); else SL(true, true, false); }
         else       { if (dual) SL(true, false, true); else SL(true, false, false); }
     } else {
@@ -972,13 +988,18 @@ static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hip
     dim3 grid(a.NRG), block(WAVES * 64);
     size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * MB * 64 * sizeof(float) : 0;
 #define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB><<<grid, block, sh, st>>>(a, NoRope{})
-    if (xf32) {
+#define SKH(XF, DU) skinny_kernel<WAVES, XF, false, DU, MB, false, false, true><<<grid, block, sh, st>>>(a, NoRope{})
+    if (a.f16) {
+        if (xf32) { if (dual) SKH(true, true); else SKH(true, false); }
+        else      { if (dual) SKH(false, true); else SKH(false, false); }
+    } else if (xf32) {
         if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
         else       { if (dual) SK(true, false, true); else SK(true, false, false); }
     } else {
         if (dual) SK(false, false, true); else SK(false, false, false);
     }
 #undef SK
+#undef SKH
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -990,6 +1011,9 @@ static int launch_skinny_norm(const LinArgs& a, bool dual, bool fp8, hipStream_t
     if (fp8) {
         if (dual) skinny_fp8_kernel<WAVES, true, false, true, true><<<grid, block, sh, st>>>(a);
         else skinny_fp8_kernel<WAVES, true, false, false, true><<<grid, block, sh, st>>>(a);
+    } else if (a.f16) {
+        if (dual) skinny_kernel<WAVES, true, false, true, 1, true, false, true><<<grid, block, sh, st>>>(a, NoRope{});
+        else skinny_kernel<WAVES, true, false, false, 1, true, false, true><<<grid, block, sh, st>>>(a, NoRope{});
     } else if (dual) skinny_kernel<WAVES, true, false, true, 1, true><<<grid, block, sh, st>>>(a, NoRope{});
     else skinny_kernel<WAVES, true, false, false, 1, true><<<grid, block, sh, st>>>(a, NoRope{});
     SM_LAUNCH_CHECK();
@@ -1019,7 +1043,7 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
 // M <= 16 rows of fp32 activations, RMSNorm fused in front when p->norm_gamma is set
 int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) {
     SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && p->w_dtype != SM_W_FP8 && !p->vt &&
-               p->remap_in == 0 && p->op_dtype == SM_OP_BF16, "sm_linear_qkv_rope: plain bf16 q/k/v weights only");
+               p->remap_in == 0, "sm_linear_qkv_rope: plain 16-bit q/k/v weights only");
     SM_REQUIRE(p->M > 0 && p->M <= 16 && p->M <= SM_MAX_SEG && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0 &&
                p->N == (re.H + 2 * re.KV) * 128, "sm_linear_qkv_rope: M <= 16 fp32 rows, K %% 32 == 0, N = (H + 2 KV) * 128 (M=%d N=%d K=%d)", p->M, p->N, p->K);
     SM_REQUIRE(!p->norm_gamma || (long)p->M * p->K <= 16384, "sm_linear_qkv_rope: fused RMSNorm needs M*K <= 16384");
@@ -1033,10 +1057,12 @@ int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) 
     const dim3 grid((re.H + 2 * re.KV) * 4), block(WAVES * 64);
     if (p->norm_gamma) {
         const size_t sh = ((size_t)WAVES * 8 * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
-        skinny_kernel<WAVES, true, false, true, 1, true, true><<<grid, block, sh, st>>>(a, re);
+        if (a.f16) skinny_kernel<WAVES, true, false, true, 1, true, true, true><<<grid, block, sh, st>>>(a, re);
+        else skinny_kernel<WAVES, true, false, true, 1, true, true><<<grid, block, sh, st>>>(a, re);
     } else {
         const size_t sh = (size_t)WAVES * 8 * 64 * sizeof(float);
-        skinny_kernel<WAVES, true, false, true, 1, false, true><<<grid, block, sh, st>>>(a, re);
+        if (a.f16) skinny_kernel<WAVES, true, false, true, 1, false, true, true><<<grid, block, sh, st>>>(a, re);
+        else skinny_kernel<WAVES, true, false, true, 1, false, true><<<grid, block, sh, st>>>(a, re);
     }
     SM_LAUNCH_CHECK();
     return SM_OK;
@@ -1050,8 +1076,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     fill_args(p, a);
     const bool w8 = p->w_dtype == SM_W_FP8;
     SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
-    SM_REQUIRE(!a.f16 || (p->x_dtype == SM_X_BF16 && !p->w2 && !w8 && !p->norm_gamma && !p->vt),
-               "sm_linear: fp16 operands run on the tiled GEMM only (16-bit x, single bf16-layout weight image, no fused norm / vt)");
+    SM_REQUIRE(!a.f16 || (!w8 && !p->precise), "sm_linear: fp16 operands exclude fp8 weights and the hi/lo activation split (precise)");
+    SM_REQUIRE(!a.f16 || p->M <= 32 || (p->x_dtype == SM_X_BF16 && !p->w2 && !p->norm_gamma),
+               "sm_linear: above 32 rows fp16 operands run on the tiled GEMM (16-bit x, single weight image, no fused norm)");
     SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
                "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
@@ -1072,7 +1099,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         a.wscale = a.wscale2 = nullptr;
     }
     const bool w8k = w8 && p->M <= 16;            // fp8 kernels in use
-    if (p->M <= 32 && !a.f16) {
+    if (p->M <= 32) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
         const bool split = xf32 && p->precise;

@@ -44,9 +44,9 @@ __global__ void f16_to_f32_kernel(const _Float16* in, float* out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
 }
-__global__ void embed_last_kernel(const int32_t* tok, const bf16_t* table, int D, float* out) {
+__global__ void embed_last_kernel(const int32_t* tok, const bf16_t* table, int D, float* out, int f16) {
     int id = *tok;
-    for (int c = threadIdx.x; c < D; c += blockDim.x) out[c] = bf2f(table[(size_t)id * D + c]);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[c] = f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c]);
 }
 __global__ void copy_i32_kernel(const int32_t* src, int32_t* dst) { *dst = *src; }
 // the tail of a decode step in ONE launch: greedy argmax of the logits (lowest index wins ties, as torch.argmax) -> pending token;
@@ -54,7 +54,7 @@ __global__ void copy_i32_kernel(const int32_t* src, int32_t* dst) { *dst = *src;
 // argmax + copy + gather: three latency-only launches per token.
 __global__ __launch_bounds__(1024) void argmax_emit_embed_kernel(const float* __restrict__ lg, int V, int32_t* __restrict__ next_tok,
                                                                  int32_t* __restrict__ emit, const bf16_t* __restrict__ table, int D,
-                                                                 float* __restrict__ emb) {
+                                                                 float* __restrict__ emb, int f16) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ int winner;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(1024) void argmax_emit_embed_kernel(const float* __
     __syncthreads();
     if (emb) {
         const int id = winner;
-        for (int c = threadIdx.x; c < D; c += blockDim.x) emb[c] = bf2f(table[(size_t)id * D + c]);
+        for (int c = threadIdx.x; c < D; c += blockDim.x) emb[c] = f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c]);
     }
 }
 
@@ -311,6 +311,10 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     if (c.vit_fp16)
         for (auto& kv : m->slots)
             if (kv.second.kind == 1 && kv.first.rfind("vit.", 0) == 0) kv.second.f16 = true;
+    SM_REQUIRE(!(c.llm_fp16 && c.weights_fp8), "llm_fp16 and weights_fp8 are exclusive (fp16 operands exclude the fp8 weight-streaming kernels)");
+    if (c.llm_fp16)      // the LLM's linear weights AND its embedding table are kept as IEEE fp16 (the reference loads its checkpoints that way, model/builder.py:54)
+        for (auto& kv : m->slots)
+            if ((kv.second.kind == 1 || kv.second.kind == 2) && kv.first.rfind("llm.", 0) == 0) kv.second.f16 = true;
     if (c.weights_fp8)
         for (auto& kv : m->slots)
             if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head"))
@@ -360,7 +364,7 @@ extern "C" int sm_model_load_tensor(sm_model* m, const char* name_c, const void*
         DevBuf tmp;
         const bf16_t* src = (const bf16_t*)data;
         const unsigned nb = (unsigned)((n + 255) / 256);
-        if (s.kind == 1 && s.f16) {     // fp16 image (vit_fp16): an fp16 checkpoint tensor goes in AS IS (builder.py:54 loads fp16)
+        if (s.f16) {     // fp16 image (vit_fp16 / llm_fp16): an fp16 checkpoint tensor goes in AS IS (builder.py:54 loads fp16)
             if (dtype != SM_DT_F16) {
                 int rc = tmp.alloc(n * 2);
                 if (rc) return rc;
@@ -1014,11 +1018,12 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
     const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh;
     float* x = s->emb.as<float>();
     int rc;
+    const int f16 = c.llm_fp16 ? 1 : 0, od = f16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every LLM operand / cache (weights are packed to match)
     for (int l = 0; l < c.llm_layers; ++l) {
         const sm_model::LayerW& w = m->R.llm[l];
         // decode (one row): both RMSNorms ride inside the weight-streaming products that consume them
         const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
-        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
         // decode: RoPE + KV append ride in the epilogue of the q/k/v product (no fp32 q/k/v round trip, one launch less per layer)
         const bool fuse_rope = fuse_norm && dh == 128 && ld >= 1024 && !w.qkv->fp8 && !g_no_fused_rope;
         {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, n, ld) : lin(m, *w.qkv, s->xnb.p, SM_X_BF16, n, ld);
@@ -1034,14 +1039,14 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
                 if ((rc = sm_linear(&a, stream))) return rc;
             }
         }
-        if (!fuse_rope && (rc = sm_rope_kv_append(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, stream))) return rc;
+        if (!fuse_rope && (rc = sm_rope_kv_append_ex(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, f16, stream))) return rc;
         if (n == 1) {
-            if ((rc = sm_llm_decode_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, stream))) return rc;
-        } else if ((rc = sm_llm_attention(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, stream))) return rc;
+            if ((rc = sm_llm_decode_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, f16, stream))) return rc;
+        } else if ((rc = sm_llm_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, f16, stream))) return rc;
         {   sm_linear_t a = lin(m, *w.o, s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if (!fuse_norm && (rc = sm_norm(x, n, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
         if (n <= 32) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel
             const Slot& gu = *w.gu;
             sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, n, ld) : lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
@@ -1055,7 +1060,7 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             sm_linear_t a = lin(m, *w.gu, s->xnb.p, SM_X_BF16, n, ld);
             a.out_f32 = s->guf.as<float>(); a.ldo = 2 * c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
-            if ((rc = sm_swiglu(s->guf.as<float>(), n, c.llm_mlp, s->actb.p, stream))) return rc;
+            if ((rc = sm_swiglu_ex(s->guf.as<float>(), n, c.llm_mlp, s->actb.p, f16, stream))) return rc;
         }
         {   sm_linear_t a = lin(m, *w.down, s->actb.p, SM_X_BF16, n, c.llm_mlp);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
@@ -1073,7 +1078,8 @@ static int llm_head(sm_stream* s, int row, void* stream, int32_t* emit_next = nu
     const int ld = c.llm_hidden;
     int rc;
     const bool fuse_norm = (ld & 31) == 0 && !g_no_fused_norm;
-    if (!fuse_norm && (rc = sm_norm(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+    const int f16 = c.llm_fp16 ? 1 : 0, od = f16 ? SM_OP_F16 : SM_OP_BF16;
+    if (!fuse_norm && (rc = sm_norm_ex(s->emb.as<float>() + (size_t)row * ld, 1, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
     sm_linear_t a = fuse_norm ? lin(m, *m->R.lm_head, s->emb.as<float>() + (size_t)row * ld, SM_X_F32, 1, ld)
                               : lin(m, *m->R.lm_head, s->xnb.p, SM_X_BF16, 1, ld);
     if (fuse_norm) { a.norm_gamma = m->R.llm_norm; a.norm_eps = c.llm_eps; }
@@ -1081,7 +1087,7 @@ static int llm_head(sm_stream* s, int row, void* stream, int32_t* emit_next = nu
     if ((rc = sm_linear(&a, stream))) return rc;
     if (!emit_next && !embed_next) return sm_argmax(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), stream);
     argmax_emit_embed_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(s->lmlog.as<float>(), c.llm_vocab, s->next_tok.as<int32_t>(), emit_next,
-                                                                 m->R.embed->buf.as<bf16_t>(), ld, embed_next ? s->emb.as<float>() : nullptr);
+                                                                 m->R.embed->buf.as<bf16_t>(), ld, embed_next ? s->emb.as<float>() : nullptr, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -1095,7 +1101,7 @@ extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* str
     int rc, done = 0, last_rows = 0;
     while (done < n) {
         int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         done += cur; last_rows = cur;
     }
@@ -1112,10 +1118,10 @@ extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, fl
     int rc, done = 0;
     while (done < n) {
         const int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), stream))) return rc;
+        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         // final norm + lm_head on all `cur` rows of this chunk (llm_head does the last row only)
-        if ((rc = sm_norm(s->emb.as<float>(), cur, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, stream))) return rc;
+        if ((rc = sm_norm_ex(s->emb.as<float>(), cur, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, c.llm_fp16 ? SM_OP_F16 : SM_OP_BF16, stream))) return rc;
         sm_linear_t a = lin(m, *m->R.lm_head, s->xnb.p, SM_X_BF16, cur, ld);
         a.out_f32 = logits + (size_t)done * V; a.ldo = V;
         if ((rc = sm_linear(&a, stream))) return rc;
@@ -1142,7 +1148,7 @@ extern "C" int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids, void* 
     // emit the pending greedy token and feed it back (its KV is appended, the next token becomes pending); from the second step on
     // the emit + embedding gather ride in the previous step's argmax launch
     copy_i32_kernel<<<1, 1, 0, st>>>(s->next_tok.as<int32_t>(), out_ids);
-    embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->R.embed->buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>());
+    embed_last_kernel<<<1, 256, 0, st>>>(s->next_tok.as<int32_t>(), m->R.embed->buf.as<bf16_t>(), m->c.llm_hidden, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0);
     SM_LAUNCH_CHECK();
     for (int j = 0; j < n_steps; ++j) {
         const bool more = j + 1 < n_steps;
@@ -1189,25 +1195,26 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         g->d_ready = true;
     }
     float* x = g->d_emb.as<float>();
+    const int f16 = c.llm_fp16 ? 1 : 0, od = f16 ? SM_OP_F16 : SM_OP_BF16;
     SmTokPtrs tok, rows;
     for (int t = 0; t < S; ++t) { tok.p[t] = act[t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[t] * n_steps; }
     for (int j = 0; j < n_steps; ++j) {
         // emit the pending token of every stream (out_ids[stream][j], rows of inactive streams untouched) and feed it back
-        if ((rc = sm_embed_tokens_seg(tok, S, m->R.embed->buf.p, ld, x, rows, j, stream))) return rc;
+        if ((rc = sm_embed_tokens_seg(tok, S, m->R.embed->buf.p, ld, x, rows, j, f16, stream))) return rc;
         for (int l = 0; l < c.llm_layers; ++l) {
             const sm_model::LayerW& w = m->R.llm[l];
-            if ((rc = sm_norm(x, S, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+            if ((rc = sm_norm_ex(x, S, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
             {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
             SmDecodeSeg seg;
             for (int t = 0; t < S; ++t) { seg.kc[t] = act[t]->kc[l].p; seg.vtc[t] = act[t]->vtc[l].p; seg.pos[t] = act[t]->kv_len; }
-            if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, seg, S_max, stream))) return rc;
-            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, stream))) return rc;
+            if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, seg, S_max, f16, stream))) return rc;
+            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, f16, stream))) return rc;
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            if ((rc = sm_norm(x, S, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+            if ((rc = sm_norm_ex(x, S, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
             {   const Slot& gu = *w.gu;
                 sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.N = c.llm_mlp;
@@ -1220,7 +1227,7 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 if ((rc = sm_linear(&a, stream))) return rc; }
         }
         for (sm_stream* s : act) s->kv_len += 1;
-        if ((rc = sm_norm(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, stream))) return rc;
+        if ((rc = sm_norm_ex(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
         {   sm_linear_t a = lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
             a.out_f32 = g->d_log.as<float>(); a.ldo = V;
             if ((rc = sm_linear(&a, stream))) return rc; }

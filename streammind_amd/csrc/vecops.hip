@@ -523,17 +523,21 @@ extern "C" int sm_gate_decide(const float* logits, int M, int32_t* decision, voi
 }
 
 // ------------------------------------------------------------------------------------------------ LLM glue
-__global__ void embed_splice_kernel(const int32_t* ids, int n, const bf16_t* table, const float* tokens, int D, float* out) {
+// f16: the 16-bit tables / outputs of the LLM glue kernels below are IEEE fp16 instead of bf16 (llm_fp16 mode)
+__global__ void embed_splice_kernel(const int32_t* ids, int n, const bf16_t* table, const float* tokens, int D, float* out, int f16) {
     int row = blockIdx.x;
     int id = ids[row];
     for (int c = threadIdx.x; c < D; c += blockDim.x)
-        out[(size_t)row * D + c] = id >= 0 ? bf2f(table[(size_t)id * D + c]) : tokens[(size_t)(-id - 1) * D + c];
+        out[(size_t)row * D + c] = id >= 0 ? (f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c])) : tokens[(size_t)(-id - 1) * D + c];
 }
-extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, void* stream) {
+int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, void* stream) {
     SM_REQUIRE(ids && table && out && n > 0, "sm_embed_splice: bad args");
-    embed_splice_kernel<<<n, 256, 0, (hipStream_t)stream>>>(ids, n, (const bf16_t*)table, tokens, D, out);
+    embed_splice_kernel<<<n, 256, 0, (hipStream_t)stream>>>(ids, n, (const bf16_t*)table, tokens, D, out, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
+}
+extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, void* stream) {
+    return sm_embed_splice_ex(ids, n, table, tokens, D, out, 0, stream);
 }
 
 // qkv fp32 [n][(H+2KV)*dh]; rotate_half: out[j] = x[j] cos - x[j+h] sin ; out[j+h] = x[j+h] cos + x[j] sin.
@@ -542,7 +546,7 @@ extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, con
 __global__ __launch_bounds__(64) void rope_kv_kernel(const float* __restrict__ qkv, int pos0, int H, int KV, int dh,
                                                      const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
                                                      bf16_t* __restrict__ q, bf16_t* __restrict__ kc, bf16_t* __restrict__ vtc,
-                                                     int S_max) {
+                                                     int S_max, int f16) {
     const int t = blockIdx.x, hd = blockIdx.y;
     const int pos = pos0 + t;
     const int half = dh >> 1;
@@ -553,27 +557,31 @@ __global__ __launch_bounds__(64) void rope_kv_kernel(const float* __restrict__ q
             const float a = x[j], b = x[j + half];
             const float o0 = a * c - b * s, o1 = b * c + a * s;
             bf16_t* dst = hd < H ? q + ((size_t)t * H + hd) * dh : kc + ((size_t)pos * KV + (hd - H)) * dh;
-            dst[j] = (bf16_t)f2bf(o0);
-            dst[j + half] = (bf16_t)f2bf(o1);
+            dst[j] = (bf16_t)cvt16_rt(o0, f16);
+            dst[j + half] = (bf16_t)cvt16_rt(o1, f16);
         }
     } else {
         const int kh = hd - H - KV;
-        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)f2bf(x[e]);
+        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)cvt16_rt(x[e], f16);
     }
+}
+int sm_rope_kv_append_ex(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab,
+                         const float* sin_tab, void* q, void* kcache, void* vtcache, int S_max, int f16, void* stream) {
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && kcache && vtcache && n > 0 && pos0 >= 0 && pos0 + n <= S_max, "sm_rope_kv_append: bad args (pos0=%d n=%d S_max=%d)", pos0, n, S_max);
+    rope_kv_kernel<<<dim3(n, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, pos0, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q,
+                                                                        (bf16_t*)kcache, (bf16_t*)vtcache, S_max, f16);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
 }
 extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab,
                                  const float* sin_tab, void* q, void* kcache, void* vtcache, int S_max, void* stream) {
-    SM_REQUIRE(qkv && q && cos_tab && sin_tab && kcache && vtcache && n > 0 && pos0 >= 0 && pos0 + n <= S_max, "sm_rope_kv_append: bad args (pos0=%d n=%d S_max=%d)", pos0, n, S_max);
-    rope_kv_kernel<<<dim3(n, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, pos0, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q,
-                                                                        (bf16_t*)kcache, (bf16_t*)vtcache, S_max);
-    SM_LAUNCH_CHECK();
-    return SM_OK;
+    return sm_rope_kv_append_ex(qkv, n, pos0, H, KV, dh, cos_tab, sin_tab, q, kcache, vtcache, S_max, 0, stream);
 }
 
 // the same for S streams x one token each: row t = stream t at ITS position, appended to ITS caches
 __global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict__ qkv, int H, int KV, int dh,
                                                          const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-                                                         bf16_t* __restrict__ q, SmDecodeSeg seg, int S_max) {
+                                                         bf16_t* __restrict__ q, SmDecodeSeg seg, int S_max, int f16) {
     const int t = blockIdx.x, hd = blockIdx.y;
     const int pos = seg.pos[t];
     bf16_t* __restrict__ kc = (bf16_t*)seg.kc[t];
@@ -586,55 +594,56 @@ __global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict
             const float a = x[j], b = x[j + half];
             const float o0 = a * c - b * s, o1 = b * c + a * s;
             bf16_t* dst = hd < H ? q + ((size_t)t * H + hd) * dh : kc + ((size_t)pos * KV + (hd - H)) * dh;
-            dst[j] = (bf16_t)f2bf(o0);
-            dst[j + half] = (bf16_t)f2bf(o1);
+            dst[j] = (bf16_t)cvt16_rt(o0, f16);
+            dst[j + half] = (bf16_t)cvt16_rt(o1, f16);
         }
     } else {
         const int kh = hd - H - KV;
-        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)f2bf(x[e]);
+        for (int e = threadIdx.x; e < dh; e += 64) vtc[((size_t)kh * dh + e) * S_max + pos] = (bf16_t)cvt16_rt(x[e], f16);
     }
 }
 int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
-                          const SmDecodeSeg& seg, int S_max, void* stream) {
+                          const SmDecodeSeg& seg, int S_max, int f16, void* stream) {
     SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_MAX_SEG, "sm_rope_kv_append_seg: bad args");
-    rope_kv_seg_kernel<<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max);
+    rope_kv_seg_kernel<<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
 
 // row t: emit stream t's pending token (out_rows.p[t][col]) and gather its embedding
 __global__ void embed_tokens_seg_kernel(SmTokPtrs tok, const bf16_t* __restrict__ table, int D, float* __restrict__ out,
-                                        SmTokPtrs out_rows, int col) {
+                                        SmTokPtrs out_rows, int col, int f16) {
     const int t = blockIdx.x;
     const int id = *tok.p[t];
     if (threadIdx.x == 0) out_rows.p[t][col] = id;
-    for (int c = threadIdx.x; c < D; c += blockDim.x) out[(size_t)t * D + c] = bf2f(table[(size_t)id * D + c]);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) out[(size_t)t * D + c] = f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c]);
 }
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table, int D, float* out, const SmTokPtrs& out_rows, int col,
-                        void* stream) {
+                        int f16, void* stream) {
     SM_REQUIRE(table && out && S > 0 && S <= SM_MAX_SEG, "sm_embed_tokens_seg: bad args");
-    embed_tokens_seg_kernel<<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col);
+    embed_tokens_seg_kernel<<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
 
-__global__ void swiglu_kernel(const float* __restrict__ gu, int M, int F, bf16_t* __restrict__ out) {
+__global__ void swiglu_kernel(const float* __restrict__ gu, int M, int F, bf16_t* __restrict__ out, int f16) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t tot = (size_t)M * (F >> 2);
     if (t >= tot) return;
     int m = (int)(t / (F >> 2)), c = (int)(t % (F >> 2)) * 4;
     f32x4 g = *(const f32x4*)(gu + (size_t)m * 2 * F + c);
     f32x4 u = *(const f32x4*)(gu + (size_t)m * 2 * F + F + c);
-    *(u32x2*)(out + (size_t)m * F + c) = u32x2{pack2bf(siluf_(g[0]) * u[0], siluf_(g[1]) * u[1]),
-                                              pack2bf(siluf_(g[2]) * u[2], siluf_(g[3]) * u[3])};
+    *(u32x2*)(out + (size_t)m * F + c) = u32x2{pack16_rt(siluf_(g[0]) * u[0], siluf_(g[1]) * u[1], f16),
+                                              pack16_rt(siluf_(g[2]) * u[2], siluf_(g[3]) * u[3], f16)};
 }
-extern "C" int sm_swiglu(const float* gu, int M, int F, void* out, void* stream) {
+int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream) {
     SM_REQUIRE(gu && out && M > 0 && F % 4 == 0, "sm_swiglu: bad args");
     size_t tot = (size_t)M * (F / 4);
-    swiglu_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(gu, M, F, (bf16_t*)out);
+    swiglu_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream>>>(gu, M, F, (bf16_t*)out, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
+extern "C" int sm_swiglu(const float* gu, int M, int F, void* out, void* stream) { return sm_swiglu_ex(gu, M, F, out, 0, stream); }
 
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ lg, int V, int32_t* out) {
     __shared__ float bv[16];

@@ -59,6 +59,7 @@ class PathConfig:
     gate_precise: bool = True
     weights_fp8: bool = False      # opt-in BASELINE config 5: fp8 gate + LLM weights (weight-streaming path only)
     vit_fp16: bool = False         # vision-tower operands in IEEE fp16 (the reference demo's precision) instead of bf16
+    llm_fp16: bool = False         # the same for the LLM (weights, embedding table, activations, q / KV caches, attention P)
 
     @property
     def vit_layers_run(self) -> int:
@@ -91,6 +92,7 @@ class PathConfig:
         c.max_frames_per_call, c.gate_precise = self.max_frames_per_call, int(self.gate_precise)
         c.weights_fp8 = int(self.weights_fp8)
         c.vit_fp16 = int(self.vit_fp16)
+        c.llm_fp16 = int(self.llm_fp16)
         return c
 
 

@@ -996,3 +996,61 @@ def test_full_depth_32_layers_prefill_and_decode():
     else:
         assert maxdiff(s.logits()[0], trace[5]) < 2e-2 * max(1.0, scale)
     assert s.kv_len == 77
+
+
+def test_llm_fp16_operands_tiny_and_full_width():
+    """llm_fp16: the LLM with IEEE fp16 weights / activations / caches (the precision the reference loads its checkpoints in,
+    model/builder.py:54) against the oracle's mixed statement with fp16 roundings.
+      * tiny dims (the 1- and 4-wave weight-streaming kernels, head_dim 64 attention): prefill logits, 12 greedy steps, the
+        teacher-forced logits of every position, a 3-stream batched decode;
+      * Mistral-7B widths, 2 layers (fused RMSNorm + q/k/v + RoPE + KV-append kernel, one-launch decode attention): logits within
+        4e-3 -- the bf16 build of the same test needs 3e-2 -- and ids equal wherever the oracle margin exceeds 8e-3."""
+    # ---- tiny
+    Wv, Wc, Wl = O.make_vit_weights(TV, 41), conn_gate_weights(TC, TG, 86), O.make_lm_weights(TL, 44)
+    m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, max_frames_per_call=6, llm_fp16=True)
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(3, TL.vocab, (40,), generator=g)
+    emb = Wl["model.embed_tokens.weight"][text]
+    ref_ids, trace = O.greedy_generate(emb, Wl, TL, 13, eos_token_id=None, prec=O.MIXED_F16, return_logits=True)
+    s = m.open_stream(max_frames=8, max_seq=128)
+    s.prefill(text.to(torch.int32).cuda())
+    assert maxdiff(s.logits()[0], trace[0]) < 4e-3
+    got = s.decode(12).cpu().tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 8e-3, (j, got, ref_ids)
+            break
+    else:
+        assert maxdiff(s.logits()[0], trace[12]) < 4e-3
+    s2 = m.open_stream(max_frames=8, max_seq=128)
+    full = O.lm_forward(emb, Wl, TL, None, O.MIXED_F16, last_only=False)
+    assert maxdiff(s2.forward_logits(text.to(torch.int32).cuda()), full) < 4e-3
+    ctxs = [torch.randint(3, TL.vocab, (n,), generator=g, dtype=torch.int32).cuda() for n in (9, 21, 33)]
+    solo = []
+    for c in ctxs:
+        t = m.open_stream(max_frames=8, max_seq=128)
+        t.prefill(c)
+        solo.append(t.decode(6).cpu().tolist())
+    grp_streams = [m.open_stream(max_frames=8, max_seq=128) for _ in ctxs]
+    for t, c in zip(grp_streams, ctxs):
+        t.prefill(c)
+    out = m.open_group(grp_streams).decode(6).cpu().tolist()
+    assert sum(a == b for a, b in zip(out, solo)) >= 2, (out, solo)
+    # ---- Mistral-7B widths
+    lcfg = O.LmCfg(hidden=4096, layers=2, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
+    Wb = O.make_lm_weights(lcfg, 77)
+    vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
+    ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
+    mb = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wb, llm_fp16=True)
+    text = torch.randint(3, lcfg.vocab, (90,), generator=g)
+    sb = mb.open_stream(max_frames=8, max_seq=256)
+    sb.prefill(text.to(torch.int32).cuda())
+    ref_ids, trace = O.greedy_generate(Wb["model.embed_tokens.weight"][text], Wb, lcfg, 7, eos_token_id=None, prec=O.MIXED_F16, return_logits=True)
+    assert maxdiff(sb.logits()[0], trace[0]) < 4e-3
+    got = sb.decode(6).cpu().tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 8e-3, (j, got, ref_ids)
+            break
+    else:
+        assert maxdiff(sb.logits()[0], trace[6]) < 4e-3
