@@ -858,6 +858,22 @@ def main():
                     "measured_on": "the last fifth of the timed steps" if prof_in_timed else
                                    f"{prof_steps} single-lane plain steps of {PB} frames right after the timed region (during the timed steps two kernels share "
                                    "the chip -- tower lanes / pipelined gate pass -- and the time between a launch's events is not that kernel's time)"}
+    fp16_llm_leg = None
+    if not a.no_decode and not a.no_aux and world == 1:
+        # the LLM with IEEE fp16 operands (llm_fp16: what the loader selects for the reference's fp16 checkpoints; logits 4e-3 from the
+        # oracle's fp16 statement where the bf16 build needs 3e-2): same bytes per token, so the same roofline
+        try:
+            cfgh = PathConfig(llm_layers=32, max_frames_per_call=1, vit_layers=2, llm_fp16=True)
+            mh = NativeModel(cfgh, f"cuda:{local}")
+            random_weights_into(mh, cfgh, seed=1234)
+            random_llm_weights_into(mh, cfgh, seed=4321)
+            mh.finalize()
+            sh_ = mh.open_stream(max_frames=512, max_seq=1024)
+            fp16_llm_leg = decode_leg(mh, sh_, cfgh)
+            fp16_llm_leg["note"] = "llm_fp16=1: LLM weights / activations / caches in IEEE fp16 (bit-exact ingestion of fp16 checkpoints); everything else as `decode`"
+            sh_.close(); mh.close()
+        except Exception as e:
+            fp16_llm_leg = {"error": repr(e)[:300]}
     fp8_leg = None
     if not a.no_decode and not a.no_fp8 and world == 1:
         # BASELINE config 5 (reported separately, never the headline: reduced-precision weights): a second replica whose gate
@@ -920,6 +936,7 @@ def main():
             "two_streams_per_gpu": two_leg,
             "rooflines_other": more_roof or None,
             "calibration": calib_leg,
+            "decode_fp16_llm": fp16_llm_leg,
             "decode_fp8_weights": fp8_leg,
         }
         if per_rank is not None:

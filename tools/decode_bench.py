@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from streammind_amd.native import NativeModel, PathConfig
 
-cfg = PathConfig(llm_layers=32, max_frames_per_call=1, vit_layers=2, weights_fp8=os.environ.get("FP8", "0") == "1")    # short ViT: perception is not measured here; FP8=1: weight-only fp8 mode
+cfg = PathConfig(llm_layers=32, max_frames_per_call=1, vit_layers=2, weights_fp8=os.environ.get("FP8", "0") == "1", llm_fp16=os.environ.get("FP16", "0") == "1")    # short ViT: perception is not measured here; FP8=1: weight-only fp8 mode; FP16=1: fp16 operands (llm_fp16)
 model = NativeModel(cfg)
 bench.random_weights_into(model, cfg, 1)
 bench.random_llm_weights_into(model, cfg, 2)
