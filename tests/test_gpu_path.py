@@ -1054,3 +1054,15 @@ def test_llm_fp16_operands_tiny_and_full_width():
             break
     else:
         assert maxdiff(sb.logits()[0], trace[6]) < 4e-3
+
+
+def test_stream_end_to_end_fp16_operands_vs_reference_golden(gold, tiny_tokenizer):
+    """The reference's own streaming loop (golden g6, minted from its fp32 run) against the drop-in in the precision the loader
+    picks for the reference's fp16 checkpoints (vit_fp16 + llm_fp16): every gate logit within the north-star's 1e-3 and the
+    generated ids equal wherever the oracle's top-2 margin exceeds 1e-2 (the bf16 build of this test: 5e-3 and 6e-2)."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from tests.util_models import check_stream_against_g6
+    Wv, Wc, Wl = O.make_vit_weights(TV, 41), conn_gate_weights(TC, TG, 86), O.make_lm_weights(TL, 44)
+    m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, max_frames_per_call=6, vit_fp16=True, llm_fp16=True)
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+    check_stream_against_g6(model, tiny_tokenizer, gold("g6_stream_tiny"), Wv, Wc, Wl, (TV, TC, TG, TL), gate_tol=1e-3, logit_tol=5e-3)
