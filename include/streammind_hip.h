@@ -233,6 +233,9 @@ typedef struct sm_config_t {
     int llm_fp16;            /* 1: the same for the LLM: linear weights, embedding table, activations, q / KV caches and the   */
                              /*    attention's P in IEEE fp16 (an fp16 checkpoint goes in bit for bit; bf16 storage would drop */
                              /*    3 of its mantissa bits and flip greedy token ids at near-ties).  Excludes weights_fp8.      */
+    int proj_fp16;           /* 1: the same for the connector + event gate: their linear weights are kept as IEEE fp16 and the */
+                             /*    fp32 activations enter the products as fp16 hi/lo pairs (gate_precise) -- an fp16 checkpoint */
+                             /*    rounded to bf16 would move the gate logits by ~5e-3, five times the 1e-3 bar.  Excludes fp8. */
 } sm_config_t;
 
 typedef struct sm_model sm_model;

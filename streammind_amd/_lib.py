@@ -45,7 +45,7 @@ class sm_config_t(C.Structure):
         ("gate_eps", f32),
         ("llm_hidden", i32), ("llm_layers", i32), ("llm_heads", i32), ("llm_kv_heads", i32), ("llm_mlp", i32),
         ("llm_vocab", i32), ("llm_eps", f32), ("llm_rope_theta", f32),
-        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32), ("llm_fp16", i32),
+        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32), ("llm_fp16", i32), ("proj_fp16", i32),
     ]
 
 

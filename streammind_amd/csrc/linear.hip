@@ -966,9 +966,12 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
     float* ws2 = dual ? ws + slab : nullptr;
     const dim3 grid(nb, S);
 #define SL(XF, SP, DU) skinny_lds_kernel<XF, SP, DU><<<grid, 512, 0, st>>>(a, ws, ws2, per)
-    if (a.f16) {           // fp16 operands: single rounding only (the hi/lo split is the bf16 paths' way to fp32-like activations)
-        if (xf32) { if (dual) skinny_lds_kernel<true, false, true, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<true, false, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
-        else { if (dual) skinny_lds_kernel<false, false, true, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<false, false, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+#define SLH(XF, SP, DU) skinny_lds_kernel<XF, SP, DU, true><<<grid, 512, 0, st>>>(a, ws, ws2, per)
+    if (a.f16) {           // fp16 operands (weights fp16; activations fp16, or an fp16 hi/lo pair in precise mode)
+        if (xf32) {
+            if (split) { if (dual) SLH(true, true, true); else SLH(true, true, false); }
+            else       { if (dual) SLH(true, false, true); else SLH(true, false, false); }
+        } else { if (dual) SLH(false, false, true); else SLH(false, false, false); }
     } else if (xf32) {
         if (split) { if (dual) SL(true, true, true); else SL(true, true, false); }
         else       { if (dual) SL(true, false, true); else SL(true, false, false); }
@@ -976,6 +979,7 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
         if (dual) SL(false, false, true); else SL(false, false, false);
     }
 #undef SL
+#undef SLH
     SM_LAUNCH_CHECK();
     const size_t nthr = (size_t)a.M * ((a.N + 3) / 4);
     splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, ws2, S, a.N);
@@ -988,10 +992,12 @@ static int launch_skinny(const LinArgs& a, bool xf32, bool split, bool dual, hip
     dim3 grid(a.NRG), block(WAVES * 64);
     size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * MB * 64 * sizeof(float) : 0;
 #define SK(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB><<<grid, block, sh, st>>>(a, NoRope{})
-#define SKH(XF, DU) skinny_kernel<WAVES, XF, false, DU, MB, false, false, true><<<grid, block, sh, st>>>(a, NoRope{})
+#define SKH(XF, SP, DU) skinny_kernel<WAVES, XF, SP, DU, MB, false, false, true><<<grid, block, sh, st>>>(a, NoRope{})
     if (a.f16) {
-        if (xf32) { if (dual) SKH(true, true); else SKH(true, false); }
-        else      { if (dual) SKH(false, true); else SKH(false, false); }
+        if (xf32) {
+            if (split) { if (dual) SKH(true, true, true); else SKH(true, true, false); }
+            else       { if (dual) SKH(true, false, true); else SKH(true, false, false); }
+        } else { if (dual) SKH(false, false, true); else SKH(false, false, false); }
     } else if (xf32) {
         if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
         else       { if (dual) SK(true, false, true); else SK(true, false, false); }
@@ -1076,7 +1082,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     fill_args(p, a);
     const bool w8 = p->w_dtype == SM_W_FP8;
     SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
-    SM_REQUIRE(!a.f16 || (!w8 && !p->precise), "sm_linear: fp16 operands exclude fp8 weights and the hi/lo activation split (precise)");
+    SM_REQUIRE(!a.f16 || !w8, "sm_linear: fp16 operands exclude fp8 weights");
     SM_REQUIRE(!a.f16 || p->M <= 32 || (p->x_dtype == SM_X_BF16 && !p->w2 && !p->norm_gamma),
                "sm_linear: above 32 rows fp16 operands run on the tiled GEMM (16-bit x, single weight image, no fused norm)");
     SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),

@@ -315,6 +315,10 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     if (c.llm_fp16)      // the LLM's linear weights AND its embedding table are kept as IEEE fp16 (the reference loads its checkpoints that way, model/builder.py:54)
         for (auto& kv : m->slots)
             if ((kv.second.kind == 1 || kv.second.kind == 2) && kv.first.rfind("llm.", 0) == 0) kv.second.f16 = true;
+    SM_REQUIRE(!(c.proj_fp16 && c.weights_fp8), "proj_fp16 and weights_fp8 are exclusive");
+    if (c.proj_fp16)     // connector + gate linears in fp16 (their activations stay fp32-class: fp16 hi/lo pairs in gate_precise mode)
+        for (auto& kv : m->slots)
+            if (kv.second.kind == 1 && kv.first.rfind("proj.", 0) == 0) kv.second.f16 = true;
     if (c.weights_fp8)
         for (auto& kv : m->slots)
             if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head"))

@@ -103,13 +103,13 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     # precision of the vision tower's operands: the reference loads EVERYTHING as fp16 (builder.py:54, tower :201) and its
     # teacher-forced evaluation casts to bf16 (eval/inference_video_ego4d_stream_parallel_new.py:160).  fp16 is the default here
     # too (gate logits 1e-4 from fp32 at full size; the LLM keeps the checkpoint's fp16 weights bit for bit and computes with fp16
-    # operands -- llm_fp16); torch_dtype=torch.bfloat16 selects bf16 operands for both.  The connector / gate weights are stored
-    # bf16 either way (their activations are carried as bf16 hi/lo pairs, i.e. fp32-class).  fp8 weights imply the bf16 LLM.
+    # operands -- llm_fp16; the connector / gate likewise -- proj_fp16, with their fp32 activations carried as fp16 hi/lo pairs);
+    # torch_dtype=torch.bfloat16 selects bf16 operands throughout.  fp8 weights imply the bf16 gate + LLM.
     tdt = kwargs.pop("torch_dtype", torch.float16)
     if tdt not in (torch.float16, torch.bfloat16):
         raise ValueError(f"torch_dtype must be torch.float16 or torch.bfloat16, got {tdt}")
     w8 = bool(kwargs.pop("weights_fp8", False))
-    over = dict(max_frames_per_call=kwargs.pop("max_frames_per_call", 8), weights_fp8=w8, llm_fp16=(tdt == torch.float16 and not w8),
+    over = dict(max_frames_per_call=kwargs.pop("max_frames_per_call", 8), weights_fp8=w8, llm_fp16=(tdt == torch.float16 and not w8), proj_fp16=(tdt == torch.float16 and not w8),
                 vit_fp16=(tdt == torch.float16 and vj.get("vision_config", vj)["hidden_size"] // vj.get("vision_config", vj)["num_attention_heads"] == 64))
     ppath = os.path.join(tower_dir, "preprocessor_config.json")
     if os.path.exists(ppath):                               # the normalisation constants belong to the tower checkpoint

@@ -60,6 +60,7 @@ class PathConfig:
     weights_fp8: bool = False      # opt-in BASELINE config 5: fp8 gate + LLM weights (weight-streaming path only)
     vit_fp16: bool = False         # vision-tower operands in IEEE fp16 (the reference demo's precision) instead of bf16
     llm_fp16: bool = False         # the same for the LLM (weights, embedding table, activations, q / KV caches, attention P)
+    proj_fp16: bool = False        # the same for the connector + gate weights (activations as fp16 hi/lo pairs in precise mode)
 
     @property
     def vit_layers_run(self) -> int:
@@ -93,6 +94,7 @@ class PathConfig:
         c.weights_fp8 = int(self.weights_fp8)
         c.vit_fp16 = int(self.vit_fp16)
         c.llm_fp16 = int(self.llm_fp16)
+        c.proj_fp16 = int(self.proj_fp16)
         return c
 
 

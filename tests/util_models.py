@@ -4,14 +4,14 @@ import torch
 from oracle import streammind_oracle as O
 
 
-def path_config(vcfg: O.VitCfg, ccfg: O.ConnCfg, gcfg: O.LmCfg, lcfg=None, max_frames_per_call=8, precise=True, weights_fp8=False, vit_fp16=False, llm_fp16=False):
+def path_config(vcfg: O.VitCfg, ccfg: O.ConnCfg, gcfg: O.LmCfg, lcfg=None, max_frames_per_call=8, precise=True, weights_fp8=False, vit_fp16=False, llm_fp16=False, proj_fp16=False):
     from streammind_amd.native import PathConfig
     kw = dict(vit_image=vcfg.image_size, vit_patch=vcfg.patch, vit_hidden=vcfg.hidden, vit_heads=vcfg.heads,
               vit_mlp=vcfg.mlp, vit_layers=vcfg.layers, vit_select_layer=vcfg.select_layer, vit_eps=vcfg.eps,
               conn_d_model=ccfg.d_model, conn_d_state=ccfg.d_state, conn_d_conv=ccfg.d_conv, conn_expand=ccfg.expand,
               conn_eps=ccfg.ln_eps, gate_layers=gcfg.layers, gate_heads=gcfg.heads, gate_kv_heads=gcfg.kv_heads,
               gate_mlp=gcfg.mlp, gate_eps=gcfg.eps, max_frames_per_call=max_frames_per_call, gate_precise=precise,
-              weights_fp8=weights_fp8, vit_fp16=vit_fp16, llm_fp16=llm_fp16)
+              weights_fp8=weights_fp8, vit_fp16=vit_fp16, llm_fp16=llm_fp16, proj_fp16=proj_fp16)
     if lcfg is None:
         kw.update(llm_layers=0)
     else:
