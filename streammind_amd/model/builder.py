@@ -77,6 +77,19 @@ def path_config_from_checkpoint(cfgj: dict, vision_cfg: dict, **overrides) -> Pa
         llm_rope_theta=cfgj.get("rope_theta") or (cfgj.get("rope_parameters") or {}).get("rope_theta", 1e4))
     if cfgj.get("head_dim") not in (None, cfgj["hidden_size"] // cfgj["num_attention_heads"]):
         raise ValueError(f"head_dim={cfgj['head_dim']} != hidden_size / num_attention_heads is not supported by the attention kernels")
+    # what the kernels hard-wire (Mistral / CLIP as the reference uses them): anything else must fail here, not compute something else
+    if vj.get("hidden_act", "quick_gelu") != "quick_gelu":
+        raise NotImplementedError(f"vision tower hidden_act={vj['hidden_act']!r}: the tower's MLP epilogue is CLIP's quick_gelu")
+    if cfgj.get("hidden_act", "silu") != "silu":
+        raise NotImplementedError(f"LLM hidden_act={cfgj['hidden_act']!r}: the gate / up kernels fuse SiLU (Mistral)")
+    if cfgj.get("tie_word_embeddings", False):
+        raise NotImplementedError("tie_word_embeddings=true: lm_head and embed_tokens are separate tensors on this path (Mistral checkpoints)")
+    if cfgj.get("attention_bias", False) or cfgj.get("mlp_bias", False):
+        raise NotImplementedError("attention_bias / mlp_bias: the LLM's projections are bias-free on this path (Mistral)")
+    rs = cfgj.get("rope_scaling") or {k: v for k, v in (cfgj.get("rope_parameters") or {}).items() if k not in ("rope_theta", "rope_type")}
+    rtype = (cfgj.get("rope_parameters") or {}).get("rope_type", (cfgj.get("rope_scaling") or {}).get("type", "default"))
+    if rtype not in ("default", None) or (cfgj.get("rope_scaling") or None):
+        raise NotImplementedError(f"rope scaling ({rtype!r}, {rs!r}): only the plain rotary embedding with rope_theta is built")
     kw.update(overrides)
     return PathConfig(**kw)
 

@@ -191,3 +191,24 @@ def test_read_video_stream_and_process_video_paths_vs_reference_golden(tmp_path,
     (tmp_path / "movie.mp4").write_bytes(b"not a video")
     with pytest.raises(ImportError, match="no decoder"):
         video_io.open_video(str(tmp_path / "movie.mp4"))
+
+
+def test_loader_rejects_configs_the_kernels_do_not_implement():
+    """path_config_from_checkpoint: a config.json that asks for something the kernels hard-wire differently (activation, tied
+    embeddings, projection biases, rope scaling, a foreign head_dim) must raise, not load and compute something else."""
+    from streammind_amd.model.builder import path_config_from_checkpoint
+    lm = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512, vocab_size=384,
+              rms_norm_eps=1e-5, rope_theta=1e6, mm_gate_config=dict(num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512))
+    vis = dict(image_size=56, patch_size=14, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=3)
+    cfg = path_config_from_checkpoint(dict(lm, mm_hidden_size=128), vis)
+    assert cfg.llm_layers == 2 and cfg.vit_hidden == 128 and cfg.llm_rope_theta == 1e6
+    assert path_config_from_checkpoint(dict(lm, rope_theta=None, rope_parameters=dict(rope_theta=5e5, rope_type="default")), vis).llm_rope_theta == 5e5
+    for bad_lm, bad_vis in ((dict(hidden_act="gelu"), {}), (dict(tie_word_embeddings=True), {}), (dict(attention_bias=True), {}),
+                            (dict(rope_scaling=dict(type="linear", factor=2.0)), {}), (dict(rope_parameters=dict(rope_theta=1e6, rope_type="yarn", factor=4.0)), {}),
+                            ({}, dict(hidden_act="gelu"))):
+        with pytest.raises(NotImplementedError):
+            path_config_from_checkpoint(dict(lm, **bad_lm), dict(vis, **bad_vis))
+    with pytest.raises(ValueError, match="head_dim"):
+        path_config_from_checkpoint(dict(lm, head_dim=128), vis)
+    with pytest.raises(ValueError, match="select feature"):
+        path_config_from_checkpoint(dict(lm, mm_vision_select_feature="cls_patch"), vis)
