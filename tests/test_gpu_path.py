@@ -1039,6 +1039,12 @@ def test_llm_fp16_operands_tiny_and_full_width():
         t.prefill(c)
     out = m.open_group(grp_streams).decode(6).cpu().tolist()
     assert sum(a == b for a, b in zip(out, solo)) >= 2, (out, solo)
+    # 20 streams: the LDS-shared weight-streaming kernel (17..32 rows) and the per-stream RoPE / attention kernels in fp16
+    many = [m.open_stream(max_frames=8, max_seq=128) for _ in range(20)]
+    for k, t in enumerate(many):
+        t.prefill(ctxs[k % 3])
+    out20 = m.open_group(many).decode(6).cpu().tolist()
+    assert sum(out20[k] == solo[k % 3] for k in range(20)) >= 17, (out20, solo)
     # ---- Mistral-7B widths
     lcfg = O.LmCfg(hidden=4096, layers=2, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
     Wb = O.make_lm_weights(lcfg, 77)
