@@ -721,7 +721,7 @@ def main():
         try:
             from streammind_amd.stream import FrameRing
             ring = FrameRing(3, LB, 336, 336, torch.device("cuda", local))
-            host_frames = frames[:4 * LB].cpu()
+            host_frames = frames[:4 * LB].cpu().pin_memory()       # what a decoder hands over: frames in page-locked host memory
             sh = model.open_stream(max_frames=LB * 24, max_seq=64)
 
             def hstep(i):
@@ -738,7 +738,7 @@ def main():
             torch.cuda.synchronize()
             d4 = (time.perf_counter() - t4) / 16
             host_leg = {"frames_per_s": round(LB / d4, 1), "frames_per_step": LB, "ms_per_step": round(d4 * 1e3, 3), "h2d_bytes_per_frame": 336 * 336 * 3,
-                        "note": "PCIe-inclusive: u8 frames start in pinned host memory every step (3-slot ring, copy stream); never the headline value"}
+                        "note": "PCIe-inclusive: u8 frames start in pinned host memory every step (async H2D on a copy stream into a 3-slot device ring); never the headline value"}
             sh.close()
         except Exception as e:
             host_leg = {"error": repr(e)[:200]}

@@ -40,9 +40,13 @@ class FrameRing:
         s = self.head
         self.head = (self.head + 1) % self.slots
         self.free[s].synchronize()                      # the slot's previous consumer finished (no-op the first time round)
-        self.host[s, :n].copy_(frames)
+        if frames.is_pinned():                          # a decoder that writes into page-locked memory: straight to the device
+            src = frames
+        else:                                           # pageable source: staged through the slot's pinned buffer (a host memcpy)
+            self.host[s, :n].copy_(frames)
+            src = self.host[s, :n]
         with torch.cuda.stream(self.copy_stream):
-            self.dev[s, :n].copy_(self.host[s, :n], non_blocking=True)
+            self.dev[s, :n].copy_(src, non_blocking=True)
             self.ready[s].record(self.copy_stream)
         return self.dev[s, :n], self.ready[s], s
 
