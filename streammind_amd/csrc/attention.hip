@@ -361,6 +361,23 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// cross-lane max steps without the canonicalising v_max_f32 x, x, x pair hipcc puts in front of fmaxf (inputs come from VALU
+// permlane swaps, so no XDL hazard applies)
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float xor16_max_raw(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max_raw(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 template <bool F16>      // F16: q / k / v / P / ctx are IEEE fp16 (the ViT's optional fp16 mode), else bf16
 __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
     constexpr int DH = 64, KROW = 128, TILE_BYTES = 16384;
@@ -500,8 +517,8 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
             const float mxb = vmax3(vmax3(s[qb][0][1][1], s[qb][0][1][2], s[qb][0][1][3]), s[qb][1][0][0], s[qb][1][0][1]);
             const float mxc = vmax3(vmax3(s[qb][1][0][2], s[qb][1][0][3], s[qb][1][1][0]), s[qb][1][1][1], s[qb][1][1][2]);
             float mx = vmax3(vmax3(mxa, mxb, mxc), s[qb][1][1][3], s[qb][1][1][3]);
-            mx = xor32_max(xor16_max(mx));
-            const float m_new = fmaxf(m_run[qb], mx);         // finite: every tile holds at least one real key
+            mx = xor32_max_raw(xor16_max_raw(mx));
+            const float m_new = vmax2(m_run[qb], mx);         // finite: every tile holds at least one real key
             const float mc = m_new * p.c;
             const bool moved = m_new != m_run[qb];
             const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));
