@@ -486,7 +486,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32, help="timed steps; 32 x 56 frames + warm-up = the 1800-frame (60 s x 30 fps) stream")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=56, help="frames per step.  >= 48: the tower runs as two concurrent half batches (two lanes, "
+    ap.add_argument("--batch", type=int, default=56, help="frames per step.  > 28: the tower runs as two concurrent half batches (two lanes, "
                                                            "sm_vit_encode); a 28-frame lane is 28 x 577 tokens = 63.1 tiles of 256 rows, so every ViT "
                                                            "GEMM is a whole number of 256-CU rounds.  --batch 28 --no-pipeline = the round-1 configuration")
     ap.add_argument("--vit-fp16", action="store_true", help="vision-tower operands in IEEE fp16 (the reference demo's precision, "
@@ -531,7 +531,7 @@ def main():
     lib = _lib.load()
     B = a.batch
     a.pipeline = not a.no_pipeline
-    lanes = 2 if (B >= 48 and os.environ.get("SM_VIT_LANES", "2") != "1") else 1
+    lanes = 2 if (B >= int(os.environ.get("SM_VIT_LANE_MIN", "29")) and os.environ.get("SM_VIT_LANES", "2") != "1") else 1
     LB = (B + 1) // 2 if lanes == 2 else B            # frames per tower lane: the batch of the single-lane legs and of the roofline segment
     concurrent = lanes == 2 or a.pipeline             # kernels of independent work share the chip during the timed steps
     cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B, vit_fp16=a.vit_fp16)

@@ -499,14 +499,14 @@ static int vit_body(sm_model* m, sm_model::VitWs* ws, int B, float* pooled, void
 struct VitLaneArgs { sm_model::VitWs* ws; int B; float* pooled; void* feats; void* stream; };
 static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl);
 
-// Two tower lanes: a call with >= SM_VIT_LANE_MIN frames (default 48; SM_VIT_LANES=1 disables) is cut in two halves that run the
+// Two tower lanes: a call with >= SM_VIT_LANE_MIN frames (default 29: more than the 28 that fill the chip's 256 CUs with exactly one round of 256-row tiles; SM_VIT_LANES=1 disables) is cut in two halves that run the
 // whole tower CONCURRENTLY, the first on the caller's stream, the second on a side stream of that caller stream (own
 // workspaces; fork / join by events, nothing for the caller to do).  The tower alternates MFMA-bound GEMM main loops with
 // HBM-bound phases (fp32-residual epilogues, LayerNorm, pooling) and a 256x256 GEMM block leaves no room for a second resident
 // block, so a single batch runs them strictly one after the other; two independent half batches fill each other's epilogues,
 // kernel tails and launch gaps (+8 % frames/s at 2 x 28 frames, tools/two_stream_bench.py).  Results are those of two calls.
 static int vit_lane_count(int B) {
-    static int lanes = -1, min_b = 48;
+    static int lanes = -1, min_b = 29;      // measured: 29 frames 1842 -> 2220 frames/s, 32: 1936 -> 2113, 40: 2001 -> 2104, 44: 2069 -> 2253; 28 as 2 x 14: 2255 -> 2209
     if (lanes < 0) {
         const char* e = getenv("SM_VIT_LANES"); lanes = e ? atoi(e) : 2;
         const char* mb = getenv("SM_VIT_LANE_MIN"); if (mb) min_b = atoi(mb);

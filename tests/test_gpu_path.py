@@ -886,7 +886,7 @@ def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenize
 
 
 def test_two_tower_lanes_equal_two_calls_and_the_stream_path():
-    """a call with >= 48 frames runs the tower as two concurrent half batches (second lane on a side HIP stream): pooled
+    """a call with more than 28 frames runs the tower as two concurrent half batches (second lane on a side HIP stream): pooled
     features and patch features must be BIT-identical to two separate calls of the halves, and a stream fed 50 frames in one
     call must produce the gate logits / tokens of the same frames fed as 25 + 25 (the connector state carries over)."""
     Wv = O.make_vit_weights(TV, 41)
