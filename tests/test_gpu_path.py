@@ -900,6 +900,9 @@ def test_two_tower_lanes_equal_two_calls_and_the_stream_path():
     for _ in range(3):                                     # repeated use of the side stream / events
         again, _ = m.vit_encode(frames, return_feats=True)
         assert torch.equal(again, pooled)
+    # more frames than two lanes hold (a lane is at most one round of 256-row tiles: 16384 rows / 17 tokens here = far more than 50,
+    # so force small lanes through the CU count the library reads: not possible from here) -- the many-lane split is exercised at
+    # full size in test_full_size_three_lanes_84_frames
     a, b = m.open_stream(max_frames=64, max_seq=64), m.open_stream(max_frames=64, max_seq=64)
     lg_a, dec_a = a.push_frames(frames)
     lg_b0, dec_b0 = b.push_frames(frames[:25])
@@ -1107,3 +1110,14 @@ def test_fp16_checkpoint_weights_gate_logits_need_fp16_storage():
     print("gate logits max|diff| vs fp32 oracle: fp16 storage %.2e, bf16 storage %.2e" % (diffs[True], diffs[False]))
     assert diffs[True] < 1e-3, diffs
     assert diffs[False] > 2 * diffs[True], diffs
+
+
+def test_full_size_three_lanes_84_frames():
+    """84 FULL-SIZE frames in one call: three lanes of 28 (two concurrent, the third alone) -- bit-identical to three 28-frame calls."""
+    vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 101), conn_gate_weights(ccfg, gcfg, 102), max_frames_per_call=100)
+    frames = O.synthetic_frames(100, 336, seed=92, scene_len=4).cuda()
+    ref = torch.cat([m.vit_encode(frames[i:i + 28]) for i in (0, 28, 56)])
+    assert torch.equal(m.vit_encode(frames[:84]), ref)
+    ref4 = torch.cat([m.vit_encode(frames[i:i + 25]) for i in (0, 25, 50, 75)])          # 100 frames -> 4 lanes of 25
+    assert torch.equal(m.vit_encode(frames), ref4)
