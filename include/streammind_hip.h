@@ -263,7 +263,8 @@ int sm_model_missing(sm_model* m, char* buf, size_t buflen);
 /* a1+a2(+K4): B frames u8 HWC [B][H][W][3] -> pooled fp32 [B][vit_hidden] (mean over patches of
  * hidden_states[-2], CLS dropped); optional raw patch features bf16 [B][P][vit_hidden]
  * (= CLIPVisionTower.forward, clip_encoder.py:41-53) and pixel_values fp32 [B][3][H][W].
- * Calls with more than 28 frames run the tower as TWO CONCURRENT half batches (the second on a side HIP stream of the caller's
+ * Calls with more than 28 frames run the tower as lanes of at most one round of 256-row tiles (28 frames at 577 tokens on 256
+ * CUs), TWO lanes at a time (the second on a side HIP stream of the caller's
  * stream, joined before the call's work on `stream` is complete from the caller's point of view; own workspaces): +4-9 %
  * frames/s, results bit-identical to two calls of the halves.  SM_VIT_LANES=1 in the environment keeps one lane.   */
 int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats_bf16_opt,
