@@ -266,7 +266,7 @@ int sm_model_missing(sm_model* m, char* buf, size_t buflen);
  * Calls with more than 28 frames run the tower as lanes of at most one round of 256-row tiles (28 frames at 577 tokens on 256
  * CUs), TWO lanes at a time (the second on a side HIP stream of the caller's
  * stream, joined before the call's work on `stream` is complete from the caller's point of view; own workspaces): +4-9 %
- * frames/s, results bit-identical to two calls of the halves.  SM_VIT_LANES=1 in the environment keeps one lane.   */
+ * frames/s, results bit-identical to separate calls of the lanes.  SM_VIT_LANES=1 in the environment keeps one lane.   */
 int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats_bf16_opt,
                   float* pixel_values_opt, void* stream);
 /* the same from normalised pixel_values [B][3][H][W] (what the reference's callers hand to CLIPVisionTower.forward) */
