@@ -481,10 +481,33 @@ def cpu_baseline(n_frames: int = 12) -> dict:
     return out
 
 
+class _PlumbingStream:
+    """SM_BENCH_PLUMBING=1 (test hook, tests/test_dist_cpu.py): stands in for the native stream so that the N > 1 CONTROL FLOW of
+    this file -- rendezvous, barriers, the gated-token exchange, the max-over-ranks reduction, rank 0's line -- can run under gloo
+    on a machine without a GPU.  It computes nothing and the line it leads to carries no measurement (`value` null,
+    `plumbing_only` true); the driver never sets the variable."""
+
+    def __init__(self, d):
+        self.d, self.num_frames = d, 0
+
+    def push_frames(self, fr):
+        self.num_frames += fr.shape[0]
+        return torch.zeros(fr.shape[0], 2), torch.zeros(fr.shape[0], dtype=torch.int32)
+
+    push_frames_pipelined = push_frames
+
+    def join(self):
+        pass
+
+    def tokens(self, t0, n):
+        return torch.zeros(n, self.d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps; 32 x 56 frames + warm-up = the 1800-frame (60 s x 30 fps) stream")
+    ap.add_argument("--steps", type=int, default=32, help="timed steps.  The timed region is always about ONE pass over the 1800-frame (60 s x 30 fps) "
+                    "stream of BASELINE configs[1]: a step is round(1800 / (steps x batch)) >= 1 calls of `--batch` frames (32 steps x 56 frames: one call)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=56, help="frames per step.  > 28: the tower runs as two concurrent half batches (two lanes, "
                                                            "sm_vit_encode); a 28-frame lane is 28 x 577 tokens = 63.1 tiles of 256 rows, so every ViT "
@@ -515,7 +538,13 @@ def main():
         local = 0
     backend = os.environ.get("SM_BENCH_BACKEND", "nccl")
     cdev = "cuda" if backend == "nccl" else "cpu"        # device of the few scalar collectives below
-    torch.cuda.set_device(local)
+    plumbing = os.environ.get("SM_BENCH_PLUMBING") == "1"      # control-flow test without a GPU (see _PlumbingStream): no measurement
+    if plumbing:
+        assert backend != "nccl", "SM_BENCH_PLUMBING needs SM_BENCH_BACKEND=gloo"
+        a.no_decode = a.no_aux = a.no_prof = a.no_cpu_baseline = a.no_fp8 = a.no_e2e = True
+    sync = (lambda: None) if plumbing else torch.cuda.synchronize
+    if not plumbing:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("SM_BENCH_FORCE_DIST") == "1":      # FORCE_DIST: exercise the RCCL calls with one rank
         import torch.distributed as dist
@@ -528,28 +557,38 @@ def main():
 
     from streammind_amd import _lib
     from streammind_amd.native import NativeModel, PathConfig
-    lib = _lib.load()
+    lib = _lib.load()                 # raises when the HIP library is missing: there is no other compute path
     B = a.batch
     a.pipeline = not a.no_pipeline
     lanes = 2 if (B >= int(os.environ.get("SM_VIT_LANE_MIN", "29")) and os.environ.get("SM_VIT_LANES", "2") != "1") else 1
     LB = (B + 1) // 2 if lanes == 2 else B            # frames per tower lane: the batch of the single-lane legs and of the roofline segment
     concurrent = lanes == 2 or a.pipeline             # kernels of independent work share the chip during the timed steps
     cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B, vit_fp16=a.vit_fp16)
-    model = NativeModel(cfg, f"cuda:{local}")
-    random_weights_into(model, cfg, seed=1234)
-    if not a.no_decode:
-        random_llm_weights_into(model, cfg, seed=4321)
-    model.finalize()
-    n_pool = max(B, min(1800, B * (a.steps + a.warmup)))          # the 60 s x 30 fps stream, or as much as is timed
-    frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
-    stream = model.open_stream(max_frames=B * (a.steps + a.warmup) + 4096, max_seq=2048)
-    torch.cuda.synchronize()
+    # BASELINE configs[1] names a 60 s x 30 fps stream: the pool is ALWAYS those 1800 frames, and the timed region is about one pass
+    # over it whatever --steps the caller picks -- a step is `cps` calls of B frames (steps x cps x B ~ 1800; the walk wraps around)
+    n_pool = max(B, 1800)
+    cps = max(1, int(round(n_pool / float(a.steps * B))))
+    if plumbing:
+        model, frames, stream = None, torch.zeros(n_pool, 1, 1, 3, dtype=torch.uint8), _PlumbingStream(cfg.conn_d_model)
+    else:
+        model = NativeModel(cfg, f"cuda:{local}")
+        random_weights_into(model, cfg, seed=1234)
+        if not a.no_decode:
+            random_llm_weights_into(model, cfg, seed=4321)
+        model.finalize()
+        frames = synthetic_frames_gpu(n_pool, 336, 1234, rank)
+        stream = model.open_stream(max_frames=B * cps * (a.steps + a.warmup) + 4096, max_seq=2048)
+    sync()
 
     def step(i):
-        off = (i * B) % (n_pool - B + 1)
-        if not a.pipeline:
-            return stream.push_frames(frames[off:off + B])
-        return stream.push_frames_pipelined(frames[off:off + B])      # same results; the gate pass of step i overlaps the tower of step i+1
+        out = None
+        for c in range(cps):
+            off = ((i * cps + c) * B) % (n_pool - B + 1)
+            if not a.pipeline:
+                out = stream.push_frames(frames[off:off + B])
+            else:
+                out = stream.push_frames_pipelined(frames[off:off + B])      # same results; the gate pass of call i overlaps the tower of call i+1
+        return out
 
     # N > 1 (BASELINE configs[3]): every step is one exchange tick.  Ranks "fire" on DIFFERENT, rank-specific steps (the random
     # gate's own decisions are not a workload): on its fire steps a rank contributes the frame tokens of the segment since its
@@ -558,7 +597,8 @@ def main():
     ex, seg_start, rows_seen = None, 0, 0
     if dist is not None:
         from streammind_amd.dist import GatedTokenExchange
-        ex = GatedTokenExchange(cfg.conn_d_model, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
+        # payload as bf16: SURVEY 8e sizes the exchange at 2 B per element (the LLM consumes the tokens as 16-bit operands anyway)
+        ex = GatedTokenExchange(cfg.conn_d_model, dtype=torch.bfloat16, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
 
     def fires(i):                        # ~ every 9th step per rank, never the same step on two ranks of an 8-GPU node
         return (i % 9) == (rank % 9)
@@ -580,20 +620,20 @@ def main():
         if ex is not None:
             exchange(i)
     prof = not a.no_prof
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
         try:                                  # every rank: push RCCL's init-time banner out of the C stdio buffer NOW, not at exit behind the JSON line
             C.CDLL(None).fflush(None)
         except Exception:
             pass
-    torch.cuda.synchronize()
+    sync()
     # HIP events around every tiled-GEMM launch break the back-to-back dispatch of the stream (~5.5 us per boundary, 4.4 % of
     # a step when every launch is bracketed), so only the LAST prof_steps of the timed region carry them.  With two tower lanes /
     # the pipelined gate pass two kernels share the chip, and the time between a launch's two events is no longer that kernel's
     # time (a 256x256 GEMM block owns its CU: concurrent GEMMs interleave at block granularity and each looks up to 2x longer):
     # then the dominant kernel is measured on prof_steps single-lane plain steps of the same lane batch RIGHT AFTER the timed region.
-    prof_steps = max(1, a.steps // 5) if prof else 0
+    prof_steps = max(1, a.steps // 5) if prof else 0          # (steps of cps calls each)
     prof_in_timed = prof and not concurrent
     if prof:
         lib.sm_prof_reset()
@@ -609,10 +649,10 @@ def main():
         last = ex.flush()
         if last is not None:
             rows_seen += int(sum(t.shape[0] for t in last))
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     dt_local = dt
     gemm_prof = None
@@ -636,11 +676,12 @@ def main():
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        mine = torch.tensor([B * a.steps / dt_local], device=cdev, dtype=torch.float64)
+        mine = torch.tensor([B * cps * a.steps / dt_local], device=cdev, dtype=torch.float64)
         allv = torch.empty(dist.get_world_size(), device=cdev, dtype=torch.float64)
         dist.all_gather_into_tensor(allv, mine)
         per_rank = [round(v, 1) for v in allv.tolist()]
     assert torch.isfinite(logits).all()
+    frames_timed = B * cps * a.steps          # per rank
     dec_leg = e2e = None
     if not a.no_decode and not a.no_e2e:
         gather, gathered = None, {"calls": 0}
@@ -648,7 +689,7 @@ def main():
             from streammind_amd.dist import allgather_gated_tokens
 
             def gather(tok):                             # every rank fires on the same scheduled tick here: the blocking two-phase form
-                out = allgather_gated_tokens(tok if cdev == "cuda" else tok.cpu(), cfg.conn_d_model)
+                out = allgather_gated_tokens((tok if cdev == "cuda" else tok.cpu()).to(torch.bfloat16), cfg.conn_d_model)
                 gathered["calls"] += 1
                 gathered["rows"] = int(sum(t.shape[0] for t in out)) if out is not None else 0
         e2e = e2e_leg(model, stream, cfg, frames, B, gather=gather)
@@ -837,14 +878,14 @@ def main():
         cnt, ms = _V(), _V()
         cnt.value, ms.value = gemm_prof
         if cnt.value:
-            PB = B if prof_in_timed else LB            # frames per profiled step
+            PB = B * cps if prof_in_timed else LB      # frames per profiled step
             flops_per_launch = vit_linear_flops_per_frame(cfg) * PB * prof_steps / cnt.value
             avg_s = ms.value * 1e-3 / cnt.value
             ach = flops_per_launch / avg_s / 1e12
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
             # being profiled): the newest committed summary is quoted and its source named
             traffic = traffic_src = None
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic.json")
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
@@ -855,6 +896,11 @@ def main():
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB,
+                    # the TIMED schedule as a whole against the same peak: every FLOP of a frame's tower (tiled GEMMs + attention, SURVEY
+                    # 8d's 366 GFLOP) x the frames timed / the timed wall clock -- what `value` is worth in MFMA terms
+                    "whole_step_frac": round((vit_linear_flops_per_frame(cfg) + cfg.vit_layers_run * 4.0 * (cfg.n_patches + 1) ** 2 * cfg.vit_hidden)
+                                             * frames_timed / dt_local / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "whole_step_note": "all tower FLOPs (GEMMs + attention) of the timed frames / timed seconds / peak: the schedule `value` is measured on",
                     "measured_on": "the last fifth of the timed steps" if prof_in_timed else
                                    f"{prof_steps} single-lane plain steps of {PB} frames right after the timed region (during the timed steps two kernels share "
                                    "the chip -- tower lanes / pipelined gate pass -- and the time between a launch's events is not that kernel's time)"}
@@ -909,18 +955,19 @@ def main():
         except Exception as e:          # the optional leg must never take the headline down
             fp8_leg = {"error": repr(e)[:300]}
     if rank == 0:
-        total_frames = world * B * a.steps
+        total_frames = world * frames_timed
         out = {
-            "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate); Mistral-7B decode tokens/sec in `decode`", "value": round(total_frames / dt, 2),
+            "metric": "streamed frames/sec (ViT-L/14-336 encode + connector + event gate); Mistral-7B decode tokens/sec in `decode`",
+            "value": None if plumbing else round(total_frames / dt, 2),
             "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp16 tower operands (fp32 accumulate / residual), bf16 connector + gate + LLM" if a.vit_fp16 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single-GPU CLIP-ViT-L/14-336 per-frame encode + Mamba connector + "
-                                   f"4-layer Mistral event gate, synthetic 336x336 30 fps stream ({n_pool}-frame pool = {n_pool / 30:.1f} s, "
-                                   f"{a.steps * B} frames timed), {B} frames per step" + (f" (two concurrent tower lanes of {LB})" if lanes == 2 else "") +
+                                   f"4-layer Mistral event gate, synthetic 336x336 30 fps 60 s stream ({n_pool} frames; the timed region walks it once: "
+                                   f"{a.steps} steps x {cps} call(s) x {B} frames = {frames_timed} frames), {B} frames per call" + (f" (two concurrent tower lanes of {LB})" if lanes == 2 else "") +
                                    (", connector + gate pass of step i under the tower of step i+1" if a.pipeline else "") +
                                    ", one stream per GPU, random-init weights of the true shapes",
-                       "frames_per_step": B, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
+                       "frames_per_step": B * cps, "frames_per_call": B, "calls_per_step": cps, "frames_timed_per_gpu": frames_timed, "stream_frames": n_pool, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             "roofline": roof,
             "decode": dec_leg,
@@ -939,6 +986,8 @@ def main():
             "decode_fp16_llm": fp16_llm_leg,
             "decode_fp8_weights": fp8_leg,
         }
+        if plumbing:
+            out["plumbing_only"] = True          # SM_BENCH_PLUMBING=1: control flow exercised, nothing measured
         if per_rank is not None:
             out["per_rank_frames_per_s"] = per_rank          # each rank's own N=1-equivalent rate (its own clock)
             out["gated_token_exchange"] = {"ticks": ex.ticks, "payload_collectives": ex.payload_collectives, "rows_received": rows_seen,

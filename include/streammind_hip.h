@@ -289,6 +289,12 @@ int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* log
  * on the stream joins by itself. */
 int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream);
 int sm_stream_join(sm_stream* s, void* stream);
+/* per-call form for callers that keep several pipelined calls in flight (one batch of look-ahead): sm_stream_pass_ticket names the
+ * pass of the LAST sm_stream_push_frames_pipelined (-1: none yet); sm_stream_join_ticket orders `stream` -- any HIP stream, e.g.
+ * a read-back stream -- behind THAT pass only, not behind passes issued after it.  A ticket stays valid until two further
+ * pipelined calls have been issued (then it names a newer pass: the wait is longer, never too short). */
+int sm_stream_pass_ticket(sm_stream* s);
+int sm_stream_join_ticket(sm_stream* s, int ticket, void* stream);
 int sm_stream_num_frames(sm_stream* s);
 const float* sm_stream_tokens(sm_stream* s);             /* device fp32 [num_frames][d_model]          */
 int sm_stream_kv_len(sm_stream* s);

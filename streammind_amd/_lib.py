@@ -92,6 +92,8 @@ SIGNATURES = {
     "sm_stream_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_stream_push_frames_pipelined": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_stream_join": (i32, [vp, vp]),
+    "sm_stream_pass_ticket": (i32, [vp]),
+    "sm_stream_join_ticket": (i32, [vp, i32, vp]),
     "sm_stream_num_frames": (i32, [vp]),
     "sm_stream_tokens": (vp, [vp]),
     "sm_stream_kv_len": (i32, [vp]),

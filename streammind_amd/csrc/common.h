@@ -37,6 +37,15 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// 32x32x16: the same 16 operand bytes per lane as 16x16x32 and twice the work per issued instruction (32 pipe cycles per SIMD,
+// back to back at exactly that rate; the 16x16x32 form issues at 17-18 cycles for its nominal 16).  A: lane l holds
+// A[l % 32][8 * (l / 32) .. +8]; B likewise; D: register j of lane l is D[8 * (j / 4) + 4 * (l / 32) + j % 4][l % 32].
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ uint32_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round to nearest even
 __device__ __forceinline__ float h2f(uint32_t b) { return (float)__builtin_bit_cast(_Float16, (uint16_t)b); }
 __device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return __builtin_bit_cast(uint32_t, f16x2{(_Float16)lo, (_Float16)hi}); }

@@ -22,6 +22,16 @@
 
 #define G2_BM 256
 #define G2_BN 256
+// 256 x 256 tile: v_mfma_f32_16x16x32 (0) or v_mfma_f32_32x32x16 (1).  Round 3, same box, M = 16156 (tools/ab_gemm.sh): the 32x32x16
+// loop is 4-7 % SLOWER on every shape (qkv 97.8 -> 102.3 us, fc1 128.8 -> 138, 4096^2 1413 -> 1318 TFLOP/s) although it issues half
+// the MFMA instructions over the same 12 conflict-free fragment reads: the loop is not bound by MFMA issue slots.  Kept for A/B.
+#ifndef G2_MFMA32
+#define G2_MFMA32 0
+#endif
+// bf16-only outputs of the 256 x 256 tile written straight from the accumulators (1) or staged through LDS (0)
+#ifndef G2_DIRECT_EPI
+#define G2_DIRECT_EPI 0
+#endif
 
 // tools/gemm_timeline.hip compiles this file with SM_GEMM_TIMELINE to stamp each block's phases (100 MHz wall clock)
 #ifdef SM_GEMM_TIMELINE
@@ -104,11 +114,38 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         g_gemm_timeline[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
     }
 #endif
+    // Accumulators of a wave's 128(n) x 64(m) sub-tile.  16x16x32 layout: acc[nf][mf], lane (g, i) holds n = nf*16 + g*4 + 0..3 of
+    // row m = mf*16 + i.  32x32x16 layout (256 x 256 tile): acc32[nb][mb], register q*4 + j of lane l holds n = nb*32 + q*8 +
+    // (l / 32)*4 + j of row m = mb*32 + l % 32.  Either way a lane owns NP "pieces" of 4 consecutive n in each of NMB row blocks;
+    // the epilogues below only see pieces.
+    constexpr bool M32 = (WN == 2) && G2_MFMA32;
+    constexpr int NP = M32 ? 16 : 8, NMB = M32 ? 2 : 4;      // pieces per row block, row blocks
+    constexpr int PS = M32 ? 8 : 16, MBS = M32 ? 32 : 16;    // n stride between pieces, rows per row block
+    const int lane_m = M32 ? (lane & 31) : i;
+    const int lane_n = M32 ? (lane >> 5) * 4 : g * 4;
     f32x4 acc[8][4];
+    f32x16 acc32[4][2];
+    if constexpr (M32) {
 #pragma unroll
-    for (int nf = 0; nf < 8; ++nf)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc32[nb][mb][j] = 0.f;
+    } else {
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
+    }
+    auto piece = [&](int p, int mb) -> f32x4 {
+        if constexpr (M32) {
+            const int q = (p & 3) * 4;
+            return f32x4{acc32[p >> 2][mb][q], acc32[p >> 2][mb][q + 1], acc32[p >> 2][mb][q + 2], acc32[p >> 2][mb][q + 3]};
+        } else {
+            return acc[p][mb];
+        }
+    };
 
     if constexpr (WN == 2) {
         // ---- 256 x 256: ring of four 32-KiB stages, one 32-deep k-step each (W: 16 packed 1-KiB fragment chunks; X: [256][32]
@@ -182,14 +219,34 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             constexpr int TAIL = decltype(tail)::value;
             const char* sw = smem + slot * STAGE;
             const char* sx = sw + 16384;
+            // 16x16x32: 4 X + 8 W fragments of the whole 32-deep step.  32x32x16: per 16-deep half h, 2 X fragments (lane l: row
+            // l % 32 of the row block, 16-byte chunk 2h + l / 32 of the 64-byte row) and 4 W fragments (rows l % 32 of a 32-row pair
+            // of packed chunks: chunk (l % 32) / 16, its lane slot (2h + l / 32) * 16 + l % 16) -- the SAME LDS image, 12 reads
+            // either way, all conflict-free (each ds_read_b128 lane group meets 16 distinct 16-byte slots mod 256 B).
             bf16x8 xf[4], wf[8];
+            if constexpr (M32) {
 #pragma unroll
-            for (int mf = 0; mf < 4; ++mf) {
-                const int ml = wm * 64 + mf * 16 + i;
-                xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const int ml = wm * 64 + mb * 32 + (lane & 31);
+                        xf[h * 2 + mb] = *(const bf16x8*)(sx + ml * 64 + (((2 * h + (lane >> 5)) ^ ((0 - (ml >> 2)) & 3)) * 16));
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        wf[h * 4 + nb] = *(const bf16x8*)(sw + (wn * 8 + nb * 2 + ((lane & 31) >> 4)) * 1024 +
+                                                          ((2 * h + (lane >> 5)) * 16 + (lane & 15)) * 16);
+            } else {
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int ml = wm * 64 + mf * 16 + i;
+                    xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+                }
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf) wf[nf] = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
             }
-#pragma unroll
-            for (int nf = 0; nf < 8; ++nf) wf[nf] = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
             if (TAIL == 0) {
                 stage(ks + 3, (slot + 3) & 3);
                 asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -204,11 +261,21 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             __builtin_amdgcn_sched_barrier(0);
             PH(1);
             // no s_setprio around the MFMA cluster: measured 3-5 % slower with it in this two-group schedule (tools/gemm_timeline)
+            if constexpr (M32) {
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf)
-                    acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb)
+                            acc32[nb][mb] = mfma32<F16>(wf[h * 4 + nb], xf[h * 2 + mb], acc32[nb][mb]);
+            } else {
+#pragma unroll
+                for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < 4; ++mf)
+                        acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
+            }
             PH(2);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -307,18 +374,75 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         // rows, 16-byte chunk index XOR (m & 31)) and written with 16 B per lane (two whole rows per wave-store): half the
         // store instructions and LDS bytes of the fp32 staging below -- 8-byte stores ran at ~4.7 B/clk/CU, store-issue-bound.
         if (fast && !vt_tile && a.out_bf16 && !a.out_f32 && !a.residual && (a.ldo_bf16 & 7) == 0 && ((uintptr_t)a.out_bf16 & 15) == 0) {
+#if G2_DIRECT_EPI
+            {
+                // EXPERIMENT: straight from the accumulators, no LDS round trip and no block barrier.  One cross-lane swap per packed
+                // register pair of two adjacent pieces leaves 8 consecutive n (16 B) of a row in each lane:
+                //   16x16 layout (v_permlane16_swap: lane groups g = 0..3 of a row hold n = 4g..4g+3 of each 16-wide fragment):
+                //     g0: frag nf n 0..7, g2: nf n 8..15, g1: nf+1 n 0..7, g3: nf+1 n 8..15  -> 64 contiguous bytes per row
+                //   32x32 layout (v_permlane32_swap): lane l: piece p, lane l + 32: piece p + 1  -> 32 contiguous bytes per row
+                const int nsel = M32 ? (lane >> 5) * 8 : (g & 1) * 16 + (g >> 1) * 8;
+                bf16_t* const __restrict__ ob = a.out_bf16 + (size_t)tile_n * BN + wn * 128 + nsel;
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf) {
-                const int nl = wn * 128 + nf * 16 + g * 4;
+                for (int mb = 0; mb < NMB; ++mb) {
+                    const int m = tile_m * G2_BM + wm * 64 + mb * MBS + lane_m;
+                    bf16_t* const __restrict__ orow = ob + (size_t)m * a.ldo_bf16;
+#pragma unroll
+                    for (int p = 0; p < NP; p += 2) {
+                        uint32_t pk[2][2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int nl = wn * 128 + (p + e) * PS + lane_n;
+                            f32x4 b4 = {0, 0, 0, 0};
+                            if (a.bias) b4 = *(const f32x4*)(a.bias + tile_n * BN + nl);
+                            const f32x4 av = piece(p + e, mb);
+                            float o[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float t = av[j] + b4[j];
+                                if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
+                                o[j] = t;
+                            }
+                            pk[e][0] = pack16<F16>(o[0], o[1]);
+                            pk[e][1] = pack16<F16>(o[2], o[3]);
+                        }
+                        u32x4 v;
+                        if constexpr (M32) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                            v = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        } else {
+                            const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                            const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                            v = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        }
+                        if (m < a.M) {
+#if G2_DIRECT_EPI == 2
+                            *(u32x4*)(orow + p * PS) = v;
+#else
+                            store16_wt(orow + p * PS, v);
+#endif
+                        }
+                    }
+                }
+                TL(3);
+                TL(4);
+                return;
+            }
+#endif
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int nl = wn * 128 + p * PS + lane_n;
                 f32x4 b4 = {0, 0, 0, 0};
                 if (a.bias) b4 = *(const f32x4*)(a.bias + tile_n * BN + nl);
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf) {
-                    const int ml = wm * 64 + mf * 16 + i;
+                for (int mb = 0; mb < NMB; ++mb) {
+                    const int ml = wm * 64 + mb * MBS + lane_m;
+                    const f32x4 av = piece(p, mb);
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float t = acc[nf][mf][j] + b4[j];
+                        float t = av[j] + b4[j];
                         if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
                         o[j] = t;
                     }
@@ -352,12 +476,12 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         if (half) { __syncthreads(); TL(3); }
         if ((wm >> 1) == half) {
 #pragma unroll
-            for (int nf = 0; nf < 8; ++nf)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int mf = 0; mf < 4; ++mf) {
-                    const int ml = (wm & 1) * 64 + mf * 16 + i;
-                    const int chunk = wn * 32 + nf * 4 + g;
-                    *(f32x4*)(smem + ml * ROWB + ((chunk ^ (ml & 31)) * 16)) = acc[nf][mf];
+                for (int mb = 0; mb < NMB; ++mb) {
+                    const int ml = (wm & 1) * 64 + mb * MBS + lane_m;
+                    const int chunk = wn * 32 + (p * PS + lane_n) / 4;
+                    *(f32x4*)(smem + ml * ROWB + ((chunk ^ (ml & 31)) * 16)) = piece(p, mb);
                 }
         }
         __syncthreads();

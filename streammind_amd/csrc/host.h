@@ -52,7 +52,8 @@ int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const 
 // fp16-aware forms of C-ABI glue ops (f16 != 0: the 16-bit tables / outputs are IEEE fp16, llm_fp16 mode); the extern "C" names keep bf16
 int sm_rope_kv_append_ex(const float* qkv, int n, int pos0, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
                          void* kcache, void* vtcache, int S_max, int f16, void* stream);
-int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, void* stream);
+int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, int vocab,
+                       int n_tok, void* stream);
 int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
                                 int splits_max, void* ctx_bf16, int f16, void* stream);                           // attention.hip

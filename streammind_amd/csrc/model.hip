@@ -951,6 +951,12 @@ extern "C" int sm_stream_join(sm_stream* s, void* stream) {
     SM_REQUIRE(s, "sm_stream_join: null");
     return auto_join(s, stream);
 }
+extern "C" int sm_stream_pass_ticket(sm_stream* s) { return (s && s->side) ? (s->flip ^ 1) : -1; }
+extern "C" int sm_stream_join_ticket(sm_stream* s, int ticket, void* stream) {
+    SM_REQUIRE(s && (ticket == 0 || ticket == 1) && s->side, "sm_stream_join_ticket: bad ticket %d / no pipelined call yet", ticket);
+    SM_HIP(hipStreamWaitEvent((hipStream_t)stream, s->ev_pass[ticket], 0));
+    return SM_OK;
+}
 
 // ---- stream group: one tick of S streams through ONE ViT batch and ONE connector + gate weight pass per <= 32 rows.
 // The reference serves one stream per model object, one frame per call (eval/video_score_stream_demo.py:283-299; "only
@@ -1117,7 +1123,7 @@ extern "C" int sm_llm_prefill(sm_stream* s, const int32_t* ids, int n, void* str
     int rc, done = 0, last_rows = 0;
     while (done < n) {
         int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, stream))) return rc;
+        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, m->c.llm_vocab, s->max_frames, stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         done += cur; last_rows = cur;
     }
@@ -1134,7 +1140,7 @@ extern "C" int sm_llm_forward_logits(sm_stream* s, const int32_t* ids, int n, fl
     int rc, done = 0;
     while (done < n) {
         const int cur = n - done < s->chunk ? n - done : s->chunk;
-        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, stream))) return rc;
+        if ((rc = sm_embed_splice_ex(ids + done, cur, m->R.embed->buf.p, s->tokens.as<float>(), ld, s->emb.as<float>(), m->c.llm_fp16 ? 1 : 0, m->c.llm_vocab, s->max_frames, stream))) return rc;
         if ((rc = llm_layers(s, cur, stream))) return rc;
         // final norm + lm_head on all `cur` rows of this chunk (llm_head does the last row only)
         if ((rc = sm_norm_ex(s->emb.as<float>(), cur, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, c.llm_fp16 ? SM_OP_F16 : SM_OP_BF16, stream))) return rc;

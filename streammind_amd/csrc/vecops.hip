@@ -524,20 +524,30 @@ extern "C" int sm_gate_decide(const float* logits, int M, int32_t* decision, voi
 
 // ------------------------------------------------------------------------------------------------ LLM glue
 // f16: the 16-bit tables / outputs of the LLM glue kernels below are IEEE fp16 instead of bf16 (llm_fp16 mode)
-__global__ void embed_splice_kernel(const int32_t* ids, int n, const bf16_t* table, const float* tokens, int D, float* out, int f16) {
+// ids >= vocab (tokens ADDED to the tokenizer after the checkpoint was written, e.g. <im_patch>; the reference grows the table by
+// fresh rows there, builder.py:186-191) and frame indices >= n_tok read as ZERO rows instead of memory behind the buffers
+// (vocab / n_tok <= 0: unchecked, the operator-level entry point)
+__global__ void embed_splice_kernel(const int32_t* ids, int n, const bf16_t* table, const float* tokens, int D, float* out, int f16,
+                                    int vocab, int n_tok) {
     int row = blockIdx.x;
     int id = ids[row];
-    for (int c = threadIdx.x; c < D; c += blockDim.x)
-        out[(size_t)row * D + c] = id >= 0 ? (f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c])) : tokens[(size_t)(-id - 1) * D + c];
+    const bool text = id >= 0;
+    const bool ok = text ? (vocab <= 0 || id < vocab) : (n_tok <= 0 || -id - 1 < n_tok);
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float v = 0.f;
+        if (ok) v = text ? (f16 ? h2f(table[(size_t)id * D + c]) : bf2f(table[(size_t)id * D + c])) : tokens[(size_t)(-id - 1) * D + c];
+        out[(size_t)row * D + c] = v;
+    }
 }
-int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, void* stream) {
+int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, int vocab,
+                       int n_tok, void* stream) {
     SM_REQUIRE(ids && table && out && n > 0, "sm_embed_splice: bad args");
-    embed_splice_kernel<<<n, 256, 0, (hipStream_t)stream>>>(ids, n, (const bf16_t*)table, tokens, D, out, f16);
+    embed_splice_kernel<<<n, 256, 0, (hipStream_t)stream>>>(ids, n, (const bf16_t*)table, tokens, D, out, f16, vocab, n_tok);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
 extern "C" int sm_embed_splice(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, void* stream) {
-    return sm_embed_splice_ex(ids, n, table, tokens, D, out, 0, stream);
+    return sm_embed_splice_ex(ids, n, table, tokens, D, out, 0, 0, 0, stream);
 }
 
 // qkv fp32 [n][(H+2KV)*dh]; rotate_half: out[j] = x[j] cos - x[j+h] sin ; out[j+h] = x[j+h] cos + x[j] sin.

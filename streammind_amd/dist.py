@@ -93,10 +93,13 @@ def allreduce(t: torch.Tensor, async_op=False):
     if not _state["initialized"]:
         return None
     cu = _comm_device(t.detach())
-    ret = tdist.all_reduce(cu, async_op=async_op)
-    if cu is not t:
-        t.copy_(cu.cpu())
-    return ret
+    if cu.device == t.device:                 # shares t's storage: reduced in place, nothing to copy back (and async stays async)
+        return tdist.all_reduce(cu, async_op=async_op)
+    # a CPU tensor under nccl went through a device copy (reference dist.py:97-109): the copy-back needs the reduced values,
+    # so the collective is completed here whatever async_op says
+    tdist.all_reduce(cu)
+    t.copy_(cu.cpu())
+    return None
 
 
 def allgather(t: torch.Tensor, cat=True) -> Union[List[torch.Tensor], torch.Tensor]:
@@ -122,7 +125,7 @@ def broadcast(t: torch.Tensor, src_rank) -> None:
     if _state["initialized"]:
         cu = _comm_device(t.detach())
         tdist.broadcast(cu, src=src_rank)
-        if cu is not t:
+        if cu.device != t.device:             # only a CPU tensor that travelled through a device copy is copied back
             t.copy_(cu.cpu())
 
 

@@ -163,7 +163,8 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
         tokenizer = AutoTokenizer.from_pretrained(model_path, model_max_length=2048, padding_side="right", use_fast=True)
     # builder.py:186-191: the patch / start / end tokens are ADDED to the tokenizer; the reference then grows the embedding by
     # freshly initialised rows (resize_token_embeddings), which no prompt of this path ever indexes -- the native vocabulary
-    # stays the checkpoint's
+    # stays the checkpoint's, and an id behind it (a prompt that spells <im_patch> out) is rejected before it reaches the device
+    # (Videollama2MistralForCausalLM._check_ids; the embedding kernel itself reads such a row as zeros)
     if cfgj.get("mm_use_im_patch_token", True):
         tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
     if cfgj.get("mm_use_im_start_end", False):

@@ -280,8 +280,21 @@ class Videollama2MistralForCausalLM:
             lg = lg.masked_fill(torch.zeros_like(drop).scatter(0, idx, drop), float("-inf"))
         return torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).to(torch.int32)
 
+    def _check_ids(self, seq: Sequence[int]) -> None:
+        """text ids must index the checkpoint's embedding table, frame sentinels the frames pushed so far.  The loader ADDS
+        <im_patch> / <im_start> / <im_end> to the tokenizer (model/builder.py; reference builder.py:186-191 then grows the table by
+        fresh rows); a prompt that spells one of them out tokenises to an id behind the table -- rejected here like torch's
+        embedding raises IndexError, instead of indexing past the device buffer (the kernel reads such rows as zeros)."""
+        vocab, T = self.native.cfg.llm_vocab, self.stream.num_frames
+        for t in seq:
+            if t >= vocab:
+                raise IndexError(f"token id {t} is outside the checkpoint's embedding table ({vocab} rows)")
+            if t < 0 and -t - 1 >= T:
+                raise IndexError(f"frame token {-t - 1} referenced, the stream holds {T}")
+
     def _begin_generate(self, seq: List[int], max_new_tokens: int) -> int:
         """prefill `seq` behind the longest cached prefix (KV prefix reuse); returns the number of new tokens that still fit"""
+        self._check_ids(seq)
         if len(seq) + max_new_tokens > self.max_seq:
             max_new_tokens = self.max_seq - len(seq)
             if max_new_tokens <= 0:
@@ -370,6 +383,7 @@ class Videollama2MistralForCausalLM:
             raise ValueError(f"spliced sequence of {len(seq)} tokens exceeds max_seq={self.max_seq}")
         self.stream.set_kv_len(0)
         self._kv_ids = []
+        self._check_ids(seq)
         logits = self.stream.forward_logits(torch.tensor(seq, dtype=torch.int32, device=self.device))
         self._kv_ids = list(seq)
         loss = None

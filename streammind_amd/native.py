@@ -235,10 +235,16 @@ class NativeStream:
               "sm_stream_push_frames_pipelined")
         # the side stream is unknown to torch's caching allocator: keep the outputs (and the frames) alive until joined
         self._inflight = getattr(self, "_inflight", [])[-4:] + [(logits, dec, frames_u8)]
+        self.last_ticket = self.lib.sm_stream_pass_ticket(self.h)
         return logits, dec
 
-    def join(self) -> None:
-        check(self.lib.sm_stream_join(self.h, _stream()), "sm_stream_join")
+    def join(self, ticket: Optional[int] = None) -> None:
+        """order the CURRENT HIP stream behind the pipelined passes: all of them (ticket None), or only the pass of the call whose
+        `last_ticket` is given -- a read-back of call i then does not wait for call i+1 (one batch of look-ahead)"""
+        if ticket is None:
+            check(self.lib.sm_stream_join(self.h, _stream()), "sm_stream_join")
+        else:
+            check(self.lib.sm_stream_join_ticket(self.h, ticket, _stream()), "sm_stream_join_ticket")
 
     def tokens(self, t0: int = 0, n: Optional[int] = None) -> torch.Tensor:
         n = self.num_frames - t0 if n is None else n

@@ -47,7 +47,8 @@ def _http_post(url: str, **kw):
 class ModelWorker:
     def __init__(self, controller_addr, worker_addr, worker_id, no_register, model_path, model_base, model_name, load_8bit=False,
                  load_4bit=False, device="cuda", *, loaded=None, post: Callable = _http_post, limit_model_concurrency: int = 5,
-                 start_heart_beat: bool = True, keywords=()):
+                 start_heart_beat: bool = True, keywords=(), max_streams: int = 16, stream_idle_s: float = 600.0,
+                 stream_max_frames: int = 4096, clock: Callable = time.monotonic):
         self.controller_addr, self.worker_addr, self.worker_id = controller_addr, worker_addr, worker_id
         self.model_path = model_path
         if model_name is None:
@@ -64,7 +65,12 @@ class ModelWorker:
             loaded = load_pretrained_model(model_path, model_base, self.model_name, load_8bit, load_4bit, device=device)
         self.tokenizer, self.model, self.image_processor, self.context_len = loaded
         self.is_multimodal = "videollama2" in self.model_name.lower() or "vlb" in self.model_name.lower()
-        self._stream_models: Dict[str, object] = {}                 # /worker_stream_frames: stream_id -> per-stream state
+        # /worker_stream_frames: stream_id -> per-stream state.  Every entry owns device memory (KV cache, token store, prefill
+        # workspaces: ~1 GB at Mistral-7B sizes), and the ids come from the network: the registry is bounded -- at most
+        # `max_streams` entries, entries idle for `stream_idle_s` are closed first, a request that would exceed the cap while
+        # every entry is live is refused in-band (error_code 1), and {"close": true} releases an entry explicitly.
+        self._stream_models: Dict[str, dict] = {}
+        self.max_streams, self.stream_idle_s, self.stream_max_frames, self._clock = int(max_streams), float(stream_idle_s), int(stream_max_frames), clock
         self._lock = threading.Lock()                               # one generation at a time per model object (it holds stream state)
         if not no_register:
             self.register_to_controller()
@@ -212,14 +218,32 @@ class ModelWorker:
             yield json.dumps({"text": server_error_msg, "error_code": 1}).encode() + b"\0"
 
     # ---- /worker_stream_frames: the streaming gate behind HTTP (no reference counterpart)
+    def _close_stream(self, stream_id: str) -> bool:
+        st = self._stream_models.pop(stream_id, None)
+        if st is None:
+            return False
+        st["model"].stream.close()                          # sm_stream_close: the device buffers go back now, not at GC time
+        return True
+
+    def _evict_idle_streams(self) -> None:
+        now = self._clock()
+        for sid in [k for k, v in self._stream_models.items() if now - v["last_used"] > self.stream_idle_s]:
+            self._close_stream(sid)
+
     def _stream_state(self, stream_id: str, reset: bool):
         from ..model.stream_model import Videollama2MistralForCausalLM
+        if reset:
+            self._close_stream(stream_id)
         st = self._stream_models.get(stream_id)
-        if st is None or reset:
-            m = Videollama2MistralForCausalLM(self.model.native, max_frames=4096,
+        if st is None:
+            self._evict_idle_streams()
+            if len(self._stream_models) >= self.max_streams:
+                raise RuntimeError(f"stream registry full ({self.max_streams} live streams)")
+            m = Videollama2MistralForCausalLM(self.model.native, max_frames=self.stream_max_frames,
                                               max_seq=self.model.max_seq, eos_token_id=self.tokenizer.eos_token_id)
             st = {"model": m, "prompt": None}
             self._stream_models[stream_id] = st
+        st["last_used"] = self._clock()
         return st
 
     @torch.inference_mode()
@@ -228,7 +252,13 @@ class ModelWorker:
         from .. import infer
         try:
             sid = str(params["stream_id"])
-            st = self._stream_state(sid, bool(params.get("reset", False)))
+            if params.get("close", False):                  # explicit release of a stream's device state
+                with self._lock:
+                    closed = self._close_stream(sid)
+                yield json.dumps({"stream_id": sid, "closed": closed, "error_code": 0}).encode() + b"\0"
+                return
+            with self._lock:
+                st = self._stream_state(sid, bool(params.get("reset", False)))
             fr = params["frames"]
             if isinstance(fr, dict):
                 frames = np.frombuffer(base64.b64decode(fr["u8"]), dtype=np.uint8).reshape(fr["shape"])
@@ -240,6 +270,7 @@ class ModelWorker:
                     video = process_video(frames[i:i + 1], self.image_processor, aspect_ratio=ar, num_frames=1)
                     text, st["prompt"] = infer(st["model"], video, "", self.tokenizer, prompt=st["prompt"],
                                                max_new_tokens=int(params.get("max_new_tokens", 1024)))
+                    st["last_used"] = self._clock()
                     yield json.dumps({"stream_id": sid, "frames_seen": st["model"].stream.num_frames, "cls_pred": int(text is not None),
                                       "text": text, "error_code": 0}).encode() + b"\0"
         except Exception as e:

@@ -120,16 +120,27 @@ class StreamingSession:
         push = self.model.stream.push_frames_pipelined if pipelined else self.model.stream.push_frames
         logits, dec = push(dev_frames)
         self.ring.release(slot)
-        return logits, dec, base, pipelined
+        return logits, dec, base, (self.model.stream.last_ticket if pipelined else None)
 
     def _collect(self, handle) -> List[StreamEvent]:
         """the one host sync of a batch (its decisions), then the replies its frames fired, in order"""
-        logits, dec, base, pipelined = handle
-        if pipelined:
-            self.model.stream.join()                    # the caller's stream waits for that batch's side-stream pass
-        dec_host = dec.cpu().tolist()
+        logits, dec, base, ticket = handle
+        if ticket is not None:
+            # read back on a stream of its own, ordered behind THIS batch's pass only: neither the host nor the compute stream
+            # waits for the tower / pass of the batch issued ahead (sm_stream_join would wait for the newest pass)
+            if getattr(self, "_rd", None) is None:
+                self._rd = torch.cuda.Stream(self.model.device)
+            with torch.cuda.stream(self._rd):
+                self.model.stream.join(ticket)
+                dec.record_stream(self._rd); logits.record_stream(self._rd)
+                dec_h = dec.to("cpu", non_blocking=False)
+                lg_h = logits.to("cpu", non_blocking=False) if self.keep_logits else None
+            dec_host = dec_h.tolist()
+        else:
+            dec_host = dec.cpu().tolist()
+            lg_h = logits.cpu() if self.keep_logits else None
         if self.keep_logits:
-            self.stats.gate_logits.append(logits.cpu())
+            self.stats.gate_logits.append(lg_h)
         self.stats.frames += len(dec_host)
         events = []
         for j, d in enumerate(dec_host):
@@ -146,8 +157,9 @@ class StreamingSession:
         """frames: iterable of u8 [H,W,3] host tensors (the decoded stream).  Yields replies as they fire.
 
         One batch of look-ahead: batch i+1 is staged and its tower enqueued BEFORE the decisions of batch i are read back, and
-        the connector + gate pass of every batch runs on the stream's side HIP stream (sm_stream_push_frames_pipelined) -- the GPU
-        never idles on the host's decision read, and the memory-bound pass overlaps the next tower.  A reply for a fire in batch i
+        the connector + gate pass of every batch runs on the stream's side HIP stream (sm_stream_push_frames_pipelined); the decision
+        read of batch i waits for batch i's pass only (per-call ticket, read-back stream), so batch i+1 keeps the GPU busy while the
+        host looks at batch i, and the memory-bound pass overlaps the next tower.  A reply for a fire in batch i
         is generated from the tokens [0, t] of its own frame: frames perceived ahead change nothing but latency."""
         buf: List[torch.Tensor] = []
         pending = None

@@ -9,7 +9,8 @@ does (the library has no CPU path).
     import streammind_amd.torch_ops                     # registers
     y = torch.ops.streammind_hip.linear(x, wp, N, K, bias, 1, None, torch.bfloat16)
     pooled = torch.ops.streammind_hip.vit_encode(model.h.value, frames_u8)
-    logits, dec = torch.ops.streammind_hip.stream_push_frames(stream.h.value, frames_u8)"""
+    st = streammind_amd.torch_ops.new_stream_state("cuda")
+    logits, dec = torch.ops.streammind_hip.stream_push_frames(stream.h.value, frames_u8, st)"""
 from __future__ import annotations
 
 import ctypes as C
@@ -30,6 +31,11 @@ def _st() -> int:
 
 def _h(handle: int) -> C.c_void_p:
     return C.c_void_p(handle)
+
+
+def new_stream_state(device) -> Tensor:
+    """the tensor that stands for one sm_stream's hidden state in the stateful ops (see the module docstring)"""
+    return torch.zeros(1, dtype=torch.int64, device=device)
 
 
 # ------------------------------------------------------------------------------------------------ operator level
@@ -138,8 +144,8 @@ def _(model, frames_u8, vit_hidden):
     return frames_u8.new_empty((frames_u8.shape[0], vit_hidden), dtype=torch.float32)
 
 
-@torch.library.custom_op(f"{NS}::stream_push_frames", mutates_args=())
-def stream_push_frames(stream: int, frames_u8: Tensor) -> Tuple[Tensor, Tensor]:
+@torch.library.custom_op(f"{NS}::stream_push_frames", mutates_args=("state",))
+def stream_push_frames(stream: int, frames_u8: Tensor, state: Tensor) -> Tuple[Tensor, Tensor]:
     """one streaming tick: ViT + connector step + gate for the new frames -> (gate logits [M, 2] fp32, decisions [M] int32)"""
     lib = _lib.load()
     f = frames_u8.contiguous()
@@ -147,60 +153,64 @@ def stream_push_frames(stream: int, frames_u8: Tensor) -> Tuple[Tensor, Tensor]:
     lg = torch.empty(M, 2, dtype=torch.float32, device=f.device)
     dc = torch.empty(M, dtype=torch.int32, device=f.device)
     check(lib.sm_stream_push_frames(_h(stream), f.data_ptr(), M, lg.data_ptr(), dc.data_ptr(), _st()), "sm_stream_push_frames")
+    state.add_(1)
     return lg, dc
 
 
 @stream_push_frames.register_fake
-def _(stream, frames_u8):
+def _(stream, frames_u8, state):
     M = frames_u8.shape[0]
     return frames_u8.new_empty((M, 2), dtype=torch.float32), frames_u8.new_empty((M,), dtype=torch.int32)
 
 
-@torch.library.custom_op(f"{NS}::stream_push_pooled", mutates_args=())
-def stream_push_pooled(stream: int, pooled: Tensor) -> Tuple[Tensor, Tensor]:
+@torch.library.custom_op(f"{NS}::stream_push_pooled", mutates_args=("state",))
+def stream_push_pooled(stream: int, pooled: Tensor, state: Tensor) -> Tuple[Tensor, Tensor]:
     lib = _lib.load()
     p = pooled.contiguous()
     M = p.shape[0]
     lg = torch.empty(M, 2, dtype=torch.float32, device=p.device)
     dc = torch.empty(M, dtype=torch.int32, device=p.device)
     check(lib.sm_stream_push_pooled(_h(stream), p.data_ptr(), M, lg.data_ptr(), dc.data_ptr(), _st()), "sm_stream_push_pooled")
+    state.add_(1)
     return lg, dc
 
 
 @stream_push_pooled.register_fake
-def _(stream, pooled):
+def _(stream, pooled, state):
     M = pooled.shape[0]
     return pooled.new_empty((M, 2), dtype=torch.float32), pooled.new_empty((M,), dtype=torch.int32)
 
 
-@torch.library.custom_op(f"{NS}::llm_prefill", mutates_args=())
-def llm_prefill(stream: int, ids: Tensor) -> Tensor:
+@torch.library.custom_op(f"{NS}::llm_prefill", mutates_args=("state",))
+def llm_prefill(stream: int, ids: Tensor, state: Tensor) -> Tensor:
     """append the spliced positions (ids >= 0 text, < 0 frame token -(i+1)) to the KV cache; returns the greedy next token [1]"""
     lib = _lib.load()
     ids = ids.to(torch.int32).contiguous()
     check(lib.sm_llm_prefill(_h(stream), ids.data_ptr(), ids.numel(), _st()), "sm_llm_prefill")
     nt = torch.empty(1, dtype=torch.int32, device=ids.device)
     check(lib.sm_stream_read_logits(_h(stream), None, nt.data_ptr(), _st()), "sm_stream_read_logits")
+    state.add_(1)
     return nt
 
 
 @llm_prefill.register_fake
-def _(stream, ids):
+def _(stream, ids, state):
     return ids.new_empty((1,), dtype=torch.int32)
 
 
-@torch.library.custom_op(f"{NS}::llm_decode", mutates_args=())
-def llm_decode(stream: int, n_steps: int, like: Tensor) -> Tensor:
-    """n greedy steps continuing the stream; `like` only names the device"""
+@torch.library.custom_op(f"{NS}::llm_decode", mutates_args=("state",))
+def llm_decode(stream: int, n_steps: int, state: Tensor) -> Tensor:
+    """n greedy steps continuing the stream"""
     lib = _lib.load()
-    out = torch.empty(n_steps, dtype=torch.int32, device=like.device)
+    out = torch.empty(n_steps, dtype=torch.int32, device=state.device)
     check(lib.sm_llm_decode(_h(stream), n_steps, out.data_ptr(), _st()), "sm_llm_decode")
+    state.add_(1)
     return out
 
 
 @llm_decode.register_fake
-def _(stream, n_steps, like):
-    return like.new_empty((n_steps,), dtype=torch.int32)
+def _(stream, n_steps, state):
+    return state.new_empty((n_steps,), dtype=torch.int32)
 
 
 OPS = ("linear", "pack_weight", "norm", "vit_attention", "pool_rows", "ingest_frames", "vit_encode", "stream_push_frames",

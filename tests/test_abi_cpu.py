@@ -91,7 +91,15 @@ def test_torch_library_ops_are_registered_with_fake_kernels():
         x = torch.empty(577, 1024, dtype=torch.bfloat16)
         y = torch.ops.streammind_hip.linear(x, torch.empty(8, dtype=torch.bfloat16), 3072, 1024, None, 1, None, torch.bfloat16)
         assert tuple(y.shape) == (577, 3072) and y.dtype == torch.bfloat16
-        lg, dc = torch.ops.streammind_hip.stream_push_frames(0, torch.empty(4, 336, 336, 3, dtype=torch.uint8))
+        st = T.new_stream_state("cpu")
+        lg, dc = torch.ops.streammind_hip.stream_push_frames(0, torch.empty(4, 336, 336, 3, dtype=torch.uint8), st)
         assert tuple(lg.shape) == (4, 2) and dc.dtype == torch.int32
+        assert tuple(torch.ops.streammind_hip.llm_decode(0, 5, st).shape) == (5,)
         assert tuple(torch.ops.streammind_hip.vit_attention(torch.empty(2 * 577, 3072, dtype=torch.float16), 2, 577, 16, 64).shape) == (1154, 1024)
         assert tuple(torch.ops.streammind_hip.pool_rows(torch.empty(5, 576, 1024)).shape) == (5, 1024)
+    # the ops that advance a stream behind its handle declare the state tensor as mutated: graph capture can neither drop, merge
+    # nor reorder them (the operator-level ops stay pure)
+    for name in ("stream_push_frames", "stream_push_pooled", "llm_prefill", "llm_decode"):
+        schema = getattr(torch.ops.streammind_hip, name).default._schema
+        assert any(a.name == "state" and a.alias_info is not None and a.alias_info.is_write for a in schema.arguments), name
+    assert not any(a.alias_info is not None and a.alias_info.is_write for a in torch.ops.streammind_hip.linear.default._schema.arguments)

@@ -145,3 +145,46 @@ def test_controller_proxies_worker_stream(gold, tiny_tokenizer):
     got = [x[:-1].decode() for x in c.worker_api_generate_stream(req)]
     assert got == json.loads(str(g["chunks"]))[0]
     assert c.worker_api_get_status() == {"model_names": ["VideoLLaMA2-7B"], "speed": 1, "queue_length": 0}
+
+
+def test_stream_registry_is_bounded(tiny_tokenizer, monkeypatch):
+    """/worker_stream_frames keeps device state per client-chosen stream_id: the registry is capped, idle entries are closed first
+    (sm_stream_close, not GC), a full registry refuses new ids in-band, {"close": true} releases one (advisor finding, round 2)."""
+    import streammind_amd.model.stream_model as SM
+    closed = []
+
+    class _S:
+        def __init__(self, name):
+            self.name = name
+
+        def close(self):
+            closed.append(self.name)
+
+    class _M:
+        n = 0
+
+        def __init__(self, native, max_frames, max_seq, eos_token_id):
+            _M.n += 1
+            self.stream = _S(_M.n)
+            self.max_frames = max_frames
+    monkeypatch.setattr(SM, "Videollama2MistralForCausalLM", _M)
+    now = [0.0]
+    w = _worker(tiny_tokenizer, "ok", max_streams=2, stream_idle_s=10.0, stream_max_frames=64, clock=lambda: now[0])
+    w.model.native, w.model.max_seq = object(), 128
+    a = w._stream_state("a", False)
+    assert a["model"].max_frames == 64 and w._stream_state("a", False) is a            # same id -> same state
+    now[0] = 1.0
+    w._stream_state("b", False)
+    with pytest.raises(RuntimeError, match="registry full"):
+        w._stream_state("c", False)                                                    # both live: refused, nothing evicted
+    assert closed == [] and set(w._stream_models) == {"a", "b"}
+    out = [json.loads(c[:-1]) for c in w.stream_frames({"stream_id": "c", "frames": []})]
+    assert out[-1]["error_code"] == 1                                                  # ... in-band on the wire
+    now[0] = 10.5                                                                      # "a" (last used 0.0) is idle now, "b" (1.0) is not
+    w._stream_state("c", False)
+    assert closed == [1] and set(w._stream_models) == {"b", "c"}
+    w._stream_state("b", True)                                                         # reset = close + reopen
+    assert closed == [1, 2] and set(w._stream_models) == {"b", "c"}
+    out = [json.loads(c[:-1]) for c in w.stream_frames({"stream_id": "c", "close": True})]
+    assert out == [{"stream_id": "c", "closed": True, "error_code": 0}] and closed == [1, 2, 3] and set(w._stream_models) == {"b"}
+    assert [json.loads(c[:-1]) for c in w.stream_frames({"stream_id": "zz", "close": True})][0]["closed"] is False
