@@ -261,15 +261,28 @@ def ingest_leg(B=28, H=720, W=1280, reps=20):
                          "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_frame": byts // B}}
 
 
-def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None):
+def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None, overlap=False, chunk=16):
     """BASELINE configs[2] shape: perception of every frame + Mistral-7B replies on SCHEDULED fires (the random-weight
     gate's own decisions are not a workload), each reply = prefill of the new context (KV prefix reuse) + exactly
-    `reply_tokens` greedy tokens (EOS ignored).  Returns stream frames/s including the replies."""
+    `reply_tokens` greedy tokens (EOS ignored).  Returns stream frames/s including the replies.
+
+    overlap: the replies run on an LLM lane (a second HIP stream): prefill + decode are enqueued there, `chunk` tokens per
+    perception step, while the perception stream goes on with the next frames; a fire that arrives during a reply follows it on
+    the lane (its context contains that reply).  Same schedule, same results (tests/test_gpu_path.py: bit-identical)."""
     torch.cuda.synchronize()
     base = stream.num_frames
     g = torch.Generator(device="cuda").manual_seed(11)
     text = torch.randint(3, cfg.llm_vocab, (60,), generator=g, device="cuda", dtype=torch.int32)
-    kv_ids = 0
+    lane = torch.cuda.Stream() if overlap else None
+    owed = 0                                     # tokens of the reply in flight not yet enqueued on the lane
+
+    def lane_decode(n):
+        nonlocal owed
+        n = min(n, owed)
+        if n > 0:
+            with torch.cuda.stream(lane):
+                stream.decode(n)
+            owed -= n
     t0 = time.perf_counter()
     n_frames = n_fires = n_tok = 0
     stream.set_kv_len(0)
@@ -286,17 +299,84 @@ def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens
             ctx.append(-(torch.arange(seg_start, T, device="cuda", dtype=torch.int32) + 1))
             ctx.append(torch.randint(3, cfg.llm_vocab, (6,), generator=g, device="cuda", dtype=torch.int32))
             new = torch.cat(ctx).contiguous()
-            stream.prefill(new)                      # only the tokens after the cached prefix: kv_len continues
-            out = stream.decode(reply_tokens)
+            if overlap:
+                lane_decode(owed)                    # the previous reply is part of this context: all of it goes first
+                lane.wait_stream(torch.cuda.current_stream())      # the frame tokens this prefill splices
+                with torch.cuda.stream(lane):
+                    stream.prefill(new)
+                new.record_stream(lane)
+                owed = reply_tokens
+            else:
+                stream.prefill(new)                  # only the tokens after the cached prefix: kv_len continues
+                out = stream.decode(reply_tokens)
             ctx = [torch.randint(3, cfg.llm_vocab, (4,), generator=g, device="cuda", dtype=torch.int32)]
             seg_start = T
             n_fires += 1
             n_tok += reply_tokens
+        if overlap:
+            lane_decode(chunk)
+    if overlap:
+        lane_decode(owed)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"frames": n_frames, "fires": n_fires, "reply_tokens": reply_tokens, "seconds": round(dt, 4),
             "frames_per_s": round(n_frames / dt, 2), "reply_tokens_per_s_overall": round(n_tok / dt, 2),
-            "kv_len_end": stream.kv_len}
+            "kv_len_end": stream.kv_len, "replies_on_llm_lane": bool(overlap)}
+
+
+def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per_iter=4, n_ctx=328):
+    """What the LLM lane buys a LIVE stream: ONE 256-token reply is decoded on the lane while the perception stream keeps encoding
+    and gating frames, `tokens_per_iter` decode steps enqueued per perception call of B frames.  Reported: the wall clock of
+    {reply + frames} together against the same reply and the same frames one after the other (what the reference's loop does:
+    eval/video_score_stream_demo.py:283-299 perceives nothing while `generate` runs), and each side's rate while sharing the chip."""
+    g = torch.Generator(device="cuda").manual_seed(19)
+    ids = torch.randint(3, cfg.llm_vocab, (n_ctx,), generator=g, device="cuda", dtype=torch.int32)
+    iters = reply_tokens // tokens_per_iter
+    n_pool = frames.shape[0]
+
+    def perceive(i):
+        stream.push_frames(frames[(i * B) % (n_pool - B + 1):][:B])
+    lane = torch.cuda.Stream()
+    # one after the other
+    stream.set_kv_len(0); stream.prefill(ids); stream.decode(8)
+    for i in range(2):
+        perceive(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stream.decode(reply_tokens)
+    torch.cuda.synchronize()
+    t_dec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for i in range(iters):
+        perceive(i)
+    torch.cuda.synchronize()
+    t_per = time.perf_counter() - t0
+    # together
+    stream.set_kv_len(0); stream.prefill(ids); stream.decode(8)
+    torch.cuda.synchronize()
+    lane.wait_stream(torch.cuda.current_stream())
+    e_lane, e_main = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        perceive(i)
+        with torch.cuda.stream(lane):
+            stream.decode(tokens_per_iter)
+    e_main.record()
+    with torch.cuda.stream(lane):
+        e_lane.record()
+    torch.cuda.synchronize()
+    t_both = time.perf_counter() - t0
+    ms_main, ms_lane = e0.elapsed_time(e_main), e0.elapsed_time(e_lane)
+    stream.set_kv_len(0)
+    F = iters * B
+    return {"reply_tokens": reply_tokens, "frames": F, "frames_per_call": B, "context_tokens": n_ctx,
+            "serial_seconds": round(t_dec + t_per, 4), "overlapped_seconds": round(t_both, 4), "speedup": round((t_dec + t_per) / t_both, 3),
+            "alone": {"decode_tokens_per_s": round(reply_tokens / t_dec, 1), "frames_per_s": round(F / t_per, 1)},
+            "sharing_the_chip": {"decode_tokens_per_s": round(reply_tokens / (ms_lane * 1e-3), 1), "frames_per_s": round(F / (ms_main * 1e-3), 1),
+                                 "note": "each side's own completion time, from HIP events on its stream; whichever finishes first leaves the chip to the other"},
+            "note": "perception of `frames` frames + one greedy reply: one after the other vs the reply on the LLM lane (second HIP stream)"}
 
 
 def streams_x1_leg(model, frames, S, ticks=20):
@@ -695,6 +775,15 @@ def main():
         e2e = e2e_leg(model, stream, cfg, frames, B, gather=gather)
         if dist is not None:
             e2e["allgather_gated_tokens"] = gathered
+        if world == 1:
+            try:       # the same schedule with the replies on the LLM lane, and what the lane buys a live stream
+                e2e["with_llm_lane"] = e2e_leg(model, stream, cfg, frames, B, overlap=True)
+                e2e["live_stream_overlap"] = live_overlap_leg(model, stream, cfg, frames, B)
+                e2e["note"] = ("frames/s of this schedule is decode-bound: 448 frames cost 0.18 s, the two 256-token replies 2 x 0.78 s, and the second "
+                               "reply's context contains the first, so the replies cannot overlap each other -- the lane hides the perception, "
+                               "not the replies (see live_stream_overlap for the resource-sharing gain)")
+            except Exception as e:
+                e2e["with_llm_lane"] = {"error": repr(e)[:300]}
     if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
         dec_leg = decode_leg(model, stream, cfg)
         if prof and world == 1:

@@ -199,7 +199,10 @@ int sm_argmax(const float* logits, int V, int32_t* out, void* stream);
  *   sm_stream <- the per-stream fields the reference keeps ON the model object
  *                (frame_feature, interval_id_list: language_model/videollama2_mistral.py:159-162) plus what
  *                the reference recomputes every frame: Mamba conv/ssm state, per-frame tokens, LLM KV cache.
- * One host thread per stream handle.  Different streams of one model may be driven concurrently on DIFFERENT HIP streams: all
+ * One host thread per stream handle.  The sm_llm_* calls of a stream may be issued on ANOTHER HIP stream than its perception calls
+ * (an "LLM lane": replies are decoded while the perception stream keeps consuming frames -- the two touch disjoint state: the
+ * perception writes token-store rows >= the rows a prefill splices, the LLM its KV cache and activation buffers; sm_llm_prefill
+ * orders its HIP stream behind the newest connector + gate pass by itself).  Different streams of one model may be driven concurrently on DIFFERENT HIP streams: all
  * per-call scratch is per sm_stream, and the vision tower's workspaces are kept per HIP stream (allocated on the first call a HIP
  * stream makes, never afterwards).  Two streams driven on two HIP streams fill each other's launch gaps and kernel tails
  * (measured +7 % aggregate frames/s at 28 frames per call each); calls issued on ONE HIP stream are ordered as usual.

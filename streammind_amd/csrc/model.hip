@@ -681,7 +681,9 @@ struct sm_stream {
     hipStream_t side = nullptr;
     hipEvent_t ev_vit = nullptr, ev_pass[2] = {nullptr, nullptr};
     DevBuf pooled_pp[2];
-    int flip = 0, last = -1;           // last: index of the event of the newest pass not yet joined by the caller's stream (-1: none)
+    int flip = 0, last = -1;           // last: index of the event of the newest pass (-1: none yet)
+    long pass_seq = 0, joined_seq = -1;   // number of the newest pass / of the pass `joined_on` was last ordered behind
+    void* joined_on = nullptr;
     ~sm_stream() {
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
         if (ev_vit) (void)hipEventDestroy(ev_vit);
@@ -691,10 +693,12 @@ struct sm_stream {
 
 // every entry point that reads or writes a stream's state on the caller's HIP stream first orders that stream behind the
 // pipelined passes still running on the side stream (a no-op when none is pending)
+// (the newest pass stays "pending" for every OTHER HIP stream that comes along -- e.g. an LLM lane next to the perception stream --,
+// only a repeated join of the same pass from the same stream is skipped)
 static int auto_join(sm_stream* s, void* stream) {
-    if (s && s->last >= 0) {
+    if (s && s->last >= 0 && !(s->joined_seq == s->pass_seq && s->joined_on == stream)) {
         SM_HIP(hipStreamWaitEvent((hipStream_t)stream, s->ev_pass[s->last], 0));
-        s->last = -1;
+        s->joined_seq = s->pass_seq; s->joined_on = stream;
     }
     return SM_OK;
 }
@@ -943,6 +947,7 @@ extern "C" int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* fram
     }
     SM_HIP(hipEventRecord(s->ev_pass[f], s->side));
     s->last = f;
+    s->pass_seq += 1;
     s->flip ^= 1;
     return SM_OK;
 }

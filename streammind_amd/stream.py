@@ -9,7 +9,15 @@ O(1)-per-frame device state instead of one blocking call per frame.
 Results are identical to the frame-at-a-time loop (`streammind_amd.infer` per frame): the gate of frame t depends only on
 frames <= t (the Mamba scan is causal and the gate sees one token), never on what the LLM said, so perceiving a batch
 ahead of the replies changes nothing but latency.  The reply for a fire at frame t is generated from exactly the
-tokens [0, t] and the prompt grown by the earlier replies, as in the reference."""
+tokens [0, t] and the prompt grown by the earlier replies, as in the reference.
+
+`run(..., overlap_replies=True)` additionally moves the replies onto an LLM LANE -- a second HIP stream: splice + prefill + greedy
+decode of a reply are enqueued there in chunks while the perception stream keeps consuming frames.  Decode at batch 1 is
+HBM-bound (~60 % of the HBM peak, ~4 % of the matrix pipes), the tower the opposite (~40 % of the MFMA peak, a fifth of the HBM
+bandwidth): sharing the chip they take each other's idle resource, and -- what matters for a live stream -- the gate keeps
+deciding on new frames while a reply is being written (the reference's loop, eval/video_score_stream_demo.py:283-299, perceives
+nothing for the ~0.8 s a 256-token reply takes).  A fire that arrives while a reply is still being decoded waits for it (its
+prompt contains that reply): replies, gate logits and the grown prompt are bit-identical to the serial order."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -96,16 +104,71 @@ class StreamingSession:
         conv.append_message(conv.roles[1], None)
         return conv.get_prompt()
 
-    def _reply(self, upto_frame: int) -> StreamEvent:
+    def _reply_inputs(self, upto_frame: int):
         m = self.model
         m.interval_id_list.append(upto_frame)
         input_ids = tokenizer_MMODAL_token(self.prompt, self.tok, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
         crit = KeywordsStoppingCriteria(["</s>"], self.tok, input_ids)
-        seq = m._expand(input_ids[0].tolist())
-        new_ids = m._generate(seq, self.max_new, [crit])
+        return m._expand(input_ids[0].tolist()), crit
+
+    def _reply_done(self, upto_frame: int, new_ids: List[int]) -> StreamEvent:
         text = self.tok.batch_decode([new_ids], skip_special_tokens=True)[0].strip()
         self.prompt += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
         return StreamEvent(upto_frame, text, new_ids)
+
+    def _reply(self, upto_frame: int) -> StreamEvent:
+        seq, crit = self._reply_inputs(upto_frame)
+        return self._reply_done(upto_frame, self.model._generate(seq, self.max_new, [crit]))
+
+    # ---- replies on the LLM lane (run(overlap_replies=True)).  One reply is in flight at a time; its decode chunks are enqueued
+    # `lane_depth` ahead on the lane's HIP stream and their ids come back through pinned memory behind an event, so the host never
+    # blocks on the lane while frames are waiting (it does when the frames have run out: _pump(block=True)).
+    def _lane_start(self, upto_frame: int) -> None:
+        m = self.model
+        seq, crit = self._reply_inputs(upto_frame)
+        self._llm.wait_stream(torch.cuda.current_stream())    # the lane starts behind everything the perception stream has been given
+        with torch.cuda.stream(self._llm):                    # (sm_llm_prefill also orders it behind the newest side-stream pass)
+            budget = m._begin_generate(seq, self.max_new)     # prefill behind the cached prefix
+        self._active = {"frame": upto_frame, "seq_len": len(seq), "crit": crit, "budget": budget, "out": [], "issued": 0, "chunks": []}
+
+    def _lane_issue(self) -> None:
+        a, m = self._active, self.model
+        while len(a["chunks"]) < self.lane_depth and a["issued"] < a["budget"]:
+            n = min(m.decode_chunk, a["budget"] - a["issued"])
+            with torch.cuda.stream(self._llm):
+                ids = m.stream.decode(n)
+                host = torch.empty(n, dtype=torch.int32).pin_memory()
+                host.copy_(ids, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._llm)
+            a["issued"] += n
+            a["chunks"].append((host, ev, ids))
+
+    def _pump(self, block: bool) -> Iterator[StreamEvent]:
+        """advance the lane: start the next queued fire, keep `lane_depth` decode chunks enqueued, take the chunks that have
+        finished (every chunk when `block`), close the reply at its stop.  Everything of the LLM is on ONE HIP stream, in order:
+        chunks enqueued past a stop are speculative -- their ids are dropped, the cache length is cut back by _accept_tokens (as
+        for the speculative tail of a serial chunk) and the next prefill simply follows them on the lane."""
+        m = self.model
+        while True:
+            if self._active is None:
+                if not self._fire_q:
+                    return
+                self._lane_start(self._fire_q.pop(0))
+            a = self._active
+            self._lane_issue()
+            closed = not a["chunks"]                           # nothing (left) to decode: the context filled the cache
+            if not closed:
+                host, ev, _ = a["chunks"][0]
+                if not block and not ev.query():
+                    return                                     # the lane is busy; perception goes on
+                ev.synchronize()
+                a["chunks"].pop(0)
+                _, done = m._accept_tokens(a["out"], host.tolist(), a["seq_len"], [a["crit"]])
+                closed = done or len(a["out"]) >= a["budget"]
+            if closed:
+                self._active = None
+                yield self._reply_done(a["frame"], a["out"])
 
     def _issue(self, frames: torch.Tensor, pipelined: bool):
         """stage one batch and enqueue its perception; returns what `_collect` needs (no host sync here)"""
@@ -122,8 +185,9 @@ class StreamingSession:
         self.ring.release(slot)
         return logits, dec, base, (self.model.stream.last_ticket if pipelined else None)
 
-    def _collect(self, handle) -> List[StreamEvent]:
-        """the one host sync of a batch (its decisions), then the replies its frames fired, in order"""
+    def _collect(self, handle, fires_only: bool = False):
+        """the one host sync of a batch (its decisions), then the replies its frames fired, in order (fires_only: the fired frame
+        numbers instead -- the caller runs the replies on the LLM lane)"""
         logits, dec, base, ticket = handle
         if ticket is not None:
             # read back on a stream of its own, ordered behind THIS batch's pass only: neither the host nor the compute stream
@@ -146,23 +210,28 @@ class StreamingSession:
         for j, d in enumerate(dec_host):
             if d == 1:
                 self.stats.fires += 1
-                events.append(self._reply(base + j + 1))
+                events.append(base + j + 1 if fires_only else self._reply(base + j + 1))
         return events
 
     def feed(self, frames: torch.Tensor) -> List[StreamEvent]:
         """frames: u8 [n,H,W,3] on the HOST (n <= batch_frames).  Returns the replies fired by these frames, in order."""
         return self._collect(self._issue(frames, pipelined=False))
 
-    def run(self, frames: Iterable[torch.Tensor]) -> Iterator[StreamEvent]:
+    def run(self, frames: Iterable[torch.Tensor], overlap_replies: bool = False, lane_depth: int = 2) -> Iterator[StreamEvent]:
         """frames: iterable of u8 [H,W,3] host tensors (the decoded stream).  Yields replies as they fire.
 
         One batch of look-ahead: batch i+1 is staged and its tower enqueued BEFORE the decisions of batch i are read back, and
         the connector + gate pass of every batch runs on the stream's side HIP stream (sm_stream_push_frames_pipelined); the decision
         read of batch i waits for batch i's pass only (per-call ticket, read-back stream), so batch i+1 keeps the GPU busy while the
         host looks at batch i, and the memory-bound pass overlaps the next tower.  A reply for a fire in batch i
-        is generated from the tokens [0, t] of its own frame: frames perceived ahead change nothing but latency."""
+        is generated from the tokens [0, t] of its own frame: frames perceived ahead change nothing but latency.
+
+        overlap_replies: replies are decoded on the LLM lane while perception goes on (module docstring); same events, same order."""
         buf: List[torch.Tensor] = []
         pending = None
+        self._fire_q, self._active, self.lane_depth = [], None, max(1, lane_depth)
+        if overlap_replies and getattr(self, "_llm", None) is None:
+            self._llm = torch.cuda.Stream(self.model.device)
 
         def batches():
             nonlocal buf
@@ -173,13 +242,25 @@ class StreamingSession:
                     buf = []
             if buf:
                 yield torch.stack(buf)
+
+        def collect(handle):
+            if not overlap_replies:
+                yield from self._collect(handle)
+                return
+            self._fire_q.extend(self._collect(handle, fires_only=True))
+            yield from self._pump(block=False)
         for b in batches():
             handle = self._issue(b, pipelined=True)
             if pending is not None:
-                yield from self._collect(pending)
+                yield from collect(pending)
+            elif overlap_replies:
+                yield from self._pump(block=False)
             pending = handle
         if pending is not None:
-            yield from self._collect(pending)
+            yield from collect(pending)
+        if overlap_replies:
+            yield from self._pump(block=True)                 # the stream has ended: finish what the lane still owes
+            torch.cuda.current_stream().wait_stream(self._llm)
 
 
 class MultiStreamSession:

@@ -238,6 +238,30 @@ def test_streaming_session_equals_frame_at_a_time(tiny, tiny_tokenizer):
     assert sess.prompt == prompt and sess.stats.frames == 12
 
 
+def test_replies_on_the_llm_lane_equal_the_serial_order(tiny, tiny_tokenizer):
+    """run(overlap_replies=True): splice + prefill + greedy decode of every reply are enqueued on a second HIP stream (the LLM lane)
+    while the perception stream keeps pushing frames; fires that arrive during a reply queue behind it.  Gate logits, fire positions,
+    reply ids / texts and the grown prompt must be BIT-IDENTICAL to the serial session (and to the reference-shaped one-frame-per-call
+    loop: eval/video_score_stream_demo.py:283-299) -- for several lane depths (speculative chunks enqueued past a stop) and batch
+    sizes (fires landing while the lane is busy)."""
+    from streammind_amd.model import Videollama2MistralForCausalLM
+    from streammind_amd.stream import StreamingSession
+    m, *_ = tiny
+    frames = O.synthetic_frames(24, TV.image_size, seed=99, scene_len=3)
+
+    def session(batch, max_new, **kw):
+        mdl = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=1024, eos_token_id=tiny_tokenizer.eos_token_id)
+        sess = StreamingSession(mdl, tiny_tokenizer, batch_frames=batch, max_new_tokens=max_new, keep_logits=True)
+        ev = [(e.frame_index, e.text, tuple(e.new_ids)) for e in sess.run((frames[i] for i in range(24)), **kw)]
+        return ev, torch.cat(sess.stats.gate_logits), sess.prompt, mdl.stream.kv_len
+    for batch, max_new in ((5, 5), (3, 40)):
+        ev0, lg0, p0, kv0 = session(batch, max_new)
+        assert len(ev0) >= 3
+        for depth in (1, 2, 4):
+            ev1, lg1, p1, kv1 = session(batch, max_new, overlap_replies=True, lane_depth=depth)
+            assert ev1 == ev0 and torch.equal(lg1, lg0) and p1 == p0 and kv1 == kv0, (batch, max_new, depth)
+
+
 def test_feature_cache_bulk_encode(tiny, tmp_path):
     """config-1 plumbing: bulk encode -> chunk files of the reference's shape and naming, then the stride."""
     from streammind_amd import feature_cache as fc
