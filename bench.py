@@ -270,6 +270,7 @@ def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens
     perception step, while the perception stream goes on with the next frames; a fire that arrives during a reply follows it on
     the lane (its context contains that reply).  Same schedule, same results (tests/test_gpu_path.py: bit-identical)."""
     torch.cuda.synchronize()
+    stream.reset()                               # a fresh stream (the token store is fixed-size: earlier legs must not fill it)
     base = stream.num_frames
     g = torch.Generator(device="cuda").manual_seed(11)
     text = torch.randint(3, cfg.llm_vocab, (60,), generator=g, device="cuda", dtype=torch.int32)
@@ -338,7 +339,7 @@ def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per
         stream.push_frames(frames[(i * B) % (n_pool - B + 1):][:B])
     lane = torch.cuda.Stream()
     # one after the other
-    stream.set_kv_len(0); stream.prefill(ids); stream.decode(8)
+    stream.reset(); stream.prefill(ids); stream.decode(8)
     for i in range(2):
         perceive(i)
     torch.cuda.synchronize()
@@ -352,7 +353,7 @@ def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per
     torch.cuda.synchronize()
     t_per = time.perf_counter() - t0
     # together
-    stream.set_kv_len(0); stream.prefill(ids); stream.decode(8)
+    stream.reset(); stream.prefill(ids); stream.decode(8)
     torch.cuda.synchronize()
     lane.wait_stream(torch.cuda.current_stream())
     e_lane, e_main = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -369,7 +370,7 @@ def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per
     torch.cuda.synchronize()
     t_both = time.perf_counter() - t0
     ms_main, ms_lane = e0.elapsed_time(e_main), e0.elapsed_time(e_lane)
-    stream.set_kv_len(0)
+    stream.reset()
     F = iters * B
     return {"reply_tokens": reply_tokens, "frames": F, "frames_per_call": B, "context_tokens": n_ctx,
             "serial_seconds": round(t_dec + t_per, 4), "overlapped_seconds": round(t_both, 4), "speedup": round((t_dec + t_per) / t_both, 3),
@@ -1015,7 +1016,7 @@ def main():
         # + LLM weights are quantised to fp8 at load time
         try:
             del stream
-            cfg8 = PathConfig(llm_layers=32, max_frames_per_call=B, weights_fp8=True)
+            cfg8 = PathConfig(llm_layers=32, max_frames_per_call=B, weights_fp8=2)
             m8 = NativeModel(cfg8, f"cuda:{local}")
             random_weights_into(m8, cfg8, seed=1234)
             random_llm_weights_into(m8, cfg8, seed=4321)
@@ -1032,6 +1033,36 @@ def main():
             torch.cuda.synchronize()
             d60 = time.perf_counter() - t1
             fp8_leg = decode_leg(m8, s8, cfg8)
+            # prefill of a 2048-token context (one chunk), three ways on the same box: weight-only fp8 (the fp8 image is expanded to a bf16
+            # scratch per call, bf16 MFMA), fp8 x fp8 MFMA on per-row-quantised activations (v_mfma_scale_f32_16x16x128_f8f6f4), and the
+            # bf16 model of the headline run
+            try:
+                gq = torch.Generator(device="cuda").manual_seed(23)
+                pids = torch.randint(3, cfg8.llm_vocab, (2048,), generator=gq, device="cuda", dtype=torch.int32)
+                spf = m8.open_stream(max_frames=8, max_seq=2048)
+
+                def pre(st_, n=3):
+                    st_.set_kv_len(0); st_.prefill(pids); torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(n):
+                        st_.set_kv_len(0); st_.prefill(pids)
+                    torch.cuda.synchronize()
+                    return round(2048 * n / (time.perf_counter() - t_), 1)
+                pf = {"tokens": 2048}
+                m8.set_fp8_mode(1); pf["weight_only_fp8_tokens_per_s"] = pre(spf)
+                m8.set_fp8_mode(2); pf["fp8_mfma_tokens_per_s"] = pre(spf)
+                spf.close()
+                if model is not None and not a.no_decode:
+                    sb = model.open_stream(max_frames=8, max_seq=2048)
+                    pf["bf16_tokens_per_s"] = pre(sb)
+                    sb.close()
+                d_, L_ = cfg8.conn_d_model, cfg8.llm_layers
+                fl = 2.0 * 2048 * (L_ * (2 * d_ * d_ + 2 * d_ * cfg8.llm_kv_heads * (d_ // cfg8.llm_heads) + 3 * d_ * cfg8.llm_mlp) + cfg8.llm_vocab * d_ / 2048)
+                pf["fp8_mfma_linear_tflops"] = round(fl * pf["fp8_mfma_tokens_per_s"] / 2048 / 1e12, 1)
+                pf["note"] = "fp8_mfma: activations quantised per token to e4m3, fp8 x fp8 on the matrix pipe at twice the bf16 MFMA rate (gemm_fp8.hip); attention, norms, RoPE as in bf16"
+                fp8_leg["prefill_2048"] = pf
+            except Exception as e:
+                fp8_leg["prefill_2048"] = {"error": repr(e)[:300]}
             fp8_leg["roofline"]["bytes_per_token"] = fp8_leg["roofline"]["bytes_per_token"] / 2 + 0.0
             fp8_leg["roofline"]["achieved"] = round(fp8_leg["roofline"]["bytes_per_token"] * fp8_leg["tokens_per_s"] / 1e9, 1)
             fp8_leg["roofline"]["frac"] = round(fp8_leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)

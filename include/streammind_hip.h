@@ -36,6 +36,7 @@ extern "C" {
 #define SM_X_F32 1
 #define SM_W_BF16 0
 #define SM_W_FP8 1
+#define SM_W_FP8_MFMA 2   /* the SM_W_FP8 image; calls with > 16 rows quantise the activations per row to e4m3 and run fp8 x fp8 MFMA */
 #define SM_OP_BF16 0  /* 16-bit operands (packed weights, x, 16-bit outputs) are bfloat16 */
 #define SM_OP_F16 1   /* ... IEEE half: tiled GEMM only (the ViT's optional fp16 mode = the reference demo's precision, builder.py:54) */
 #define SM_TILE_AUTO 0
@@ -89,7 +90,11 @@ typedef struct sm_linear_t {
      * (row length vt_ld) instead of out_bf16.                                                      */
     void* vt;
     int vt_n0, vt_S, vt_dh, vt_ld;
-    /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 (sm_quant_pack_weight_fp8 image + per-row scales) */
+    /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 / SM_W_FP8_MFMA (sm_quant_pack_weight_fp8 image + per-row scales).
+     * Up to 16 rows both fp8 kinds stream the weights once and expand them in registers (bf16 activations).  Above 16 rows
+     * SM_W_FP8 expands the image to a bf16 scratch and runs the bf16 GEMM (weight-only fp8: bf16 activations), SM_W_FP8_MFMA
+     * quantises every activation row to e4m3 (scale max|x|/448, the weights' rule) and multiplies on the fp8 matrix instruction
+     * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 rate): y = sx[m] sw[n] sum_k qx qw.  Needs K % 128 == 0, else as SM_W_FP8. */
     int w_dtype;
     const float* w_scale;
     const float* w2_scale;
@@ -230,6 +235,8 @@ typedef struct sm_config_t {
     int weights_fp8;         /* 1: gate + LLM linear weights are quantised to fp8 (per-row scale) at load time and every  */
                              /*    decode/gate product streams them as fp8 (prefill chunks expand them to bf16 per call); */
                              /*    BASELINE config 5, opt-in: numerics differ from the bf16 checkpoint                     */
+                             /* 2: the same images; calls with more than 16 rows (prefill chunks, teacher-forced evaluation) */
+                             /*    quantise their activation rows to e4m3 and run fp8 x fp8 on the matrix pipe (SM_W_FP8_MFMA) */
     int vit_fp16;            /* 1: the vision tower's GEMM / attention operands (weights + activations) are IEEE fp16 instead */
                              /*    of bf16 -- the precision the reference's demo loads the model in (model/builder.py:54:      */
                              /*    torch_dtype=float16); same MFMA rate, fp32 accumulation and fp32 residual stream as before */
@@ -260,6 +267,8 @@ int sm_model_load_tensor(sm_model* m, const char* name, const void* data, int dt
 /* checks that every tensor the path reads has been loaded; builds derived tables (RoPE) */
 int sm_model_finalize(sm_model* m, void* stream);
 void sm_model_destroy(sm_model* m);
+/* weights_fp8 models: switch between weight-only fp8 (1) and fp8 x fp8 MFMA above 16 rows (2) at run time (same weight images) */
+int sm_model_set_fp8_mode(sm_model* m, int mode);
 /* names of tensors still missing, '\n'-separated, into buf (for error messages) */
 int sm_model_missing(sm_model* m, char* buf, size_t buflen);
 

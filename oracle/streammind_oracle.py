@@ -120,10 +120,22 @@ class Prec:
             return x.to(self.dtype).to(F32)
         return x
 
+    fp8_act_rows = 0         # > 0: a linear with at least this many activation rows multiplies per-row e4m3-quantised activations
+
+    def lin_in(self, x: Tensor) -> Tensor:
+        """input of an LLM linear.  In the fp8-MFMA mode (weights_fp8 = 2; no reference counterpart: the definition of the HIP
+        build's own opt-in mode) calls with more than 16 rows quantise every activation ROW to e4m3 with the weights' rule
+        (fp8_quantize_rows) before the product; the values returned here are what the fp8 matrix instruction multiplies."""
+        if self.fp8_act_rows and x.dim() == 2 and x.shape[0] >= self.fp8_act_rows:
+            return fp8_quantize_rows(x)[0]
+        return x
+
 
 FP32 = Prec("fp32")
 MIXED = Prec("mixed")
 MIXED_F16 = Prec("mixed", torch.float16)      # the ViT's optional fp16-operand mode (the reference demo's precision)
+MIXED_FP8ACT = Prec("mixed")                  # bf16 roundings + fp8 activation rows for products of >= 17 rows (BASELINE configs[4])
+MIXED_FP8ACT.fp8_act_rows = 17
 
 
 def bf16_round(x: Tensor) -> Tensor:
@@ -554,7 +566,7 @@ def lm_forward(embeds: Tensor, W: Dict[str, Tensor], cfg: LmCfg, cache: Optional
     x = embeds
     for i in range(cfg.layers):
         p = f"{prefix}model.layers.{i}."
-        h = prec.act(rms_norm(x, W[p + "input_layernorm.weight"], cfg.eps))
+        h = prec.lin_in(prec.act(rms_norm(x, W[p + "input_layernorm.weight"], cfg.eps)))
         q = linear(h, W[p + "self_attn.q_proj.weight"]).reshape(S_new, H, dh)
         k = linear(h, W[p + "self_attn.k_proj.weight"]).reshape(S_new, KV, dh)
         v = linear(h, W[p + "self_attn.v_proj.weight"]).reshape(S_new, KV, dh)
@@ -583,12 +595,12 @@ def lm_forward(embeds: Tensor, W: Dict[str, Tensor], cfg: LmCfg, cache: Optional
         else:
             ctx = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), vv)
         ctx = prec.act(ctx.reshape(S_new, H * dh))
-        x = x + linear(ctx, W[p + "self_attn.o_proj.weight"])
-        h = prec.act(rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.eps))
+        x = x + linear(prec.lin_in(ctx), W[p + "self_attn.o_proj.weight"])
+        h = prec.lin_in(prec.act(rms_norm(x, W[p + "post_attention_layernorm.weight"], cfg.eps)))
         a = prec.act(silu(linear(h, W[p + "mlp.gate_proj.weight"])) * linear(h, W[p + "mlp.up_proj.weight"]))
-        x = x + linear(a, W[p + "mlp.down_proj.weight"])
+        x = x + linear(prec.lin_in(a), W[p + "mlp.down_proj.weight"])
     x = rms_norm(x[-1:] if last_only else x, W[prefix + "model.norm.weight"], cfg.eps)
-    logits = linear(prec.act(x), W[prefix + "lm_head.weight"])
+    logits = linear(prec.lin_in(prec.act(x)), W[prefix + "lm_head.weight"])
     return logits[0] if last_only else logits
 
 

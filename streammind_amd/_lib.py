@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("STREAMMIND_HIP_LIB", LIB_PATH)
 
 SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU = 0, 1, 2, 3, 4
 SM_X_BF16, SM_X_F32 = 0, 1
-SM_W_BF16, SM_W_FP8 = 0, 1
+SM_W_BF16, SM_W_FP8, SM_W_FP8_MFMA = 0, 1, 2
 SM_OP_BF16, SM_OP_F16 = 0, 1
 SM_DT_BF16, SM_DT_F32, SM_DT_F16 = 0, 1, 2
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "sm_model_load_tensor": (i32, [vp, C.c_char_p, vp, i32, i32, C.POINTER(C.c_int64), vp]),
     "sm_model_finalize": (i32, [vp, vp]),
     "sm_model_destroy": (None, [vp]),
+    "sm_model_set_fp8_mode": (i32, [vp, i32]),
     "sm_model_missing": (i32, [vp, C.c_char_p, sz]),
     "sm_vit_encode": (i32, [vp, vp, i32, vp, vp, vp, vp]),
     "sm_vit_encode_pixels": (i32, [vp, vp, i32, i32, vp, vp, vp]),

@@ -1039,7 +1039,7 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
     a.ldo = p->ldo; a.ldo_bf16 = p->ldo_bf16;
     a.remap_in = p->remap_in; a.remap_out = p->remap_out; a.remap_off = p->remap_off;
     a.vt = (bf16_t*)p->vt; a.vt_n0 = p->vt_n0; a.vt_S = p->vt_S; a.vt_dh = p->vt_dh; a.vt_ld = p->vt_ld;
-    const bool w8 = p->w_dtype == SM_W_FP8;
+    const bool w8 = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
     a.f16 = p->op_dtype == SM_OP_F16;
@@ -1048,7 +1048,7 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
 // the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): bf16 weights, head_dim 128,
 // M <= 16 rows of fp32 activations, RMSNorm fused in front when p->norm_gamma is set
 int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) {
-    SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && p->w_dtype != SM_W_FP8 && !p->vt &&
+    SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && p->w_dtype == SM_W_BF16 && !p->vt &&
                p->remap_in == 0, "sm_linear_qkv_rope: plain 16-bit q/k/v weights only");
     SM_REQUIRE(p->M > 0 && p->M <= 16 && p->M <= SM_MAX_SEG && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0 &&
                p->N == (re.H + 2 * re.KV) * 128, "sm_linear_qkv_rope: M <= 16 fp32 rows, K %% 32 == 0, N = (H + 2 KV) * 128 (M=%d N=%d K=%d)", p->M, p->N, p->K);
@@ -1080,7 +1080,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p->out_f32 || p->out_bf16 || p->vt, "sm_linear: no output");
     LinArgs a;
     fill_args(p, a);
-    const bool w8 = p->w_dtype == SM_W_FP8;
+    const bool w8 = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
     SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
     SM_REQUIRE(!a.f16 || !w8, "sm_linear: fp16 operands exclude fp8 weights");
     SM_REQUIRE(!a.f16 || p->M <= 32 || (p->x_dtype == SM_X_BF16 && !p->w2 && !p->norm_gamma),
@@ -1093,6 +1093,11 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
     const bool xf32 = p->x_dtype == SM_X_F32;
+    if (p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && !p->w2 && !xf32 && !p->vt && p->remap_in == 0) {
+        // fp8 x fp8 on the matrix pipe: activation rows quantised to e4m3, no bf16 expansion of the weights (gemm_fp8.hip)
+        SmProfScope prof(SM_PROF_GEMM, st);
+        return launch_gemm_fp8(a, st);
+    }
     if (w8 && p->M > 16) {
         // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
         // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes

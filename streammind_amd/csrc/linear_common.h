@@ -93,4 +93,5 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
-int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);     // gemm256.hip (256 x bn tile; a.f16 selects the fp16 build)
+int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);
+int launch_gemm_fp8(LinArgs& a, hipStream_t st);                           // gemm_fp8.hip (fp8 x fp8 MFMA, activations quantised per row)     // gemm256.hip (256 x bn tile; a.f16 selects the fp16 build)

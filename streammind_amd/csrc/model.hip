@@ -481,13 +481,20 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
 }
 
 extern "C" void sm_model_destroy(sm_model* m) { delete m; }
+// fp8 models only: 1 = weight-only fp8 everywhere, 2 = fp8 x fp8 MFMA for calls with more than 16 rows (same weight images: the
+// choice is made per call, so one model can be measured both ways)
+extern "C" int sm_model_set_fp8_mode(sm_model* m, int mode) {
+    SM_REQUIRE(m && m->c.weights_fp8 >= 1 && (mode == 1 || mode == 2), "sm_model_set_fp8_mode: needs a weights_fp8 model and mode 1 or 2");
+    m->c.weights_fp8 = mode;
+    return SM_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ ViT
 static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dtype, int M, int ldx) {
     sm_linear_t a;
     memset(&a, 0, sizeof(a));
     a.w = w.buf.p; a.N = w.N; a.K = w.K; a.x = x; a.x_dtype = x_dtype; a.M = M; a.ldx = ldx;
-    if (w.fp8) { a.w_dtype = SM_W_FP8; a.w_scale = w.scale.as<float>(); }
+    if (w.fp8) { a.w_dtype = m->c.weights_fp8 == 2 ? SM_W_FP8_MFMA : SM_W_FP8; a.w_scale = w.scale.as<float>(); }
     if (w.f16) a.op_dtype = SM_OP_F16;
     return a;
 }
@@ -1074,7 +1081,7 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
         if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
-        if (n <= 32) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel
+        if (n <= (c.weights_fp8 == 2 ? 16 : 32)) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel (fp8 MFMA mode: above 16 rows the tiled fp8 product)
             const Slot& gu = *w.gu;
             sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, n, ld) : lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
             if (fuse_norm) { a.norm_gamma = w.ln2_w; a.norm_eps = c.llm_eps; }

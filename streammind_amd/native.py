@@ -57,7 +57,8 @@ class PathConfig:
     llm_rope_theta: float = 1e6
     max_frames_per_call: int = 8
     gate_precise: bool = True
-    weights_fp8: bool = False      # opt-in BASELINE config 5: fp8 gate + LLM weights (weight-streaming path only)
+    weights_fp8: int = 0           # opt-in BASELINE config 5: 1 = fp8 gate + LLM weights (weight-only: bf16 activations); 2 = the same,
+                                   # and calls with > 16 rows run fp8 x fp8 MFMA on per-row-quantised activations (gemm_fp8.hip)
     vit_fp16: bool = False         # vision-tower operands in IEEE fp16 (the reference demo's precision) instead of bf16
     llm_fp16: bool = False         # the same for the LLM (weights, embedding table, activations, q / KV caches, attention P)
     proj_fp16: bool = False        # the same for the connector + gate weights (activations as fp16 hi/lo pairs in precise mode)
@@ -137,6 +138,10 @@ class NativeModel:
         buf = C.create_string_buffer(1 << 16)
         self.lib.sm_model_missing(self.h, buf, len(buf))
         return [s for s in buf.value.decode().split("\n") if s]
+
+    def set_fp8_mode(self, mode: int) -> None:
+        """weights_fp8 models: 1 = weight-only fp8, 2 = fp8 x fp8 MFMA for calls with more than 16 rows (same weight images)"""
+        check(self.lib.sm_model_set_fp8_mode(self.h, int(mode)), "sm_model_set_fp8_mode")
 
     def finalize(self) -> None:
         check(self.lib.sm_model_finalize(self.h, _stream()), "sm_model_finalize")
@@ -411,8 +416,9 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
            w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
            norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front."""
+           out: Optional[torch.Tensor] = None, fp8_mfma: bool = False) -> torch.Tensor:
+    """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front.
+    fp8_mfma (with w_scale): SM_W_FP8_MFMA -- above 16 rows the activations are quantised per row and the product is fp8 x fp8."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32, torch.float16)
     if x.dtype == torch.float16:       # fp16 operands: `wp` must be the packed image of fp16 weights (pack_weight moves 16-bit words)
@@ -428,7 +434,7 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     a.precise, a.M, a.ldx = int(precise), M, x.shape[1]
     a.bias, a.act = _p(bias), act
     if w_scale is not None:
-        a.w_dtype, a.w_scale, a.w2_scale = _lib.SM_W_FP8, w_scale.data_ptr(), _p(w2_scale)
+        a.w_dtype, a.w_scale, a.w2_scale = (_lib.SM_W_FP8_MFMA if fp8_mfma else _lib.SM_W_FP8), w_scale.data_ptr(), _p(w2_scale)
     if residual is not None:
         a.residual, a.ldr = residual.data_ptr(), residual.shape[1]
     if norm_gamma is not None:

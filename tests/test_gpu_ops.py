@@ -347,6 +347,39 @@ def test_linear_fp8_weights_more_than_16_rows(nat, M, N, K, dual):
         assert relerr(y, f(wd)) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,act,use_res,out16", [(17, 256, 128, 0, False, False), (28, 512, 1024, 0, True, False), (300, 768, 4096, 1, False, True),
+                                                   (328, 6144, 4096, 0, False, False), (577, 200, 384, 0, True, False), (2048, 1024, 14336, 0, True, False)])
+def test_linear_fp8_mfma_vs_its_definition(nat, M, N, K, act, use_res, out16):
+    """BASELINE configs[4] ("CDNA4 fp8 MFMA"): SM_W_FP8_MFMA with more than 16 rows -- activation rows quantised to e4m3 by the HIP
+    quantiser (scale max|x|/448, the weights' rule), fp8 x fp8 products on v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 1), fp32
+    accumulation, sx[m] * sw[n] on the way out.  Against the mode's definition in fp64 on the SAME quantised operands
+    (O.fp8_quantize_rows for both): every fp8 product is exact in fp32, so what is left is accumulation order -- 2e-5 of the
+    largest output (fp32 outputs), one 16-bit rounding more for bf16 outputs.  Shapes: one and many k-blocks, ragged M / N, the
+    64- and the 128-row tile (M = 2048 x N = 1024: 512 tiles), K = 14336 (Mistral's down-projection)."""
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = O.bf16_round(rnd((M, K), 2))
+    x[3] *= 37.0; x[M - 1] *= 0.01                      # rows of very different magnitude: the scale is per row
+    x = O.bf16_round(x)
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4) if use_res else None
+    wq, sc = nat.pack_weight_fp8(w.cuda().bfloat16())
+    wd, sw = O.fp8_quantize_rows(w)
+    xd, sx = O.fp8_quantize_rows(x)
+    assert torch.equal(sc.cpu(), sw)
+    y = nat.linear(x.cuda().bfloat16(), wq, N, K, bias=bias.cuda(), act=act, residual=None if res is None else res.cuda(), w_scale=sc,
+                   fp8_mfma=True, out_dtype=torch.bfloat16 if out16 else torch.float32)
+    ref = xd.double() @ wd.double().t() + bias.double()
+    if act == 1:
+        ref = O.quick_gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    assert relerr(y, ref.float()) < (5e-3 if out16 else 2e-5)
+    # it is NOT the weight-only product: bf16 activations against the same fp8 weights differ by the activations' e4m3 rounding
+    ref_wo = x.double() @ wd.double().t() + bias.double()
+    if act == 0 and res is None:
+        assert relerr(y, ref_wo.float()) > 1e-3
+
+
 @pytest.mark.parametrize("H,W,pad", [(360, 640, True), (360, 640, False), (500, 280, True), (500, 280, False), (120, 160, True),
                                       (336, 336, True), (337, 335, False), (1080, 1920, True)])
 def test_ingest_frames_bit_exact(nat, H, W, pad):

@@ -525,6 +525,52 @@ def test_fp8_weights_mode_gate_and_llm(gold):
             break
 
 
+def test_fp8_mfma_mode_prefill_and_teacher_forced_vs_its_oracle():
+    """weights_fp8 = 2 (BASELINE configs[4], "CDNA4 fp8 MFMA"): the LLM products of calls with more than 16 rows -- a prefill chunk,
+    a teacher-forced forward -- run fp8 x fp8 on the matrix pipe with per-row e4m3 activations; decode steps (one row) keep the
+    weight-streaming kernels with bf16 activations.  The PRODUCT itself is pinned exactly at operator level
+    (test_linear_fp8_mfma_vs_its_definition: 2e-5 against fp64 on the same quantised operands).  End to end the mode is checked against
+    the oracle on the dequantised weights with O.MIXED_FP8ACT (the same per-row quantisation in front of every linear of >= 17 rows),
+    with the tolerance the mode itself allows: an e4m3 activation has 3 mantissa bits, so the bf16-level differences between two
+    correct implementations (0.6 % rms of the logits in the weight-only mode, tools/fp8_mode_probe.py) flip ~3 % of the activation
+    roundings per linear by a whole fp8 step -- measured 4.9 % rms / 0.21 max on logits of magnitude 3.2, the same size as the
+    effect of quantising the activations at all (5.6 % / 0.30).  Asserted: 8 % rms, 0.35 max, ids where the margin allows."""
+    Wv = O.make_vit_weights(TV, 41)
+    Wc = conn_gate_weights(TC, TG, 86)
+    Wl = O.make_lm_weights(TL, 44)
+    m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, weights_fp8=2)
+    Wc8 = {k: (O.fp8_quantize_rows(v)[0] if (k.startswith("cls_net.") and v.dim() == 2 and "embed_tokens" not in k) else v) for k, v in Wc.items()}
+    Wl8 = fp8_view(Wl)
+    pooled = torch.randn(6, TC.mm_hidden, generator=torch.Generator().manual_seed(4))
+    s = m.open_stream(max_frames=32, max_seq=128)
+    lg, _ = s.push_pooled(pooled.cuda())
+    tok = O.connector_scan(pooled, Wc8, TC)
+    assert maxdiff(lg, O.gate_logits_shortcut(tok, Wc8, TG)) < 1e-3           # the gate (<= 16 rows per pass) is the weight-only mode's
+    ids = torch.cat([torch.tensor([1, 7, 9]), -(torch.arange(6) + 1), torch.tensor([11, 12] * 9), torch.tensor([5, 33, 71])]).to(torch.int32)      # 30 rows: one fp8-MFMA chunk
+    s.prefill(ids.cuda())
+    logits, _ = s.logits()
+    table = Wl["model.embed_tokens.weight"]
+    emb = torch.cat([table[[1, 7, 9]], tok, table[[11, 12] * 9], table[[5, 33, 71]]])
+    ref_ids, trace = O.greedy_generate(emb, Wl8, TL, 5, eos_token_id=None, prec=O.MIXED_FP8ACT, return_logits=True)
+    rms = lambda t: float(t.float().pow(2).mean().sqrt())
+    assert maxdiff(logits, trace[0]) < 0.35 and rms(logits.cpu() - trace[0]) < 0.08 * rms(trace[0])
+    got = s.decode(4).cpu().tolist()                                            # one-row steps: weight-streaming kernels on the context's K/V
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 0.7
+            break
+    s.set_kv_len(0)
+    all_lg = s.forward_logits(ids.cuda()).cpu()                                 # teacher-forced: lm_head on all 30 rows is an fp8-MFMA product too
+    ref_all = O.lm_forward(emb, Wl8, TL, O.KVCache(), O.MIXED_FP8ACT, last_only=False)
+    assert maxdiff(all_lg, ref_all) < 0.35 and rms(all_lg - ref_all) < 0.08 * rms(ref_all)
+    # the run-time switch: the same model in the weight-only mode is the round-2 path (3e-2 from ITS oracle)
+    m.set_fp8_mode(1)
+    s.set_kv_len(0)
+    s.prefill(ids.cuda())
+    _, wo_trace = O.greedy_generate(emb, Wl8, TL, 1, eos_token_id=None, prec=O.MIXED, return_logits=True)
+    assert maxdiff(s.logits()[0], wo_trace[0]) < 3e-2
+
+
 # ---------------------------------------------------------------------------------------------- f1 (SURVEY 8f): teacher-forced evaluation
 def _f1_clips(g):
     frames = O.synthetic_frames(int(g["clip_lens"].sum()), TV.image_size, seed=int(g["seed_frames"]), scene_len=int(g["scene_len"]))
