@@ -1063,10 +1063,17 @@ def main():
                 fp8_leg["prefill_2048"] = pf
             except Exception as e:
                 fp8_leg["prefill_2048"] = {"error": repr(e)[:300]}
+            if not a.no_aux:
+                try:      # 16 streams decoding together on the fp8 weights (one 16-row fp8 weight pass per step; compare group_decode[streams=16])
+                    g8 = group_decode_leg(m8, cfg8, sizes=(16,))
+                    fp8_leg["group_decode_16_streams"] = {"tokens_per_s": g8["tokens_per_s"][0], "ms_per_step": g8["ms_per_step"][0]}
+                except Exception as e:
+                    fp8_leg["group_decode_16_streams"] = {"error": repr(e)[:200]}
             fp8_leg["roofline"]["bytes_per_token"] = fp8_leg["roofline"]["bytes_per_token"] / 2 + 0.0
             fp8_leg["roofline"]["achieved"] = round(fp8_leg["roofline"]["bytes_per_token"] * fp8_leg["tokens_per_s"] / 1e9, 1)
             fp8_leg["roofline"]["frac"] = round(fp8_leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)
-            fp8_leg["note"] = "weight-only fp8 (OCP e4m3, per-row scales) for gate + LLM, bf16 activations and KV; opt-in mode"
+            fp8_leg["note"] = ("fp8 (OCP e4m3, per-row scales) gate + LLM weights, opt-in mode: decode and the gate (<= 16 rows) stream the fp8 weights with bf16 "
+                               "activations; calls with more rows (prefill, teacher-forced) run fp8 x fp8 MFMA on per-token-quantised activations (weights_fp8 = 2)")
             fp8_leg["stress_60fps"] = {"frames": n60, "seconds": round(d60, 3), "frames_per_s": round(n60 / d60, 1),
                                        "realtime_factor_at_60fps": round(n60 / d60 / 60.0, 1),
                                        "note": "BASELINE configs[4]: 60 fps x 60 s synthetic stream, full CLIP tower (bf16) + connector + fp8-weight gate; "

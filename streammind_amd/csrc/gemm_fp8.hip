@@ -13,8 +13,10 @@
 // chunk 2q followed by its 16 bytes of chunk 2q + 1 -- the fp8 image needs no repacking -- and the activation quantiser writes X
 // in exactly that k order.  The block scales of the MX format are all 1 (e8m0 127): the per-row scales are applied in fp32 on
 // the way out.
-// Tile 128(n) x BM(m) x 128(k) per 4-wave block (BM = 128, or 64 when M is small: more blocks, less padding), two LDS stages of
-// (16 + BM/8) KiB filled by global_load_lds one k-block ahead, one barrier per k-block; a wave owns 64(n) x BM/2(m).
+// Tile 128(n) x BM(m) x 128(k) per 4-wave block (BM = 128, or 64 when M is small: more blocks, less padding), a ring of three LDS
+// stages of (16 + BM/8) KiB filled by global_load_lds TWO k-blocks ahead (a k-block is only 8-16 MFMAs per wave: one block of
+// cover does not hide an L2 round trip), counted waits, one barrier per k-block; a wave owns 64(n) x BM/2(m).
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 
@@ -23,8 +25,9 @@
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // ---------------------------------------------------------------------------------------------- activation quantiser
-// one block per 16 rows; wave w finds the row maxima of rows 4w..4w+3, then every thread writes 16-byte fragment pieces.
-// x: 16-bit (bf16 or fp16) [M][ldx]; rows >= M quantise to zero.  K % 128 == 0.
+// grid (16-row groups, column slices): every block finds the row maxima of its 16 rows (wave w: rows 4w..4w+3; the slices of a
+// row group each read the rows once more -- L2 hits -- so that a 300-row call is 4 x 19 blocks instead of 19), then writes the
+// 16-byte fragment pieces of its slice of k-blocks.  x: 16-bit (bf16 or fp16) [M][ldx]; rows >= M quantise to zero.  K % 128 == 0.
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int M, int K, int ldx, int f16,
                                                              u32x4* __restrict__ xq, float* __restrict__ xscale) {
     __shared__ float s_inv[16];
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
         if (lane == 0) {
             const float sc = m > 0.f ? m * (1.0f / 448.0f) : 1.0f;          // the weights' rule (rowscale_kernel)
             s_inv[wave * 4 + r] = row < M ? 1.0f / sc : 0.f;
-            if (row < M) xscale[row] = sc;
+            if (row < M && blockIdx.y == 0) xscale[row] = sc;
         }
     }
     __syncthreads();
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     const float inv = s_inv[j];
     const bf16_t* xr = x + (size_t)(row < M ? row : 0) * ldx;
     const int KB = K >> 7;
-    for (int c = wave; c < KB * 2; c += 4) {             // c = 2q + h: the 16-byte half h of k-block q
+    const int cper = (KB * 2 + gridDim.y - 1) / gridDim.y, c0 = blockIdx.y * cper, c1 = c0 + cper < KB * 2 ? c0 + cper : KB * 2;
+    for (int c = c0 + wave; c < c1; c += 4) {            // c = 2q + h: the 16-byte half h of k-block q
         const int k0 = (c >> 1) * 128 + (c & 1) * 64 + g * 8;
         uint32_t o[4];
 #pragma unroll
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
 // ---------------------------------------------------------------------------------------------- the GEMM
 template <int BM>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4* __restrict__ xq, const float* __restrict__ xscale,
-                                                          int tiles_m, int tiles_n) {
+                                                          int tiles_m, int tiles_n, int k_per, float* __restrict__ ws) {
     constexpr int MF = BM / 32;                       // 16-row m fragments per wave
     constexpr int XP = BM / 8;                        // 1-KiB X pieces per stage
     constexpr int STAGE = 16384 + XP * 1024;
@@ -99,8 +103,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tile_n = bid / tiles_m, tile_m = bid - tile_n * tiles_m;      // m fastest: the blocks of a column tile share its weights
-    const int KB = a.K >> 7, KSP = (a.KS + 1) >> 1;
+    const int KBall = a.K >> 7, KSP = (a.KS + 1) >> 1;
     const int MRG = (a.M + 15) >> 4;
+    // split-K (ws != nullptr): blockIdx.y owns k-blocks [q0, q0 + KB) and leaves sx[m] * its partial sums in slab blockIdx.y
+    const int q0 = blockIdx.y * k_per;
+    const int KB = KBall - q0 < k_per ? KBall - q0 : k_per;
 
     // staging sources: wave w brings W pieces 4w..4w+3 (row groups 2w, 2w+1; two chunks each) and X pieces (XP/4)w..
     const char* wsrc[4];
@@ -110,14 +117,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4
         const int pi = wave * 4 + p;
         int rgg = tile_n * 8 + (pi >> 1);
         if (rgg >= a.NRG) rgg = a.NRG - 1;
-        wsrc[p] = (const char*)a.w + ((size_t)rgg * KSP + (pi & 1)) * 1024 + lane * 16;
+        wsrc[p] = (const char*)a.w + ((size_t)rgg * KSP + 2 * q0 + (pi & 1)) * 1024 + lane * 16;
     }
 #pragma unroll
     for (int p = 0; p < XP / 4; ++p) {
         const int pj = wave * (XP / 4) + p;
         int rgm = tile_m * (BM / 16) + (pj >> 1);
         if (rgm >= MRG) rgm = MRG - 1;
-        xsrc[p] = (const char*)xq + (((size_t)rgm * KB) * 2 + (pj & 1)) * 1024 + lane * 16;
+        xsrc[p] = (const char*)xq + (((size_t)rgm * KBall + q0) * 2 + (pj & 1)) * 1024 + lane * 16;
     }
     auto stage = [&](int q, int slot) {
         char* sb = smem + slot * STAGE;
@@ -132,12 +139,22 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
 
+    constexpr int NST = 3;
     stage(0, 0);
+    if (KB > 1) stage(1, 1);
+    int slot = 0;
     for (int q = 0; q < KB; ++q) {
-        const int slot = q & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of k-block q have landed
-        __syncthreads();                                          // ... everyone's; and every wave is done reading the other slot
-        if (q + 1 < KB) stage(q + 1, slot ^ 1);
+        // this wave's pieces of k-block q have landed (the batch of q + 1 may stay in flight: vmcnt retires in order) ...
+        if (q + 1 < KB) {
+            if constexpr (XP == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // raw s_barrier: __syncthreads() is an LDS fence, and with LDS-DMA in flight hipcc turns that into s_waitcnt vmcnt(0) -- the
+        // loads issued two k-blocks ahead would be waited for at once (measured: 3 us per k-block, an L2 round trip each)
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; and every wave is done reading the slot of k-block q - 1
+        if (q + 2 < KB) stage(q + 2, slot == 0 ? 2 : slot - 1);   // = (q + 2) % 3, the slot k-block q - 1 was read from
         const char* sw = smem + slot * STAGE;
         const char* sx = sw + 16384;
         i32x8 bf[MF];
@@ -156,9 +173,61 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4
             for (int mf = 0; mf < MF; ++mf)          // cbsz = blgp = 0: both operands e4m3; block scales e8m0 127 = 1.0
                 acc[nf][mf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, bf[mf], acc[nf][mf], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
+        slot = slot == NST - 1 ? 0 : slot + 1;
     }
-    // epilogue: D[n = 4g + j][m = i] of each 16 x 16 block; the activation-row scale here, the weight-row scale, bias, activation,
-    // residual and the stores in store4 (linear_common.h)
+    // epilogue: D[n = 4g + j][m = i] of each 16 x 16 block.  Full tiles (the LLM's linears: N % 128 == 0): the row scales, the bias
+    // and the residual pieces of a whole row block are fetched up front as 16-byte vectors (store4's per-element scalar loads
+    // behind a wait each made the epilogue as long as the k-loop); ragged N / special outputs take the generic store4.
+    if (ws) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = tile_m * BM + wm * (BM / 2) + mf * 16 + i;
+            if (m >= a.M) continue;
+            const float sxm = xscale[m];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n0 = tile_n * 128 + wn * 64 + nf * 16 + g * 4;
+                if (n0 >= a.N) continue;                            // (split-K needs N % 4 == 0: whole pieces)
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[nf][mf][j] * sxm;
+                *(f32x4*)(ws + ((size_t)blockIdx.y * a.M + m) * a.N + n0) = o;
+            }
+        }
+        return;
+    }
+    const bool fast = (tile_n + 1) * 128 <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 && (a.ldr & 3) == 0 && a.act == SM_ACT_NONE;
+    if (fast) {
+        f32x4 sw4[4], b4[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n0 = tile_n * 128 + wn * 64 + nf * 16 + g * 4;
+            sw4[nf] = *(const f32x4*)(a.wscale + n0);
+            b4[nf] = a.bias ? *(const f32x4*)(a.bias + n0) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = tile_m * BM + wm * (BM / 2) + mf * 16 + i;
+            if (m >= a.M) continue;
+            const float sxm = xscale[m];
+            f32x4 r4[4];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n0 = tile_n * 128 + wn * 64 + nf * 16 + g * 4;
+                r4[nf] = a.residual ? *(const f32x4*)(a.residual + (size_t)m * a.ldr + n0) : f32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n0 = tile_n * 128 + wn * 64 + nf * 16 + g * 4;
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[nf][mf][j] * sxm * sw4[nf][j] + b4[nf][j] + r4[nf][j];
+                if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + n0) = o;
+                if (a.out_bf16) *(u32x2*)(a.out_bf16 + (size_t)m * a.ldo_bf16 + n0) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
         const int m = tile_m * BM + wm * (BM / 2) + mf * 16 + i;
@@ -196,24 +265,34 @@ int launch_gemm_fp8(LinArgs& a, hipStream_t st) {
     }
     u32x4* xq = (u32x4*)ws;
     float* xscale = (float*)(ws + qbytes);
-    quant_rows_fp8_kernel<<<MRG, 256, 0, st>>>((const bf16_t*)a.x, a.M, a.K, a.ldx, a.f16, xq, xscale);
+    const int qsl = MRG >= 256 ? 1 : (MRG >= 64 ? 4 : 8);                 // column slices per row group: enough blocks to fill the chip
+    quant_rows_fp8_kernel<<<dim3(MRG, qsl), 256, 0, st>>>((const bf16_t*)a.x, a.M, a.K, a.ldx, a.f16, xq, xscale);
     SM_LAUNCH_CHECK();
     static bool attr_set = false;
     if (!attr_set) {
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 16 * 1024)));
-        SM_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (16384 + 8 * 1024)));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (16384 + 16 * 1024)));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_fp8_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (16384 + 8 * 1024)));
         attr_set = true;
     }
     const int tiles_n = cdiv(a.N, 128);
     // 128-row tiles once they fill the chip twice over (two blocks per CU), else 64-row tiles: more blocks, less row padding
     const bool big = (long)cdiv(a.M, 128) * tiles_n >= 512;
-    if (big) {
-        const int tiles_m = cdiv(a.M, 128);
-        gemm_fp8_kernel<128><<<tiles_m * tiles_n, 256, 2 * (16384 + 16 * 1024), st>>>(a, xq, xscale, tiles_m, tiles_n);
-    } else {
-        const int tiles_m = cdiv(a.M, 64);
-        gemm_fp8_kernel<64><<<tiles_m * tiles_n, 256, 2 * (16384 + 8 * 1024), st>>>(a, xq, xscale, tiles_m, tiles_n);
+    const int tiles_m = cdiv(a.M, big ? 128 : 64);
+    // split-K (the kernel can leave sx[m] * partial sums in fp32 slabs for launch_splitk_reduce) was measured at M = 328 on the
+    // Mistral shapes and is NOT used: qkv 44 -> 55 us, o 38 -> 46 us, down 113 -> 112 us -- the slab round trip costs what the
+    // extra blocks gain (SM_FP8_SPLITK=n forces n slices for experiments).
+    int S = 1, k_per = KB;
+    {
+        static int force = -1;
+        if (force < 0) { const char* e = getenv("SM_FP8_SPLITK"); force = e ? atoi(e) : 0; }
+        if (force > 1 && !big && (a.N & 3) == 0 && KB >= 2 * force) { k_per = cdiv(KB, force); S = cdiv(KB, k_per); }
     }
+    float* slabs = nullptr;
+    if (S > 1) { int rc = splitk_workspace(st, (size_t)S * a.M * a.N * sizeof(float), &slabs); if (rc) return rc; }
+    const dim3 grid(tiles_m * tiles_n, S);
+    if (big) gemm_fp8_kernel<128><<<grid, 256, 3 * (16384 + 16 * 1024), st>>>(a, xq, xscale, tiles_m, tiles_n, k_per, slabs);
+    else gemm_fp8_kernel<64><<<grid, 256, 3 * (16384 + 8 * 1024), st>>>(a, xq, xscale, tiles_m, tiles_n, k_per, slabs);
     SM_LAUNCH_CHECK();
+    if (S > 1) return launch_splitk_reduce(a, slabs, S, a.N, st);          // fixed slab order: deterministic; wscale / bias / act / residual there
     return SM_OK;
 }

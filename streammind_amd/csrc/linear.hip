@@ -786,7 +786,7 @@ __global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, co
 #include <mutex>
 static std::mutex g_ws_mu;
 static std::map<hipStream_t, std::pair<float*, size_t>> g_ws;
-static int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
+int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     auto& e = g_ws[st];
     if (e.second < bytes) {
@@ -795,6 +795,12 @@ static int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
         e.second = bytes;
     }
     *out = e.first;
+    return SM_OK;
+}
+int launch_splitk_reduce(const LinArgs& a, const float* ws, int S, int ldw, hipStream_t st) {
+    const size_t nthr = (size_t)a.M * ((a.N + 3) / 4);
+    splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, ldw);
+    SM_LAUNCH_CHECK();
     return SM_OK;
 }
 
@@ -949,7 +955,6 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     }
 }
 
-static int splitk_workspace(hipStream_t st, size_t bytes, float** out);
 static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
     const int nb = (a.NRG + 7) / 8;
     static int target = -1;

@@ -1,5 +1,5 @@
 """tiled-GEMM micro-benchmark on the Mistral-7B prefill / teacher-forced shapes.   python tools/gemm_bench_llm.py [M]
-(SM_GEMM_TILE=128|256128|256 forces a tile variant)"""
+(SM_GEMM_TILE=128|256128|256 forces a tile variant; FP8=1: fp8 weight image + fp8 x fp8 MFMA, FP8=wo: weight-only fp8)"""
 import os, sys, ctypes as C
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,15 +10,21 @@ tot = 0.0
 for name, N, K in [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 32000, 4096)]:
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
     x = torch.randn(M, K, device="cuda").bfloat16()
-    wp = native.pack_weight(w)
+    F8 = os.environ.get("FP8", "")
+    kw = {}
+    if F8:
+        wp, sc = native.pack_weight_fp8(w)
+        kw = dict(w_scale=sc, fp8_mfma=(F8 == "1"))
+    else:
+        wp = native.pack_weight(w)
     del w
     for _ in range(2):
-        native.linear(x, wp, N, K, out_dtype=torch.float32)
+        native.linear(x, wp, N, K, out_dtype=torch.float32, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        native.linear(x, wp, N, K, out_dtype=torch.float32)
+        native.linear(x, wp, N, K, out_dtype=torch.float32, **kw)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     tot += us * (1 if name == "lm_head" else 32)
