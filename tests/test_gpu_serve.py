@@ -24,7 +24,7 @@ def worker(tiny_tokenizer):
     from streammind_amd.serve.model_worker import ModelWorker
     Wv, Wc, Wl = O.make_vit_weights(TV, 41), conn_gate_weights(TC, TG, 86), O.make_lm_weights(TL, 44)
     m = build_native(TV, TC, TG, Wv, Wc, TL, Wl, max_frames_per_call=8)
-    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=256, eos_token_id=tiny_tokenizer.eos_token_id)
+    model = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
     return ModelWorker("", "http://w", "t0", True, "x", None, "VideoLLaMA2-7B", loaded=(tiny_tokenizer, model, PROC, 2048))
 
 
