@@ -351,6 +351,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 //   V LDS image: byte(key, d) = key*128 + (((d >> 4) ^ h(key)) * 32) + (d & 15)*2, h = ((key >> 1) & 1) | (((key >> 3) & 1) << 1):
 //   the 8 rows x 32 B that one 32-lane phase of the transpose read touches land on 8 different 32-byte bank groups.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+// VIT_TR_ASM=1: the V^T transpose reads as inline asm.  Behind the builtin hipcc waits `vmcnt(0)` in front of the first V^T read of
+// a tile (it cannot tell that LDS read from the LDS-DMA of the NEXT tile, issued at the top of this one).  Measured (round 3, same
+// box, B = 28): builtin 73.6 us, asm 76.3 us -- the next tile has long landed by then (QK^T + softmax take longer than an L2 round
+// trip), and the asm reads pin the schedule.  Kept for A/B, off.
+#ifndef VIT_TR_ASM
+#define VIT_TR_ASM 0
+#endif
 template <bool F16>
 __device__ __forceinline__ bf16x8 make8(const float (&e)[8]) {
     const u32x4 u = {pack16<F16>(e[0], e[1]), pack16<F16>(e[2], e[3]), pack16<F16>(e[4], e[5]), pack16<F16>(e[6], e[7])};
@@ -555,6 +562,33 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
             if (PART && kb == 1 && half) continue;
             lsum[0] = mfma16<F16>(ones, pf[0][kb], lsum[0]);
             lsum[1] = mfma16<F16>(ones, pf[1][kb], lsum[1]);
+#if VIT_TR_ASM
+            // The transpose reads are inline asm: behind the BUILTIN hipcc put `s_waitcnt vmcnt(0)` in front of the first V^T read of
+            // every tile (an LDS access it cannot tell apart from the LDS-DMA of the NEXT tile that was issued at the top of this
+            // one) -- the prefetched tile was waited for in the middle of the tile it was meant to hide behind.  Two d-blocks (four
+            // reads) per wait; the registers pass through the wait so that the MFMAs cannot be scheduled in front of it.
+#pragma unroll
+            for (int d2 = 0; d2 < 4; d2 += 2) {
+                s16x4 t[2][2];
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int key = kb * 32 + g * 8 + u * 4 + (i >> 2);
+                        const int hk = ((key >> 1) & 1) | (((key >> 3) & 1) << 1);
+                        const uint32_t ad = (uint32_t)(uintptr_t)(lds_ptr_a)(Vl + key * 128 + (((d2 + dd) ^ hk) * 32) + (i & 3) * 8);
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(t[dd][u]) : "v"(ad));
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[1][0]), "+v"(t[1][1]));
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    union { bf16x8 v; s16x4 hlf[2]; } vf;
+                    vf.hlf[0] = t[dd][0]; vf.hlf[1] = t[dd][1];
+                    o[0][d2 + dd] = mfma16<F16>(vf.v, pf[0][kb], o[0][d2 + dd]);
+                    o[1][d2 + dd] = mfma16<F16>(vf.v, pf[1][kb], o[1][d2 + dd]);
+                }
+            }
+#else
 #pragma unroll
             for (int df = 0; df < 4; ++df) {
                 union { bf16x8 v; s16x4 hlf[2]; } vf;
@@ -568,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
                 o[0][df] = mfma16<F16>(vf.v, pf[0][kb], o[0][df]);
                 o[1][df] = mfma16<F16>(vf.v, pf[1][kb], o[1][df]);
             }
+#endif
         }
     };
     if (nk >= 64) issue(0, 0, std::false_type{}); else issue(0, 0, std::true_type{});

@@ -1,7 +1,8 @@
 """Teacher-forced evaluation metrics: the per-video arithmetic of
 eval/inference_video_ego4d_stream_parallel_new.py:143-359 on the outputs of `model(..., llm_eval=True)` /
 `model(..., model_type="cls", data_type="eval")`.  Plain tensor bookkeeping on a few hundred numbers per video; the
-logits come from the HIP path (sm_llm_forward_logits, the gate step)."""
+logits come from the HIP path (sm_llm_forward_logits, the gate step).  Pinned by golden g16: the script's two loop bodies,
+compiled from its own source and executed on synthetic outputs (the script itself needs the missing data/ package)."""
 from __future__ import annotations
 
 from typing import Dict, List, Sequence

@@ -201,6 +201,26 @@ def test_eval_metrics_hand_cases(gold):
     assert torch.equal(M.relaxed_correct(torch.tensor([0, 1, 0]), torch.tensor([1, 0, 0]), 0), torch.tensor([False, False, True]))
 
 
+def test_eval_metrics_equal_the_reference_script(gold):
+    """golden g16 = the two evaluation loop bodies of eval/inference_video_ego4d_stream_parallel_new.py (:193-232 LLM branch, :263-345
+    gate branch, with relaxed_correct :128-138) compiled from the script's own source and EXECUTED on synthetic model outputs
+    (oracle/make_golden.py g16_eval_metrics): what the script appended to its accumulators per video is what eval_metrics returns."""
+    import json
+    from streammind_amd import eval_metrics as M
+    g = gold("g16_eval_metrics")
+    for i in range(int(g["n_gate"])):
+        ref = json.loads(str(g[f"gate_ref{i}"]))
+        r = M.gate_metrics(torch.from_numpy(g[f"gate_logits{i}"]), torch.from_numpy(g[f"gate_labels{i}"]))
+        for k in ("accuracy", "true_positive_rate", "true_negative_rate", "time_total", "correct_time_total"):
+            assert abs(r[k] - ref[k]) < 1e-6, (i, k, r[k], ref[k])
+        assert r["time_diffs"] == ref["time_diffs"]
+    for i in range(int(g["n_llm"])):
+        ref = json.loads(str(g[f"llm_ref{i}"]))
+        r = M.llm_turn_metrics(torch.from_numpy(g[f"llm_logits{i}"].astype("float32")), torch.from_numpy(g[f"llm_labels{i}"]))
+        for k, v in ref.items():
+            assert abs(r[k] - v) < 1e-5 * max(1.0, abs(v)), (i, k, r[k], v)
+
+
 # ---------------------------------------------------------------------------------------------- f2 (SURVEY 8f): ingest front-end
 def _g10_frames(g, name):
     H, W = g[f"{name}_hw"].tolist()
