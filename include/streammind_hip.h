@@ -43,6 +43,7 @@ extern "C" {
 #define SM_TILE_128 128
 #define SM_TILE_256 256
 #define SM_TILE_256x128 256128
+#define SM_TILE_256_ONE_TILE_PER_BLOCK 2561   /* the 256x256 kernel without its persistent (tile-walking) variant */
 
 const char* sm_last_error(void);
 int sm_abi_version(void);

@@ -16,8 +16,12 @@ typedef uint16_t bf16_t;   // raw storage type in HBM
 // 16-byte WRITE-THROUGH store (global_store_dwordx4 ... sc1): the line leaves the XCD's L2 as it is written instead of
 // staying dirty until the end-of-kernel L2 write-back.  Big outputs that the NEXT kernel reads (GEMM / LayerNorm / attention
 // results) use it: with plain stores every kernel boundary paid dirty-bytes / ~6 TB/s (5.5-7 us behind a ViT-batch GEMM).
+// The trailing s_nop is part of the contract: a VMEM store of more than 64 bits reads its data registers over more than one cycle,
+// and a VALU write of those registers in the next wait states corrupts the tail of the data (ISA "manually inserted wait states").
+// hipcc pads that hazard for stores it can see -- not inside inline asm: the persistent GEMM's epilogue (address arithmetic of the
+// next store allocated into the data registers of the previous one) wrote an address word into 1 of 40 000 outputs without it.
 __device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // round-to-nearest-even fp32 -> bf16 bits (hardware v_cvt_pk_bf16_f32; NaN stays NaN); matches torch .to(bfloat16)

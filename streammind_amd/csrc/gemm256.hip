@@ -521,8 +521,239 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     TL(4);
 }
 
+// ---------------------------------------------------------------------------------------------- persistent variant
+// One 8-wave block per CU walks the tiles the dispatcher would have handed that CU one after the other (block b: XCD b % 8, slot
+// b / 8; tiles slot, slot + 32, ... of the XCD's band), for bf16-only outputs with several tiles per CU (the ViT's QKV and fc1
+// products: 3 and 4 rounds at 28 frames).  What it removes is the seam between two tiles of a CU -- in the one-tile-per-block
+// kernel: epilogue 4.0-8.7 us with the matrix pipes idle, ~2.4 us until the next block's waves are up, 1.4 us until its first
+// operands have crossed L2 (tools/gemm_timeline.hip) -- by keeping the k-loop's DMA pipeline running ACROSS the seam:
+//   * the last three k-steps of a tile issue the first three k-steps of the NEXT tile (instead of nothing), the fourth follows as
+//     soon as the last fragment reads of the old tile are done, so the next tile's k-loop starts with its operands in LDS;
+//   * the epilogue therefore cannot use the ring: bias / activation / packing happen in registers, and the bf16 tile leaves through
+//     a 32-KiB window behind the ring (LDS = 128 + 32 KiB, all of a CU's) in four passes of 256 rows x 64 columns (every wave
+//     contributes 8 pieces per pass, so all four SIMDs write), 16-byte write-through stores;
+//   * waits are counted by hand across the seam (vmcnt retires in order, the epilogue's stores sit between the prefetched stages
+//     and the stages issued by the new tile's first k-steps): the new tile's k-steps 0 and 1 wait for nothing (their stages were
+//     waited for before the first store), k-step 2 waits for everything older than its own two batches (the stores have had the
+//     rest of the epilogue and two k-steps to drain).
+// The arithmetic is that of gemm256_kernel (same fragment order, same accumulation order): results are bit-identical.
+// Every barrier is a raw s_barrier: __syncthreads() is an LDS fence, which hipcc turns into s_waitcnt vmcnt(0) while LDS-DMA is in
+// flight -- exactly the wait this kernel exists to avoid.
+template <int ACT, bool F16>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m, int tiles_n, int cb) {
+    constexpr int BN = 256;
+    constexpr int STAGE = 32768, WINDOW = 4 * STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int wn = wave >> 2, wm = wave & 3;
+    const int KS = a.KS;
+    const int nblk = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int q = nblk >> 3;                          // tiles per XCD band (the launcher guarantees nblk % 8 == 0)
+    if (slot0 >= q) return;
+
+    struct Tile { const char* wbase[2]; const char* xbase; uint32_t xoff[2]; int tile_m, tile_n; };
+    auto locate = [&](int idx, Tile& t) {
+        int tile_m, tile_n;
+        if (cb > 0) {                                 // blocked walk inside the band, as gemm256_kernel
+            const int rows_x = q / tiles_n;
+            const int cg = idx / (rows_x * cb), rem = idx - cg * rows_x * cb;
+            const int r = rem / cb;
+            tile_m = xcd * rows_x + r;
+            tile_n = cg * cb + (rem - r * cb);
+        } else {
+            const int bid = xcd * q + idx;
+            tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n;
+        }
+        t.tile_m = tile_m; t.tile_n = tile_n;
+        t.xbase = (const char*)a.x + (size_t)tile_m * G2_BM * a.ldx * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int rgg = tile_n * 16 + wave * 2 + j;
+            if (rgg >= a.NRG) rgg = a.NRG - 1;
+            t.wbase[j] = (const char*)a.w + (size_t)rgg * KS * 1024;
+            const int row = (wave * 2 + j) * 16 + (lane >> 2);
+            int rl = row;
+            if (tile_m * G2_BM + row >= a.M) rl = a.M - 1 - tile_m * G2_BM;
+            const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+            t.xoff[j] = (uint32_t)(rl * a.ldx + chunk * 8) * 2;
+        }
+    };
+    const uint32_t woff = lane * 16;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    auto dma = [&](const char* sbase, uint32_t voff, uint32_t dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
+    };
+    auto stage = [&](const Tile& t, int ks, int slot) {
+        const uint32_t sb = lds0 + slot * STAGE + wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma(t.wbase[j] + (size_t)ks * 1024, woff, sb + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma(t.xbase + (size_t)ks * 64, t.xoff[j], sb + 16384 + j * 1024);
+    };
+
+    Tile cur, nxt;
+    int idx = slot0;
+    locate(idx, cur);
+    nxt = cur;
+    // prologue = the state behind a seam: stages 0..2 landed, stage 3 in flight (the tile body then needs no "first tile" variant --
+    // a branch inside the body makes hipcc shuffle the 128 accumulators at the join, 130+ spills)
+    stage(cur, 0, 0);
+    stage(cur, 1, 1);
+    stage(cur, 2, 2);
+    stage(cur, 3, 3);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[8][4];
+    // MODE: what the R interval of a k-step issues and waits for
+    //   0 steady: stage ks + 3 of this tile, leave two batches in flight      1 / 2 last tile's tail: nothing to issue, vmcnt(4) / (0)
+    //   3 the tile's last three k-steps when another tile follows: stage ks + 3 - KS of the NEXT tile, two batches in flight
+    //   4 / 5 k-steps 0 / 1 behind a seam: nothing / stage ks + 3 to issue, NO wait (stages 1 and 2 were waited for before the
+    //     epilogue's stores were issued; waiting on a count here would wait for the stores)
+    auto kstep = [&](int ks, auto mode, int slot) {
+        constexpr int MODE = decltype(mode)::value;
+        const char* sw = smem + slot * STAGE;
+        const char* sx = sw + 16384;
+        bf16x8 xf[4], wf[8];
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int ml = wm * 64 + mf * 16 + i;
+            xf[mf] = *(const bf16x8*)(sx + ml * 64 + ((g ^ ((0 - (ml >> 2)) & 3)) * 16));
+        }
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) wf[nf] = *(const bf16x8*)(sw + (wn * 8 + nf) * 1024 + lane * 16);
+        if (MODE == 0) {
+            stage(cur, ks + 3, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else if (MODE == 1) {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        } else if (MODE == 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (MODE == 3) {
+            stage(nxt, ks + 3 - KS, (slot + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else if (MODE == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            stage(cur, ks + 3, (slot + 3) & 3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf)
+                acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using M0 = std::integral_constant<int, 0>; using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>; using M5 = std::integral_constant<int, 5>;
+
+    while (true) {
+        const int nidx = idx + nslots;
+        const bool has_next = nidx < q;
+        locate(has_next ? nidx : idx, nxt);            // behind the last tile the "next" stages re-fetch this tile's (never read): no tail variant
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = f32x4{0, 0, 0, 0};
+        if (wn == 1) __builtin_amdgcn_s_barrier();                  // the two wave groups run one barrier apart (gemm256_kernel)
+        // ---- k-loop (KS % 4 == 0, KS >= 8: ring slot = ks & 3 at compile time)
+        kstep(0, M4{}, 0);
+        kstep(1, M5{}, 1);
+        kstep(2, M0{}, 2);
+        kstep(3, M0{}, 3);
+        int ks = 4;
+        for (; ks + 4 < KS; ks += 4) {
+            kstep(ks, M0{}, 0); kstep(ks + 1, M0{}, 1); kstep(ks + 2, M0{}, 2); kstep(ks + 3, M0{}, 3);
+        }
+        kstep(ks, M0{}, 0);
+        kstep(ks + 1, M3{}, 1); kstep(ks + 2, M3{}, 2); kstep(ks + 3, M3{}, 3);
+        if (wn == 0) __builtin_amdgcn_s_barrier();                  // realign: every wave is done with the ring's last stage
+        // ---- epilogue, register phase: bias, activation, packing (all waves at once: four SIMDs).
+        // Every per-lane address of the epilogue is derived from an OPAQUE copy of the thread id, re-made per tile: from the plain
+        // one hipcc hoists ~60 tile-invariant address registers out of the tile loop and keeps them alive through the k-loop, whose
+        // 128 accumulators + 48 fragment registers leave no room for them (147 spills).
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        const int lane_e = tid_e & 63, i_e = lane_e & 15, g_e = lane_e >> 4;
+        uint32_t pk[8][4][2];
+#pragma unroll
+        for (int nf = 0; nf < 8; ++nf) {
+            const int nl = wn * 128 + nf * 16 + g_e * 4;
+            f32x4 b4 = {0, 0, 0, 0};
+            if (a.bias) b4 = *(const f32x4*)(a.bias + cur.tile_n * BN + nl);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[nf][mf][j] + b4[j];
+                    if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
+                    o[j] = t;
+                }
+                pk[nf][mf][0] = pack16<F16>(o[0], o[1]);
+                pk[nf][mf][1] = pack16<F16>(o[2], o[3]);
+            }
+        }
+        // the next tile's fourth stage goes into the slot the old tile's last k-step was read from; then stages 1 and 2 of the next
+        // tile are waited for BEFORE any store is issued (stage 0 was waited for in the last k-step)
+        __builtin_amdgcn_sched_barrier(0);
+        stage(nxt, 3, 3);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // ---- window passes: pass qn moves columns [32 qn, 32 qn + 32) of both 128-column halves (fragments 2 qn, 2 qn + 1 of
+        // every wave).  Window row = 128 B (8 chunks of 16 B: 4 of the wn = 0 half, 4 of the wn = 1 half), chunk index XOR
+        // ((row >> 1) & 7): the 16 lanes of a ds_write_b64 group meet 16 distinct (row parity, chunk) bank groups.
+        char* const win = smem + WINDOW;
+        bf16_t* const __restrict__ ob = a.out_bf16;
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    const int row = wm * 64 + mf * 16 + i_e;
+                    const int chunk = wn * 4 + e * 2 + (g_e >> 1);
+                    *(u32x2*)(win + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16) + (g_e & 1) * 8) = u32x2{pk[qn * 2 + e][mf][0], pk[qn * 2 + e][mf][1]};
+                }
+            // (the s_barrier builtin is no memory operation to the optimiser: without the compiler fences on BOTH sides it moved window
+            // reads in front of the barrier -- 1 in 40 000 outputs stale)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = j * 512 + tid_e;
+                const int row = id >> 3, c = id & 7;
+                const u32x4 v = *(const u32x4*)(win + row * 128 + ((c ^ ((row >> 1) & 7)) * 16));
+                const int m = cur.tile_m * G2_BM + row;
+                const int n = cur.tile_n * BN + (c >> 2) * 128 + qn * 32 + (c & 3) * 8;
+                if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + n, v);
+            }
+            if (qn < 3) {                                           // the window is free again (the reads were consumed by the stores)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (!has_next) break;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur = nxt; idx = nidx;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dummy stages behind the last tile must not outlive the block's LDS
+}
+
 template <int WN, bool F16>
-static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
+static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persistent = true) {
     constexpr int BN = 128 * WN;
     constexpr int LDS = WN == 2 ? 4 * 32768 : 3 * (BN * 64 + 16384);
     const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, BN);
@@ -545,6 +776,32 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
         while (g > 1 && tiles_n % g) --g;
         if (g > 1) cb = tiles_n / g;
     }
+    if constexpr (WN == 2) {
+        // persistent variant: bf16-only full tiles, several tiles per CU, whole XCD bands (SM_GEMM_PERSIST=0 switches it off)
+        static int persist = -1, n_cu = 0;
+        if (persist < 0) {
+            const char* e = getenv("SM_GEMM_PERSIST");
+            persist = e ? atoi(e) : 1;
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            static bool attr_p = false;
+            if (!attr_p) {
+                SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<0, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+                SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<1, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+                attr_p = true;
+            }
+        }
+        const bool bf16_only = a.out_bf16 && !a.out_f32 && !a.residual && !a.vt && a.remap_in == 0 && (a.ldo_bf16 & 7) == 0 &&
+                               ((uintptr_t)a.out_bf16 & 15) == 0 && (a.N % BN) == 0 && (act == SM_ACT_NONE || act == SM_ACT_QUICK_GELU);
+        if (persist && allow_persistent && bf16_only && n_cu >= 8 && (n_cu & 7) == 0 && (nblk & 7) == 0 && nblk > n_cu && (a.KS & 3) == 0 && a.KS >= 8 &&
+            (cb == 0 || (nblk >> 3) % tiles_n == 0)) {
+            const dim3 pgrid(n_cu);
+            if (act == SM_ACT_NONE) gemm256p_kernel<0, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            else gemm256p_kernel<1, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            SM_LAUNCH_CHECK();
+            return SM_OK;
+        }
+    }
     if (act == SM_ACT_NONE) gemm256_kernel<0, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
     else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
     else gemm256_kernel<-1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
@@ -555,6 +812,7 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st) {
 // bn = 256: one 8-wave block per CU; bn = 128: two independent 4-wave blocks per CU (their phases drift apart, so one
 // block's barriers / epilogue overlap the other's MFMAs)
 int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st) {
-    if (a.f16) return bn == 128 ? launch_wn<1, true>(a, act, st) : launch_wn<2, true>(a, act, st);
-    return bn == 128 ? launch_wn<1, false>(a, act, st) : launch_wn<2, false>(a, act, st);
+    const bool np = bn == 257;                    // SM_TILE_256_ONE_TILE_PER_BLOCK: never the persistent variant (tests, A/B)
+    if (a.f16) return bn == 128 ? launch_wn<1, true>(a, act, st) : launch_wn<2, true>(a, act, st, !np);
+    return bn == 128 ? launch_wn<1, false>(a, act, st) : launch_wn<2, false>(a, act, st, !np);
 }

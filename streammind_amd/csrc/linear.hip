@@ -1179,6 +1179,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         if (hint == 128) bn = 0;
         if (hint == 256128 && ok) bn = 128;
         if (hint == 256 && ok) bn = 256;
+        if (hint == 2561 && ok) bn = 257;
         if (bn) {
             SmProfScope prof(SM_PROF_GEMM, st);
             return launch_gemm256(a, p->act, bn, st);

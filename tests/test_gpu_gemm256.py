@@ -12,7 +12,7 @@ from oracle import streammind_oracle as O
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-SM_TILE_128, SM_TILE_256, SM_TILE_256x128 = 128, 256, 256128
+SM_TILE_128, SM_TILE_256, SM_TILE_256x128, SM_TILE_256_ONE = 128, 256, 256128, 2561
 
 
 @pytest.fixture(scope="module")
@@ -90,6 +90,27 @@ def test_gemm256_vit_batch_shapes_vs_fp64(nat, name, M, N, K, act, use_res, out_
     else:
         y2 = nat.linear(x.cuda().bfloat16(), wp, N, K, bias=bias.cuda(), act=act, out_dtype=out_dtype, tile_hint=SM_TILE_256x128)
     assert relerr(y2, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(VIT_M, 3072, 1024, 0), (VIT_M, 4096, 1024, 1), (VIT_M - 300, 2048, 4096, 0), (44 * 577, 3072, 256, 1),
+                                       (VIT_M, 1024, 1024, 0)])
+@pytest.mark.parametrize("f16", [False, True])
+def test_persistent_gemm256_is_bit_identical(nat, M, N, K, act, f16):
+    """gemm256p_kernel (one block per CU walking its tiles, the k-loop's DMA pipeline running across the tile seam, epilogue through
+    the 32-KiB window) against gemm256_kernel (one tile per block) on the same inputs: same fragment and accumulation order, so the
+    bf16 / fp16 outputs must be IDENTICAL -- for 3 / 4 / 8 tiles per CU, a ragged last row tile, a short k-loop (KS = 8) and a
+    grid that does not qualify (N = 1024: one round, stays on the one-tile kernel).  Repeated: a race would show as a difference."""
+    dt = torch.float16 if f16 else torch.bfloat16
+    w = rnd((N, K), 51, K ** -0.5).to(dt)
+    x = rnd((M, K), 52).to(dt)
+    bias = rnd((N,), 53, 0.1)
+    wp = nat.pack_weight(w.cuda())
+    xg = x.cuda()
+    ref = nat.linear(xg, wp, N, K, bias=bias.cuda(), act=act, out_dtype=dt, tile_hint=SM_TILE_256_ONE)
+    for _ in range(3):
+        y = nat.linear(xg, wp, N, K, bias=bias.cuda(), act=act, out_dtype=dt, tile_hint=SM_TILE_256)
+        assert torch.equal(y, ref)
+    assert relerr(ref, ref_linear(x.float(), w.float(), bias, act, None)) < (6e-4 if f16 else 5e-3)
 
 
 def test_gemm256_patch_embed_remap_vs_fp64(nat):
