@@ -980,12 +980,31 @@ def main():
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
                     break
+            # the same launches as rocprofv3 saw them (committed kernel trace of `--batch 28 --no-pipeline`): HIP-event brackets keep the next
+            # kernel from being dispatched behind the previous one's tail, which a persistent launch pays in full
+            ktrace = None
+            try:
+                import csv as _csv
+                for rnd in ("r03", "r02"):
+                    kf = os.path.join(ROOT, "profiles", f"{rnd}_bench_steps_kernel_stats.csv")
+                    if os.path.exists(kf):
+                        rows = [r for r in _csv.DictReader(open(kf)) if r["Name"].startswith(("void gemm256_kernel", "void gemm256p_kernel"))]
+                        n_k = sum(int(r["Calls"]) for r in rows)
+                        if n_k:
+                            av = sum(float(r["TotalDurationNs"]) for r in rows) / n_k * 1e-3
+                            fl = vit_linear_flops_per_frame(cfg) * LB / 93.0
+                            ktrace = {"avg_launch_us": round(av, 2), "launches": n_k, "frac": round(fl / (av * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                      "source": f"profiles/{rnd}_bench_steps_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --batch 28 --no-pipeline`, a separate run)"}
+                        break
+            except Exception:
+                ktrace = None
             big = PB * (cfg.n_patches + 1) >= 192 * 64
-            roof = {"kernel": "gemm256_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups)" if big else
+            roof = {"kernel": "gemm256_kernel / gemm256p_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups; "
+                              "persistent tile walk for the multi-tile bf16-output shapes)" if big else
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 8 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB,
+                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "kernel_trace": ktrace,
                     # the TIMED schedule as a whole against the same peak: every FLOP of a frame's tower (tiled GEMMs + attention, SURVEY
                     # 8d's 366 GFLOP) x the frames timed / the timed wall clock -- what `value` is worth in MFMA terms
                     "whole_step_frac": round((vit_linear_flops_per_frame(cfg) + cfg.vit_layers_run * 4.0 * (cfg.n_patches + 1) ** 2 * cfg.vit_hidden)
