@@ -385,8 +385,14 @@ __device__ __forceinline__ float xor32_max_raw(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return vmax2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+#ifndef VIT_ATTN_WAVES
+#define VIT_ATTN_WAVES 4       // waves (of 32 queries) per block: 4 = 128 queries, 8 = 256 queries per staged K / V tile.  Round 3, same box,
+                               // B = 28: 8 waves 83.8 us against 75.6 us for 4 -- 40 % less K / V staging per FLOP buys nothing (the
+                               // kernel is bound by each wave's own MFMA + VALU stream) and barriers over 8 waves wait longer
+#endif
 template <bool F16>      // F16: q / k / v / P / ctx are IEEE fp16 (the ViT's optional fp16 mode), else bf16
-__global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
+__global__ __launch_bounds__(VIT_ATTN_WAVES * 64, 8 / VIT_ATTN_WAVES) void vit_attn_kernel(AttnP p) {
+    constexpr int NW = VIT_ATTN_WAVES, PPW = 8 / NW;      // 1-KiB K (and V) pieces of a tile each wave brings
     constexpr int DH = 64, KROW = 128, TILE_BYTES = 16384;
     __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
         if (grp >= p.H * p.nbatch) return;
         h = grp % p.H; b = grp / p.H;
     }
-    const int q0 = qtile * 128 + wave * 32;
+    const int q0 = qtile * (NW * 32) + wave * 32;
     bf16x8 qf[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -422,12 +428,12 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
     const int nk = p.nk;
 
     // per-lane DMA sources: wave w issues K pieces 2w, 2w+1 and V pieces 2w, 2w+1 (1 KiB = 8 LDS rows each)
-    const bf16_t* ksrc[2];
-    const bf16_t* vsrc[2];
-    int krow[2], vrow[2];
+    const bf16_t* ksrc[PPW];
+    const bf16_t* vsrc[PPW];
+    int krow[PPW], vrow[PPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int R = (wave * 2 + j) * 8 + (lane >> 3), slot = lane & 7;
+    for (int j = 0; j < PPW; ++j) {
+        const int R = (wave * PPW + j) * 8 + (lane >> 3), slot = lane & 7;
         // K: LDS row R holds key inv(R) (rows permuted so that S^T accumulators are PV B-operands), chunk cc at slot cc ^ (R & 7)
         const int r5 = R & 31;
         const int key = (R & 32) | (((r5 >> 2) & 3) << 3) | (((r5 >> 4) & 1) << 2) | (r5 & 3);
@@ -446,15 +452,15 @@ __global__ __launch_bounds__(256, 2) void vit_attn_kernel(AttnP p) {
         char* Kl = lds + bufi * TILE_BYTES;
         char* Vl = Kl + 8192;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PPW; ++j) {
             const bf16_t* ks = ksrc[j];
             const bf16_t* vs = vsrc[j];
             if (CLAMP) {
                 ks -= (long)max(kt0 + krow[j] - (nk - 1), 0) * p.k_rs;
                 vs -= (long)max(kt0 + vrow[j] - (nk - 1), 0) * p.v_rs;
             }
-            __builtin_amdgcn_global_load_lds((gbl_ptr_a)ks, (lds_ptr_a)(Kl + (wave * 2 + j) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_ptr_a)vs, (lds_ptr_a)(Vl + (wave * 2 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)ks, (lds_ptr_a)(Kl + (wave * PPW + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)vs, (lds_ptr_a)(Vl + (wave * PPW + j) * 1024), 16, 0, 0);
             ksrc[j] += kadv;
             vsrc[j] += vadv;
         }
@@ -657,14 +663,15 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
 
 static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
+    if (p.v && dh == 64) p.nqt = cdiv(p.nq, VIT_ATTN_WAVES * 32);
     dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
     SmProfScope prof(SM_PROF_ATTN, st);
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
     SM_REQUIRE(!f16 || (p.v && dh == 64) || p.causal, "attention: fp16 operands on the ViT fast path (row-major V, head_dim 64) and the causal LLM path");
     if (p.v) {
-        if (dh == 64 && f16) vit_attn_kernel<true><<<grid, 256, 0, st>>>(p);
-        else if (dh == 64) vit_attn_kernel<false><<<grid, 256, 0, st>>>(p);
+        if (dh == 64 && f16) vit_attn_kernel<true><<<grid, VIT_ATTN_WAVES * 64, 0, st>>>(p);
+        else if (dh == 64) vit_attn_kernel<false><<<grid, VIT_ATTN_WAVES * 64, 0, st>>>(p);
         else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
     } else if (p.causal) {
         if (f16) {
