@@ -604,6 +604,8 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     ap.add_argument("--no-decode", action="store_true", help="skip the Mistral-7B decode tokens/s leg")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (teacher-forced eval, ingest front-end, per-call latency)")
+    ap.add_argument("--stream-frames", type=int, default=1800, help="frames of the synthetic stream (default: the 60 s x 30 fps of BASELINE configs[1]).  Only for "
+                    "rocprofv3 COUNTER passes, which intercept every dispatch: generating 1800 frames is ~25 000 small launches and crashed the profiler")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -647,7 +649,7 @@ def main():
     cfg = PathConfig(llm_layers=0 if a.no_decode else 32, max_frames_per_call=B, vit_fp16=a.vit_fp16)
     # BASELINE configs[1] names a 60 s x 30 fps stream: the pool is ALWAYS those 1800 frames, and the timed region is about one pass
     # over it whatever --steps the caller picks -- a step is `cps` calls of B frames (steps x cps x B ~ 1800; the walk wraps around)
-    n_pool = max(B, 1800)
+    n_pool = max(B, a.stream_frames)
     cps = max(1, int(round(n_pool / float(a.steps * B))))
     if plumbing:
         model, frames, stream = None, torch.zeros(n_pool, 1, 1, 3, dtype=torch.uint8), _PlumbingStream(cfg.conn_d_model)

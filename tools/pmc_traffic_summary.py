@@ -10,9 +10,10 @@ def load(d, cname):
             if r["Counter_Name"] != cname:
                 continue
             n = r["Kernel_Name"]
-            for key in ("gemm256_kernel", "gemm_kernel", "attn_kernel", "skinny_lds_kernel", "skinny_kernel", "splitk_reduce", "norm_wave_fixed"):
+            for key in ("gemm256p_kernel", "gemm256_kernel", "gemm_kernel", "attn_kernel", "skinny_lds_kernel", "skinny_kernel", "splitk_reduce", "norm_wave_fixed"):
                 if key in n:
                     agg[key][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+                    break
     return agg
 
 
@@ -32,7 +33,10 @@ for k in f:
                                               "write_size_kb": (sum(w[k][g]) / len(w[k][g])) if w[k].get(g) else None}
                                      for g, v in sorted(f[k].items())}}
 if "gemm256_kernel" in out["kernels"]:
-    out["hbm_bytes_per_launch"] = out["kernels"]["gemm256_kernel"]["hbm_bytes_per_launch"]
-    out["kernel"] = "gemm256_kernel"
+    # the dominant kernel = the 256x256 tiled GEMM in both forms (one tile per block; persistent tile walk): launch-weighted average
+    ks = [out["kernels"][k] for k in ("gemm256_kernel", "gemm256p_kernel") if k in out["kernels"]]
+    n = sum(k["launches"] for k in ks)
+    out["hbm_bytes_per_launch"] = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in ks) / n
+    out["kernel"] = "gemm256_kernel + gemm256p_kernel (launch-weighted)"
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out["kernels"].items()}))

@@ -21,10 +21,10 @@ cp "$(find /tmp/prof_stats1 -name '*kernel_stats.csv' | head -1)" $O/kernel_stat
 rm -rf /tmp/prof_dec; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -- python tools/decode_bench.py 64 1024 > $O/decode_profiled.log 2>&1
 cp "$(find /tmp/prof_dec -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_decode.csv
 rm -rf /tmp/pmc_f /tmp/pmc_w
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
 rm -rf /tmp/pmc_m
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_mfma_summary.py /tmp/pmc_m $O/mfma_util.json
 head -8 $O/kernel_stats_steps_default.csv | cut -c1-160; head -12 $O/kernel_stats_steps.csv | cut -c1-160; head -8 $O/kernel_stats_decode.csv | cut -c1-160
