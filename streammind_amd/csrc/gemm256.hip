@@ -533,9 +533,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 //     a 32-KiB window behind the ring (LDS = 128 + 32 KiB, all of a CU's) in four passes of 256 rows x 64 columns (every wave
 //     contributes 8 pieces per pass, so all four SIMDs write), 16-byte write-through stores;
 //   * waits are counted by hand across the seam (vmcnt retires in order, the epilogue's stores sit between the prefetched stages
-//     and the stages issued by the new tile's first k-steps): the new tile's k-steps 0 and 1 wait for nothing (their stages were
-//     waited for before the first store), k-step 2 waits for everything older than its own two batches (the stores have had the
-//     rest of the epilogue and two k-steps to drain).
+//     and the stages issued by the new tile's first k-steps): all four prefetched stages are waited for before the first store
+//     (the register phase covers the fourth's flight), the new tile's k-steps 0..2 wait for nothing, k-step 3 waits for everything
+//     older than its own two batches (the stores have had the rest of the epilogue and three k-steps to drain).
 // The arithmetic is that of gemm256_kernel (same fragment order, same accumulation order): results are bit-identical.
 // Every barrier is a raw s_barrier: __syncthreads() is an LDS fence, which hipcc turns into s_waitcnt vmcnt(0) while LDS-DMA is in
 // flight -- exactly the wait this kernel exists to avoid.
@@ -598,20 +598,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
     int idx = slot0;
     locate(idx, cur);
     nxt = cur;
-    // prologue = the state behind a seam: stages 0..2 landed, stage 3 in flight (the tile body then needs no "first tile" variant --
+    // prologue = the state behind a seam: stages 0..3 landed (the tile body then needs no "first tile" variant --
     // a branch inside the body makes hipcc shuffle the 128 accumulators at the join, 130+ spills)
     stage(cur, 0, 0);
     stage(cur, 1, 1);
     stage(cur, 2, 2);
     stage(cur, 3, 3);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     f32x4 acc[8][4];
     // MODE: what the R interval of a k-step issues and waits for
     //   0 steady: stage ks + 3 of this tile, leave two batches in flight      1 / 2 last tile's tail: nothing to issue, vmcnt(4) / (0)
     //   3 the tile's last three k-steps when another tile follows: stage ks + 3 - KS of the NEXT tile, two batches in flight
-    //   4 / 5 k-steps 0 / 1 behind a seam: nothing / stage ks + 3 to issue, NO wait (stages 1 and 2 were waited for before the
+    //   4 / 5 k-steps 0 / 1, 2 behind a seam: nothing / stage ks + 3 to issue, NO wait (stages 1..3 were waited for before the
     //     epilogue's stores were issued; waiting on a count here would wait for the stores)
     auto kstep = [&](int ks, auto mode, int slot) {
         constexpr int MODE = decltype(mode)::value;
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         // ---- k-loop (KS % 4 == 0, KS >= 8: ring slot = ks & 3 at compile time)
         kstep(0, M4{}, 0);
         kstep(1, M5{}, 1);
-        kstep(2, M0{}, 2);
+        kstep(2, M5{}, 2);
         kstep(3, M0{}, 3);
         int ks = 4;
         for (; ks + 4 < KS; ks += 4) {
@@ -677,6 +677,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         kstep(ks, M0{}, 0);
         kstep(ks + 1, M3{}, 1); kstep(ks + 2, M3{}, 2); kstep(ks + 3, M3{}, 3);
         if (wn == 0) __builtin_amdgcn_s_barrier();                  // realign: every wave is done with the ring's last stage
+        // the next tile's fourth stage goes into the slot the old tile's last k-step was read from -- issued BEFORE the register phase,
+        // which then covers its flight: behind it all four prefetched stages are waited for and no store has been issued yet
+        stage(nxt, 3, 3);
         // ---- epilogue, register phase: bias, activation, packing (all waves at once: four SIMDs).
         // Every per-lane address of the epilogue is derived from an OPAQUE copy of the thread id, re-made per tile: from the plain
         // one hipcc hoists ~60 tile-invariant address registers out of the tile loop and keeps them alive through the k-loop, whose
@@ -703,11 +706,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
                 pk[nf][mf][1] = pack16<F16>(o[2], o[3]);
             }
         }
-        // the next tile's fourth stage goes into the slot the old tile's last k-step was read from; then stages 1 and 2 of the next
-        // tile are waited for BEFORE any store is issued (stage 0 was waited for in the last k-step)
         __builtin_amdgcn_sched_barrier(0);
-        stage(nxt, 3, 3);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- window passes: pass qn moves columns [32 qn, 32 qn + 32) of both 128-column halves (fragments 2 qn, 2 qn + 1 of
         // every wave).  Window row = 128 B (8 chunks of 16 B: 4 of the wn = 0 half, 4 of the wn = 1 half), chunk index XOR
         // ((row >> 1) & 7): the 16 lanes of a ds_write_b64 group meet 16 distinct (row parity, chunk) bank groups.
