@@ -15,6 +15,9 @@
 // residual outputs are staged as fp32 in two 128-row halves and written as whole rows.  All stores are write-through
 // (sc1), the activation is resolved at compile time and the pointers are __restrict__ so the passes are not serialised
 // on store round trips (see linear.hip).  tools/gemm_timeline.hip prints the per-block phase times.
+// Round 3: gemm256p_kernel (below) is the PERSISTENT form of the same 256 x 256 loop for bf16-only outputs with several tiles per
+// CU -- one block per CU walks its tiles and keeps the LDS-DMA pipeline running across the seam between two tiles (in situ: fc1
+// 138 -> 125 us, QKV 96 -> 87 us on the same box; bit-identical results).
 #include <stdlib.h>
 #include <type_traits>
 
