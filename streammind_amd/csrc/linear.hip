@@ -247,103 +247,6 @@ __device__ __forceinline__ void norm_finish(const LinArgs& a, float* nsum, bf16_
     __builtin_amdgcn_s_barrier();
 }
 
-// same block/wave decomposition as skinny_kernel, weights streamed as fp8 pairs of k-steps
-template <int WAVES, bool XF32, bool SPLIT, bool DUAL, bool NORM = false>
-__global__ __launch_bounds__(WAVES * 64) void skinny_fp8_kernel(LinArgs a) {
-    static_assert(!NORM || (XF32 && !SPLIT), "fused RMSNorm: fp32 activations, one rounding");
-    extern __shared__ __attribute__((aligned(16))) float red[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rg = blockIdx.x;
-    const int KS = a.KS, KSP = (KS + 1) >> 1;
-    const int i = lane & 15, g = lane >> 4;
-    const u32x4* wp = (const u32x4*)a.w + (size_t)rg * KSP * 64 + lane;
-    const u32x4* wp2 = DUAL ? (const u32x4*)a.w2 + (size_t)rg * KSP * 64 + lane : nullptr;
-    const bool valid = i < a.M;
-    const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
-    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    constexpr int U = DUAL ? 2 : 4;          // 16-byte weight loads in flight per wave (8 measured slower: 378 vs 437 tokens/s, short K loops fall into the tail loop)
-    int kp = wave;
-    bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);     // NORM: normalised bf16 rows [M][K]
-    auto body = [&](u32x4 q, u32x4 q2, int kpi) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ks = 2 * kpi + h;
-            bf16x8 xh, xl;
-            if constexpr (NORM) {
-                union { bf16x8 v; u32x4 u; } r;
-                r.u = u32x4{0, 0, 0, 0};
-                if (valid && ks < KS) r.u = *(const u32x4*)(xs + (size_t)i * a.K + ks * 32 + g * 8);
-                xh = r.v;
-            } else {
-                load_x<XF32, SPLIT>(xrow, ks * 32 + g * 8, valid && ks < KS, xh, xl);
-            }
-            const bf16x8 wf = fp8x8_to_bf16(h ? q[2] : q[0], h ? q[3] : q[1]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xh, acc, 0, 0, 0);
-            if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xl, acc, 0, 0, 0);
-            if (DUAL) {
-                const bf16x8 wf2 = fp8x8_to_bf16(h ? q2[2] : q2[0], h ? q2[3] : q2[1]);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xh, acc2, 0, 0, 0);
-                if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xl, acc2, 0, 0, 0);
-            }
-        }
-    };
-    if constexpr (NORM) {
-        f32x4 t[4], gm[4];
-        norm_issue<WAVES>(a, wave, lane, t, gm);
-        u32x4 q0[U], q20[U];
-        const bool have0 = kp + (U - 1) * WAVES < KSP;
-        if (have0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                q0[u] = __builtin_nontemporal_load(wp + (size_t)(kp + u * WAVES) * 64);
-                if (DUAL) q20[u] = __builtin_nontemporal_load(wp2 + (size_t)(kp + u * WAVES) * 64);
-            }
-        }
-        norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
-        if (have0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) body(q0[u], DUAL ? q20[u] : q0[u], kp + u * WAVES);
-            kp += U * WAVES;
-        }
-    }
-    for (; kp + (U - 1) * WAVES < KSP; kp += U * WAVES) {
-        u32x4 q[U], q2[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            q[u] = __builtin_nontemporal_load(wp + (size_t)(kp + u * WAVES) * 64);
-            if (DUAL) q2[u] = __builtin_nontemporal_load(wp2 + (size_t)(kp + u * WAVES) * 64);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) body(q[u], DUAL ? q2[u] : q[u], kp + u * WAVES);
-    }
-    for (; kp < KSP; kp += WAVES) {
-        const u32x4 q = __builtin_nontemporal_load(wp + (size_t)kp * 64);
-        const u32x4 q2 = DUAL ? __builtin_nontemporal_load(wp2 + (size_t)kp * 64) : q;
-        body(q, q2, kp);
-    }
-    if (WAVES > 1) {
-        constexpr int PER = DUAL ? 8 : 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            red[(wave * PER + r) * 64 + lane] = acc[r];
-            if (DUAL) red[(wave * PER + 4 + r) * 64 + lane] = acc2[r];
-        }
-        __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s = 0.f, s2 = 0.f;
-            for (int w = 0; w < WAVES; ++w) {
-                s += red[(w * PER + r) * 64 + lane];
-                if (DUAL) s2 += red[(w * PER + 4 + r) * 64 + lane];
-            }
-            acc[r] = s;
-            if (DUAL) acc2[r] = s2;
-        }
-    }
-    store4(a, i, rg * 16 + g * 4, acc, DUAL ? &acc2 : nullptr);
-}
-
 // one lane's share of the fused RoPE / KV-append epilogue: row `row` (= stream), head slot hs (q heads, then k heads, then v
 // heads), dims d0..d0+3 in `lo` and d0+64..d0+67 in `hi` of a 128-wide head.  Same arithmetic as rope_kv_kernel (vecops.hip).
 template <bool F16 = false>
@@ -371,12 +274,171 @@ static __device__ __forceinline__ void rope_store(const SmRopeEpi& re, int row, 
     }
 }
 
+// ---- fp8 weight streaming (M <= 16): same block / wave decomposition as skinny_kernel, the weights as fp8 pairs of k-steps.
+// Wave w owns the 1 KiB chunks kp = w + c * WAVES of its row group and keeps D of them IN FLIGHT at all times (register ring:
+// consume the oldest, issue the next into its registers -- the compiler's in-order vmcnt accounting gives the counted waits);
+// the ragged rest is issued in one go behind the last full round.  Round 2's loop issued a batch, waited for all of it and
+// fetched each x fragment under an exec-masked branch between the MFMAs (eight serial L2 round trips per batch: the fp8 down
+// projection of a decode step took as long as the bf16 one).  The x fragments now ride the ring (unmasked loads, row clamped,
+// zeroed by a select), and everything the epilogue needs -- the row scales, the residual rows -- is fetched FIRST, as vectors
+// (store4's per-element loads were twelve more serial round trips).
+// ROPE: the fused q/k/v product of a decode step, as skinny_kernel's (row groups rg and rg + 4 of one image, RoPE + KV append
+// in the epilogue).
+struct NoRope {};
+template <int WAVES, bool XF32, bool SPLIT, bool DUAL, bool NORM = false, bool ROPE = false>
+__global__ __launch_bounds__(WAVES * 64, ROPE ? 2 : 4) void skinny_fp8_kernel(LinArgs a, std::conditional_t<ROPE, SmRopeEpi, NoRope> re) {
+    static_assert(!NORM || (XF32 && !SPLIT), "fused RMSNorm: fp32 activations, one rounding");
+    static_assert(!ROPE || DUAL, "fused RoPE: the two halves of a head ride the dual accumulators");
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = ROPE ? (int)((blockIdx.x >> 2) * 8 + (blockIdx.x & 3)) : (int)blockIdx.x;
+    const int KS = a.KS, KSP = (KS + 1) >> 1;
+    const int i = lane & 15, g = lane >> 4;
+    const u32x4* wp = (const u32x4*)a.w + (size_t)rg * KSP * 64 + lane;
+    const u32x4* wp2 = ROPE ? (const u32x4*)a.w + (size_t)(rg + 4) * KSP * 64 + lane : DUAL ? (const u32x4*)a.w2 + (size_t)rg * KSP * 64 + lane : nullptr;
+    const bool valid = i < a.M;
+    const char* xrow = (const char*)a.x + (size_t)(valid ? i : 0) * a.ldx * (XF32 ? 4 : 2);
+    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+
+    // epilogue operands, first in the vector-memory queue (wave 0 stores)
+    const int n0 = rg * 16 + g * 4;
+    const bool fast = ROPE || ((a.N & 15) == 0 && a.remap_in == 0 && !a.vt && !a.bias && (((size_t)a.wscale | (size_t)a.wscale2) & 15) == 0 &&
+                               (!a.residual || ((a.ldr & 3) == 0 && ((size_t)a.residual & 15) == 0)) &&
+                               (!a.out_f32 || ((a.ldo & 3) == 0 && ((size_t)a.out_f32 & 15) == 0)) &&
+                               (!a.out_bf16 || ((a.ldo_bf16 & 3) == 0 && ((size_t)a.out_bf16 & 7) == 0)));
+    f32x4 sc = {1, 1, 1, 1}, sc2 = {1, 1, 1, 1}, res = {0, 0, 0, 0};
+    if (fast && wave == 0) {
+        sc = *(const f32x4*)(a.wscale + n0);
+        if (ROPE) sc2 = *(const f32x4*)(a.wscale + n0 + 64);
+        else if (DUAL) sc2 = *(const f32x4*)(a.wscale2 + n0);
+        if (!ROPE && a.residual && valid) res = *(const f32x4*)(a.residual + (size_t)i * a.ldr + n0);
+    }
+
+    constexpr int D = (DUAL || (XF32 && !NORM)) ? 2 : 4;          // chunks (16 B per lane and matrix) in flight per wave; 128 VGPRs = 16 waves per CU
+    const int nw = wave < KSP ? (KSP - wave + WAVES - 1) / WAVES : 0;       // chunks of this wave
+    bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);     // NORM: normalised bf16 rows [M][K]
+    // raw x of one chunk (two k-steps), fetched with the weights; NORM reads its fragments from LDS when the chunk is consumed
+    struct XRaw { std::conditional_t<XF32, f32x4, u32x4> v[XF32 ? 4 : 2]; };
+    auto issue = [&](int c, u32x4& q, u32x4& q2, XRaw& x) {
+        const int kp = wave + c * WAVES;
+        q = __builtin_nontemporal_load(wp + (size_t)kp * 64);
+        if (DUAL) q2 = __builtin_nontemporal_load(wp2 + (size_t)kp * 64);
+        if constexpr (!NORM) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ks = min(2 * kp + h, KS - 1);              // odd KS: the pair's second half re-reads the first (zeroed below)
+                if constexpr (XF32) {
+                    x.v[2 * h] = *(const f32x4*)(xrow + (size_t)(ks * 32 + g * 8) * 4);
+                    x.v[2 * h + 1] = *(const f32x4*)(xrow + (size_t)(ks * 32 + g * 8) * 4 + 16);
+                } else {
+                    x.v[h] = *(const u32x4*)(xrow + (size_t)(ks * 32 + g * 8) * 2);
+                }
+            }
+        }
+    };
+    auto consume = [&](const u32x4& q, const u32x4& q2, const XRaw& x, int c) {
+        const int kp = wave + c * WAVES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ks = 2 * kp + h;
+            const bool on = valid && ks < KS;
+            bf16x8 xh, xl;
+            if constexpr (NORM) {
+                union { bf16x8 v; u32x4 u; } r;
+                r.u = u32x4{0, 0, 0, 0};
+                if (on) r.u = *(const u32x4*)(xs + (size_t)i * a.K + ks * 32 + g * 8);
+                xh = r.v;
+            } else if constexpr (XF32) {
+                const f32x4 z = {0, 0, 0, 0};
+                split_x<SPLIT>(on ? x.v[2 * h] : z, on ? x.v[2 * h + 1] : z, xh, xl);
+            } else {
+                union { bf16x8 v; u32x4 u; } r;
+                r.u = on ? x.v[h] : u32x4{0, 0, 0, 0};
+                xh = r.v;
+            }
+            const bf16x8 wf = fp8x8_to_bf16(h ? q[2] : q[0], h ? q[3] : q[1]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xh, acc, 0, 0, 0);
+            if (SPLIT) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xl, acc, 0, 0, 0);
+            if (DUAL) {
+                const bf16x8 wf2 = fp8x8_to_bf16(h ? q2[2] : q2[0], h ? q2[3] : q2[1]);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xh, acc2, 0, 0, 0);
+                if (SPLIT) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, xl, acc2, 0, 0, 0);
+            }
+        }
+    };
+    u32x4 q[D], q2[D];
+    XRaw xq[D];
+    f32x4 t[4], gm[4];
+    if constexpr (NORM) norm_issue<WAVES>(a, wave, lane, t, gm);          // before the weights: vmcnt retires in order
+    const int first = min(nw, D);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < first) issue(u, q[u], q2[u], xq[u]);
+    if constexpr (NORM) norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
+    int done = 0, issued = first;
+    for (; issued + D <= nw; issued += D, done += D) {             // steady state: no branches, counted waits
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            consume(q[u], q2[u], xq[u], done + u);
+            issue(issued + u, q[u], q2[u], xq[u]);
+            __builtin_amdgcn_sched_barrier(0);          // or the scheduler sinks every issue behind the last consume: a batch again
+        }
+    }
+    const int rem = nw - issued;              // < D chunks left to issue: each takes the registers of the chunk just consumed
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < first) {
+            consume(q[u], q2[u], xq[u], done + u);
+            if (u < rem) issue(issued + u, q[u], q2[u], xq[u]);
+        }
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u)
+        if (u < rem) consume(q[u], q2[u], xq[u], issued + u);
+    if (WAVES > 1) {
+        constexpr int PER = DUAL ? 8 : 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[(wave * PER + r) * 64 + lane] = acc[r];
+            if (DUAL) red[(wave * PER + 4 + r) * 64 + lane] = acc2[r];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.f, s2 = 0.f;
+            for (int w = 0; w < WAVES; ++w) {
+                s += red[(w * PER + r) * 64 + lane];
+                if (DUAL) s2 += red[(w * PER + 4 + r) * 64 + lane];
+            }
+            acc[r] = s;
+            if (DUAL) acc2[r] = s2;
+        }
+    }
+    if constexpr (ROPE) {
+        for (int row = 0; row < a.M; ++row)
+            if (i == row) rope_store<false>(re, row, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3) * 16 + g * 4, acc * sc, acc2 * sc2);
+        return;
+    } else {
+        if (!fast) { store4(a, i, n0, acc, DUAL ? &acc2 : nullptr); return; }
+        if (!valid || n0 >= a.N) return;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r] * sc[r];
+            if (DUAL) v = siluf_(v) * (acc2[r] * sc2[r]);
+            else v = apply_act_rt(v, a.act);
+            o[r] = v + res[r];
+        }
+        if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)i * a.ldo + n0) = o;
+        if (a.out_bf16) *(u32x2*)(a.out_bf16 + (size_t)i * a.ldo_bf16 + n0) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ skinny (M <= 16)
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
 // reduce through LDS.  Weights stream HBM -> VGPR with non-temporal 16-byte loads; x comes from L2.
 // NORM: RMSNorm of the activations fused in front (norm_issue / norm_finish above; decode q/k/v, gate/up, lm_head at one row)
-struct NoRope {};
 // ROPE: the fused q/k/v product of a decode step (head_dim 128).  Block b streams row groups rg = (b / 4) * 8 + b % 4 and
 // rg + 4 of the SAME weight image (the DUAL machinery: two accumulators over one activation fragment), i.e. dims d and d + 64
 // of one head land in the same lane, and the epilogue applies rotate_half RoPE and writes q / the K cache / the V^T cache
@@ -832,7 +894,7 @@ template <int WAVES>
 static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
     dim3 grid(a.NRG), block(WAVES * 64);
     size_t sh = WAVES > 1 ? (size_t)WAVES * (dual ? 8 : 4) * 64 * sizeof(float) : 0;
-#define SK(XF, SP, DU) skinny_fp8_kernel<WAVES, XF, SP, DU><<<grid, block, sh, st>>>(a)
+#define SK(XF, SP, DU) skinny_fp8_kernel<WAVES, XF, SP, DU><<<grid, block, sh, st>>>(a, NoRope{})
     if (xf32) {
         if (split) { if (dual) SK(true, true, true); else SK(true, true, false); }
         else       { if (dual) SK(true, false, true); else SK(true, false, false); }
@@ -1020,8 +1082,8 @@ static int launch_skinny_norm(const LinArgs& a, bool dual, bool fp8, hipStream_t
     dim3 grid(a.NRG), block(WAVES * 64);
     const size_t sh = ((size_t)WAVES * (dual ? 8 : 4) * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
     if (fp8) {
-        if (dual) skinny_fp8_kernel<WAVES, true, false, true, true><<<grid, block, sh, st>>>(a);
-        else skinny_fp8_kernel<WAVES, true, false, false, true><<<grid, block, sh, st>>>(a);
+        if (dual) skinny_fp8_kernel<WAVES, true, false, true, true><<<grid, block, sh, st>>>(a, NoRope{});
+        else skinny_fp8_kernel<WAVES, true, false, false, true><<<grid, block, sh, st>>>(a, NoRope{});
     } else if (a.f16) {
         if (dual) skinny_kernel<WAVES, true, false, true, 1, true, false, true><<<grid, block, sh, st>>>(a, NoRope{});
         else skinny_kernel<WAVES, true, false, false, 1, true, false, true><<<grid, block, sh, st>>>(a, NoRope{});
@@ -1050,11 +1112,13 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
     a.f16 = p->op_dtype == SM_OP_F16;
 }
 
-// the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): bf16 weights, head_dim 128,
-// M <= 16 rows of fp32 activations, RMSNorm fused in front when p->norm_gamma is set
+// the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): 16-bit or fp8 weights, head_dim
+// 128, M <= 16 rows of fp32 activations, RMSNorm fused in front when p->norm_gamma is set
 int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) {
-    SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && p->w_dtype == SM_W_BF16 && !p->vt &&
-               p->remap_in == 0, "sm_linear_qkv_rope: plain 16-bit q/k/v weights only");
+    const bool w8 = p && (p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA);
+    SM_REQUIRE(p && p->w && p->x && !p->w2 && !p->bias && !p->residual && p->act == SM_ACT_NONE && (p->w_dtype == SM_W_BF16 || w8) && !p->vt &&
+               p->remap_in == 0, "sm_linear_qkv_rope: plain q/k/v weights only");
+    SM_REQUIRE(!w8 || (p->w_scale && ((size_t)p->w_scale & 15) == 0 && p->op_dtype == SM_OP_BF16), "sm_linear_qkv_rope: fp8 weights need 16-byte aligned row scales and bf16 operands");
     SM_REQUIRE(p->M > 0 && p->M <= 16 && p->M <= SM_MAX_SEG && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0 &&
                p->N == (re.H + 2 * re.KV) * 128, "sm_linear_qkv_rope: M <= 16 fp32 rows, K %% 32 == 0, N = (H + 2 KV) * 128 (M=%d N=%d K=%d)", p->M, p->N, p->K);
     SM_REQUIRE(!p->norm_gamma || (long)p->M * p->K <= 16384, "sm_linear_qkv_rope: fused RMSNorm needs M*K <= 16384");
@@ -1066,6 +1130,16 @@ int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) 
     constexpr int WAVES = 8;
     SM_REQUIRE(a.KS >= WAVES * 4, "sm_linear_qkv_rope: K too small");
     const dim3 grid((re.H + 2 * re.KV) * 4), block(WAVES * 64);
+    if (w8) {
+        if (p->norm_gamma) {
+            const size_t sh = ((size_t)WAVES * 8 * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
+            skinny_fp8_kernel<WAVES, true, false, true, true, true><<<grid, block, sh, st>>>(a, re);
+        } else {
+            skinny_fp8_kernel<WAVES, true, false, true, false, true><<<grid, block, (size_t)WAVES * 8 * 64 * sizeof(float), st>>>(a, re);
+        }
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
     if (p->norm_gamma) {
         const size_t sh = ((size_t)WAVES * 8 * 64 + WAVES * 16) * sizeof(float) + (size_t)a.M * a.K * 2;
         if (a.f16) skinny_kernel<WAVES, true, false, true, 1, true, true, true><<<grid, block, sh, st>>>(a, re);

@@ -1059,7 +1059,7 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
         if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
         // decode: RoPE + KV append ride in the epilogue of the q/k/v product (no fp32 q/k/v round trip, one launch less per layer)
-        const bool fuse_rope = fuse_norm && dh == 128 && ld >= 1024 && !w.qkv->fp8 && !g_no_fused_rope;
+        const bool fuse_rope = fuse_norm && dh == 128 && ld >= 1024 && !g_no_fused_rope;
         {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, n, ld) : lin(m, *w.qkv, s->xnb.p, SM_X_BF16, n, ld);
             if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
             if (fuse_rope) {

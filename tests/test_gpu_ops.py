@@ -273,6 +273,28 @@ def test_skinny_linear_fp8_weights(nat, M, N, K, mode):
     assert relerr(y, ref_bf16) < 0.2
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 4096, 14336), (5, 64, 96), (16, 256, 8192), (2, 32, 32 * 37), (1, 48, 64 * 67), (3, 16, 32)])
+@pytest.mark.parametrize("x16,out16", [(True, False), (False, True)])
+def test_skinny_fp8_ring_and_vector_epilogue(nat, M, N, K, x16, out16):
+    """the decode shapes of the fp8 weight-streaming kernel: no bias, residual rows, N a multiple of 16 -- the epilogue that
+    fetches scales and residual as vectors ahead of the weights -- over chunk counts that leave every kind of tail behind
+    the register ring (fewer chunks than the ring holds, a ragged rest, an odd number of k-steps, idle waves).  Against the
+    oracle's definition, 2e-5 relative with the same single bf16 rounding of x on both sides."""
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x = rnd((M, K), 2)
+    res = rnd((M, N), 3)
+    wq, sc = nat.pack_weight_fp8(w.cuda().bfloat16())
+    wd = O.fp8_quantize_rows(w)[0]
+    xr = O.bf16_round(x)
+    xg = x.cuda().bfloat16() if x16 else xr.cuda()
+    y = nat.linear(xg, wq, N, K, w_scale=sc, residual=res.cuda(), out_dtype=torch.bfloat16 if out16 else torch.float32)
+    ref = (xr.double() @ wd.double().t() + res.double()).float()
+    if out16:
+        assert relerr(y.float(), ref) < 4e-3          # half a bf16 ulp of the largest output is 2^-8 = 3.9e-3
+    else:
+        assert relerr(y, ref) < 2e-5
+
+
 def test_skinny_dual_fp8(nat):
     M, N, K = 4, 1024, 512
     wg, wu = O.bf16_round(rnd((N, K), 1, K ** -0.5)), O.bf16_round(rnd((N, K), 2, K ** -0.5))

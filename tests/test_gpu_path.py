@@ -461,15 +461,21 @@ def test_full_size_28_frames_bf16_tower_vs_bf16_mode_oracle(fullsize):
             assert int(dec[j]) == O.gate_decision(ref[j])
 
 
-def test_full_width_llm_two_layers_prefill_and_decode():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_full_width_llm_two_layers_prefill_and_decode(fp8):
     """Mistral-7B widths (4096 / 32 q heads / 8 kv heads x 128 / MLP 14336), 2 layers, small vocab: prefill logits of a
     90-token context (text + frame tokens through the splice) and 6 greedy decode steps (flash-decoding path) against
-    the oracle in mixed precision.  Logits tolerance 3e-2 on O(1) values; ids must match where the margin is larger."""
+    the oracle in mixed precision.  Logits tolerance 3e-2 on O(1) values; ids must match where the margin is larger.
+    fp8: the same with weights_fp8 = 1 against the oracle on the dequantised weights -- at these widths the decode steps run
+    the fp8 weight-streaming kernels as the 7B model does (16-wave ring for o / down, the fused RMSNorm + q/k/v + RoPE +
+    KV-append kernel, the fused RMSNorm + SwiGLU pair)."""
     lcfg = O.LmCfg(hidden=4096, layers=2, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
     Wl = O.make_lm_weights(lcfg, 77)
     vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
     ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
-    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl, weights_fp8=fp8)
+    if fp8:
+        Wl = fp8_view(Wl)
     g = torch.Generator().manual_seed(9)
     toks = torch.randn(30, 4096, generator=g)
     text = torch.randint(3, lcfg.vocab, (60,), generator=g)
