@@ -370,24 +370,33 @@ __global__ __launch_bounds__(WAVES * 64, ROPE ? 2 : 4) void skinny_fp8_kernel(Li
     XRaw xq[D];
     f32x4 t[4], gm[4];
     if constexpr (NORM) norm_issue<WAVES>(a, wave, lane, t, gm);          // before the weights: vmcnt retires in order
-    const int first = min(nw, D);
+    int done = 0, issued, live;
+    if (nw >= 2 * D) {
+        // the ring proper.  Its own straight-line entry: with the predicated issues of the short case in front of the loop the
+        // compiler's wait-count analysis merges both entries and drains the queue (vmcnt(0)) at the top of every round
 #pragma unroll
-    for (int u = 0; u < D; ++u)
-        if (u < first) issue(u, q[u], q2[u], xq[u]);
-    if constexpr (NORM) norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
-    int done = 0, issued = first;
-    for (; issued + D <= nw; issued += D, done += D) {             // steady state: no branches, counted waits
+        for (int u = 0; u < D; ++u) issue(u, q[u], q2[u], xq[u]);
+        if constexpr (NORM) norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
+        issued = live = D;
+        for (; issued + D <= nw; issued += D, done += D) {             // steady state: no branches, counted waits
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-            consume(q[u], q2[u], xq[u], done + u);
-            issue(issued + u, q[u], q2[u], xq[u]);
-            __builtin_amdgcn_sched_barrier(0);          // or the scheduler sinks every issue behind the last consume: a batch again
+            for (int u = 0; u < D; ++u) {
+                consume(q[u], q2[u], xq[u], done + u);
+                issue(issued + u, q[u], q2[u], xq[u]);
+                __builtin_amdgcn_sched_barrier(0);          // or the scheduler sinks every issue behind the last consume: a batch again
+            }
         }
+    } else {
+        issued = live = min(nw, D);
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (u < live) issue(u, q[u], q2[u], xq[u]);
+        if constexpr (NORM) norm_finish<WAVES>(a, red + (size_t)WAVES * (DUAL ? 8 : 4) * 64, xs, wave, lane, t, gm);
     }
     const int rem = nw - issued;              // < D chunks left to issue: each takes the registers of the chunk just consumed
 #pragma unroll
     for (int u = 0; u < D; ++u)
-        if (u < first) {
+        if (u < live) {
             consume(q[u], q2[u], xq[u], done + u);
             if (u < rem) issue(issued + u, q[u], q2[u], xq[u]);
         }
