@@ -314,7 +314,10 @@ __global__ __launch_bounds__(WAVES * 64, ROPE ? 2 : 4) void skinny_fp8_kernel(Li
         if (!ROPE && a.residual && valid) res = *(const f32x4*)(a.residual + (size_t)i * a.ldr + n0);
     }
 
-    constexpr int D = (DUAL || (XF32 && !NORM)) ? 2 : 4;          // chunks (16 B per lane and matrix) in flight per wave; 128 VGPRs = 16 waves per CU
+    // chunks (16 B per lane and matrix) in flight per wave; 128 VGPRs = 16 waves per CU.  Measured on one box (Mistral-7B decode,
+    // tokens/s): 3 or 4 chunks for the dual kernel (138 / 146 VGPRs, one block per CU) 479 / 482 vs 512; 16 waves for the
+    // fused q/k/v kernel 511 vs 512
+    constexpr int D = (DUAL || (XF32 && !NORM)) ? 2 : 4;
     const int nw = wave < KSP ? (KSP - wave + WAVES - 1) / WAVES : 0;       // chunks of this wave
     bf16_t* const xs = (bf16_t*)(red + (size_t)WAVES * (DUAL ? 8 : 4) * 64 + WAVES * 16);     // NORM: normalised bf16 rows [M][K]
     // raw x of one chunk (two k-steps), fetched with the weights; NORM reads its fragments from LDS when the chunk is consumed
