@@ -446,6 +446,9 @@ __global__ __launch_bounds__(WAVES * 64, ROPE ? 2 : 4) void skinny_fp8_kernel(Li
     }
 }
 
+#ifndef SKINNY_RING
+#define SKINNY_RING 1          // 0: the batch loops of rounds 1-2 for every shape (same-box A/B with tools/build_variant.sh)
+#endif
 // ------------------------------------------------------------------------------------------------ skinny (M <= 16)
 // One block = one 16-row group of W (two groups, one per matrix, when DUAL); its WAVES waves split K (k-step
 // ks goes to wave ks % WAVES so the block walks the packed row-group contiguously, 1 KiB per wave-load) and
@@ -531,58 +534,133 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             }
         }
     };
-    if constexpr (NORM) {
-        float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;
-        f32x4 t[4], gm[4];
-        norm_issue<WAVES>(a, wave, lane, t, gm);
-        bf16x8 wa0[U], wb0[U];
-        const bool have0 = ks + (U - 1) * WAVES < KS;
-        if (have0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                wa0[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
-                if (DUAL) wb0[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+#if SKINNY_RING
+    if constexpr (MB == 1 && !SPLIT) {
+        // <= 16 rows, one rounding of x: the register ring of skinny_fp8_kernel (D k-steps of 1 KiB per matrix in flight per
+        // wave, x fragments fetched with the weights, same accumulation order as the batch loops below: bit-identical results)
+        constexpr int D = 4;
+        const int nw = wave < KS ? (KS - wave + WAVES - 1) / WAVES : 0;
+        struct XRaw { std::conditional_t<XF32, f32x4, u32x4> v[XF32 ? 2 : 1]; };
+        auto issue = [&](int c, bf16x8& q, bf16x8& q2, XRaw& x) {
+            const int kk = wave + c * WAVES;
+            q = __builtin_nontemporal_load(wp + (size_t)kk * 64);
+            if (DUAL) q2 = __builtin_nontemporal_load(wp2 + (size_t)kk * 64);
+            if constexpr (!NORM) {
+                if constexpr (XF32) {
+                    x.v[0] = *(const f32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 4);
+                    x.v[1] = *(const f32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 4 + 16);
+                } else {
+                    x.v[0] = *(const u32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 2);
+                }
             }
+        };
+        auto consume = [&](const bf16x8& q, const bf16x8& q2, const XRaw& x, int c) {
+            bf16x8 xh, xl;
+            if constexpr (NORM) {
+                xfrag(0, wave + c * WAVES, xh, xl);
+            } else if constexpr (XF32) {
+                const f32x4 z = {0, 0, 0, 0};
+                split_x<false, F16>(valid[0] ? x.v[0] : z, valid[0] ? x.v[1] : z, xh, xl);
+            } else {
+                union { bf16x8 v; u32x4 u; } r;
+                r.u = valid[0] ? x.v[0] : u32x4{0, 0, 0, 0};
+                xh = r.v;
+            }
+            acc[0] = mfma16<F16>(q, xh, acc[0]);
+            if (DUAL) acc2[0] = mfma16<F16>(q2, xh, acc2[0]);
+        };
+        bf16x8 q[D], q2[D];
+        XRaw xq[D];
+        f32x4 t[4], gm[4];
+        float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;
+        if constexpr (NORM) norm_issue<WAVES>(a, wave, lane, t, gm);
+        int done = 0, issued, live;
+        if (nw >= 2 * D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) issue(u, q[u], q2[u], xq[u]);
+            if constexpr (NORM) norm_finish<WAVES, F16>(a, nsum, xs, wave, lane, t, gm);
+            issued = live = D;
+            for (; issued + D <= nw; issued += D, done += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    consume(q[u], q2[u], xq[u], done + u);
+                    issue(issued + u, q[u], q2[u], xq[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            issued = live = min(nw, D);
+#pragma unroll
+            for (int u = 0; u < D; ++u)
+                if (u < live) issue(u, q[u], q2[u], xq[u]);
+            if constexpr (NORM) norm_finish<WAVES, F16>(a, nsum, xs, wave, lane, t, gm);
         }
-        norm_finish<WAVES, F16>(a, nsum, xs, wave, lane, t, gm);
-        if (have0) { mfmas(wa0, wb0, ks); ks += U * WAVES; }
-    }
-    for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
-        bf16x8 wa[U], wb[U];
+        const int rem = nw - issued;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            wa[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
-            if (DUAL) wb[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+        for (int u = 0; u < D; ++u)
+            if (u < live) {
+                consume(q[u], q2[u], xq[u], done + u);
+                if (u < rem) issue(issued + u, q[u], q2[u], xq[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < D - 1; ++u)
+            if (u < rem) consume(q[u], q2[u], xq[u], issued + u);
+    } else
+#endif
+    {
+        if constexpr (NORM) {
+            float* nsum = red + (size_t)WAVES * (DUAL ? 8 : 4) * 64;
+            f32x4 t[4], gm[4];
+            norm_issue<WAVES>(a, wave, lane, t, gm);
+            bf16x8 wa0[U], wb0[U];
+            const bool have0 = ks + (U - 1) * WAVES < KS;
+            if (have0) {
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    wa0[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
+                    if (DUAL) wb0[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+                }
+            }
+            norm_finish<WAVES, F16>(a, nsum, xs, wave, lane, t, gm);
+            if (have0) { mfmas(wa0, wb0, ks); ks += U * WAVES; }
         }
-        if constexpr (NORM) { mfmas(wa, wb, ks); continue; }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            bf16x8 xh[U], xl[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) load_x<XF32, SPLIT, F16>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
-#pragma unroll
+        for (; ks + (U - 1) * WAVES < KS; ks += U * WAVES) {
+            bf16x8 wa[U], wb[U];
+    #pragma unroll
             for (int u = 0; u < U; ++u) {
-                acc[mb] = mfma16<F16>(wa[u], xh[u], acc[mb]);
-                if (SPLIT) acc[mb] = mfma16<F16>(wa[u], xl[u], acc[mb]);
-                if (DUAL) {
-                    acc2[mb] = mfma16<F16>(wb[u], xh[u], acc2[mb]);
-                    if (SPLIT) acc2[mb] = mfma16<F16>(wb[u], xl[u], acc2[mb]);
+                wa[u] = __builtin_nontemporal_load(wp + (size_t)(ks + u * WAVES) * 64);
+                if (DUAL) wb[u] = __builtin_nontemporal_load(wp2 + (size_t)(ks + u * WAVES) * 64);
+            }
+            if constexpr (NORM) { mfmas(wa, wb, ks); continue; }
+    #pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bf16x8 xh[U], xl[U];
+    #pragma unroll
+                for (int u = 0; u < U; ++u) load_x<XF32, SPLIT, F16>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
+    #pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    acc[mb] = mfma16<F16>(wa[u], xh[u], acc[mb]);
+                    if (SPLIT) acc[mb] = mfma16<F16>(wa[u], xl[u], acc[mb]);
+                    if (DUAL) {
+                        acc2[mb] = mfma16<F16>(wb[u], xh[u], acc2[mb]);
+                        if (SPLIT) acc2[mb] = mfma16<F16>(wb[u], xl[u], acc2[mb]);
+                    }
                 }
             }
         }
-    }
-    for (; ks < KS; ks += WAVES) {
-        bf16x8 wa = __builtin_nontemporal_load(wp + (size_t)ks * 64), wb;
-        if (DUAL) wb = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            bf16x8 xh, xl;
-            xfrag(mb, ks, xh, xl);
-            acc[mb] = mfma16<F16>(wa, xh, acc[mb]);
-            if (SPLIT) acc[mb] = mfma16<F16>(wa, xl, acc[mb]);
-            if (DUAL) {
-                acc2[mb] = mfma16<F16>(wb, xh, acc2[mb]);
-                if (SPLIT) acc2[mb] = mfma16<F16>(wb, xl, acc2[mb]);
+        for (; ks < KS; ks += WAVES) {
+            bf16x8 wa = __builtin_nontemporal_load(wp + (size_t)ks * 64), wb;
+            if (DUAL) wb = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+    #pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bf16x8 xh, xl;
+                xfrag(mb, ks, xh, xl);
+                acc[mb] = mfma16<F16>(wa, xh, acc[mb]);
+                if (SPLIT) acc[mb] = mfma16<F16>(wa, xl, acc[mb]);
+                if (DUAL) {
+                    acc2[mb] = mfma16<F16>(wb, xh, acc2[mb]);
+                    if (SPLIT) acc2[mb] = mfma16<F16>(wb, xl, acc2[mb]);
+                }
             }
         }
     }
