@@ -2,6 +2,7 @@
 # End-of-round measurement set (run on the GPU box via gpurun): full GPU test suite, default bench line, rocprofv3 kernel
 # stats of the same command, PMC traffic passes.  Summaries land in gpurun_out/round/ -- copy what is to be judged to profiles/.
 set -u
+ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round; mkdir -p $O
 timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
@@ -20,6 +21,9 @@ cp "$(find /tmp/prof_stats1 -name '*kernel_stats.csv' | head -1)" $O/kernel_stat
 # the decode step on its own (Mistral-7B, 64 tokens after a 328-token prefill)
 rm -rf /tmp/prof_dec; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -- python tools/decode_bench.py 64 1024 > $O/decode_profiled.log 2>&1
 cp "$(find /tmp/prof_dec -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_decode.csv
+# ... and with fp8 weights (weight-only mode, FP8=1)
+rm -rf /tmp/prof_dec8; FP8=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec8 -- python tools/decode_bench.py 64 1024 > $O/decode_fp8_profiled.log 2>&1
+cp "$(find /tmp/prof_dec8 -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_decode_fp8.csv
 rm -rf /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
