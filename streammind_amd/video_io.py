@@ -4,7 +4,7 @@ callers use, and the streaming sampler `read_video_stream` (eval/video_score_str
 The reference decodes on the CPU with decord (one thread, video_score_stream_demo.py:218; mm_utils.py:419), imageio (.gif,
 mm_utils.py:400-407) or moviepy (.webm, :409-418).  None of them -- nor ffmpeg, OpenCV, PyAV, rocDecode -- exists in this
 image, so the codec is an ADAPTOR: `open_video` serves what can be decoded with what is here (frame arrays, .npy / .npz,
-directories of still images, multi-frame .gif / .tiff / .webp through PIL) and hands every other container to whichever of
+directories of still images, multi-frame .gif / .tiff / .webp through PIL, Motion-JPEG .avi through a RIFF walk + PIL) and hands every other container to whichever of
 decord / cv2 / imageio the deployment has installed.  Everything after the decoder (sampling, expand2square, PIL-exact
 resize, centre crop, normalisation) is this build's own and runs on the GPU (`mm_utils.process_video`, `sm_ingest_frames`).
 
@@ -101,6 +101,100 @@ class PilMultiFrameVideo(ArrayVideo):
         super().__init__(frames, fps)
 
 
+class MjpegAviVideo:
+    """Motion-JPEG in an AVI (RIFF) container -- what capture cards and many cameras write -- read without a codec library: the
+    RIFF chunk walk is done here and every frame is a baseline JPEG that PIL decodes (lazily, random access through the chunk
+    table).  Frames stored without Huffman tables (the `AVI1` convention: tables implied) get the standard JPEG tables spliced
+    in before decoding.  fps = dwRate / dwScale of the video stream header, else 1e6 / dwMicroSecPerFrame.  Anything that is
+    not MJPG raises, so `open_video` falls through to the installed decoders."""
+
+    _std_dht = None
+
+    def __init__(self, path: str):
+        import struct
+        with open(path, "rb") as f:
+            data = f.read()
+        if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+            raise ValueError(f"{path}: not a RIFF AVI file")
+        self._data = data
+        self._frames: List[Tuple[int, int]] = []          # (offset, size) of every video chunk, in stream order
+        self.fps = 0.0
+        handler = compression = None
+        usec = 0
+
+        def walk(lo: int, hi: int):
+            nonlocal handler, compression, usec
+            pos = lo
+            while pos + 8 <= hi:
+                cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
+                body = pos + 8
+                if cid == b"LIST":
+                    if data[body:body + 4] in (b"hdrl", b"strl", b"movi", b"rec "):
+                        walk(body + 4, min(body + size, hi))
+                elif cid == b"avih" and size >= 4:
+                    usec = struct.unpack_from("<I", data, body)[0]
+                elif cid == b"strh" and size >= 28 and data[body:body + 4] == b"vids" and handler is None:
+                    handler = data[body + 4:body + 8]
+                    scale, rate = struct.unpack_from("<II", data, body + 20)
+                    if scale and rate:
+                        self.fps = rate / scale
+                elif cid == b"strf" and size >= 20 and compression is None and handler is not None:
+                    compression = data[body + 16:body + 20]
+                elif cid[2:4] in (b"dc", b"db") and cid[:2].isdigit() and size > 0:
+                    self._frames.append((body, size))
+                pos = body + size + (size & 1)                # chunks are word aligned
+
+        walk(12, len(data))
+        tags = {t.upper() for t in (handler, compression) if t}
+        if not tags & {b"MJPG", b"JPEG", b"AVRN", b"LJPG"} or not self._frames:
+            raise ValueError(f"{path}: AVI video stream is {handler!r}/{compression!r}, not Motion-JPEG")
+        if not self.fps:
+            self.fps = 1e6 / usec if usec else 30.0
+
+    @classmethod
+    def _standard_tables(cls) -> bytes:
+        """the DHT segments of the standard (ITU T.81 Annex K) Huffman tables, taken from a JPEG libjpeg writes with its defaults"""
+        if cls._std_dht is None:
+            import io
+            from PIL import Image
+            buf = io.BytesIO()
+            Image.new("RGB", (16, 16), (120, 60, 200)).save(buf, "JPEG", quality=75, optimize=False)
+            b, pos, out = buf.getvalue(), 2, b""
+            while pos + 4 <= len(b) and b[pos] == 0xFF and b[pos + 1] != 0xDA:
+                seg = 2 + int.from_bytes(b[pos + 2:pos + 4], "big")
+                if b[pos + 1] == 0xC4:
+                    out += b[pos:pos + seg]
+                pos += seg
+            cls._std_dht = out
+        return cls._std_dht
+
+    def _jpeg(self, i: int) -> bytes:
+        off, size = self._frames[int(i)]
+        j = self._data[off:off + size]
+        sos = j.find(b"\xff\xda")
+        if sos > 0 and j.find(b"\xff\xc4", 0, sos) < 0:         # no DHT before the scan: tables implied
+            j = j[:sos] + self._standard_tables() + j[sos:]
+        return j
+
+    def __len__(self) -> int:
+        return len(self._frames)
+
+    def get_avg_fps(self) -> float:
+        return float(self.fps)
+
+    def _load(self, i: int) -> np.ndarray:
+        import io
+        from PIL import Image
+        with Image.open(io.BytesIO(self._jpeg(i))) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def __getitem__(self, i) -> _Frames:
+        return _Frames(self._load(i))
+
+    def get_batch(self, ids: Sequence[int]) -> _Frames:
+        return _Frames(np.stack([self._load(i) for i in ids]))
+
+
 class _DecordVideo:
     def __init__(self, path: str):
         from decord import VideoReader, cpu
@@ -164,6 +258,11 @@ def open_video(src, fps: float | None = None):
     if low.endswith((".gif", ".tif", ".tiff", ".webp")):
         return PilMultiFrameVideo(src)
     errors: List[str] = []
+    if low.endswith(".avi"):
+        try:
+            return MjpegAviVideo(src)                           # Motion-JPEG: decodable with what this image has (RIFF walk + PIL)
+        except ValueError as e:
+            errors.append(f"built-in MJPEG reader: {e}")
     for name, cls in (("decord", _DecordVideo), ("cv2", _Cv2Video), ("imageio", _ImageioVideo)):
         try:
             return cls(src)

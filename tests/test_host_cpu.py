@@ -193,6 +193,74 @@ def test_read_video_stream_and_process_video_paths_vs_reference_golden(tmp_path,
         video_io.open_video(str(tmp_path / "movie.mp4"))
 
 
+def _write_mjpeg_avi(path, jpegs, w, h, rate, scale, handler=b"MJPG"):
+    """a minimal RIFF AVI: hdrl (avih + one vids stream) and a movi list of 00dc chunks, word aligned, with an idx1 behind it"""
+    import struct
+
+    def chunk(cid, body):
+        return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+    def lst(kind, body):
+        return b"LIST" + struct.pack("<I", len(body) + 4) + kind + body
+
+    avih = struct.pack("<14I", int(1e6 * scale / rate), 0, 0, 0x10, len(jpegs), 0, 1, 0, w, h, 0, 0, 0, 0)
+    strh = b"vids" + handler + struct.pack("<IHHIIIIIIII", 0, 0, 0, 0, scale, rate, 0, len(jpegs), 0, 0, 0) + struct.pack("<4h", 0, 0, w, h)
+    strf = struct.pack("<IiiHH", 40, w, h, 1, 24) + handler + struct.pack("<IiiII", w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi = lst(b"movi", b"".join(chunk(b"00dc", j) for j in jpegs))
+    idx1 = chunk(b"idx1", b"".join(struct.pack("<4sIII", b"00dc", 0x10, 0, len(j)) for j in jpegs))
+    body = b"AVI " + hdrl + movi + idx1
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_mjpeg_avi_is_read_without_a_codec_library(tmp_path):
+    """f2: a Motion-JPEG AVI (the one real container this image can decode: RIFF walk here, baseline JPEG through PIL) behind
+    the decord surface the streaming loop uses -- frame count, fps = dwRate / dwScale, random access, and the sampler on top;
+    frames written WITHOUT Huffman tables (the AVI1 convention) decode to the same pixels as with them; an AVI holding
+    another codec falls through to the installed decoders (none here: ImportError naming the reason)."""
+    import io
+    from PIL import Image
+    from streammind_amd import video_io
+    n, w, h = 13, 48, 32
+    rng = np.random.default_rng(5)
+    base = np.kron(rng.integers(0, 255, (4, 6, 3)), np.ones((8, 8, 1))).astype(np.uint8)          # blocky: survives JPEG closely
+    frames, jpegs, bare = [], [], []
+    for j in range(n):
+        fr = np.clip(base.astype(int) + 9 * j, 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(fr).save(buf, "JPEG", quality=95, optimize=False, subsampling=0)
+        b = buf.getvalue()
+        frames.append(fr); jpegs.append(b)
+        out, pos = b[:2], 2                                   # the same frame with its DHT segments stripped
+        while b[pos + 1] != 0xDA:
+            seg = 2 + int.from_bytes(b[pos + 2:pos + 4], "big")
+            if b[pos + 1] != 0xC4:
+                out += b[pos:pos + seg]
+            pos += seg
+        bare.append(out + b[pos:])
+        assert b"\xff\xc4" not in bare[-1][:bare[-1].find(b"\xff\xda")]
+    _write_mjpeg_avi(tmp_path / "cam.avi", jpegs, w, h, 30000, 1001)
+    _write_mjpeg_avi(tmp_path / "cam_bare.avi", bare, w, h, 25, 1)
+    vr = video_io.open_video(str(tmp_path / "cam.avi"))
+    assert isinstance(vr, video_io.MjpegAviVideo) and len(vr) == n and abs(vr.get_avg_fps() - 30000 / 1001) < 1e-9
+    ref = [np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in jpegs]
+    for j in (0, 7, n - 1, 3):
+        got = vr[j].asnumpy()
+        assert got.shape == (h, w, 3) and np.array_equal(got, ref[j]) and np.abs(got.astype(int) - frames[j]).max() <= 6
+    assert np.array_equal(vr.get_batch([1, 5, 9]).asnumpy(), np.stack([ref[1], ref[5], ref[9]]))
+    vb = video_io.open_video(str(tmp_path / "cam_bare.avi"))
+    assert len(vb) == n and vb.get_avg_fps() == 25.0
+    for j in range(n):
+        assert np.array_equal(vb[j].asnumpy(), ref[j])
+    ids, _ = video_io.read_video_stream(str(tmp_path / "cam_bare.avi"), 5)
+    assert ids.tolist() == list(range(0, n - 1, 5))
+    assert [fid for fid, _ in video_io.stream_frames(str(tmp_path / "cam_bare.avi"), 5)] == ids.tolist()
+    _write_mjpeg_avi(tmp_path / "h264.avi", jpegs, w, h, 25, 1, handler=b"H264")
+    with pytest.raises(ImportError, match="not Motion-JPEG"):
+        video_io.open_video(str(tmp_path / "h264.avi"))
+
+
 def test_loader_rejects_configs_the_kernels_do_not_implement():
     """path_config_from_checkpoint: a config.json that asks for something the kernels hard-wire differently (activation, tied
     embeddings, projection biases, rope scaling, a foreign head_dim) must raise, not load and compute something else."""
