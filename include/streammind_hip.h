@@ -31,6 +31,7 @@ extern "C" {
 #define SM_ACT_LEAKY_RELU 2 /* F.leaky_relu slope 0.01: PreNet/PostNet builder.py:168,178      */
 #define SM_ACT_SOFTPLUS 3   /* F.softplus on dt: mamba_simple.py:238                           */
 #define SM_ACT_SILU 4
+#define SM_ACT_GELU 5       /* nn.GELU() exact (erf): build_mlp of the STC readout builder.py:566-571 */
 
 #define SM_X_BF16 0
 #define SM_X_F32 1
@@ -167,6 +168,18 @@ int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, float* conv_s
 int sm_mamba_ssm_step(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank,
                       const float* xz, int M, int di, int d_state, const float* A_log, const float* Dp,
                       float* ssm_state, float* y, void* stream);
+/* STC connector pieces (builder.py:574-749, the stock VideoLLaMA2 projector; timm RegStage Bottleneck = 1x1 conv -> depthwise 3x3 ->
+ * squeeze-excite -> 1x1 conv, LayerNorm2d + SiLU).  Position-major ("NHWC") rows: 1x1 convolutions are sm_linear, LayerNorm2d is
+ * sm_norm over the channels of a row; these four are the rest (stc.hip).
+ * depthwise 3x3, stride 1, zero padding 1, no bias: x fp32 [F][H][W][C], w fp32 [9][C] tap-major ((dy+1)*3 + dx+1) -> out fp32 */
+int sm_dwconv3x3_nhwc(const float* x, int F, int H, int W, int C, const float* w_tap_major, float* out, void* stream);
+/* SEModule tail: out[r][c] = x[r][c] * sigmoid(gate_logits[r / P][c]), rows r < F*P; 16-bit (op_dtype) and / or fp32 output */
+int sm_se_scale(const float* x, const float* gate_logits, int F, int P, int C, void* out_16, float* out_f32, int op_dtype, void* stream);
+/* Bottleneck tail: out = act(a + b) over n fp32 elements (n %% 4 == 0), SM_ACT_*; 16-bit (op_dtype) and / or fp32 output */
+int sm_add_act(const float* a, const float* b, size_t n, int act, float* out_f32, void* out_16, int op_dtype, void* stream);
+/* nn.Conv3d(kernel = stride = (kt,kh,kw), padding = pad) as a GEMM (builder.py:608-617): 16-bit x [B][T][H][W][C] -> 16-bit rows
+ * [B*To*Ho*Wo][kt*kh*kw*C], column (((dt*kh)+dy)*kw+dx)*C + c, zeros in the padding; To = (T + 2 pad - kt)/kt + 1 etc. */
+int sm_conv3d_patches(const void* x_16, int B, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* out_16, void* stream);
 /* repeat_kv for the seq-len-1 gate shortcut: v fp32 [M][KV*dh] -> out fp32 [M][H*dh], head h <- h/(H/KV) */
 int sm_repeat_kv(const float* v, int M, int KV, int H, int dh, float* out, void* stream);
 /* a9 (videollama2_arch.py:938-941): decision[m] = argmax(softmax(logits[m][0:2])), ties -> 0          */

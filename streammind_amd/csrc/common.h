@@ -107,6 +107,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case 2: return v >= 0.f ? v : 0.01f * v;                          // leaky_relu, slope 0.01
         case 3: return v > 20.f ? v : log1pf(__expf(v));                  // softplus (beta 1, threshold 20)
         case 4: return siluf_(v);
+        case 5: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // nn.GELU() (exact, erf): STC readout builder.py:566-571
         default: return v;
     }
 }
