@@ -180,6 +180,10 @@ int sm_add_act(const float* a, const float* b, size_t n, int act, float* out_f32
 /* nn.Conv3d(kernel = stride = (kt,kh,kw), padding = pad) as a GEMM (builder.py:608-617): 16-bit x [B][T][H][W][C] -> 16-bit rows
  * [B*To*Ho*Wo][kt*kh*kw*C], column (((dt*kh)+dy)*kw+dx)*C + c, zeros in the padding; To = (T + 2 pad - kt)/kt + 1 etc. */
 int sm_conv3d_patches(const void* x_16, int B, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* out_16, void* stream);
+/* nn.AvgPool3d(kernel = stride = (kt,kh,kw)) + SM_ACT_* (STPConnector / SpatialPool sampler, builder.py:751-758,790-796): x fp32
+ * [B][T][H][W][C] -> [B][T/kt][H/kh][W/kw][C] (floor), fp32 and / or 16-bit (op_dtype) */
+int sm_avgpool3d_nhwc(const float* x, int B, int T, int H, int W, int C, int kt, int kh, int kw, int act, float* out_f32, void* out_16,
+                      int op_dtype, void* stream);
 /* repeat_kv for the seq-len-1 gate shortcut: v fp32 [M][KV*dh] -> out fp32 [M][H*dh], head h <- h/(H/KV) */
 int sm_repeat_kv(const float* v, int M, int KV, int H, int dh, float* out, void* stream);
 /* a9 (videollama2_arch.py:938-941): decision[m] = argmax(softmax(logits[m][0:2])), ties -> 0          */

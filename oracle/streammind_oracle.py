@@ -1003,6 +1003,138 @@ def clip_frame_indices(duration: int, local_fps: float, num_frames: int, scheme:
 
 
 # ----------------------------------------------------------------------------------------------
+# STC connector (the stock VideoLLaMA2 projector, builder.py:574-749)
+# ----------------------------------------------------------------------------------------------
+# PARITY STATUS.  The reference class is built from timm.models.regnet.RegStage (timm==1.0.11, requirements.txt:341), which is
+# NOT in /root/reference and not installed here.  What follows restates (a) the reference's own code -- the rearranges, the
+# Conv3d(k = s = downsample, padding 1) + SiLU sampler, the readout MLP (builder.py:566-571,583-653) -- which IS pinned by golden
+# g17 (the reference class itself, instantiated with depth = 0 so that no timm object is needed, make_golden.py), and (b) timm's
+# published RegStage / Bottleneck / SEModule / LayerNormAct2d algorithm, "PARITY UNPINNED": no golden vector can be minted for
+# it in this image.  Restated from timm 1.0.x regnet.py:
+#   RegStage(depth, in, out, stride 1): blocks b1..b{depth}; b1 maps in -> out, the rest out -> out
+#   Bottleneck (defaults bottle_ratio 1, group_size 1, se_ratio 0.25, downsample 'conv1x1', linear_out False):
+#     conv1 = 1x1 conv (no bias) -> LayerNorm over channels -> act          (in -> out)
+#     conv2 = 3x3 conv, groups = channels (depthwise), padding 1 (no bias) -> LayerNorm -> act
+#     se    = x * sigmoid(fc2(act(fc1(mean_hw(x)))))  with fc1: out -> round(in_chs * 0.25), biases, the stage's act
+#     conv3 = 1x1 conv (no bias) -> LayerNorm (no act)
+#     shortcut = 1x1 conv (no bias) -> LayerNorm when in != out, identity otherwise;  y = act(conv3 + shortcut)
+#   LayerNorm2d handed to ConvNormAct becomes LayerNormAct2d: affine, eps 1e-5, normalising the channel vector of each position.
+# State-dict names are timm's (s1.b1.conv1.conv.weight, .conv1.bn.weight/.bias, .se.fc1.weight/.bias, .downsample.conv.weight ...).
+
+@dataclass
+class StcCfg:
+    mm_hidden: int = 1024            # config.mm_hidden_size (CLIP width)
+    hidden: int = 4096               # config.hidden_size
+    depth: int = 4                   # RegStage depth (builder.py:575 default)
+    mlp_depth: int = 2               # readout layers (build_mlp)
+    downsample: Tuple[int, int, int] = (2, 2, 2)
+    ln_eps: float = 1e-5             # timm LayerNormAct2d default
+    sampler: str = "conv"            # "conv": Conv3d + SiLU (STCConnector; pad 0 = STCConnectorV35), "pool": AvgPool3d + SiLU (STPConnector)
+    pad: int = 1
+
+
+def stc_weight_shapes(cfg: StcCfg) -> Dict[str, Tuple[int, ...]]:
+    shp: Dict[str, Tuple[int, ...]] = {}
+    for stage, cin in (("s1", cfg.mm_hidden), ("s2", cfg.hidden)):
+        for i in range(cfg.depth):
+            bi = cin if i == 0 else cfg.hidden
+            p = f"{stage}.b{i + 1}."
+            rd = int(round(bi * 0.25))
+            shp[p + "conv1.conv.weight"] = (cfg.hidden, bi, 1, 1)
+            shp[p + "conv2.conv.weight"] = (cfg.hidden, 1, 3, 3)
+            shp[p + "conv3.conv.weight"] = (cfg.hidden, cfg.hidden, 1, 1)
+            for c in ("conv1", "conv2", "conv3"):
+                shp[p + c + ".bn.weight"] = (cfg.hidden,)
+                shp[p + c + ".bn.bias"] = (cfg.hidden,)
+            shp[p + "se.fc1.weight"] = (rd, cfg.hidden, 1, 1)
+            shp[p + "se.fc1.bias"] = (rd,)
+            shp[p + "se.fc2.weight"] = (cfg.hidden, rd, 1, 1)
+            shp[p + "se.fc2.bias"] = (cfg.hidden,)
+            if bi != cfg.hidden:
+                shp[p + "downsample.conv.weight"] = (cfg.hidden, bi, 1, 1)
+                shp[p + "downsample.bn.weight"] = (cfg.hidden,)
+                shp[p + "downsample.bn.bias"] = (cfg.hidden,)
+    if cfg.sampler == "conv":
+        shp["sampler.0.weight"] = (cfg.hidden, cfg.hidden) + tuple(cfg.downsample)   # depth 0 (s1 = nn.Identity) therefore needs mm_hidden == hidden
+        shp["sampler.0.bias"] = (cfg.hidden,)
+    shp["readout.0.weight"] = (cfg.hidden, cfg.hidden)
+    shp["readout.0.bias"] = (cfg.hidden,)
+    for j in range(1, cfg.mlp_depth):
+        shp[f"readout.{2 * j}.weight"] = (cfg.hidden, cfg.hidden)
+        shp[f"readout.{2 * j}.bias"] = (cfg.hidden,)
+    return shp
+
+
+def make_stc_weights(cfg: StcCfg, seed: int) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+    for n, shp in stc_weight_shapes(cfg).items():
+        if n.endswith("bn.weight"):
+            W[n] = bf16_round(1.0 + 0.1 * torch.randn(*shp, generator=g))
+        elif n.endswith("bias"):
+            W[n] = _randn(g, shp, 0.05)
+        elif "conv2" in n:
+            W[n] = _randn(g, shp, 0.3)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            W[n] = _randn(g, shp, fan_in ** -0.5)
+    return W
+
+
+def _ln2d(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    """LayerNorm over the channel vector of every position of x [N, C, H, W] (timm LayerNorm2d / LayerNormAct2d)"""
+    return torch.nn.functional.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+
+
+def stc_bottleneck(x: Tensor, W: Dict[str, Tensor], p: str, cfg: StcCfg, prec: Prec = FP32) -> Tensor:
+    """one timm regnet Bottleneck on x [N, Cin, H, W] (see the block comment above)"""
+    Fn = torch.nn.functional
+    C = W[p + "conv1.conv.weight"].shape[0]
+    short = x
+    y = silu(_ln2d(Fn.conv2d(prec.act(x), W[p + "conv1.conv.weight"]), W[p + "conv1.bn.weight"], W[p + "conv1.bn.bias"], cfg.ln_eps))
+    y = silu(_ln2d(Fn.conv2d(y, W[p + "conv2.conv.weight"], padding=1, groups=C), W[p + "conv2.bn.weight"], W[p + "conv2.bn.bias"], cfg.ln_eps))
+    z = y.mean((2, 3), keepdim=True)
+    z = silu(Fn.conv2d(z, W[p + "se.fc1.weight"], W[p + "se.fc1.bias"]))
+    z = Fn.conv2d(z, W[p + "se.fc2.weight"], W[p + "se.fc2.bias"])
+    y = y * torch.sigmoid(z)
+    y = _ln2d(Fn.conv2d(prec.act(y), W[p + "conv3.conv.weight"]), W[p + "conv3.bn.weight"], W[p + "conv3.bn.bias"], cfg.ln_eps)
+    if p + "downsample.conv.weight" in W:
+        short = _ln2d(Fn.conv2d(prec.act(x), W[p + "downsample.conv.weight"]), W[p + "downsample.bn.weight"], W[p + "downsample.bn.bias"], cfg.ln_eps)
+    return silu(y + short)
+
+
+def stc_forward(x: Tensor, W: Dict[str, Tensor], cfg: StcCfg, prec: Prec = FP32) -> Tensor:
+    """STCConnector.forward without the classifier branches (builder.py:630-653): x [B, T, L, D] (L a square number of patch
+    tokens) -> tokens [B, T' * H' * W', hidden]; T' = (T + 2 pad - kt) // kt + 1 and likewise for the grid (Conv3d), T // kt for the pooling sampler.
+    prec = MIXED rounds the operand of every GEMM-shaped product (1x1 convolutions, Conv3d, readout) to bf16, as the HIP path does;
+    the small squeeze-excite products and everything pointwise stay fp32."""
+    Fn = torch.nn.functional
+    B, T, L, D = x.shape
+    hw = int(L ** 0.5)
+    y = x.reshape(B * T, hw, hw, D).permute(0, 3, 1, 2).to(F32)                  # "(b t) d h w"
+    for i in range(cfg.depth):
+        y = stc_bottleneck(y, W, f"s1.b{i + 1}.", cfg, prec)
+    C = y.shape[1]
+    y = y.reshape(B, T, C, hw, hw).permute(0, 2, 1, 3, 4)                         # "b d t h w"
+    if cfg.sampler == "conv":
+        y = silu(Fn.conv3d(prec.act(y), W["sampler.0.weight"], W["sampler.0.bias"], stride=tuple(cfg.downsample), padding=cfg.pad))
+    else:
+        y = silu(Fn.avg_pool3d(y, tuple(cfg.downsample)))                         # builder.py:757
+    nt, nh, nw = y.shape[2:]
+    y = y.permute(0, 2, 1, 3, 4).reshape(B * nt, C, nh, nw)
+    for i in range(cfg.depth):
+        y = stc_bottleneck(y, W, f"s2.b{i + 1}.", cfg, prec)
+    y = y.reshape(B, nt, C, nh * nw).permute(0, 1, 3, 2).reshape(B, nt * nh * nw, C)   # "b (t h w) d"
+    y = linear(prec.act(y), W["readout.0.weight"], W["readout.0.bias"])
+    for j in range(1, cfg.mlp_depth):
+        y = Fn.gelu(y)                                                            # nn.GELU() default: exact erf form
+        y = linear(prec.act(y), W[f"readout.{2 * j}.weight"], W[f"readout.{2 * j}.bias"])
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
 # seeded synthetic weights / frames (shared by tests, smoke and bench -- plain torch CPU generator)
 # ----------------------------------------------------------------------------------------------
 

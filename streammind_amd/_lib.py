@@ -75,6 +75,7 @@ SIGNATURES = {
     "sm_se_scale": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, vp]),
     "sm_add_act": (i32, [vp, vp, sz, i32, vp, vp, i32, vp]),
     "sm_conv3d_patches": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sm_avgpool3d_nhwc": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "sm_gate_decide": (i32, [vp, i32, vp, vp]),
     "sm_embed_splice": (i32, [vp, i32, vp, vp, i32, vp, vp]),
     "sm_rope_kv_append": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),

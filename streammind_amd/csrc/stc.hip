@@ -123,3 +123,41 @@ extern "C" int sm_conv3d_patches(const void* x_16, int B, int T, int H, int W, i
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
+
+// nn.AvgPool3d(kernel = stride = (kt, kh, kw)) + activation (STPConnector / SpatialPool sampler, builder.py:751-758,790-796):
+// x fp32 [B][T][H][W][C] -> act(mean over each kt x kh x kw block) as fp32 and / or 16-bit [B][T/kt][H/kh][W/kw][C] (floor: a ragged
+// border is dropped, as PyTorch does without ceil_mode)
+__global__ __launch_bounds__(256) void avgpool3d_kernel(const float* __restrict__ x, int T, int H, int W, int C, int kt, int kh, int kw, int To, int Ho,
+                                                         int Wo, int act, float* __restrict__ o32, bf16_t* __restrict__ o16, int f16, size_t total4) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int c4 = C >> 2;
+    const int c = (int)(t % c4) * 4;
+    const size_t r = t / c4;
+    const int wo = (int)(r % Wo), ho = (int)((r / Wo) % Ho), to = (int)((r / ((size_t)Wo * Ho)) % To);
+    const size_t b = r / ((size_t)Wo * Ho * To);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int dt = 0; dt < kt; ++dt)
+        for (int dy = 0; dy < kh; ++dy)
+            for (int dx = 0; dx < kw; ++dx) {
+                const f32x4 v = *(const f32x4*)(x + ((((b * T + to * kt + dt) * H + ho * kh + dy) * W + wo * kw + dx) * (size_t)C + c));
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+    const float inv = 1.0f / (float)(kt * kh * kw);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = apply_act(acc[j] * inv, act);
+    if (o32) *(f32x4*)(o32 + r * (size_t)C + c) = o;
+    if (o16) *(u32x2*)(o16 + r * (size_t)C + c) = u32x2{pack16_rt(o[0], o[1], f16), pack16_rt(o[2], o[3], f16)};
+}
+extern "C" int sm_avgpool3d_nhwc(const float* x, int B, int T, int H, int W, int C, int kt, int kh, int kw, int act, float* out_f32, void* out_16,
+                                 int op_dtype, void* stream) {
+    SM_REQUIRE(x && (out_f32 || out_16) && B > 0 && C > 0 && (C & 3) == 0 && kt > 0 && kh > 0 && kw > 0 && T >= kt && H >= kh && W >= kw,
+               "sm_avgpool3d_nhwc: bad args (C %% 4 == 0, at least one full block per axis)");
+    const int To = T / kt, Ho = H / kh, Wo = W / kw;
+    const size_t total4 = (size_t)B * To * Ho * Wo * (C >> 2);
+    avgpool3d_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, T, H, W, C, kt, kh, kw, To, Ho, Wo, act, out_f32, (bf16_t*)out_16,
+                                                                                      op_dtype == SM_OP_F16, total4);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}

@@ -416,7 +416,7 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
            w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
            norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
-           out: Optional[torch.Tensor] = None, fp8_mfma: bool = False) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, fp8_mfma: bool = False, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front.
     fp8_mfma (with w_scale): SM_W_FP8_MFMA -- above 16 rows the activations are quantised per row and the product is fp8 x fp8."""
     lib = _lib.load()
@@ -449,7 +449,11 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     out_dtype = out.dtype
     if out_dtype == torch.float32:
         a.out_f32, a.ldo = out.data_ptr(), N
+        if out16 is not None:        # the same result also as a 16-bit copy (operand of the next product) from the same epilogue
+            assert out16.shape == out.shape and out16.dtype == (torch.float16 if a_f16 else torch.bfloat16) and out16.is_contiguous()
+            a.out_bf16, a.ldo_bf16 = out16.data_ptr(), N
     else:
+        assert out16 is None
         a.out_bf16, a.ldo_bf16 = out.data_ptr(), N
     check(lib.sm_linear(C.byref(a), _stream()), "sm_linear")
     return out

@@ -221,6 +221,45 @@ def test_eval_metrics_equal_the_reference_script(gold):
             assert abs(r[k] - v) < 1e-5 * max(1.0, abs(v)), (i, k, r[k], v)
 
 
+def stc_cfg_from_golden(g, i):
+    c = json.loads(str(g[f"cfg{i}"]))
+    cfg = O.StcCfg(mm_hidden=c["mm_hidden"], hidden=c["hidden"], depth=0, mlp_depth=c["mlp_depth"], downsample=tuple(c["downsample"]),
+                   sampler=c["sampler"], pad=c["pad"])
+    return c, cfg
+
+
+def test_g17_stc_sampler_and_readout_vs_reference(gold):
+    """golden g17 = the reference's own STCConnector / STCConnectorV35 / STPConnector / SpatialConv / SpatialPool classes run at
+    depth 0 (builder.py:574-796; no timm object involved): the oracle's rearranges, Conv3d / AvgPool3d sampler and GELU readout
+    reproduce their tokens.  The RegStage half of the oracle is a restatement of timm and stays "parity unpinned"."""
+    g = gold("g17_stc_connector")
+    for i in range(int(g["n"])):
+        c, cfg = stc_cfg_from_golden(g, i)
+        W = O.make_stc_weights(cfg, c["seed"])
+        out = O.stc_forward(torch.from_numpy(g[f"x{i}"]), W, cfg)
+        assert tuple(out.shape) == tuple(g[f"ref{i}"].shape), c
+        close(g[f"ref{i}"], out, 2e-5)
+
+
+def test_stc_oracle_regstage_structure():
+    """the restated timm stage: shapes, the state-dict names a stock VideoLLaMA2 checkpoint uses, the shortcut rule (1x1 conv + LN
+    only where the width changes), and a hand-checkable property -- with the last LayerNorm's gain zeroed a block is
+    silu(beta3 + shortcut), whatever the rest of it computes."""
+    cfg = O.StcCfg(mm_hidden=32, hidden=64, depth=2)
+    W = O.make_stc_weights(cfg, 3)
+    assert "s1.b1.downsample.conv.weight" in W and "s1.b2.downsample.conv.weight" not in W and "s2.b1.downsample.conv.weight" not in W
+    assert W["s1.b1.se.fc1.weight"].shape == (8, 64, 1, 1) and W["s1.b2.se.fc1.weight"].shape == (16, 64, 1, 1)      # round(in_chs * 0.25)
+    assert W["s1.b1.conv2.conv.weight"].shape == (64, 1, 3, 3)                                                        # depthwise
+    x = torch.randn(3, 64, 5, 5)
+    W2 = dict(W)
+    W2["s1.b2.conv3.bn.weight"] = torch.zeros(64)
+    y = O.stc_bottleneck(x, W2, "s1.b2.", cfg)
+    want = O.silu(W2["s1.b2.conv3.bn.bias"][None, :, None, None] + x)
+    assert torch.allclose(y, want, atol=1e-6)
+    t = O.stc_forward(torch.randn(2, 4, 16, 32), W, cfg)
+    assert t.shape == (2, 3 * 3 * 3, 64) and torch.isfinite(t).all()
+
+
 # ---------------------------------------------------------------------------------------------- f2 (SURVEY 8f): ingest front-end
 def _g10_frames(g, name):
     H, W = g[f"{name}_hw"].tolist()
