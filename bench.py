@@ -242,6 +242,52 @@ def latency_leg(model, frames, sizes=(1, 2, 4, 8), reps=25):
     return out
 
 
+def stc_leg(T=8, reps=5):
+    """the stock VideoLLaMA2 STC connector (builder.py:574-653) at its default widths -- CLIP 1024 -> 4096, two
+    RegStages of depth 4 around the Conv3d(2,2,2) sampler, GELU readout -- on T frames of 24 x 24 patch tokens, random weights.
+    FLOPs = the GEMM-shaped products only (1x1 convolutions, Conv3d, readout)."""
+    from types import SimpleNamespace
+    from streammind_amd.model.stc_connector import STCConnector
+    g = torch.Generator(device="cuda").manual_seed(11)
+    m = STCConnector(SimpleNamespace(mm_hidden_size=1024, hidden_size=4096))
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g, device="cuda") * std
+    sd = {}
+    for k in m.expected_keys():
+        if k.endswith("bn.weight"):
+            sd[k] = 1.0 + rn(4096, std=0.1)
+        elif k.endswith("bias"):
+            sd[k] = rn(256 if k.endswith("s1.b1.se.fc1.bias") else 1024 if "se.fc1" in k else 4096)
+        elif "conv2" in k:
+            sd[k] = rn(4096, 1, 3, 3, std=0.3)
+        elif "se.fc1" in k:
+            sd[k] = rn(256 if k.startswith("s1.b1.") else 1024, 4096, 1, 1)
+        elif "se.fc2" in k:
+            sd[k] = rn(4096, 256 if k.startswith("s1.b1.") else 1024, 1, 1)
+        elif k == "sampler.0.weight":
+            sd[k] = rn(4096, 4096, 2, 2, 2, std=0.005)
+        elif k.startswith("readout"):
+            sd[k] = rn(4096, 4096, std=0.015)
+        else:
+            sd[k] = rn(4096, 1024 if (k.startswith("s1.b1.") and ("conv1" in k or "downsample" in k)) else 4096, 1, 1, std=0.02)
+    m.load_state_dict(sd)
+    del sd
+    x = torch.randn(1, T, 576, 1024, generator=g, device="cuda").bfloat16()
+    out = m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = m(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    P1, To = T * 576, (T + 2 - 2) // 2 + 1
+    P2 = To * 169
+    fl = 2.0 * P1 * (1024 * 4096 * 2 + 4096 * 4096 * 7) + 2.0 * P2 * (8 * 4096 * 4096) + 2.0 * P2 * 4096 * 4096 * 8 + 2.0 * P2 * 4096 * 4096 * 2
+    return {"frames": T, "tokens_out": int(out.shape[1]), "ms": round(dt * 1e3, 3), "gemm_tflops": round(fl / dt / 1e12, 1), "gemm_gflop": round(fl / 1e9, 1),
+            "note": "offline projector of stock VideoLLaMA2 checkpoints (mm_projector_type stc_connector); not on the streaming path"}
+
+
 def ingest_leg(B=28, H=720, W=1280, reps=20):
     """decoded 720p u8 frames -> expand2square + PIL-exact bicubic resize + centre crop -> 336x336 u8
     (sm_ingest_frames), device-resident.  Algorithmic bytes per frame = H*W*3 read + 336*336*3 written."""
@@ -936,6 +982,13 @@ def main():
             calib_leg = calibration_leg()
         except Exception as e:
             calib_leg = {"error": repr(e)[:200]}
+    stc_res = None
+    if world == 1 and not a.no_aux:
+        try:
+            stc_res = stc_leg()
+        except Exception as e:
+            stc_res = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     streams_leg = None
     if world == 1 and not a.no_aux:
         try:
@@ -1123,6 +1176,7 @@ def main():
             "end_to_end": e2e,
             "teacher_forced_eval": tf_leg,
             "ingest_frontend": ing_leg,
+            "stc_connector": stc_res,
             "per_call_latency": lat_leg,
             "streams_x1": streams_leg,
             "fp16_tower": fp16_tower_leg,
