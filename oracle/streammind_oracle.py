@@ -1010,7 +1010,9 @@ def clip_frame_indices(duration: int, local_fps: float, num_frames: int, scheme:
 # Conv3d(k = s = downsample, padding 1) + SiLU sampler, the readout MLP (builder.py:566-571,583-653) -- which IS pinned by golden
 # g17 (the reference class itself, instantiated with depth = 0 so that no timm object is needed, make_golden.py), and (b) timm's
 # published RegStage / Bottleneck / SEModule / LayerNormAct2d algorithm, "PARITY UNPINNED": no golden vector can be minted for
-# it in this image.  Restated from timm 1.0.x regnet.py:
+# it in this image.  Its block topology IS cross-checked against an independent implementation of the same RegNet-Y block that
+# ships here (transformers' RegNetYLayer with its norms / activations swapped, tests/test_oracle_golden.py); timm's own choice
+# of knobs (LayerNormAct2d eps 1e-5, SE activation = the stage's act, group_size 1) stays restated-only.  From timm 1.0.x regnet.py:
 #   RegStage(depth, in, out, stride 1): blocks b1..b{depth}; b1 maps in -> out, the rest out -> out
 #   Bottleneck (defaults bottle_ratio 1, group_size 1, se_ratio 0.25, downsample 'conv1x1', linear_out False):
 #     conv1 = 1x1 conv (no bias) -> LayerNorm over channels -> act          (in -> out)

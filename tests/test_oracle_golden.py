@@ -260,6 +260,47 @@ def test_stc_oracle_regstage_structure():
     assert t.shape == (2, 3 * 3 * 3, 64) and torch.isfinite(t).all()
 
 
+def test_stc_oracle_bottleneck_topology_vs_transformers_regnet_y_layer():
+    """An INDEPENDENT implementation of the RegNet-Y block ships with this image: transformers' `RegNetYLayer` (1x1 conv ->
+    grouped 3x3 -> squeeze-excite with round(in / 4) channels -> 1x1 conv, shortcut = 1x1 conv + norm only when the width changes,
+    activation on the sum).  It is not timm (whose RegStage the reference imports and which is absent), but it is the same block
+    of the same paper written by other hands: with its BatchNorms swapped for LayerNorm-over-channels, its activations for SiLU
+    and groups_width 1 (depthwise, timm's group_size 1 default), the oracle's restated Bottleneck reproduces it to 1e-5.  What
+    stays restated-only are timm's choices of those knobs (LayerNormAct2d eps 1e-5, SE activation = the stage's act)."""
+    from transformers import RegNetConfig
+    from transformers.models.regnet.modeling_regnet import RegNetYLayer
+
+    class LN2d(torch.nn.Module):
+        def __init__(self, w, b, eps):
+            super().__init__()
+            self.w, self.b, self.eps = w, b, eps
+
+        def forward(self, x):
+            return torch.nn.functional.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), self.w, self.b, self.eps).permute(0, 3, 1, 2)
+    for cin, c in ((32, 64), (64, 64)):
+        cfg = O.StcCfg(mm_hidden=cin, hidden=c, depth=1)
+        W = O.make_stc_weights(cfg, 7)
+        p = "s1.b1."
+        hf = RegNetYLayer(RegNetConfig(hidden_act="silu", groups_width=1), cin, c, stride=1).eval()
+        for j, name in enumerate(("conv1", "conv2")):
+            hf.layer[j].convolution.weight.data.copy_(W[p + name + ".conv.weight"])
+            hf.layer[j].normalization = LN2d(W[p + name + ".bn.weight"], W[p + name + ".bn.bias"], cfg.ln_eps)
+        assert hf.layer[1].convolution.groups == c
+        se = hf.layer[2].attention
+        se[0].weight.data.copy_(W[p + "se.fc1.weight"]); se[0].bias.data.copy_(W[p + "se.fc1.bias"])
+        se[1] = torch.nn.SiLU()
+        se[2].weight.data.copy_(W[p + "se.fc2.weight"]); se[2].bias.data.copy_(W[p + "se.fc2.bias"])
+        hf.layer[3].convolution.weight.data.copy_(W[p + "conv3.conv.weight"])
+        hf.layer[3].normalization = LN2d(W[p + "conv3.bn.weight"], W[p + "conv3.bn.bias"], cfg.ln_eps)
+        if cin != c:
+            hf.shortcut.convolution.weight.data.copy_(W[p + "downsample.conv.weight"])
+            hf.shortcut.normalization = LN2d(W[p + "downsample.bn.weight"], W[p + "downsample.bn.bias"], cfg.ln_eps)
+        else:
+            assert isinstance(hf.shortcut, torch.nn.Identity) and p + "downsample.conv.weight" not in W
+        x = torch.randn(2, cin, 6, 5, generator=torch.Generator().manual_seed(9))
+        close(hf(x.clone()), O.stc_bottleneck(x, W, p, cfg), 1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- f2 (SURVEY 8f): ingest front-end
 def _g10_frames(g, name):
     H, W = g[f"{name}_hw"].tolist()
