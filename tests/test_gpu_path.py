@@ -1011,16 +1011,18 @@ def test_two_tower_lanes_equal_two_calls_and_the_stream_path():
     assert torch.equal(a.tokens(0, 50), b.tokens(0, 50))
 
 
-def test_group_decode_full_width_16_streams_one_launch_attention():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_group_decode_full_width_16_streams_one_launch_attention(fp8):
     """Mistral-7B widths (head_dim 128, 32 / 8 heads), one layer: 16 streams with contexts of 390..690 tokens decoded together --
     S x KV = 128 blocks, so the batched step takes the ONE-LAUNCH decode attention (in-block merge) at contexts where a single
     stream takes the key-split + merge pair, and its q/k/v rows go through the per-stream RoPE / KV append.  Every stream's ids and
-    last logits against its own solo decode."""
+    last logits against its own solo decode.  fp8: the same on fp8 weights -- solo steps run the fused RMSNorm / RoPE fp8 kernels
+    on one row, the batched step the 16-row fp8 weight-streaming kernels behind separate norm and RoPE launches."""
     lcfg = O.LmCfg(hidden=4096, layers=1, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
     Wl = O.make_lm_weights(lcfg, 78)
     vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
     ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate(layers=1)
-    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl, weights_fp8=fp8)
     g = torch.Generator().manual_seed(12)
     S, n_new = 16, 5
     lens = [390 + 20 * t for t in range(S)]
