@@ -240,6 +240,9 @@ typedef struct sm_config_t {
     float img_mean[3], img_std[3];
     /* connector (multimodal_projector/builder.py:390-399, mamba_simple.py:31-58) */
     int conn_mm_hidden, conn_d_model, conn_d_state, conn_d_conv, conn_expand, conn_dt_rank;
+    /* conn_d_state == 0 (with gate_layers == 0): a model WITHOUT the Mamba connector and the event gate -- tower + LLM only, for stock
+     * VideoLLaMA2 checkpoints whose projector (the STC family) runs above this ABI and hands its tokens to sm_stream_write_tokens;
+     * mm_projector.* tensors are then ignored by sm_model_load_tensor and the sm_stream_push_* / sm_group_push_* calls fail */
     float conn_eps;
     /* gate = ClsNet (builder.py:370-385) */
     int gate_hidden, gate_layers, gate_heads, gate_kv_heads, gate_mlp;

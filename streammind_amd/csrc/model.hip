@@ -218,7 +218,12 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     SM_REQUIRE(c.vit_hidden / c.vit_heads == 64 || c.vit_hidden / c.vit_heads == 128, "vit head_dim must be 64 or 128");
     SM_REQUIRE(c.vit_image % c.vit_patch == 0, "image size must be a multiple of the patch size");
     SM_REQUIRE(c.conn_mm_hidden == c.vit_hidden, "connector input width must equal the ViT width");
-    SM_REQUIRE(c.conn_d_model % 32 == 0 && c.conn_d_state <= 32 && c.conn_d_conv <= 8, "connector dims");
+    SM_REQUIRE(c.conn_d_model % 32 == 0 && c.conn_d_state >= 0 && c.conn_d_state <= 32 && c.conn_d_conv <= 8, "connector dims");
+    // conn_d_state == 0: no Mamba connector and no event gate in this model (stock VideoLLaMA2 checkpoints: their projector -- the
+    // STC family -- runs above the C ABI, streammind_amd/model/stc_connector.py, and hands its tokens over with
+    // sm_stream_write_tokens); the tower and the LLM are unchanged, the push entry points refuse
+    const bool has_conn = c.conn_d_state > 0;
+    SM_REQUIRE(has_conn || c.gate_layers == 0, "a model without connector (conn_d_state == 0) has no gate: gate_layers must be 0");
     SM_REQUIRE(c.gate_hidden == c.conn_d_model, "gate width must equal the connector width");
     SM_REQUIRE(c.gate_hidden % 32 == 0 && c.gate_mlp % 32 == 0 && c.gate_heads % c.gate_kv_heads == 0, "gate dims");
     SM_REQUIRE(c.max_frames_per_call >= 1, "max_frames_per_call >= 1");
@@ -255,6 +260,7 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     }
     // ---- connector
     const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
+    if (has_conn) {
     add_linear(m, "proj.pre", d, c.conn_mm_hidden, {"proj.pre_net.fc3.weight"}, d);
     add_f32(m, "proj.pre_net.fc3.bias", d);
     const std::string sp = "proj.mamba_model.ssms.0.";
@@ -283,6 +289,9 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
     add_f32(m, "proj.cls_net.cls_model.model.norm.weight", d);
     add_linear(m, "proj.gate_head", 2, d, {"proj.cls_net.cls_model.lm_head.weight"}, 2);
     m->ignored_prefixes.push_back("proj.cls_net.cls_model.model.embed_tokens.");
+    } else {
+        m->ignored_prefixes.push_back("proj.");         // the projector's tensors belong to the host-side connector class
+    }
     m->ignored_prefixes.push_back("vit.post_layernorm.");
     m->ignored_prefixes.push_back("vit.embeddings.position_ids");
     m->ignored_prefixes.push_back("vit.visual_projection.");        // CLIPVisionModelWithProjection / full CLIP directories
@@ -453,6 +462,7 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
             w.ln1_w = F(p + "layer_norm1.weight"); w.ln1_b = F(p + "layer_norm1.bias"); w.ln2_w = F(p + "layer_norm2.weight"); w.ln2_b = F(p + "layer_norm2.bias");
         }
         const std::string sp = "proj.mamba_model.ssms.0.";
+        if (c.conn_d_state > 0) {
         R.pre = S("proj.pre"); R.pre_b = F("proj.pre_net.fc3.bias"); R.cn_w = F(sp + "norm.weight"); R.cn_b = F(sp + "norm.bias");
         R.in_proj = S("proj.in_proj"); R.conv_w = F(sp + "mixer.conv1d.weight"); R.conv_b = F(sp + "mixer.conv1d.bias");
         R.x_proj = S("proj.x_proj"); R.dt_proj = S("proj.dt_proj"); R.dt_b = F(sp + "mixer.dt_proj.bias");
@@ -467,6 +477,7 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
             w.ln1_w = F(p + "input_layernorm.weight"); w.ln2_w = F(p + "post_attention_layernorm.weight");
         }
         R.gate_norm = F("proj.cls_net.cls_model.model.norm.weight"); R.gate_head = S("proj.gate_head");
+        }
         R.llm.resize(c.llm_layers);
         for (int l = 0; l < c.llm_layers; ++l) {
             const std::string p = "llm.model.layers." + std::to_string(l) + ".";
@@ -813,6 +824,8 @@ extern "C" int sm_stream_read_logits(sm_stream* s, float* out, int32_t* next_tok
 static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int S, int F, const SmSegStates& conv, const SmSegStates& ssm,
                           const SmSegStates& tokdst, float* logits, int32_t* decisions, void* stream) {
     const sm_config_t& c = m->c;
+    SM_REQUIRE(c.conn_d_state > 0, "this model was created without the Mamba connector / event gate (conn_d_state == 0): frames cannot be pushed, "
+                                   "hand tokens over with sm_stream_write_tokens");
     const int M = S * F;
     const int d = c.conn_d_model, di = c.conn_expand * d, R = c.conn_dt_rank, ds = c.conn_d_state;
     const int xd = cdiv(R + 2 * ds, 32) * 32 + 32;

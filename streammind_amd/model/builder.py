@@ -107,7 +107,10 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     if not os.path.isdir(model_path):
         raise FileNotFoundError(f"{model_path}: hub ids cannot be resolved here (no network): pass a local checkpoint directory")
     cfgj = json.load(open(os.path.join(model_path, "config.json")))
-    if "mamba" not in (cfgj.get("mm_projector_type") or ""):
+    ptype = cfgj.get("mm_projector_type") or ""
+    from .stc_connector import _TYPES as _STC_TYPES
+    stc = ptype in _STC_TYPES           # stock VideoLLaMA2 projectors (builder.py:139-154): tower + host-side connector + LLM, no event gate
+    if "mamba" not in ptype and not stc:
         raise ValueError(f"Unsupported projector type {cfgj.get('mm_projector_type')}!!!")      # videollama2_arch.py:321
     tower_dir = cfgj.get("mm_vision_tower")
     if not tower_dir or not os.path.isdir(tower_dir):
@@ -129,6 +132,8 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
         pj = json.load(open(ppath))
         if pj.get("image_mean") and pj.get("image_std"):
             over.update(img_mean=tuple(pj["image_mean"]), img_std=tuple(pj["image_std"]))
+    if stc:
+        over.update(conn_d_state=0, gate_layers=0)          # native model without the Mamba connector / gate (sm_config_t.conn_d_state)
     cfg = path_config_from_checkpoint(cfgj, vj, **over)
     # Mistral's sliding window (4096 for Mistral-7B-v0.1, null for v0.2): the attention kernels are full-causal, which equals
     # the windowed attention as long as the context stays inside the window -- so the KV capacity is capped at it
@@ -141,12 +146,19 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
         raise ValueError(f"max_seq={max_seq} exceeds the checkpoint's sliding_window={window}: the attention kernels are full-causal")
     dev = "cuda:0" if device == "cuda" else device
     nat = NativeModel(cfg, dev)
+    proj_sd = {}                                            # STC family: the projector's tensors go to the host-side connector class
     for k, v in _checkpoint_tensors(model_path):
-        nat.load_tensor(k, v)
+        if stc and "mm_projector." in k:
+            proj_sd[k.split("mm_projector.", 1)[1]] = v
+        else:
+            nat.load_tensor(k, v)
     pbin = os.path.join(model_path, "mm_projector.bin")
     if os.path.exists(pbin):                                # builder.py:141-142 -> load_mm_projector
         for k, v in torch.load(pbin, map_location="cpu", weights_only=True).items():
-            nat.load_tensor(k if "mm_projector." in k else "model.mm_projector." + k, v)
+            if stc:
+                proj_sd[k.split("mm_projector.", 1)[1] if "mm_projector." in k else k] = v
+            else:
+                nat.load_tensor(k if "mm_projector." in k else "model.mm_projector." + k, v)
     if any(m.startswith("vit.") for m in nat.missing()):    # the tower is delay-loaded from its own checkpoint (clip_encoder.py:18-29)
         for k, v in _checkpoint_tensors(tower_dir):
             # a full CLIP directory also holds text_model.*, visual_projection, text_projection, logit_scale: never read
@@ -174,4 +186,8 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     model = Videollama2MistralForCausalLM(nat, max_frames=kwargs.pop("max_frames", 4096), max_seq=max_seq,
                                           eos_token_id=tokenizer.eos_token_id)
     model.config = SimpleNamespace(**cfgj)
+    if stc:
+        from .stc_connector import build_vision_projector
+        pc = SimpleNamespace(mm_projector_type=ptype, mm_hidden_size=cfgj.get("mm_hidden_size", cfg.vit_hidden), hidden_size=cfgj["hidden_size"])
+        model.mm_projector = build_vision_projector(pc, device=dev).load_state_dict(proj_sd)
     return tokenizer, model, image_processor, context_len

@@ -173,7 +173,8 @@ class Videollama2MistralForCausalLM:
         self.native = native
         self.config = native.cfg                       # load_pretrained_model replaces it by the checkpoint's config.json namespace
         self.vision_tower = CLIPVisionTower(native)
-        self.mm_projector = Video_Mamba_seq(native)
+        # conn_d_state == 0: a stock VideoLLaMA2 checkpoint -- load_pretrained_model puts the STC-family connector here
+        self.mm_projector = Video_Mamba_seq(native) if native.cfg.conn_d_state > 0 else None
         self.stream: NativeStream = native.open_stream(max_frames=max_frames, max_seq=max_seq)
         self.max_seq = max_seq
         self.interval_id_list: List[int] = []          # videollama2_mistral.py:162 (never reset by the demo loop)
@@ -206,6 +207,9 @@ class Videollama2MistralForCausalLM:
     # ---- a3/a5-a9: one call = the new frame(s) of this tick
     @torch.no_grad()
     def _perceive(self, images_or_videos: torch.Tensor) -> Tuple[torch.Tensor, int]:
+        if self.native.cfg.conn_d_state == 0:
+            raise NotImplementedError("this checkpoint has a stock VideoLLaMA2 projector (no Mamba connector, no event gate): only the offline "
+                                      "generate() path exists for it; the streaming calls need mm_projector_type 'mamba'")
         x = images_or_videos
         assert x.dim() == 4, "expected [n,3,H,W] pixel_values or [n,H,W,3] uint8 frames"      # videollama2_arch.py:179 (5-D after unsqueeze)
         if x.shape[0] > 600:
@@ -406,6 +410,8 @@ class Videollama2MistralForCausalLM:
         """all clips -> ViT -> one connector pass (stream reset first); sentinels -> (optionally sub-sampled) frame indices.
         -> (sequence of ids with frame positions as -(index+1), per-position 'is frame' flags, gate logits of every frame)."""
         self.frame_feature = None
+        if self.native.cfg.conn_d_state == 0:
+            return self._splice_clips_stc(ids, clips, keys, features)
         counts, all_logits = [], []
         for clip in clips:
             if clip.shape[0] > 600 and not features:
@@ -440,6 +446,39 @@ class Videollama2MistralForCausalLM:
                 seq.append(int(t))
                 is_frame.append(False)
         return seq, is_frame, torch.cat(all_logits), feature_idx
+
+    def _splice_clips_stc(self, ids: Sequence[int], clips, keys, features: bool):
+        """stock VideoLLaMA2 path (videollama2_arch.py:113-133 encode_images_or_videos -> temporal_aggregator :303-309): every clip
+        [t, 3, H, W] (or u8 [t, H, W, 3], or with `features` the tower's [t, 576, C]) -> tower -> [1, t, 576, C] -> STC-family
+        connector -> tokens [n, hidden], appended to the token store and spliced at the clip's sentinel."""
+        counts = []
+        for clip in clips:
+            clip = clip.to(self.device)
+            if features:
+                feats = clip[0] if clip.dim() == 4 else clip
+            elif clip.dtype == torch.uint8 and clip.shape[-1] == 3:
+                B = self.native.cfg.max_frames_per_call
+                feats = torch.cat([self.native.vit_encode(clip[i:i + B].contiguous(), return_feats=True)[1] for i in range(0, clip.shape[0], B)])
+            else:
+                feats = self.vision_tower(clip)
+            toks = self.mm_projector(feats.unsqueeze(0))[0].contiguous()
+            self.stream.write_tokens(self.stream.num_frames, toks)
+            counts.append(int(toks.shape[0]))
+        ends = [sum(counts[:i + 1]) for i in range(len(counts))]
+        starts = [0] + ends[:-1]
+        sentinels = [MMODAL_TOKEN_INDEX[key.upper()] for key in keys]
+        seq: List[int] = []
+        is_frame: List[bool] = []
+        k = 0
+        for t in ids:
+            if t in sentinels:
+                seq.extend(-(f + 1) for f in range(starts[k], ends[k]))
+                is_frame.extend([True] * counts[k])
+                k += 1
+            else:
+                seq.append(int(t))
+                is_frame.append(False)
+        return seq, is_frame, torch.empty(0, 2), ends
 
     @torch.no_grad()
     def generate(self, inputs: Optional[torch.Tensor] = None, images_or_videos=None, modal_list=None, **kwargs):

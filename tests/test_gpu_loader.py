@@ -108,8 +108,11 @@ def test_loader_errors(tmp_path, gold):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B", load_4bit=True)
     with pytest.raises(NotImplementedError):
         load_pretrained_model(ck, "base", "VideoLLaMA2-7B")
-    json.dump(dict(cfg, mm_projector_type="stc_connector"), open(cfgp, "w"))
+    json.dump(dict(cfg, mm_projector_type="mlp2x_gelu"), open(cfgp, "w"))
     with pytest.raises(ValueError, match="Unsupported projector type"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B")
+    json.dump(dict(cfg, mm_projector_type="stc_connector"), open(cfgp, "w"))       # a Mamba checkpoint labelled STC: the connector's tensors are not there
+    with pytest.raises(KeyError, match="STC connector: missing tensors"):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B")
     json.dump(dict(cfg, mm_vision_tower="openai/clip-vit-large-patch14-336"), open(cfgp, "w"))
     with pytest.raises(FileNotFoundError, match="not a local directory"):
@@ -128,3 +131,58 @@ def test_loader_errors(tmp_path, gold):
     torch.save({k: sd[k]}, os.path.join(ck, "mm_projector.bin"))
     with pytest.raises(ValueError, match="incomplete.*layers.1.gu"):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B")
+
+
+def test_stock_videollama2_checkpoint_with_stc_connector_loads_and_generates(tmp_path, gold, tiny_tokenizer):
+    """SURVEY 8f row f4, the tail: a checkpoint laid out as the reference saves it but with `mm_projector_type: stc_connector`
+    (builder.py:139-146: the stock VideoLLaMA2 projector, timm state-dict names, an unused cls_net riding along).  The loader
+    builds the native model WITHOUT the Mamba connector and gate (sm_config_t.conn_d_state = 0), hands the projector's tensors
+    to the host-side STCConnector, and `model.generate(ids, images_or_videos=[clip], modal_list=["video"])` runs tower -> STC ->
+    splice of all 27 tokens -> greedy decode (videollama2_arch.py:113-133,303-309).  Against the oracle: spliced tokens at the
+    connector's bf16 noise level (tests/test_gpu_stc.py), prefill logits, ids wherever the margin allows; the streaming calls
+    refuse (no event gate in such a checkpoint)."""
+    from safetensors.torch import load_file, save_file
+    from streammind_amd.model.stc_connector import STCConnector
+    ck, (Wv, Wc, Wl) = _write_checkpoint(tmp_path, gold("g12_checkpoint_layout"), "as_saved_by_the_reference")
+    scfg = O.StcCfg(mm_hidden=TV.hidden, hidden=TL.hidden, depth=4)
+    Ws = O.make_stc_weights(scfg, 77)
+    t = {k: v for k, v in load_file(os.path.join(ck, "model.safetensors")).items() if "mm_projector." not in k}
+    t.update({"model.mm_projector." + k: v.to(torch.float16).contiguous() for k, v in Ws.items()})
+    t["model.mm_projector.cls_net.cls_model.lm_head.weight"] = torch.zeros(2, TL.hidden, dtype=torch.float16)
+    save_file(t, os.path.join(ck, "model.safetensors"))
+    cfg = json.load(open(os.path.join(ck, "config.json")))
+    cfg["mm_projector_type"] = "stc_connector"
+    cfg.pop("mm_gate_config", None)
+    json.dump(cfg, open(os.path.join(ck, "config.json"), "w"))
+    from videollama2.model.builder import load_pretrained_model
+    tokenizer, model, processor, _ = load_pretrained_model(ck, None, "VideoLLaMA2-7B", torch_dtype=torch.bfloat16)      # bf16 operands: the oracle's mode
+    assert isinstance(model.mm_projector, STCConnector) and model.native.cfg.conn_d_state == 0 and model.native.cfg.gate_layers == 0
+    frames = O.synthetic_frames(4, TV.image_size, seed=31, scene_len=2)
+    pix = O.preprocess_frames(frames, TV.image_size)
+    ids = [1, 5, 9, -201, 11, 12, 13]
+    out = model.generate(torch.tensor([ids]), images_or_videos=[pix], modal_list=["video"], do_sample=False, max_new_tokens=6)
+    toks = model.stream.tokens().cpu()
+    assert toks.shape == (27, TL.hidden)                                     # (4 + 2 - 2) // 2 + 1 = 3 frames x 3 x 3
+    # oracle: tower (bf16 mode) -> STC -> splice -> greedy decode
+    Ws16 = {k: v.to(torch.float16).float() for k, v in Ws.items()}
+    feats = O.vit_features(pix, Wv, TV, O.MIXED)
+    ref_tok = O.stc_forward(O.bf16_round(feats)[None], Ws16, scfg, O.MIXED)[0]
+    noise = ((ref_tok - O.stc_forward(O.bf16_round(feats)[None], Ws16, scfg, O.FP32)[0]).abs().max() / ref_tok.abs().max()).item()
+    err = ((toks - ref_tok).abs().max() / ref_tok.abs().max()).item()
+    print(f"stc tokens through the loader: {err:.2e} of the largest token (oracle bf16 vs fp32: {noise:.2e})")
+    assert err < 3 * noise + 1e-3
+    table = Wl["model.embed_tokens.weight"]
+    emb = torch.cat([table[[1, 5, 9]], toks, table[[11, 12, 13]]])           # the GPU's own tokens: isolates the LLM side of the comparison
+    ref_ids, trace = O.greedy_generate(emb, Wl, TL, 6, eos_token_id=tokenizer.eos_token_id, prec=O.MIXED, return_logits=True)
+    got = out[0].tolist()
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 6e-2, (j, got, ref_ids)
+            break
+    # u8 frames and pre-extracted tower features take the same route
+    out_u8 = model.generate(torch.tensor([ids]), images_or_videos=[frames], modal_list=["video"], do_sample=False, max_new_tokens=6)
+    assert model.stream.tokens().shape == (27, TL.hidden) and out_u8.shape[0] == 1
+    with pytest.raises(NotImplementedError, match="event gate"):
+        model.stream_generate_demo(torch.tensor([ids]), images_or_videos=frames[:1], modal_list=["video"], tokenizer=tokenizer)
+    with pytest.raises(Exception, match="without the Mamba connector"):
+        model.stream.push_frames(frames[:1].cuda())
