@@ -1136,6 +1136,31 @@ def stc_forward(x: Tensor, W: Dict[str, Tensor], cfg: StcCfg, prec: Prec = FP32)
     return y
 
 
+def make_mlp_projector_weights(mm_hidden: int, hidden: int, mlp_depth: int, seed: int, sequential: bool = True) -> Dict[str, Tensor]:
+    """state dict of build_vision_projector's `mlp{N}x_gelu` (nn.Sequential names "0.weight", "2.weight", ...) or `linear`
+    (nn.Linear names) projector, builder.py:121-132"""
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+    for j in range(mlp_depth):
+        k = mm_hidden if j == 0 else hidden
+        pre = f"{2 * j}." if sequential else ""
+        W[pre + "weight"] = _randn(g, (hidden, k), k ** -0.5)
+        W[pre + "bias"] = _randn(g, (hidden,), 0.05)
+    return W
+
+
+def mlp_projector_forward(x: Tensor, W: Dict[str, Tensor], mlp_depth: int, sequential: bool = True, prec: Prec = FP32) -> Tensor:
+    """temporal_aggregator for `linear` / `mlp{N}x_gelu` (videollama2_arch.py:293-294): mm_projector(frames_features.mean(1)) with
+    the projector of builder.py:121-132; x [b, t, l, d] -> [b, l, hidden]"""
+    y = x.to(F32).mean(1)
+    for j in range(mlp_depth):
+        pre = f"{2 * j}." if sequential else ""
+        if j:
+            y = torch.nn.functional.gelu(y)
+        y = linear(prec.act(y), W[pre + "weight"], W[pre + "bias"])
+    return y
+
+
 # ----------------------------------------------------------------------------------------------
 # seeded synthetic weights / frames (shared by tests, smoke and bench -- plain torch CPU generator)
 # ----------------------------------------------------------------------------------------------

@@ -109,7 +109,9 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     cfgj = json.load(open(os.path.join(model_path, "config.json")))
     ptype = cfgj.get("mm_projector_type") or ""
     from .stc_connector import _TYPES as _STC_TYPES
-    stc = ptype in _STC_TYPES           # stock VideoLLaMA2 projectors (builder.py:139-154): tower + host-side connector + LLM, no event gate
+    import re
+    # stock VideoLLaMA2 projectors (builder.py:119-154): tower + host-side projector + LLM, no event gate
+    stc = ptype in _STC_TYPES or ptype == "linear" or re.match(r"^mlp(\d+)x_gelu$", ptype) is not None
     if "mamba" not in ptype and not stc:
         raise ValueError(f"Unsupported projector type {cfgj.get('mm_projector_type')}!!!")      # videollama2_arch.py:321
     tower_dir = cfgj.get("mm_vision_tower")

@@ -225,17 +225,78 @@ class SpatialPool(STPConnector):           # builder.py:788-794
         super().__init__(config, downsample=downsample, depth=depth, mlp_depth=mlp_depth, **kw)
 
 
+class MlpGeluProjector:
+    """builder.py:121-132: `linear` / `mlp{N}x_gelu` -- nn.Linear(mm_hidden, hidden) [+ (GELU, nn.Linear(hidden, hidden)) x (N - 1)],
+    applied by temporal_aggregator to the MEAN OVER THE FRAMES of the tower features (videollama2_arch.py:293-294): [b, t, l, d] ->
+    [b, l, hidden].  State-dict names are nn.Sequential's ("0.weight", "2.weight", ...) or nn.Linear's ("weight", "bias")."""
+
+    def __init__(self, config, mlp_depth: int = 1, device: str = "cuda:0"):
+        self.encoder_hidden_size, self.hidden_size, self.mlp_depth = int(config.mm_hidden_size), int(config.hidden_size), int(mlp_depth)
+        self.sequential = getattr(config, "mm_projector_type", "linear") != "linear"
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self._loaded = False
+
+    def expected_keys(self):
+        if not self.sequential:
+            return ["weight", "bias"]
+        return [f"{2 * j}.{k}" for j in range(self.mlp_depth) for k in ("weight", "bias")]
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        keys = self.expected_keys()
+        missing = [k for k in keys if k not in sd]
+        if missing:
+            raise KeyError(f"projector: missing tensors {missing}")
+        if strict and [k for k in sd if k not in keys]:
+            raise KeyError(f"projector: unexpected tensors {[k for k in sd if k not in keys][:6]}")
+        self.layers = []
+        for j in range(self.mlp_depth):
+            w = sd[keys[2 * j]].detach().to(self.device, torch.bfloat16).contiguous()
+            self.layers.append((nat.pack_weight(w), sd[keys[2 * j + 1]].detach().to(self.device, torch.float32).contiguous(), w.shape[1]))
+        self._loaded = True
+        return self
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: tower features [b, t, l, d] -> [b, l, hidden] fp32 (the frame mean is taken here, as temporal_aggregator does)"""
+        if not self._loaded:
+            raise RuntimeError("projector: load_state_dict() first")
+        if x.dim() != 4 or x.shape[-1] != self.encoder_hidden_size:
+            raise ValueError(f"projector: expected [b, t, l, {self.encoder_hidden_size}], got {tuple(x.shape)}")
+        B, T, L, D = (int(v) for v in x.shape)
+        x = x.to(self.device)
+        if x.dtype not in (torch.bfloat16, torch.float32, torch.float16):
+            x = x.float()
+        x = x.contiguous()
+        dt = {torch.bfloat16: _lib.SM_DT_BF16, torch.float32: _lib.SM_DT_F32, torch.float16: _lib.SM_DT_F16}[x.dtype]
+        mean = torch.empty(B, L * D, dtype=torch.float32, device=self.device)
+        check(self.lib.sm_pool_rows(x.data_ptr(), dt, B, T, L * D, mean.data_ptr(), _st()), "sm_pool_rows")     # mean over t of [b][t][l*d]
+        h = torch.empty(B * L, D, dtype=torch.bfloat16, device=self.device)
+        zero = torch.zeros_like(mean)
+        check(self.lib.sm_add_act(mean.data_ptr(), zero.data_ptr(), B * L * D, _lib.SM_ACT_NONE, None, h.data_ptr(), _lib.SM_OP_BF16, _st()), "sm_add_act")
+        for j, (w, b, k) in enumerate(self.layers):
+            last = j == self.mlp_depth - 1
+            h = nat.linear(h, w, self.hidden_size, k, bias=b, act=_lib.SM_ACT_NONE if last else _lib.SM_ACT_GELU,
+                           out_dtype=torch.float32 if last else torch.bfloat16)
+        return h.reshape(B, L, self.hidden_size)
+
+    __call__ = forward
+
+
 _TYPES = {"stc_connector": STCConnector, "stp_connector": STPConnector, "stc_connector_v35": STCConnectorV35,
           "spatial_conv": SpatialConv, "spatial_pool": SpatialPool}
 
 
 def build_vision_projector(config, **kwargs):
     """builder.py:119-158 for the STC family.  `mamba` (the StreamMind connector) lives inside the native model
-    (`streammind_amd.model.builder.load_pretrained_model`); the pooled linear / mlpNx_gelu projectors of plain VideoLLaMA2 are
-    not part of this build."""
+    (`streammind_amd.model.builder.load_pretrained_model`); `identity` has no reader in temporal_aggregator upstream
+    (videollama2_arch.py:293-321 raises for it) and is not built."""
+    import re
     t = getattr(config, "mm_projector_type", "linear")
     if t in _TYPES:
         return _TYPES[t](config, **kwargs)
+    m = re.match(r"^mlp(\d+)x_gelu$", t)
+    if m or t == "linear":
+        return MlpGeluProjector(config, mlp_depth=int(m.group(1)) if m else 1, **kwargs)
     if t == "mamba":
         raise ValueError("mm_projector_type 'mamba' is built into the native model: use streammind_amd.model.builder.load_pretrained_model")
     raise ValueError(f"Unknown projector type: {t}")

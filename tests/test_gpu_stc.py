@@ -182,6 +182,28 @@ def test_stc_stock_videollama2_widths():
         m(x.cuda(), cls_demo=True)
 
 
+def test_pooled_projectors_vs_reference_golden(gold):
+    """`linear` / `mlp{N}x_gelu` (builder.py:121-132 + the frame mean of videollama2_arch.py:293-294) on the C ABI against golden
+    g17's reference outputs: the mean over the frames is one sm_pool_rows pass over [b][t][l*d], the MLP is sm_linear with the
+    exact-GELU epilogue; bf16 operands against the reference's fp32 -> the bf16 budget, 2e-5 against the oracle's bf16 mode
+    for the single-layer case."""
+    from types import SimpleNamespace
+    from streammind_amd.model import stc_connector as S
+    g = gold("g17_stc_connector")
+    for i in range(int(g["n_mlp"])):
+        c = json.loads(str(g[f"mcfg{i}"]))
+        W = O.make_mlp_projector_weights(c["mm_hidden"], c["hidden"], c["depth"], c["seed"], sequential=c["type"] != "linear")
+        m = S.build_vision_projector(SimpleNamespace(mm_projector_type=c["type"], mm_hidden_size=c["mm_hidden"], hidden_size=c["hidden"]))
+        assert isinstance(m, S.MlpGeluProjector) and m.mlp_depth == c["depth"]
+        x = torch.from_numpy(g[f"mx{i}"])
+        out = m.load_state_dict(W)(x.cuda())
+        ref = torch.from_numpy(g[f"mref{i}"])
+        mixed = O.mlp_projector_forward(x, W, c["depth"], c["type"] != "linear", O.MIXED)
+        print(c["type"], f"vs bf16-mode oracle {relerr(out, mixed):.2e}, vs reference fp32 {relerr(out, ref):.2e}")
+        assert out.shape == ref.shape and relerr(out, ref) < 1e-2 and relerr(out, mixed) < (2e-5 if c["depth"] == 1 else 2e-3)
+        assert relerr(m(x.cuda().bfloat16()), O.mlp_projector_forward(O.bf16_round(x), W, c["depth"], c["type"] != "linear", O.MIXED)) < 2e-3
+
+
 def test_stc_loader_and_dispatch():
     from types import SimpleNamespace
     from streammind_amd.model import stc_connector as S

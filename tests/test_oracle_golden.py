@@ -241,6 +241,16 @@ def test_g17_stc_sampler_and_readout_vs_reference(gold):
         close(g[f"ref{i}"], out, 2e-5)
 
 
+def test_g17_pooled_projectors_vs_reference(gold):
+    """golden g17, second half: build_vision_projector's `linear` / `mlp{N}x_gelu` modules (builder.py:121-132) applied to the
+    frame mean as temporal_aggregator does (videollama2_arch.py:293-294)"""
+    g = gold("g17_stc_connector")
+    for i in range(int(g["n_mlp"])):
+        c = json.loads(str(g[f"mcfg{i}"]))
+        W = O.make_mlp_projector_weights(c["mm_hidden"], c["hidden"], c["depth"], c["seed"], sequential=c["type"] != "linear")
+        close(g[f"mref{i}"], O.mlp_projector_forward(torch.from_numpy(g[f"mx{i}"]), W, c["depth"], c["type"] != "linear"), 1e-6)
+
+
 def test_stc_oracle_regstage_structure():
     """the restated timm stage: shapes, the state-dict names a stock VideoLLaMA2 checkpoint uses, the shortcut rule (1x1 conv + LN
     only where the width changes), and a hand-checkable property -- with the last LayerNorm's gain zeroed a block is
