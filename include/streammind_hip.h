@@ -175,7 +175,8 @@ int sm_mamba_ssm_step(const float* xc, const float* delta, const float* x_dbl, i
 int sm_dwconv3x3_nhwc(const float* x, int F, int H, int W, int C, const float* w_tap_major, float* out, void* stream);
 /* SEModule tail: out[r][c] = x[r][c] * sigmoid(gate_logits[r / P][c]), rows r < F*P; 16-bit (op_dtype) and / or fp32 output */
 int sm_se_scale(const float* x, const float* gate_logits, int F, int P, int C, void* out_16, float* out_f32, int op_dtype, void* stream);
-/* Bottleneck tail: out = act(a + b) over n fp32 elements (n %% 4 == 0), SM_ACT_*; 16-bit (op_dtype) and / or fp32 output */
+/* Bottleneck tail: out = act(a + b) over n fp32 elements (n %% 4 == 0), SM_ACT_*; 16-bit (op_dtype) and / or fp32 output; b may be
+ * NULL (out = act(a): with SM_ACT_NONE a plain fp32 -> 16-bit conversion) */
 int sm_add_act(const float* a, const float* b, size_t n, int act, float* out_f32, void* out_16, int op_dtype, void* stream);
 /* nn.Conv3d(kernel = stride = (kt,kh,kw), padding = pad) as a GEMM (builder.py:608-617): 16-bit x [B][T][H][W][C] -> 16-bit rows
  * [B*To*Ho*Wo][kt*kh*kw*C], column (((dt*kh)+dy)*kw+dx)*C + c, zeros in the padding; To = (T + 2 pad - kt)/kt + 1 etc. */

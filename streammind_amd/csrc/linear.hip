@@ -1286,6 +1286,12 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const bool dual = p->w2 != nullptr;
         SmProfScope prof(SM_PROF_SKINNY, st);
         if (p->norm_gamma) {
+            // the dual (gate / up) kernel as 4-wave blocks: 896 blocks of 8 waves are 1.75 rounds of the 512 block slots of the chip,
+            // smaller blocks leave a shorter tail (Mistral-7B decode 343.5 -> 346.8 tokens/s, fp8 519 -> 524); the single-matrix
+            // kernels (lm_head) measured unchanged.  SM_NORM_WAVES=8 restores the 8-wave blocks (A/B)
+            static int nw = -1;
+            if (nw < 0) { const char* e = getenv("SM_NORM_WAVES"); nw = e ? atoi(e) : 0; }
+            if (dual && nw != 8 && a.KS >= 8) return launch_skinny_norm<4>(a, dual, w8k, st);
             if (a.KS >= 32) return launch_skinny_norm<8>(a, dual, w8k, st);
             if (a.KS >= 8) return launch_skinny_norm<4>(a, dual, w8k, st);
             return launch_skinny_norm<1>(a, dual, w8k, st);

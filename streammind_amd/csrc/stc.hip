@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void add_act_kernel(const float* __restrict__ 
                                                        float* __restrict__ o32, bf16_t* __restrict__ o16, int f16, size_t n4) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n4) return;
-    const f32x4 u = *(const f32x4*)(a + t * 4), v = *(const f32x4*)(b + t * 4);
+    const f32x4 u = *(const f32x4*)(a + t * 4), v = b ? *(const f32x4*)(b + t * 4) : f32x4{0, 0, 0, 0};      // b == NULL: act(a), e.g. a plain 16-bit cast
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = apply_act(u[j] + v[j], act);
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void add_act_kernel(const float* __restrict__ 
     if (o16) *(u32x2*)(o16 + t * 4) = u32x2{pack16_rt(o[0], o[1], f16), pack16_rt(o[2], o[3], f16)};
 }
 extern "C" int sm_add_act(const float* a, const float* b, size_t n, int act, float* out_f32, void* out_16, int op_dtype, void* stream) {
-    SM_REQUIRE(a && b && (out_f32 || out_16) && n > 0 && (n & 3) == 0, "sm_add_act: bad args (n %% 4 == 0)");
+    SM_REQUIRE(a && (out_f32 || out_16) && n > 0 && (n & 3) == 0, "sm_add_act: bad args (n %% 4 == 0)");
     const size_t n4 = n >> 2;
     add_act_kernel<<<(unsigned)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, b, act, out_f32, (bf16_t*)out_16, op_dtype == SM_OP_F16, n4);
     SM_LAUNCH_CHECK();

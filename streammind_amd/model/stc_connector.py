@@ -271,8 +271,7 @@ class MlpGeluProjector:
         mean = torch.empty(B, L * D, dtype=torch.float32, device=self.device)
         check(self.lib.sm_pool_rows(x.data_ptr(), dt, B, T, L * D, mean.data_ptr(), _st()), "sm_pool_rows")     # mean over t of [b][t][l*d]
         h = torch.empty(B * L, D, dtype=torch.bfloat16, device=self.device)
-        zero = torch.zeros_like(mean)
-        check(self.lib.sm_add_act(mean.data_ptr(), zero.data_ptr(), B * L * D, _lib.SM_ACT_NONE, None, h.data_ptr(), _lib.SM_OP_BF16, _st()), "sm_add_act")
+        check(self.lib.sm_add_act(mean.data_ptr(), None, B * L * D, _lib.SM_ACT_NONE, None, h.data_ptr(), _lib.SM_OP_BF16, _st()), "sm_add_act")
         for j, (w, b, k) in enumerate(self.layers):
             last = j == self.mlp_depth - 1
             h = nat.linear(h, w, self.hidden_size, k, bias=b, act=_lib.SM_ACT_NONE if last else _lib.SM_ACT_GELU,

@@ -61,6 +61,9 @@ def test_se_scale_and_add_act(lib):
         p32, p16 = torch.empty(7, 20, device="cuda"), torch.empty(7, 20, dtype=torch.bfloat16, device="cuda")
         check(lib.sm_add_act(ag.data_ptr(), bg.data_ptr(), 140, act, p32.data_ptr(), p16.data_ptr(), _lib.SM_OP_BF16, st()), "add_act")
         assert relerr(p32, fn((a + b).double()).float()) < 2e-6 and torch.equal(p16.cpu(), p32.cpu().bfloat16())
+    p16 = torch.empty(7, 20, dtype=torch.bfloat16, device="cuda")
+    check(lib.sm_add_act(ag.data_ptr(), None, 140, _lib.SM_ACT_NONE, None, p16.data_ptr(), _lib.SM_OP_BF16, st()), "cast")     # b = NULL: a cast
+    assert torch.equal(p16.cpu(), a.bfloat16())
 
 
 @pytest.mark.parametrize("B,T,H,W,Cn,k,pad", [(1, 4, 4, 4, 8, (2, 2, 2), 1), (2, 5, 6, 6, 16, (2, 2, 2), 1), (1, 3, 5, 5, 16, (1, 2, 2), 1),
