@@ -108,8 +108,11 @@ def test_loader_errors(tmp_path, gold):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B", load_4bit=True)
     with pytest.raises(NotImplementedError):
         load_pretrained_model(ck, "base", "VideoLLaMA2-7B")
-    json.dump(dict(cfg, mm_projector_type="mlp2x_gelu"), open(cfgp, "w"))
+    json.dump(dict(cfg, mm_projector_type="identity"), open(cfgp, "w"))             # no reader in temporal_aggregator upstream either
     with pytest.raises(ValueError, match="Unsupported projector type"):
+        load_pretrained_model(ck, None, "VideoLLaMA2-7B")
+    json.dump(dict(cfg, mm_projector_type="mlp2x_gelu"), open(cfgp, "w"))
+    with pytest.raises(KeyError, match="projector: missing tensors"):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B")
     json.dump(dict(cfg, mm_projector_type="stc_connector"), open(cfgp, "w"))       # a Mamba checkpoint labelled STC: the connector's tensors are not there
     with pytest.raises(KeyError, match="STC connector: missing tensors"):
