@@ -189,3 +189,42 @@ def test_stock_videollama2_checkpoint_with_stc_connector_loads_and_generates(tmp
         model.stream_generate_demo(torch.tensor([ids]), images_or_videos=frames[:1], modal_list=["video"], tokenizer=tokenizer)
     with pytest.raises(Exception, match="without the Mamba connector"):
         model.stream.push_frames(frames[:1].cuda())
+
+
+def test_stock_videollama2_checkpoint_with_mlp2x_gelu_projector(tmp_path, gold):
+    """the pooled projector of plain VideoLLaMA2 checkpoints (`mm_projector_type: mlp2x_gelu`, builder.py:121-128; frame mean in
+    temporal_aggregator, videollama2_arch.py:293-294) through the same loader: nn.Sequential names ("0.weight", "2.weight") in the
+    checkpoint, 16 tokens (one per patch position) spliced for a 4-frame clip.  Tokens 2e-3 from the oracle on the oracle's
+    bf16-mode tower features chain (tower differences included: 1e-2 budget), ids as in the STC test."""
+    from safetensors.torch import load_file, save_file
+    from streammind_amd.model.stc_connector import MlpGeluProjector
+    from videollama2.model.builder import load_pretrained_model
+    ck, (Wv, Wc, Wl) = _write_checkpoint(tmp_path, gold("g12_checkpoint_layout"), "as_saved_by_the_reference")
+    Wp = O.make_mlp_projector_weights(TV.hidden, TL.hidden, 2, 79)
+    t = {k: v for k, v in load_file(os.path.join(ck, "model.safetensors")).items() if "mm_projector." not in k}
+    t.update({"model.mm_projector." + k: v.to(torch.float16).contiguous() for k, v in Wp.items()})
+    save_file(t, os.path.join(ck, "model.safetensors"))
+    cfg = json.load(open(os.path.join(ck, "config.json")))
+    cfg["mm_projector_type"] = "mlp2x_gelu"
+    cfg.pop("mm_gate_config", None)
+    json.dump(cfg, open(os.path.join(ck, "config.json"), "w"))
+    tokenizer, model, processor, _ = load_pretrained_model(ck, None, "VideoLLaMA2-7B", torch_dtype=torch.bfloat16)
+    assert isinstance(model.mm_projector, MlpGeluProjector) and model.native.cfg.conn_d_state == 0
+    frames = O.synthetic_frames(4, TV.image_size, seed=33, scene_len=2)
+    pix = O.preprocess_frames(frames, TV.image_size)
+    ids = [1, 5, 9, -201, 11, 12]
+    out = model.generate(torch.tensor([ids]), images_or_videos=[pix], modal_list=["video"], do_sample=False, max_new_tokens=5)
+    toks = model.stream.tokens().cpu()
+    assert toks.shape == (16, TL.hidden)
+    feats = O.vit_features(pix, Wv, TV, O.MIXED)
+    ref_tok = O.mlp_projector_forward(O.bf16_round(feats)[None], Wp, 2, True, O.MIXED)[0]
+    err = ((toks - ref_tok).abs().max() / ref_tok.abs().max()).item()
+    print(f"mlp2x_gelu tokens through the loader: {err:.2e} of the largest token")
+    assert err < 1e-2
+    table = Wl["model.embed_tokens.weight"]
+    emb = torch.cat([table[[1, 5, 9]], toks, table[[11, 12]]])
+    ref_ids, trace = O.greedy_generate(emb, Wl, TL, 5, eos_token_id=tokenizer.eos_token_id, prec=O.MIXED, return_logits=True)
+    for j, (a, b) in enumerate(zip(out[0].tolist(), ref_ids)):
+        if a != b:
+            assert float(torch.topk(trace[j], 2).values.diff().abs()) < 6e-2, (j, out[0].tolist(), ref_ids)
+            break
