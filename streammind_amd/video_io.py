@@ -111,9 +111,10 @@ class MjpegAviVideo:
     _std_dht = None
 
     def __init__(self, path: str):
+        import mmap
         import struct
-        with open(path, "rb") as f:
-            data = f.read()
+        self._file = open(path, "rb")              # mapped, not read: camera recordings run to gigabytes and frames are decoded lazily
+        data = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ) if os.path.getsize(path) else b""
         if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"AVI ":
             raise ValueError(f"{path}: not a RIFF AVI file")
         self._data = data
@@ -170,7 +171,7 @@ class MjpegAviVideo:
 
     def _jpeg(self, i: int) -> bytes:
         off, size = self._frames[int(i)]
-        j = self._data[off:off + size]
+        j = bytes(self._data[off:off + size])
         sos = j.find(b"\xff\xda")
         if sos > 0 and j.find(b"\xff\xc4", 0, sos) < 0:         # no DHT before the scan: tables implied
             j = j[:sos] + self._standard_tables() + j[sos:]
