@@ -780,8 +780,8 @@ extern "C" int sm_stream_reset(sm_stream* s, void* stream) {
     SM_REQUIRE(s, "sm_stream_reset: null");
     { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     hipStream_t st = (hipStream_t)stream;
-    SM_HIP(hipMemsetAsync(s->conv_state.p, 0, s->conv_state.bytes, st));
-    SM_HIP(hipMemsetAsync(s->ssm_state.p, 0, s->ssm_state.bytes, st));
+    if (s->conv_state.bytes) SM_HIP(hipMemsetAsync(s->conv_state.p, 0, s->conv_state.bytes, st));
+    if (s->ssm_state.bytes) SM_HIP(hipMemsetAsync(s->ssm_state.p, 0, s->ssm_state.bytes, st));      // none in a model without connector
     s->T = 0; s->kv_len = 0;
     return SM_OK;
 }
