@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
     if constexpr (MB == 1 && !SPLIT) {
         // <= 16 rows, one rounding of x: the register ring of skinny_fp8_kernel (D k-steps of 1 KiB per matrix in flight per
         // wave, x fragments fetched with the weights, same accumulation order as the batch loops below: bit-identical results)
-        constexpr int D = 4;
+        constexpr int D = 4;          // deeper rings for the single-matrix kernels (o / down) measured slower: D = 6 / 8 -> 336 / 340 vs 345 tokens/s
         const int nw = wave < KS ? (KS - wave + WAVES - 1) / WAVES : 0;
         struct XRaw { std::conditional_t<XF32, f32x4, u32x4> v[XF32 ? 2 : 1]; };
         auto issue = [&](int c, bf16x8& q, bf16x8& q2, XRaw& x) {
