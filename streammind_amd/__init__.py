@@ -1,7 +1,8 @@
 """streammind_amd -- MI355X-native drop-in for the StreamMind streaming hot path.
 
-Public API mirrors the reference: `model_init` (streammind/__init__.py:14-35, eval/video_score_stream_demo.py:42-63) and the
-streaming `infer` (eval/video_score_stream_demo.py:66-125).  All arithmetic runs in libstreammind_hip.so."""
+Public API mirrors the reference's package surface (streammind/__init__.py:14-103): `model_init`, the offline `infer` -> str and
+`x_infer`.  The streaming tick (eval/video_score_stream_demo.py:66-125) is `streammind_amd.eval.video_score_stream_demo.infer`,
+re-exported as `stream_infer`.  All arithmetic runs in libstreammind_hip.so."""
 from __future__ import annotations
 
 from functools import partial
@@ -29,32 +30,6 @@ def model_init(model_path=None, model_name="VideoLLaMA2-7B", model_base=None):
     return model, partial(process_video, aspect_ratio=None, processor=processor, num_frames=num_frames), tokenizer, version
 
 
-def infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_instruct", score_video=None, prompt=None,
-          max_new_tokens=1024):
-    """One streaming tick: the new frame(s) in `video`, the running `prompt` (None on the first call).
-    -> (reply text | None, prompt).  eval/video_score_stream_demo.py:66-125, line for line in control flow."""
-    modal_index = MMODAL_TOKEN_INDEX["VIDEO"]
-    conv = conv_templates["mistral_instruct"].copy()
-    tensor = video if video.dtype == torch.uint8 else video.half()
-    tensor = tensor.to(model.device)
-    if prompt is None:
-        conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n")
-        conv.append_message(conv.roles[1], None)
-        prompt = conv.get_prompt()
-    input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_index, return_tensors="pt").unsqueeze(0)
-    pad = tokenizer.pad_token_id if tokenizer.pad_token_id is not None else -1
-    attention_masks = input_ids.ne(pad).long()
-    stop_str = conv.sep if conv.sep_style in [SeparatorStyle.SINGLE] else conv.sep2
-    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
-    outputs, cls_pred = model.stream_generate_demo(
-        input_ids, attention_mask=attention_masks, images_or_videos=tensor, modal_list=["video"], do_sample=do_sample,
-        temperature=0.2 if do_sample else 0.0, max_new_tokens=max_new_tokens, use_cache=True,
-        stopping_criteria=[stopping_criteria], pad_token_id=tokenizer.eos_token_id, score_video=score_video, tokenizer=tokenizer)
-    if cls_pred == 1:
-        prompt += " " + outputs + " </s>[INST] <video>\n [/INST]"
-    return outputs, prompt
-
-
 def _generate_reply(model, tokenizer, prompt: str, clips, stop_str: str, do_sample: bool, max_new_tokens: int) -> str:
     """tokenise `prompt` around its <video> sentinel, greedy-generate with the keyword stop, decode the new ids"""
     ids = tokenizer_MMODAL_token(prompt, tokenizer, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
@@ -66,11 +41,12 @@ def _generate_reply(model, tokenizer, prompt: str, clips, stop_str: str, do_samp
     return tokenizer.batch_decode(new_ids, skip_special_tokens=True)[0].strip()
 
 
-def infer_offline(model, video, instruct, tokenizer, do_sample=False, version="llama_2", max_new_tokens=1024):
-    """Offline whole-clip question answering -- what the reference's package-level `infer` does
-    (streammind/__init__.py:38-91): "<video>\n" + instruct in the `version` conversation template, every frame of `video`
-    through the ViT and the connector, ONE generate.  (This package's `infer` is the streaming tick of
-    eval/video_score_stream_demo.py, hence the different name.)"""
+def infer(model, video, instruct, tokenizer, do_sample=False, version="llama_2", max_new_tokens=1024):
+    """streammind/__init__.py:38-91 -> str: offline whole-clip question answering -- "<video>\n" + instruct in the `version`
+    conversation template, every frame of `video` [T, C, H, W] through the ViT and the connector, ONE generate, the decoded reply.
+    `max_new_tokens` (hard-coded 1024 upstream, :84) is the one added keyword, last and defaulted.  The STREAMING tick of the same
+    name lives where the reference keeps it, `eval/video_score_stream_demo.py:66-125` (`streammind_amd.eval.video_score_stream_demo.infer`,
+    exported here as `stream_infer`)."""
     conv = conv_templates[version].copy()
     conv.append_message(conv.roles[0], DEFAULT_MMODAL_TOKEN["VIDEO"] + "\n" + instruct)
     conv.append_message(conv.roles[1], None)
@@ -90,4 +66,15 @@ def x_infer(video, question, model, tokenizer, mode="vanilla", do_sample=False, 
     """streammind/__init__.py:94-103: the three question styles of the offline benchmarks"""
     if mode not in _X_INFER_SUFFIX:
         raise ValueError(f"x_infer: unknown mode {mode!r}")
-    return infer_offline(model, video, question + _X_INFER_SUFFIX[mode], tokenizer, do_sample=do_sample, version=version)
+    return infer(model, video, question + _X_INFER_SUFFIX[mode], tokenizer, do_sample=do_sample, version=version)
+
+
+def stream_infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_instruct", score_video=None, prompt=None,
+                 max_new_tokens=1024):
+    """the streaming tick under a name of its own: eval/video_score_stream_demo.py:66-125 -> (reply | None, prompt)"""
+    from .eval.video_score_stream_demo import infer as _tick
+    return _tick(model, video, instruct, tokenizer, do_sample=do_sample, version=version, score_video=score_video, prompt=prompt,
+                 max_new_tokens=max_new_tokens)
+
+
+infer_offline = infer          # round <= 3 name of the offline API

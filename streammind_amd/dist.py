@@ -80,6 +80,13 @@ def is_local_master() -> bool:
     return _state["local_rank"] == 0
 
 
+def new_group(ranks: List[int]):
+    """dist.py:86-89"""
+    if _state["initialized"]:
+        return tdist.new_group(ranks=ranks)
+    return None
+
+
 def barrier():
     if _state["initialized"]:
         tdist.barrier()

@@ -61,9 +61,18 @@ def subsample_features(feats: torch.Tensor, segment: int = SEGMENT) -> torch.Ten
     return feats[:, ::segment]                                            # process_clip_encoder.py:75
 
 
-def process_file(path: str) -> str:
-    """stride one cached chunk; output goes to the sibling `..._fps` tree (process_clip_encoder.py:71-76)."""
+def process_file(video_encoder_path: str, progress_bar=None, lock=None) -> str:
+    """stride one cached chunk; output goes to the sibling `..._fps` tree (process_clip_encoder.py:69-84).  progress_bar / lock:
+    the reference's tqdm bar and threading.Lock (updated under the lock, :79-80), optional here.  Returns the output path (the
+    reference returns a status sentence built around it, and swallows errors into that sentence; errors raise here)."""
+    path = video_encoder_path
     out = path.replace("features_video_encode_ddp", "features_video_encode_ddp_fps")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     torch.save(subsample_features(torch.load(path)), out)
+    if progress_bar is not None:
+        if lock is not None:
+            with lock:
+                progress_bar.update(1)
+        else:
+            progress_bar.update(1)
     return out

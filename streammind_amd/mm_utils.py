@@ -36,7 +36,7 @@ def _crop_side(processor) -> int:
         return int(getattr(size, "height"))
 
 
-def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NUM_FRAMES, image_grid: bool = False,
+def process_video(video_path, processor=None, aspect_ratio="pad", num_frames: int = NUM_FRAMES, image_grid: bool = False,
                   sample_scheme: str = "uniform") -> torch.Tensor:
     """list of PIL images / HWC arrays (or an [n,H,W,3] uint8 array) -> uint8 frames tensor [n,S,S,3], S = the
     processor's crop size (336).
@@ -47,7 +47,9 @@ def process_video(video, processor=None, aspect_ratio=None, num_frames: int = NU
     identities); any other size goes through the device ingest front-end (`sm_ingest_frames`:
     expand2square with int(image_mean * 255) when aspect_ratio == "pad", PIL-exact bicubic shortest-edge resize, centre
     crop) and comes back as a CUDA tensor.  A path goes through `video_io.open_video` (decoder adaptor) and the reference's
-    frame sampling first."""
+    frame sampling first.  Parameter names and defaults are the reference's (mm_utils.py:377; `video_path` is a path OR the frame
+    list, as in its list branch :449-451; the streaming caller always passes aspect_ratio=None through its partial)."""
+    video = video_path
     if isinstance(video, str):
         # mm_utils.py:399-435: open, sample `num_frames` ids ("uniform") or one per second ("fps"), cap at MAX_FRAMES, fetch.
         # The decoder is an adaptor (video_io.open_video): .gif at the reference's constant 10 fps, other containers through
@@ -112,9 +114,10 @@ def get_model_name_from_path(model_path: str) -> str:
     return parts[-2] + "_" + parts[-1] if parts[-1].startswith("checkpoint-") else parts[-1]
 
 
-def expand2square(img, background_color):
+def expand2square(pil_img, background_color):
     """mm_utils.py:257-268 on a PIL image or an HWC uint8 array: centre the picture on a square canvas of `background_color`
     (the streaming path does this on the GPU inside sm_ingest_frames; this host form serves callers that hold single images)."""
+    img = pil_img
     arr = np.asarray(img)
     h, w = arr.shape[:2]
     if h == w:
@@ -130,9 +133,10 @@ def expand2square(img, background_color):
     return Image.fromarray(out, mode=img.mode)
 
 
-def process_image(image, processor=None, aspect_ratio="pad", num_frames: int = NUM_FRAMES, image_grid: bool = False) -> torch.Tensor:
+def process_image(image_path, processor=None, aspect_ratio="pad", num_frames: int = NUM_FRAMES, image_grid: bool = False) -> torch.Tensor:
     """mm_utils.py:356-374 for an already decoded picture (PIL image or HWC uint8 array; opening a path is left to the caller):
     the image repeated `num_frames` times through the same front-end as process_video."""
+    image = image_path
     if isinstance(image, str):
         raise NotImplementedError("image decoding is outside this build: pass a PIL image or an HWC uint8 array")
     frame = np.asarray(image.convert("RGB") if hasattr(image, "convert") else image)
@@ -165,5 +169,5 @@ class KeywordsStoppingCriteria:
         outputs = self.tokenizer.batch_decode(output_ids[:, -offset:], skip_special_tokens=True)[0]
         return any(keyword in outputs for keyword in self.keywords)
 
-    def __call__(self, output_ids: torch.Tensor, scores=None, **kwargs) -> bool:
+    def __call__(self, output_ids: torch.Tensor, scores, **kwargs) -> bool:
         return all(self.call_for_batch(output_ids[i].unsqueeze(0), scores) for i in range(output_ids.shape[0]))

@@ -285,7 +285,7 @@ _TYPES = {"stc_connector": STCConnector, "stp_connector": STPConnector, "stc_con
           "spatial_conv": SpatialConv, "spatial_pool": SpatialPool}
 
 
-def build_vision_projector(config, **kwargs):
+def build_vision_projector(config, delay_load=False, **kwargs):
     """builder.py:119-158 for the STC family.  `mamba` (the StreamMind connector) lives inside the native model
     (`streammind_amd.model.builder.load_pretrained_model`); `identity` has no reader in temporal_aggregator upstream
     (videollama2_arch.py:293-321 raises for it) and is not built."""

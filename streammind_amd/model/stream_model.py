@@ -21,13 +21,64 @@ class CLIPVisionTower:
     """drop-in for clip_encoder.py:7-84: images [N,3,H,W] (normalised pixel_values, any float dtype) or a list of [3,H,W]
     -> hidden_states[select_layer][:, 1:] as [N, num_patches, hidden] in the input dtype."""
 
-    def __init__(self, native: NativeModel, select_feature: str = "patch"):
-        self.native = native
-        self.select_layer = native.cfg.vit_select_layer
-        self.select_feature = select_feature
-        self.is_loaded = True
+    def __init__(self, vision_tower, args=None, delay_load=False, select_feature: Optional[str] = None):
+        """clip_encoder.py:9-29 signature.  `vision_tower`: the tower checkpoint -- a local CLIP directory (config.json +
+        weights; the reference passes the same string to CLIPVisionModel.from_pretrained, hub ids need a network) -- or, inside
+        this build, the NativeModel that already holds the tower.  `args`: the config namespace the reference reads
+        mm_vision_select_layer / mm_vision_select_feature from (:15-16).  delay_load=True defers reading the directory to
+        load_model() as upstream (:18-22)."""
+        self.vision_tower_name = vision_tower if isinstance(vision_tower, str) else None
+        self.select_layer = getattr(args, "mm_vision_select_layer", -2)
+        self.select_feature = select_feature or getattr(args, "mm_vision_select_feature", "patch")
+        self._fp16 = bool(getattr(args, "vit_fp16", False))
+        self._max_frames = int(getattr(args, "max_frames_per_call", 8))
+        self.is_loaded = False
+        self.native = None
+        if isinstance(vision_tower, NativeModel):
+            self.native = vision_tower
+            self.select_layer = vision_tower.cfg.vit_select_layer
+            self.is_loaded = True
+        elif not delay_load:
+            self.load_model()
 
-    def feature_select(self, feats: torch.Tensor) -> torch.Tensor:
+    def load_model(self):
+        """clip_encoder.py:24-29: read the tower's own checkpoint directory into a tower-only native model (no connector, no gate,
+        no LLM: sm_config_t.conn_d_state = gate_layers = llm_layers = 0)."""
+        import json
+        import os
+        from .builder import _TOWER_ROOTS, _checkpoint_tensors
+        d = self.vision_tower_name
+        if not d or not os.path.isdir(d):
+            raise FileNotFoundError(f"vision tower {d!r} is not a local directory (hub ids cannot be resolved here)")
+        vj = json.load(open(os.path.join(d, "config.json")))
+        vj = vj.get("vision_config", vj)
+        over = {}
+        pp = os.path.join(d, "preprocessor_config.json")
+        if os.path.exists(pp):
+            pj = json.load(open(pp))
+            if pj.get("image_mean") and pj.get("image_std"):
+                over.update(img_mean=tuple(pj["image_mean"]), img_std=tuple(pj["image_std"]))
+        cfg = PathConfig(vit_image=vj["image_size"], vit_patch=vj["patch_size"], vit_hidden=vj["hidden_size"],
+                         vit_heads=vj["num_attention_heads"], vit_mlp=vj["intermediate_size"], vit_layers=vj["num_hidden_layers"],
+                         vit_select_layer=self.select_layer, vit_eps=vj.get("layer_norm_eps", 1e-5), conn_d_state=0, gate_layers=0,
+                         llm_layers=0, max_frames_per_call=self._max_frames, vit_fp16=self._fp16, **over)
+        nat = NativeModel(cfg)
+        for k, v in _checkpoint_tensors(d):
+            if k.startswith("vision_model."):
+                nat.load_tensor("model.vision_tower.vision_tower." + k, v)
+            elif k.startswith(_TOWER_ROOTS):
+                nat.load_tensor("model.vision_tower.vision_tower.vision_model." + k, v)
+        if nat.missing():
+            raise ValueError(f"vision tower checkpoint incomplete, missing: {nat.missing()[:8]}")
+        nat.finalize()
+        self.native, self.is_loaded = nat, True
+
+    def feature_select(self, image_forward_outs) -> torch.Tensor:
+        """clip_encoder.py:31-39.  The native tower emits hidden_states[select_layer] with the CLS row already dropped, so the
+        argument here is that tensor; an HF-style output object (with .hidden_states) is sliced as upstream."""
+        feats = image_forward_outs
+        if hasattr(image_forward_outs, "hidden_states"):
+            feats = image_forward_outs.hidden_states[self.select_layer][:, 1:]
         if self.select_feature == "patch":
             return feats
         raise ValueError(f"Unexpected select feature: {self.select_feature}")   # clip_encoder.py:38 ('cls_patch' needs the CLS row)
@@ -94,8 +145,8 @@ class Video_Mamba_seq:
         self.native = native
 
     @torch.no_grad()
-    def __call__(self, x: torch.Tensor, cls_inference=False, cls_training=False, cls_demo=False, frames_features_shape=[],
-                 prompt_time_input_ids=None, prompt_time_lable=None):
+    def forward(self, x: torch.Tensor, cls_inference=False, cls_training=False, cls_demo=False, frames_features_shape=[],
+                prompt_time_input_ids=None, prompt_time_lable=None):
         if (cls_inference or cls_training) and prompt_time_input_ids is not None and prompt_time_input_ids.numel() > 1:
             # builder.py:424-494: needs gate token ids 32000/32001 that its own 2-word ClsNet does not have
             raise NotImplementedError("the prompt-conditioned gate branch is debug-broken in the reference (builder.py:422-494)")
@@ -124,6 +175,8 @@ class Video_Mamba_seq:
         if cls_demo:
             return tokens, logits[-1]
         return tokens
+
+    __call__ = forward
 
 
 GATE_CLASS_WEIGHT = (0.15, 0.85)                                   # CrossEntropyLoss(weight=...) of builder.py:345-349

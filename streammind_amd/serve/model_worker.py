@@ -249,7 +249,7 @@ class ModelWorker:
     @torch.inference_mode()
     def stream_frames(self, params: dict):
         """one tick per decoded frame, exactly the demo loop (eval/video_score_stream_demo.py:283-299) on a named stream"""
-        from .. import infer
+        from ..eval.video_score_stream_demo import infer
         try:
             sid = str(params["stream_id"])
             if params.get("close", False):                  # explicit release of a stream's device state

@@ -6,7 +6,7 @@ O(1)-per-frame device state instead of one blocking call per frame.
         --> ONE device->host read of the batch's decisions
         --> for every fired frame, in order: splice + prefill (KV prefix reuse) + greedy decode, prompt growth
 
-Results are identical to the frame-at-a-time loop (`streammind_amd.infer` per frame): the gate of frame t depends only on
+Results are identical to the frame-at-a-time loop (`streammind_amd.stream_infer` per frame): the gate of frame t depends only on
 frames <= t (the Mamba scan is causal and the gate sees one token), never on what the LLM said, so perceiving a batch
 ahead of the replies changes nothing but latency.  The reply for a fire at frame t is generated from exactly the
 tokens [0, t] and the prompt grown by the earlier replies, as in the reference.
@@ -272,7 +272,7 @@ class MultiStreamSession:
                           grown prompt (KV prefix reuse), then all of them decode in lock step through sm_group_llm_decode -- one
                           pass over the LLM weights per step -- until each hits its own stop.
 
-    Per stream the results are those of its own `streammind_amd.infer` loop (same gate decisions, same prompt growth; the
+    Per stream the results are those of its own `streammind_amd.stream_infer` loop (same gate decisions, same prompt growth; the
     reply ids are the greedy ids of the same logits up to fp32 summation order).  `models`: one
     Videollama2MistralForCausalLM per stream, all built on the SAME NativeModel."""
 

@@ -224,7 +224,7 @@ def test_streaming_session_equals_frame_at_a_time(tiny, tiny_tokenizer):
     a = Videollama2MistralForCausalLM(m, max_frames=64, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
     prompt, ref_events, ref_logits = None, [], []
     for i in range(12):
-        text, prompt = streammind_amd.infer(a, frames[i:i + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=5)
+        text, prompt = streammind_amd.stream_infer(a, frames[i:i + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=5)
         ref_logits.append(a.last_gate_logits.cpu())
         if text is not None:
             ref_events.append((i + 1, text))
@@ -736,7 +736,7 @@ def test_offline_generate_vs_reference_golden(tiny, gold, tiny_tokenizer):
                 assert float(g["margins_all"][j]) < 2 * 3e-2, (st, j, got, want)     # twice the stated logit tolerance
                 break
     # u8 frames through the same path (the drop-in keeps frames as uint8) and the package-level API
-    text = streammind_amd.infer_offline(model, frames, "a b", tiny_tokenizer, version="mistral_instruct", max_new_tokens=4)
+    text = streammind_amd.infer(model, frames, "a b", tiny_tokenizer, version="mistral_instruct", max_new_tokens=4)
     assert isinstance(text, str)
     # score_video=True: the same clip handed over as PRE-EXTRACTED tower features (feature-cache path) gives the same reply
     feats = model.get_vision_tower()(pix)
@@ -954,7 +954,7 @@ def test_group_batched_decode_equals_solo_decode(tiny):
 
 def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenizer):
     """MultiStreamSession (group perception + batched decode of the fired streams) against S independent reference-shaped
-    loops (`streammind_amd.infer`, one frame per call): per stream the same fire positions, the same prompt growth and the same
+    loops (`streammind_amd.stream_infer`, one frame per call): per stream the same fire positions, the same prompt growth and the same
     replies."""
     import streammind_amd
     from streammind_amd.model import Videollama2MistralForCausalLM
@@ -967,7 +967,7 @@ def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenize
         a = Videollama2MistralForCausalLM(m, max_frames=32, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id)
         prompt, ev = None, []
         for t in range(T):
-            text, prompt = streammind_amd.infer(a, frames[s, t:t + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=6)
+            text, prompt = streammind_amd.stream_infer(a, frames[s, t:t + 1], "", tiny_tokenizer, prompt=prompt, max_new_tokens=6)
             if text is not None:
                 ev.append((t + 1, text))
         ref_events.append(ev); ref_prompts.append(prompt)

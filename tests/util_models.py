@@ -57,7 +57,7 @@ LOGIT_TOL = 3e-2          # bf16-activation budget on the tiny LLM's O(1) logits
 
 
 def check_stream_against_g6(model, tokenizer, g, Wv, Wc, Wl, cfgs, to_video=lambda fr: fr, gate_tol=5e-3, logit_tol=LOGIT_TOL):
-    """Drive `streammind_amd.infer` frame by frame exactly like eval/video_score_stream_demo.py:283-299 and compare with golden
+    """Drive `streammind_amd.stream_infer` frame by frame exactly like eval/video_score_stream_demo.py:283-299 and compare with golden
     g6 (the reference's own stream_generate_demo trace): gate logits of every frame (5e-3: bf16 ViT in front), decisions, fire
     positions, and -- with the reference's prompt teacher-forced after every fire -- the generated ids, which must equal the
     reference's wherever the oracle's top-2 logit margin exceeds TWICE the stated logit tolerance (2 x 3e-2)."""
@@ -69,7 +69,7 @@ def check_stream_against_g6(model, tokenizer, g, Wv, Wc, Wl, cfgs, to_video=lamb
     st = O.StreamOracleState()
     for i in range(n):
         golden_prompt_before = prompt
-        text, prompt = streammind_amd.infer(model, to_video(frames[i:i + 1]), "", tokenizer, prompt=prompt, max_new_tokens=int(g["max_new"]))
+        text, prompt = streammind_amd.stream_infer(model, to_video(frames[i:i + 1]), "", tokenizer, prompt=prompt, max_new_tokens=int(g["max_new"]))
         d = (model.last_gate_logits.float().cpu() - torch.as_tensor(g["gate_logits"][i])).abs().max().item()
         assert d < gate_tol, (i, d)
         pred = int(g["preds"][i])
