@@ -359,6 +359,11 @@ const float* sm_stream_logits(sm_stream* s);
  * logits fp32 [vocab] and the pending greedy token int32) */
 int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, void* stream);
 int sm_stream_read_logits(sm_stream* s, float* out_opt, int32_t* next_token_out_opt, void* stream);
+/* the connector's recurrent state after the frames pushed so far (Mamba.step's conv_state / ssm_state, mamba_simple.py:208-253):
+ * conv fp32 [d_inner][d_conv] (the last d_conv inputs per channel, oldest first), ssm fp32 [d_inner][d_state]; either may be NULL.
+ * For checkpoint / resume of a stream and for the long-horizon parity tests (the reference holds no such state: it re-scans
+ * the whole history every frame, videollama2_arch.py:190-191). */
+int sm_stream_read_state(sm_stream* s, float* conv_out, float* ssm_out, void* stream);
 /* overwrite / append per-frame tokens [t0, t0+n) from caller-computed fp32 features (t0 <= num_frames): lets a
  * caller that already holds connector outputs (e.g. restored from a cache) seed the stream                 */
 int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream);

@@ -432,9 +432,11 @@ def pool_patches(feats: Tensor) -> Tensor:
     return feats.mean(dim=-2)
 
 
-def mamba_scan(u: Tensor, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
+def mamba_scan(u: Tensor, W: Dict[str, Tensor], cfg: ConnCfg, return_state: bool = False):
     """Mamba.forward non-fused branch (mamba_simple.py:168-205) + selective_scan_ref
-    (selective_scan_interface.py:91-157), batch 1: u [T, d_model] -> [T, d_model]."""
+    (selective_scan_interface.py:91-157), batch 1: u [T, d_model] -> [T, d_model].
+    return_state: also the state the recurrent form (Mamba.step, :208-253) would hold after frame T -- the last d_conv conv inputs
+    per channel (oldest first; what mamba_simple.py:160-163 copies into conv_state) and the scan's last h (last_state, :196-199)."""
     T = u.shape[0]
     di, ds, R = cfg.d_inner, cfg.d_state, cfg.dt_rank
     xz = u @ W[CONN + "mixer.in_proj.weight"].t()                      # [T, 2*di]
@@ -455,16 +457,21 @@ def mamba_scan(u: Tensor, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
         ys.append(h @ Cm[t])
     y = torch.stack(ys) + xc * W[CONN + "mixer.D"]
     y = y * silu(z)
-    return y @ W[CONN + "mixer.out_proj.weight"].t()
+    out = y @ W[CONN + "mixer.out_proj.weight"].t()
+    if return_state:
+        return out, ConnState(xp[T - 1:T - 1 + cfg.d_conv].t().contiguous(), h)
+    return out
 
 
-def connector_scan(pooled: Tensor, W: Dict[str, Tensor], cfg: ConnCfg) -> Tensor:
-    """Reference form: all T frames at once. pooled [T, mm_hidden] -> tokens [T, d_model]."""
+def connector_scan(pooled: Tensor, W: Dict[str, Tensor], cfg: ConnCfg, return_state: bool = False):
+    """Reference form: all T frames at once. pooled [T, mm_hidden] -> tokens [T, d_model]  (+ ConnState with return_state)."""
     t0 = leaky_relu(linear(pooled, W["pre_net.fc3.weight"], W["pre_net.fc3.bias"]))
     u = layer_norm(t0, W[CONN + "norm.weight"], W[CONN + "norm.bias"], cfg.ln_eps)
-    r = mamba_scan(u, W, cfg) + t0                                       # ssm.py:83
+    m = mamba_scan(u, W, cfg, return_state)
+    r = (m[0] if return_state else m) + t0                               # ssm.py:83
     lnf = layer_norm(r, W["mamba_model.norm_fn.weight"], W["mamba_model.norm_fn.bias"], cfg.ln_eps)
-    return linear(leaky_relu(lnf), W["post_net.fc3.weight"], W["post_net.fc3.bias"])
+    tok = linear(leaky_relu(lnf), W["post_net.fc3.weight"], W["post_net.fc3.bias"])
+    return (tok, m[1]) if return_state else tok
 
 
 @dataclass

@@ -111,6 +111,7 @@ SIGNATURES = {
     "sm_stream_set_next_token": (i32, [vp, vp, vp]),
     "sm_stream_logits": (vp, [vp]),
     "sm_stream_read_tokens": (i32, [vp, i32, i32, vp, vp]),
+    "sm_stream_read_state": (i32, [vp, vp, vp, vp]),
     "sm_stream_read_logits": (i32, [vp, vp, vp, vp]),
     "sm_stream_write_tokens": (i32, [vp, i32, i32, vp, vp]),
     "sm_group_create": (i32, [C.POINTER(vp), i32, C.POINTER(vp)]),

@@ -803,6 +803,13 @@ extern "C" int sm_stream_read_tokens(sm_stream* s, int t0, int n, float* out, vo
     SM_HIP(hipMemcpyAsync(out, s->tokens.as<float>() + (size_t)t0 * d, (size_t)n * d * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SM_OK;
 }
+extern "C" int sm_stream_read_state(sm_stream* s, float* conv_out, float* ssm_out, void* stream) {
+    SM_REQUIRE(s && s->conv_state.bytes && s->ssm_state.bytes, "sm_stream_read_state: null stream / model without connector");
+    { int jrc = auto_join(s, stream); if (jrc) return jrc; }
+    if (conv_out) SM_HIP(hipMemcpyAsync(conv_out, s->conv_state.p, s->conv_state.bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (ssm_out) SM_HIP(hipMemcpyAsync(ssm_out, s->ssm_state.p, s->ssm_state.bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SM_OK;
+}
 extern "C" int sm_stream_write_tokens(sm_stream* s, int t0, int n, const float* src, void* stream) {
     SM_REQUIRE(s && src && t0 >= 0 && n > 0 && t0 <= s->T && t0 + n <= s->max_frames, "sm_stream_write_tokens: [%d, %d) not appendable (T=%d, cap=%d)", t0, t0 + n, s ? s->T : 0, s ? s->max_frames : 0);
     { int jrc = auto_join(s, stream); if (jrc) return jrc; }

@@ -257,6 +257,15 @@ class NativeStream:
         check(self.lib.sm_stream_read_tokens(self.h, t0, n, out.data_ptr(), _stream()), "sm_stream_read_tokens")
         return out
 
+    def state(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(conv_state [d_inner, d_conv], ssm_state [d_inner, d_state]) of the connector's recurrence after the frames pushed so far"""
+        c = self.model.cfg
+        di = c.conn_expand * c.conn_d_model
+        conv = torch.empty(di, c.conn_d_conv, dtype=torch.float32, device=self.model.device)
+        ssm = torch.empty(di, c.conn_d_state, dtype=torch.float32, device=self.model.device)
+        check(self.lib.sm_stream_read_state(self.h, conv.data_ptr(), ssm.data_ptr(), _stream()), "sm_stream_read_state")
+        return conv, ssm
+
     def write_tokens(self, t0: int, toks: torch.Tensor) -> None:
         assert toks.dtype == torch.float32 and toks.is_cuda and toks.is_contiguous()
         check(self.lib.sm_stream_write_tokens(self.h, t0, toks.shape[0], toks.data_ptr(), _stream()), "sm_stream_write_tokens")
