@@ -764,9 +764,22 @@ __device__ __forceinline__ void tile_rows_epilogue(const char* __restrict__ smem
 // WV = 8: the same tile on 8 waves (4(n) x 2(m), each 2x4 fragments): with one block per CU a 4-wave block leaves ONE wave
 // per SIMD, whose DMA issues, fragment reads and MFMAs then run strictly one after the other (~0.75 us per k-tile against
 // 0.27 us of MFMA issue); two waves per SIMD overlap each other.
-template <int ACT, int WV = 4, bool F16 = false>   // ACT: compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
+// STAGES = 4 (8 waves only): a RING of four 32-KiB stages, loads issued THREE k-tiles ahead, one barrier per k-tile.  The two-stage
+// loop issues the loads of tile t+1 only after the trailing barrier of tile t-1, so every k-tile pays one full load latency
+// (L2 ~0.2 us, HBM ~0.5 us: measured 0.6-0.75 us per k-tile where the 32 MFMAs per SIMD take 0.22); a CU can stage 145 KB/us
+// from L2 (tools/experiments/stage_ubench.hip), i.e. a 32-KiB stage in 0.22 us -- with three stages in flight the loop is
+// MFMA-bound.  One frame through the ViT (M = 577, 40-160 tiles, one partial round) is the case this is for.
+#ifdef SM_GEMM128_TIMELINE
+__device__ long long* g_tl128;
+extern "C" int sm_debug_set_timeline128(long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tl128), &p, sizeof(p)) == hipSuccess ? 0 : -2; }
+#define TL128(k) do { if (threadIdx.x == 0 && g_tl128) g_tl128[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TL128(k) do {} while (0)
+#endif
+template <int ACT, int WV = 4, bool F16 = false, int STAGES = 2>   // ACT: compile-time activation of the fast epilogue (SM_ACT_NONE / SM_ACT_QUICK_GELU); -1: runtime a.act
 __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    TL128(0);
     constexpr int NF = 16 / WV;                // 16-row weight fragments per wave: 4 (2 x 2 waves) or 2 (4 x 2 waves)
     constexpr int J = 16 / WV;                 // W pieces (and X pieces) of 1 KiB each wave stages per k-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -823,6 +836,88 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
         }
     };
 
+    if constexpr (STAGES >= 4) {
+        static_assert(WV == 8, "the ring loop counts 4 loads per wave and stage");
+        // ---- ring loop.  The two-stage loop below puts every wave of the block through the same three phases between two barriers
+        // (issue DMA | read fragments | multiply): with the waves in lockstep the CU's vector-memory path, LDS and matrix pipes are
+        // busy one after the other -- 0.83 us per k-tile measured with everything L2-warm, where each resource alone needs <= 0.22.
+        // Here a wave keeps TWO fragment sets in registers and the iteration is skewed around its single barrier:
+        //     read set B <- (stage t, k 32..63)      | multiply set A (stage t, k 0..31)
+        //     wait + barrier: stage t+1 has landed, nobody reads stage t-1 any more
+        //     issue DMA of stage t+STAGES-1 (into the slot of t-1), read set A <- (stage t+1, k 0..31)   | multiply set B
+        // so the fragment reads and the DMA issue of every wave sit under its own MFMAs.  Past the end the last tile is fetched
+        // again (never read) and a stale slot is read (never multiplied into a stored result): the body has no branches.
+        constexpr int AHEAD = STAGES - 1;
+        const int n_it = KT - kt0;
+#pragma unroll
+        for (int p = 0; p < AHEAD; ++p) stage(kt0 + p < KT ? kt0 + p : KT - 1, p);
+        const int wbase = wn * NF * 2048 + lane * 16;
+        int xbase[2];
+#pragma unroll
+        for (int ksl = 0; ksl < 2; ++ksl) xbase[ksl] = 16384 + (wm * 64 + i) * 128 + (((ksl * 4 + g) ^ (i & 7)) * 16);
+        bf16x8 wA[NF], xA[4], wB[NF], xB[4];
+        auto ldfrag = [&](const char* sb, int ksl, bf16x8 (&wf)[NF], bf16x8 (&xf)[4]) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const bf16x8*)(sb + wbase + nf * 2048 + ksl * 1024);
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) xf[mf] = *(const bf16x8*)(sb + xbase[ksl] + mf * 2048);
+        };
+        auto mma = [&](const bf16x8 (&wf)[NF], const bf16x8 (&xf)[4]) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mfma16<F16>(wf[nf], xf[mf], acc[nf][mf]);
+        };
+        if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TL128(1);
+        ldfrag(smem, 0, wA, xA);
+        int slot = 0;
+        for (int it = 0; it < n_it; ++it) {
+            const char* sb = smem + slot * GEMM_STAGE_BYTES;
+            ldfrag(sb, 1, wB, xB);
+            mma(wA, xA);
+            // set A was read an iteration ago: its MFMAs start at once and set B's reads go into their gaps (reads in front would
+            // put set B under the same lgkmcnt(0) as set A: the counter is in order and hipcc cannot count across the back edge)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+            if constexpr (AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nslot = slot + 1 == STAGES ? 0 : slot + 1;
+            const int fslot = slot == 0 ? STAGES - 1 : slot - 1;          // (it + STAGES - 1) % STAGES
+            const int ktn = kt0 + it + AHEAD;
+            stage(ktn < KT ? ktn : KT - 1, fslot);
+            ldfrag(smem + nslot * GEMM_STAGE_BYTES, 0, wA, xA);
+            mma(wB, xB);
+            // one MFMA in front, then DMA issues and fragment reads in the gaps of the remaining MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            slot = nslot;
+        }
+        // the dummy stages still in flight land in the slots the epilogue stages the tile through; the stale fragment reads must be done
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
     stage(kt0, 0);
     for (int kt = kt0; kt < KT; ++kt) {
         const int buf = (kt - kt0) & 1;
@@ -836,6 +931,9 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
         __builtin_amdgcn_s_barrier();
         const char* sw = smem + buf * GEMM_STAGE_BYTES;
         const char* sx = sw + 16384;
+#ifdef SM_GEMM128_TIMELINE
+        if (kt == kt0) TL128(1);
+#endif
 #pragma unroll
         for (int ksl = 0; ksl < 2; ++ksl) {
             bf16x8 wf[NF], xf[4];
@@ -856,6 +954,8 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    }
+    TL128(2);
     // ---- epilogue: stage the fp32 tile through LDS ([128 m][128 n] fp32 = the whole 64 KiB; 16-byte chunk index
     // XOR-swizzled with (m & 31) so both the fragment-shaped writes and the row-shaped reads are conflict-free),
     // then every wave walks whole rows: 512 B contiguous per row to HBM.
@@ -901,6 +1001,7 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
             store4(a, tile_m * GEMM_BM + ml, tile_n * GEMM_BN + chunk * 4, v, nullptr);
         }
     }
+    TL128(3);
 }
 
 // sum of the split-K slabs (fixed order: deterministic) + the real epilogue; one thread per 4 outputs.  ws2 != nullptr: the
@@ -1366,6 +1467,12 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
         SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0, 8, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1, 8, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1, 8, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<0, 8, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<1, 8, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
+        SM_HIP(hipFuncSetAttribute((const void*)gemm_kernel<-1, 8, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_STAGE_BYTES));
         attr_set = true;
     }
     // Few tiles (a single frame through the ViT: 40-160 tiles; LLM prefill chunks): split-K so that ~256 blocks exist, but
@@ -1382,10 +1489,18 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     if (S > KTall) S = KTall;
     if (S < 1 || p->vt || (p->N & 3) || p->M > 4096) S = 1;
     const bool wv8 = use_w8 == 2 || (use_w8 == 1 && tiles * S <= 256);
+    static int use_ring = -1;                       // SM_GEMM_RING=0: the two-stage loop everywhere (A/B)
+    if (use_ring < 0) { const char* e = getenv("SM_GEMM_RING"); use_ring = e ? atoi(e) : 1; }
+    // the ring kernel owns its CU (128 KiB of LDS): it wins where the whole grid is ONE partial round (one frame: QKV 14.9 -> 13.8 us
+    // in situ, its k-loop 0.83 -> 0.41 us per k-tile L2-warm), and loses where the two-stage kernel's second resident block per CU hides
+    // prologues and epilogues across rounds (4 / 8 frames per call: 3.88 -> 3.98 / 5.48 -> 5.70 ms)
+    const bool ring = use_ring && (wv8 || a.f16) && (tiles * S <= 256 || use_ring == 2);
     SmProfScope prof(SM_PROF_GEMM, st);
 #define GEMM_LAUNCH(ACT, ARGS, GRID)                                                                                         \
     do {                                                                                                                     \
-        if (a.f16) gemm_kernel<ACT, 8, true><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);               \
+        if (ring && a.f16) gemm_kernel<ACT, 8, true, 4><<<GRID, 512, 4 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);    \
+        else if (ring) gemm_kernel<ACT, 8, false, 4><<<GRID, 512, 4 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);       \
+        else if (a.f16) gemm_kernel<ACT, 8, true><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);          \
         else if (wv8) gemm_kernel<ACT, 8><<<GRID, 512, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                  \
         else gemm_kernel<ACT, 4><<<GRID, 256, 2 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);                           \
     } while (0)
