@@ -246,6 +246,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(LinArgs a, const u32x4
 // per-HIP-stream workspace of the quantised activations (grown on demand; steady state allocates nothing)
 static std::mutex g_xq_mu;
 static std::map<hipStream_t, std::pair<void*, size_t>> g_xq;
+void release_fp8_workspace(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_xq_mu);
+    auto e = g_xq.find(st);
+    if (e != g_xq.end()) { if (e->second.first) (void)hipFree(e->second.first); g_xq.erase(e); }
+}
 
 int launch_gemm_fp8(LinArgs& a, hipStream_t st) {
     SM_REQUIRE((a.K & 127) == 0 && a.wscale && !a.w2 && !a.vt && a.remap_in == 0, "gemm_fp8: K %% 128 == 0, one fp8 weight image with row scales, plain outputs");

@@ -1059,6 +1059,20 @@ int launch_splitk_reduce(const LinArgs& a, const float* ws, int S, int ldw, hipS
 
 // bf16 expansion of fp8 weights for M > 16 (per HIP stream, grown on demand; slot 0 = w, slot 1 = w2)
 static std::map<hipStream_t, std::pair<void*, size_t>> g_dq[2];
+void release_fp8_workspace(hipStream_t st);                                 // gemm_fp8.hip
+// a HIP stream this library created is about to be destroyed (already synchronised): drop the slabs keyed on it
+void release_stream_workspaces(hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(g_ws_mu);
+        auto w = g_ws.find(st);
+        if (w != g_ws.end()) { if (w->second.first) (void)hipFree(w->second.first); g_ws.erase(w); }
+        for (auto& dq : g_dq) {
+            auto d = dq.find(st);
+            if (d != dq.end()) { if (d->second.first) (void)hipFree(d->second.first); dq.erase(d); }
+        }
+    }
+    release_fp8_workspace(st);
+}
 static int dequant_fp8(hipStream_t st, int which, const void* w8, const float* scale, int N, int K, const void** out) {
     const int KS = (K + 31) / 32, KSP = (KS + 1) / 2, NRG = (N + 15) / 16;
     const size_t bytes = (size_t)NRG * KS * 1024;
@@ -1363,7 +1377,7 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
     const bool xf32 = p->x_dtype == SM_X_F32;
-    if (p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && !p->w2 && !xf32 && !p->vt && p->remap_in == 0) {
+    if (p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && (p->ldx & 7) == 0 && !p->precise && !p->w2 && !xf32 && !p->vt && p->remap_in == 0) {
         // fp8 x fp8 on the matrix pipe: activation rows quantised to e4m3, no bf16 expansion of the weights (gemm_fp8.hip)
         SmProfScope prof(SM_PROF_GEMM, st);
         return launch_gemm_fp8(a, st);

@@ -16,6 +16,7 @@
 #include "host.h"
 
 int sm_pack_weight_ks(const void* w, int N, int K, int ldw, int KS, void* out, void* stream);   // linear.hip
+void release_stream_workspaces(hipStream_t st);                                                 // linear.hip
 extern "C" size_t sm_packed_fp8_bytes(int N, int K);
 extern "C" int sm_quant_pack_weight_fp8(const void* w, int N, int K, int ldw, void* out, float* scale_out, void* stream);
 
@@ -151,9 +152,10 @@ struct sm_model {
         return SM_OK;
     }
     // second tower lane of a caller stream (sm_vit_encode with >= SM_VIT_LANE_MIN frames): a side HIP stream + fork / join events
-    struct Lane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    // `more`: further side streams (+ their join events) of the frame lanes of a SMALL call (2..8 frames: one lane per frame, see vit_small_lanes)
+    struct Lane { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; std::vector<hipStream_t> more; std::vector<hipEvent_t> more_join; };
     std::map<void*, Lane> lanes;
-    int lane_of(void* stream, Lane** out) {
+    int lane_of(void* stream, Lane** out, int n_more = 0) {
         std::lock_guard<std::mutex> lk(ws_mu);
         Lane& L = lanes[stream];
         if (!L.side) {
@@ -161,14 +163,23 @@ struct sm_model {
             SM_HIP(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
             SM_HIP(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
         }
+        while ((int)L.more.size() < n_more) {
+            hipStream_t st; hipEvent_t ev;
+            SM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            L.more.push_back(st);
+            SM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            L.more_join.push_back(ev);
+        }
         *out = &L;
         return SM_OK;
     }
     ~sm_model() {
         for (auto& kv : lanes) {
-            if (kv.second.side) { (void)hipStreamSynchronize(kv.second.side); (void)hipStreamDestroy(kv.second.side); }
+            if (kv.second.side) { (void)hipStreamSynchronize(kv.second.side); release_stream_workspaces(kv.second.side); (void)hipStreamDestroy(kv.second.side); }
             if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
             if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+            for (auto st : kv.second.more) { (void)hipStreamSynchronize(st); release_stream_workspaces(st); (void)hipStreamDestroy(st); }
+            for (auto ev : kv.second.more_join) (void)hipEventDestroy(ev);
         }
     }
     // RoPE tables for the LLM
@@ -514,7 +525,7 @@ extern "C" int sm_patchify_pixels(const void* pix, int dtype, int B, int H, int 
 extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
                           float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);
 static int vit_body(sm_model* m, sm_model::VitWs* ws, int B, float* pooled, void* feats, void* stream);
-struct VitLaneArgs { sm_model::VitWs* ws; int B; float* pooled; void* feats; void* stream; };
+struct VitLaneArgs { sm_model::VitWs* ws; int B; float* pooled; void* feats; void* stream; int f0 = 0; };   // f0: first frame slot of the lane inside `ws` (frame lanes of a small call share one workspace)
 static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl);
 
 // Two tower lanes: a call with >= SM_VIT_LANE_MIN frames (default 29: more than the 28 that fill the chip's 256 CUs with exactly one round of 256-row tiles; SM_VIT_LANES=1 disables) is cut in two halves that run the
@@ -531,14 +542,48 @@ static int vit_lane_count(int B) {
     }
     return lanes >= 2 && B >= min_b ? 2 : 1;
 }
-template <class Front>      // front(ws, first frame, frames, stream): fills ws->patches for `frames` frames starting at `first frame`
+// Frame lanes of a SMALL call (2 .. 8 frames: the reference's own operating point is a tick of one or a few new frames).
+// One frame through the tower is ~185 dependent launches of 5-15 us, most of it the fixed cost of a dependent launch (a kernel that
+// does nothing takes 4.7 us between two others; profiles/r04_tick_b1_timeline.txt) and none of them fills the chip (577 rows = 40-160
+// tiles of 128 x 128): the frames of a small call are independent, so each gets its own HIP stream and the launch chains run side by
+// side (same workspace, disjoint frame slots; fork / join by events like the two big lanes).  Results are those of one-frame calls.
+static int vit_small_lanes(int B) {
+    static int max_l = -1, max_b = 8;
+    if (max_l < 0) {
+        const char* e = getenv("SM_VIT_SMALL_LANES"); max_l = e ? atoi(e) : 8;
+        const char* mb = getenv("SM_VIT_SMALL_MAX"); if (mb) max_b = atoi(mb);
+        if (max_l > 8) max_l = 8;
+    }
+    if (B < 2 || B > max_b || max_l < 2) return 1;
+    return B < max_l ? B : max_l;
+}
+template <class Front>      // front(patches, first frame, frames, stream): fills the patch matrix `patches` for `frames` frames starting at `first frame`
 static int vit_encode_lanes(sm_model* m, int B, float* pooled, void* feats, void* stream, Front front) {
     const sm_config_t& c = m->c;
     sm_model::VitWs* ws;
     int rc = m->vit_workspace(stream, &ws);
     if (rc) return rc;
+    if (const int sl = vit_small_lanes(B); sl > 1) {
+        sm_model::Lane* L;
+        if ((rc = m->lane_of(stream, &L, sl - 1))) return rc;
+        VitLaneArgs args[8];
+        SM_HIP(hipEventRecord(L->fork, (hipStream_t)stream));
+        for (int i = 0; i < sl; ++i) {
+            const int f0 = (int)((long)B * i / sl), f1 = (int)((long)B * (i + 1) / sl);
+            void* st = i == 0 ? stream : (void*)L->more[i - 1];
+            if (i) SM_HIP(hipStreamWaitEvent((hipStream_t)st, L->fork, 0));
+            args[i] = VitLaneArgs{ws, f1 - f0, pooled + (size_t)f0 * c.vit_hidden, feats ? (char*)feats + (size_t)f0 * m->P * c.vit_hidden * 2 : nullptr, st, f0};
+            if ((rc = front((char*)ws->patches.p + (size_t)f0 * m->P * m->Kpe * 2, f0, f1 - f0, st))) return rc;
+        }
+        if ((rc = vit_body_lanes(m, args, sl))) return rc;
+        for (int i = 1; i < sl; ++i) {
+            SM_HIP(hipEventRecord(L->more_join[i - 1], L->more[i - 1]));
+            SM_HIP(hipStreamWaitEvent((hipStream_t)stream, L->more_join[i - 1], 0));
+        }
+        return SM_OK;
+    }
     if (vit_lane_count(B) == 1) {
-        if ((rc = front(ws, 0, B, stream))) return rc;
+        if ((rc = front(ws->patches.p, 0, B, stream))) return rc;
         return vit_body(m, ws, B, pooled, feats, stream);
     }
     sm_model::Lane* L;
@@ -561,8 +606,8 @@ static int vit_encode_lanes(sm_model* m, int B, float* pooled, void* feats, void
         VitLaneArgs two[2] = {{ws, f1 - f0, pooled + (size_t)f0 * c.vit_hidden, feats ? (char*)feats + (size_t)f0 * m->P * c.vit_hidden * 2 : nullptr, stream},
                               {ws1, f2 - f1, pooled + (size_t)f1 * c.vit_hidden, feats ? (char*)feats + (size_t)f1 * m->P * c.vit_hidden * 2 : nullptr, (void*)L->side}};
         const int n2 = f2 > f1 ? 2 : 1;
-        if ((rc = front(ws, f0, f1 - f0, stream))) return rc;
-        if (n2 == 2 && (rc = front(ws1, f1, f2 - f1, (void*)L->side))) return rc;
+        if ((rc = front(ws->patches.p, f0, f1 - f0, stream))) return rc;
+        if (n2 == 2 && (rc = front(ws1->patches.p, f1, f2 - f1, (void*)L->side))) return rc;
         if ((rc = vit_body_lanes(m, two, n2))) return rc;
     }
     SM_HIP(hipEventRecord(L->join, L->side));
@@ -576,8 +621,8 @@ extern "C" int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* p
     const sm_config_t& c = m->c;
     const size_t fpx = (size_t)c.vit_image * c.vit_image * 3;
     // a1: u8 ring buffer -> normalised bf16 patch matrix
-    return vit_encode_lanes(m, B, pooled, feats, stream, [&](sm_model::VitWs* ws, int f0, int nf, void* st) {
-        return sm_preprocess_patches(frames + (size_t)f0 * fpx, nf, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, ws->patches.p, m->Kpe,
+    return vit_encode_lanes(m, B, pooled, feats, stream, [&](void* patches, int f0, int nf, void* st) {
+        return sm_preprocess_patches(frames + (size_t)f0 * fpx, nf, c.vit_image, c.vit_image, c.vit_patch, c.img_mean, c.img_std, patches, m->Kpe,
                                      pix ? pix + (size_t)f0 * fpx : nullptr, c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, st);
     });
 }
@@ -587,8 +632,8 @@ extern "C" int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int d
     SM_REQUIRE(pixel_values && pooled && B >= 1 && B <= m->Bmax, "sm_vit_encode_pixels: B=%d outside [1, %d]", B, m->Bmax);
     const sm_config_t& c = m->c;
     const size_t fpx = (size_t)c.vit_image * c.vit_image * 3 * (dtype == SM_DT_F32 ? 4 : 2);
-    return vit_encode_lanes(m, B, pooled, feats, stream, [&](sm_model::VitWs* ws, int f0, int nf, void* st) {
-        return sm_patchify_pixels((const char*)pixel_values + (size_t)f0 * fpx, dtype, nf, c.vit_image, c.vit_image, c.vit_patch, ws->patches.p, m->Kpe,
+    return vit_encode_lanes(m, B, pooled, feats, stream, [&](void* patches, int f0, int nf, void* st) {
+        return sm_patchify_pixels((const char*)pixel_values + (size_t)f0 * fpx, dtype, nf, c.vit_image, c.vit_image, c.vit_patch, patches, m->Kpe,
                                   c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16, st);
     });
 }
@@ -602,10 +647,12 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
     int rc;
     const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
 #define LANES for (int li = 0; li < nl; ++li)
-#define LV const VitLaneArgs& L = lanes[li]; float* x = L.ws->x.as<float>(); bf16_t* xn = L.ws->xn.as<bf16_t>(); const int M = L.B * S; void* stream = L.stream; (void)x; (void)xn; (void)M
+#define LV const VitLaneArgs& L = lanes[li]; const size_t r0 = (size_t)L.f0 * S; float* x = L.ws->x.as<float>() + r0 * D; bf16_t* xn = L.ws->xn.as<bf16_t>() + r0 * D; \
+    char* w_patches = (char*)L.ws->patches.p + (size_t)L.f0 * P * m->Kpe * 2; char* w_qkv = (char*)L.ws->qkv.p + r0 * 3 * D * 2; char* w_ctx = (char*)L.ws->ctx.p + r0 * D * 2; \
+    char* w_hmid = (char*)L.ws->hmid.p + r0 * c.vit_mlp * 2; const int M = L.B * S; void* stream = L.stream; (void)x; (void)xn; (void)M; (void)w_patches; (void)w_qkv; (void)w_ctx; (void)w_hmid
     // patch-embed GEMM (+ position embedding) into token rows 1..P of every frame; CLS row; pre_layrnorm in place
     LANES { LV;
-        sm_linear_t a = lin(m, *R.patch, L.ws->patches.p, SM_X_BF16, L.B * P, m->Kpe);
+        sm_linear_t a = lin(m, *R.patch, w_patches, SM_X_BF16, L.B * P, m->Kpe);
         a.out_f32 = x; a.ldo = D;
         a.residual = R.pos; a.ldr = D;
         a.remap_in = P; a.remap_out = S; a.remap_off = 1;
@@ -619,14 +666,14 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             if ((rc = sm_norm_ex(x, M, D, D, w.ln1_w, w.ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.qkv, xn, SM_X_BF16, M, D);
             a.bias = w.qkv_b;
-            a.out_bf16 = L.ws->qkv.p; a.ldo_bf16 = 3 * D;
+            a.out_bf16 = w_qkv; a.ldo_bf16 = 3 * D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         // V is transposed inside the attention kernel's LDS staging (a V^T side output of the QKV GEMM cost ~50 us of
         // scalar 2-byte stores per layer at 28 frames)
         LANES { LV;
-            if ((rc = sm_vit_attention(L.ws->qkv.p, nullptr, L.ws->ctx.p, L.B, S, H, dh, 0, od, stream))) return rc;
-            sm_linear_t a = lin(m, *w.out, L.ws->ctx.p, SM_X_BF16, M, D);
+            if ((rc = sm_vit_attention(w_qkv, nullptr, w_ctx, L.B, S, H, dh, 0, od, stream))) return rc;
+            sm_linear_t a = lin(m, *w.out, w_ctx, SM_X_BF16, M, D);
             a.bias = w.out_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
@@ -635,11 +682,11 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             if ((rc = sm_norm_ex(x, M, D, D, w.ln2_w, w.ln2_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.fc1, xn, SM_X_BF16, M, D);
             a.bias = w.fc1_b; a.act = SM_ACT_QUICK_GELU;
-            a.out_bf16 = L.ws->hmid.p; a.ldo_bf16 = c.vit_mlp;
+            a.out_bf16 = w_hmid; a.ldo_bf16 = c.vit_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         LANES { LV;
-            sm_linear_t a = lin(m, *w.fc2, L.ws->hmid.p, SM_X_BF16, M, c.vit_mlp);
+            sm_linear_t a = lin(m, *w.fc2, w_hmid, SM_X_BF16, M, c.vit_mlp);
             a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
@@ -703,7 +750,7 @@ struct sm_stream {
     long pass_seq = 0, joined_seq = -1;   // number of the newest pass / of the pass `joined_on` was last ordered behind
     void* joined_on = nullptr;
     ~sm_stream() {
-        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (side) { (void)hipStreamSynchronize(side); release_stream_workspaces(side); (void)hipStreamDestroy(side); }
         if (ev_vit) (void)hipEventDestroy(ev_vit);
         for (auto e : ev_pass) if (e) (void)hipEventDestroy(e);
     }

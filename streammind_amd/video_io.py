@@ -129,7 +129,10 @@ class MjpegAviVideo:
             while pos + 8 <= hi:
                 cid, size = data[pos:pos + 4], struct.unpack_from("<I", data, pos + 4)[0]
                 body = pos + 8
-                if cid == b"LIST":
+                if cid == b"RIFF":                             # OpenDML: `RIFF....AVIX` continuation segments follow the first RIFF
+                    if data[body:body + 4] in (b"AVI ", b"AVIX"):
+                        walk(body + 4, min(body + size, hi))
+                elif cid == b"LIST":
                     if data[body:body + 4] in (b"hdrl", b"strl", b"movi", b"rec "):
                         walk(body + 4, min(body + size, hi))
                 elif cid == b"avih" and size >= 4:
@@ -141,11 +144,14 @@ class MjpegAviVideo:
                         self.fps = rate / scale
                 elif cid == b"strf" and size >= 20 and compression is None and handler is not None:
                     compression = data[body + 16:body + 20]
-                elif cid[2:4] in (b"dc", b"db") and cid[:2].isdigit() and size > 0:
-                    self._frames.append((body, size))
+                elif cid[2:4] in (b"dc", b"db") and cid[:2].isdigit():
+                    if size > 0:
+                        self._frames.append((body, size))
+                    elif self._frames:                          # zero-length chunk = dropped frame: the player repeats the previous one,
+                        self._frames.append(self._frames[-1])   # so frame index keeps tracking time
                 pos = body + size + (size & 1)                # chunks are word aligned
 
-        walk(12, len(data))
+        walk(0, len(data))                                      # every top-level RIFF segment (`AVI ` then any number of `AVIX`)
         tags = {t.upper() for t in (handler, compression) if t}
         if not tags & {b"MJPG", b"JPEG", b"AVRN", b"LJPG"} or not self._frames:
             raise ValueError(f"{path}: AVI video stream is {handler!r}/{compression!r}, not Motion-JPEG")

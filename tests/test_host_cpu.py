@@ -261,6 +261,40 @@ def test_mjpeg_avi_is_read_without_a_codec_library(tmp_path):
         video_io.open_video(str(tmp_path / "h264.avi"))
 
 
+def test_mjpeg_avi_opendml_segments_and_dropped_frames(tmp_path):
+    """OpenDML AVI (what ffmpeg / capture tools write past ~1 GiB): frames continue in top-level `RIFF....AVIX` segments behind the
+    first `RIFF....AVI `; a zero-length `00dc` chunk is a dropped frame and repeats its predecessor, so frame index keeps tracking
+    time.  Every frame of every segment is returned, in order."""
+    import io
+    import struct
+    from PIL import Image
+    from streammind_amd import video_io
+    w, h = 32, 16
+    jpegs = []
+    for j in range(7):
+        buf = io.BytesIO()
+        Image.fromarray(np.full((h, w, 3), 20 + 30 * j, np.uint8)).save(buf, "JPEG", quality=90)
+        jpegs.append(buf.getvalue())
+    _write_mjpeg_avi(tmp_path / "seg.avi", jpegs[:3], w, h, 30, 1)
+
+    def chunk(cid, body):
+        return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+    def avix(js):
+        movi = b"movi" + b"".join(chunk(b"00dc", j) for j in js)
+        body = b"AVIX" + b"LIST" + struct.pack("<I", len(movi)) + movi
+        return b"RIFF" + struct.pack("<I", len(body)) + body
+
+    with open(tmp_path / "seg.avi", "ab") as f:
+        f.write(avix([jpegs[3], b"", jpegs[4]]))              # a dropped frame inside the second segment
+        f.write(avix(jpegs[5:]))
+    vr = video_io.open_video(str(tmp_path / "seg.avi"))
+    assert isinstance(vr, video_io.MjpegAviVideo) and len(vr) == 8
+    order = [0, 1, 2, 3, 3, 4, 5, 6]
+    for i, j in enumerate(order):
+        assert np.array_equal(vr[i].asnumpy(), np.asarray(Image.open(io.BytesIO(jpegs[j])).convert("RGB"))), i
+
+
 def test_loader_rejects_configs_the_kernels_do_not_implement():
     """path_config_from_checkpoint: a config.json that asks for something the kernels hard-wire differently (activation, tied
     embeddings, projection biases, rope scaling, a foreign head_dim) must raise, not load and compute something else."""
