@@ -113,6 +113,16 @@ typedef struct sm_linear_t {
     /* SM_OP_BF16 (default) or SM_OP_F16: w is then the packed image of fp16 values (sm_pack_weight is type-agnostic: it moves
      * 16-bit words), x and out_bf16 hold fp16.  Same MFMA rate, fp32 accumulation either way. */
     int op_dtype;
+    /* LayerNorm of the FINISHED output row, behind the epilogue ("post-LN"): post_ln_gamma != NULL (with post_ln_beta) asks for
+     * post_ln_out[m][0..N) = 16-bit(LN(out_f32[m][:]) * gamma + beta) (op_dtype), the operand of the next product, next to out_f32.
+     * Needs out_f32, remap_in == 0 and no vt.  Where the product runs as split-K slabs (few tiles: one frame through the tower)
+     * the slab sum, bias, residual and the LayerNorm of the row are ONE pass (a wave per row, N == 1024); everywhere else the call
+     * ends with the sm_norm_ex launch the caller would have made -- the same arithmetic (two-pass mean / variance) either way. */
+    const float* post_ln_gamma;
+    const float* post_ln_beta;
+    float post_ln_eps;
+    void* post_ln_out;
+    int post_ln_ldo;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 
@@ -393,6 +403,65 @@ int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int F, float* 
  * generate loops (videollama2_mistral.py:426-431; "only support batch size 1"): batch-1 decode is bound by streaming 14.2 GB
  * of weights per token, which S streams share here. */
 int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_host, int n_steps, int32_t* out_ids_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * f2 ingest front-end, codec half: baseline JPEG (Motion-JPEG AVI frames, stills) -> RGB u8 in HBM (csrc/jpeg.hip).  Replaces the
+ * decord / PIL decode in front of the streaming loop (eval/video_score_stream_demo.py:212-225, mm_utils.py:399-435) for the one codec
+ * this image can decode.  The bit-serial Huffman stage runs on the host (one frame per call, thread-safe, no HIP call inside); the
+ * dequantisation, the 8x8 inverse DCT, the chroma upsampling and the colour conversion run on the GPU with libjpeg's own integer
+ * arithmetic (islow IDCT, fancy upsampling, 16-bit colour tables): byte for byte what PIL / libjpeg-turbo returns.
+ * Baseline sequential, 8-bit, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0, restart intervals, implied (standard) Huffman tables;
+ * anything else is SM_EINVAL with the reason in sm_last_error() and the caller keeps its host decoder.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct sm_jpeg_info_t {
+    int width, height, ncomp;
+    int hs[3], vs[3];                 /* sampling factors per component (luma: 1 or 2; chroma 1)                              */
+    int mcu_w, mcu_h, mcus_x, mcus_y;
+    int blocks_x[3], blocks_y[3];     /* 8x8 blocks per component plane (padded to whole MCUs)                                */
+    int coef_offset[3];               /* first coefficient of each component inside one frame's coefficient image            */
+    int coef_count;                   /* int16 coefficients per frame                                                        */
+} sm_jpeg_info_t;
+int sm_jpeg_info(const uint8_t* data, size_t len, sm_jpeg_info_t* info);
+/* host -> host: coefs int16 [coef_count] (natural order inside a block, blocks row-major per plane), qt uint16 [3][64] (natural order,
+ * per component).  want != NULL: fail unless the frame has that geometry (frames of one clip share it). */
+int sm_jpeg_decode_coefs(const uint8_t* data, size_t len, const sm_jpeg_info_t* want, int16_t* coefs, uint16_t* qt);
+size_t sm_jpeg_planes_bytes(const sm_jpeg_info_t* info, int n_frames);
+/* device: coefs [n][coef_count], qt [n][3][64] -> rgb u8 [n][height][width][3]; planes: scratch of sm_jpeg_planes_bytes bytes */
+int sm_jpeg_reconstruct(const int16_t* coefs, const uint16_t* qt, const sm_jpeg_info_t* info, int n_frames, uint8_t* planes, uint8_t* rgb, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gated-token exchange between the GPUs of one node (csrc/comm.hip).  Replaces allgather_diff_shape
+ * (/root/reference/streammind/dist.py:122-146: an all-gather of the per-rank row counts, a host read, then an all-gather of the rows
+ * padded to the largest count) and its caller, the distributed evaluation loop (eval/inference_video_score_stream_ddp.py).
+ * MI355X form: xGMI is point to point, so every rank writes its rows straight into a mailbox in every peer's HBM (hipIpc-mapped,
+ * fine-grained), one hop, all links at once; a tick whose gate stayed silent moves one 16-byte header per peer and no payload.
+ * One process per GPU; two processes on one GPU are a valid world (how the single-GPU test box exercises it).
+ *
+ *   sm_comm_init(rank, world, max_rows, row_bytes)     mailbox of 2 x world slots of max_rows x row_bytes (row_bytes % 16 == 0)
+ *   sm_comm_export(handle_out[sm_comm_handle_bytes()])  this rank's mailbox handle; the CALLER moves the handles of all ranks
+ *   sm_comm_connect(all_handles[world][handle_bytes])   (any transport, as an ncclUniqueId travels) and maps the peers here
+ *   sm_comm_post(rows, n_rows, stream)                  tick t of this rank: n_rows (0 = silent) rows, device pointer, 16-B aligned
+ *   sm_comm_collect(counts_out, payload_out, stream)    tick t of every rank: counts_out int32 [world] (device, may be NULL; -1 = that
+ *                                                      rank did not arrive within SM_COMM_TIMEOUT_MS, default 5000), payload_out
+ *                                                      [world][max_rows][row_bytes] (device, may be NULL): rows [0, count) of each rank
+ *   sm_comm_host_counts(parity, counts_out[world])      the same counts from the pinned host mirror of tick parity (t & 1), valid once
+ *                                                      `stream` has passed that collect; error if a rank timed out
+ *   sm_allgather_gated(...)                             post + collect of one tick (the blocking form)
+ * post and collect alternate (post t, collect t, post t+1, ...); on one HIP stream per rank, or on streams ordered by events.
+ * ---------------------------------------------------------------------------------------------- */
+#define SM_COMM_MAX_RANKS 16
+typedef struct sm_comm sm_comm;
+int sm_comm_handle_bytes(void);
+int sm_comm_init(int rank, int world, int max_rows, int row_bytes, sm_comm** out);
+int sm_comm_export(sm_comm* c, void* handle_out);
+int sm_comm_connect(sm_comm* c, const void* all_handles);
+void sm_comm_destroy(sm_comm* c);
+int sm_comm_post(sm_comm* c, const void* rows, int n_rows, void* stream);
+int sm_comm_collect(sm_comm* c, int32_t* counts_out, void* payload_out, void* stream);
+int sm_comm_host_counts(sm_comm* c, int tick_parity, int32_t* counts_out);
+int sm_allgather_gated(sm_comm* c, const void* rows, int n_rows, int32_t* counts_out, void* payload_out, void* stream);
+int sm_comm_max_rows(sm_comm* c);
+int sm_comm_tick(sm_comm* c);
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline leg; no reference counterpart -- the reference has only commented-out

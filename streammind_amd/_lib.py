@@ -32,6 +32,7 @@ class sm_linear_t(C.Structure):
         ("vt", vp), ("vt_n0", i32), ("vt_S", i32), ("vt_dh", i32), ("vt_ld", i32),
         ("w_dtype", i32), ("w_scale", vp), ("w2_scale", vp),
         ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32), ("op_dtype", i32),
+        ("post_ln_gamma", vp), ("post_ln_beta", vp), ("post_ln_eps", f32), ("post_ln_out", vp), ("post_ln_ldo", i32),
     ]
 
 
@@ -47,6 +48,11 @@ class sm_config_t(C.Structure):
         ("llm_vocab", i32), ("llm_eps", f32), ("llm_rope_theta", f32),
         ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32), ("llm_fp16", i32), ("proj_fp16", i32),
     ]
+
+
+class sm_jpeg_info_t(C.Structure):
+    _fields_ = [("width", i32), ("height", i32), ("ncomp", i32), ("hs", i32 * 3), ("vs", i32 * 3), ("mcu_w", i32), ("mcu_h", i32),
+                ("mcus_x", i32), ("mcus_y", i32), ("blocks_x", i32 * 3), ("blocks_y", i32 * 3), ("coef_offset", i32 * 3), ("coef_count", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/streammind_hip.h declares
@@ -120,6 +126,21 @@ SIGNATURES = {
     "sm_group_push_frames": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_group_push_pooled": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_group_llm_decode": (i32, [vp, C.POINTER(C.c_int32), i32, vp, vp]),
+    "sm_jpeg_info": (i32, [vp, sz, C.POINTER(sm_jpeg_info_t)]),
+    "sm_jpeg_decode_coefs": (i32, [vp, sz, C.POINTER(sm_jpeg_info_t), vp, vp]),
+    "sm_jpeg_planes_bytes": (sz, [C.POINTER(sm_jpeg_info_t), i32]),
+    "sm_jpeg_reconstruct": (i32, [vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp]),
+    "sm_comm_handle_bytes": (i32, []),
+    "sm_comm_init": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
+    "sm_comm_export": (i32, [vp, vp]),
+    "sm_comm_connect": (i32, [vp, vp]),
+    "sm_comm_destroy": (None, [vp]),
+    "sm_comm_post": (i32, [vp, vp, i32, vp]),
+    "sm_comm_collect": (i32, [vp, vp, vp, vp]),
+    "sm_comm_host_counts": (i32, [vp, i32, C.POINTER(C.c_int32)]),
+    "sm_allgather_gated": (i32, [vp, vp, i32, vp, vp, vp]),
+    "sm_comm_max_rows": (i32, [vp]),
+    "sm_comm_tick": (i32, [vp]),
     "sm_prof_enable": (i32, [i32]),
     "sm_prof_reset": (i32, []),
     "sm_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f32)]),

@@ -1034,6 +1034,69 @@ __global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, co
     store4(a, m, n0, v, ws2 ? &v2 : nullptr);
 }
 
+// Split-K slabs -> finished fp32 row AND its LayerNorm in one pass (sm_linear_t.post_ln_*; one frame through the ViT).  One wave per
+// row of D = 256 * NV columns, a lane owns columns lane*4 + j*256 -- the layout and the arithmetic of norm_wave_fixed_kernel (mean,
+// then the sum of squared deviations, in registers), and the slab sum / bias / residual order of splitk_reduce_kernel + store4: the
+// two outputs are bit for bit what the two separate launches wrote.  Replaces two dependent launches (~5 us of fixed cost each at
+// this size) and the re-read of the row by one.
+struct PostLn { const float* gamma; const float* beta; float eps; bf16_t* out; int ldo; };
+template <int NV>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(LinArgs a, const float* __restrict__ ws, int S, int ldw, PostLn ln) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const size_t sstride = (size_t)a.M * ldw;
+    const float* wr = ws + (size_t)row * ldw + lane * 4;
+    f32x4 t[8][NV], r[NV], b[NV], v[NV];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) t[u][j] = u < S ? *(const f32x4*)(wr + (size_t)u * sstride + j * 256) : f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + j * 256;
+        r[j] = a.residual ? *(const f32x4*)(a.residual + (size_t)row * a.ldr + c) : f32x4{0, 0, 0, 0};
+        b[j] = a.bias ? *(const f32x4*)(a.bias + c) : f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u < S) acc += t[u][j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float o = acc[e];
+            if (a.bias) o += b[j][e];
+            if (a.residual) o += r[j][e];
+            v[j][e] = o;
+        }
+        *(f32x4*)(a.out_f32 + (size_t)row * a.ldo + lane * 4 + j * 256) = v[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    s = wave_sum(s);
+    const float mu = s * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q += d * d; }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q * (1.0f / D) + ln.eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + j * 256;
+        const f32x4 gm = *(const f32x4*)(ln.gamma + c), bt = *(const f32x4*)(ln.beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rstd * gm[e] + bt[e];
+        *(u32x2*)(ln.out + (size_t)row * ln.ldo + c) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
+    }
+}
+
 // per-HIP-stream split-K workspace (grown on demand; steady state allocates nothing)
 #include <map>
 #include <mutex>
@@ -1358,7 +1421,21 @@ int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) 
     return SM_OK;
 }
 
+extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
+                          float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);                        // vecops.hip
+static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done);
 extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
+    SM_REQUIRE(p, "sm_linear: null args");
+    if (p->post_ln_gamma)
+        SM_REQUIRE(p->post_ln_beta && p->post_ln_out && p->out_f32 && p->remap_in == 0 && !p->vt && !p->w2 && p->post_ln_ldo >= p->N && (p->post_ln_ldo & 3) == 0,
+                   "sm_linear: post-LN needs gamma, beta, a 16-bit output [M][post_ln_ldo >= N, %% 4 == 0], an fp32 output and plain rows");
+    bool ln_done = false;
+    int rc = linear_impl(p, stream, &ln_done);
+    if (rc || !p->post_ln_gamma || ln_done) return rc;
+    return sm_norm_ex(p->out_f32, p->M, p->N, p->ldo, p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, 0, nullptr, p->post_ln_out, p->post_ln_ldo,
+                      p->op_dtype, stream);
+}
+static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
     SM_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "sm_linear: bad dims M=%d N=%d K=%d", p->M, p->N, p->K);
     SM_REQUIRE(p->out_f32 || p->out_bf16 || p->vt, "sm_linear: no output");
@@ -1499,7 +1576,20 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     int S = tiles <= 128 ? 256 / tiles : 1;
     if (S > 4) S = 4;
     while (S > 1 && KTall / S < 16) --S;
-    if (force_s > 0) S = force_s;
+    // a post-LN call pays for a second pass anyway (the LayerNorm of the finished rows): as slabs + the fused slab-sum / LayerNorm pass
+    // the product costs one launch less than GEMM + LayerNorm, so slabs pay even for short K loops (out-proj, K = 1024: 4 k-tiles each)
+    static int ln_fuse = -1, ln_smax = 6;
+    if (ln_fuse < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse = e ? atoi(e) : 1; const char* m = getenv("SM_POST_LN_SMAX"); if (m) ln_smax = atoi(m); }
+    const bool ln_ok = ln_fuse && p->post_ln_gamma && p->N == 1024 && tiles <= 128 && p->act == SM_ACT_NONE && !w8 && (p->ldo & 3) == 0 &&
+                       (!p->residual || (p->ldr & 3) == 0) && p->M <= 4096 && ln_smax >= 2;
+    if (ln_ok) {
+        S = 256 / tiles;
+        if (S > ln_smax) S = ln_smax;
+        if (S > 8) S = 8;
+        while (S > 2 && KTall / S < 4) --S;
+        if (S < 2) S = 2;
+    }
+    if (force_s > 0 && !ln_ok) S = force_s;
     if (S > KTall) S = KTall;
     if (S < 1 || p->vt || (p->N & 3) || p->M > 4096) S = 1;
     const bool wv8 = use_w8 == 2 || (use_w8 == 1 && tiles * S <= 256);
@@ -1527,6 +1617,13 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         b.remap_in = 0; b.vt = nullptr;
         GEMM_LAUNCH(0, b, dim3(tiles, S));
         SM_LAUNCH_CHECK();
+        if (ln_ok && S >= 2) {
+            const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo};
+            splitk_reduce_ln_kernel<4><<<cdiv(p->M, 4), 256, 0, st>>>(a, ws, S, p->N, ln);
+            SM_LAUNCH_CHECK();
+            *ln_done = true;
+            return SM_OK;
+        }
         const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
         splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, p->N);
         SM_LAUNCH_CHECK();

@@ -547,10 +547,14 @@ static int vit_lane_count(int B) {
 // does nothing takes 4.7 us between two others; profiles/r04_tick_b1_timeline.txt) and none of them fills the chip (577 rows = 40-160
 // tiles of 128 x 128): the frames of a small call are independent, so each gets its own HIP stream and the launch chains run side by
 // side (same workspace, disjoint frame slots; fork / join by events like the two big lanes).  Results are those of one-frame calls.
+// MEASURED AND LEFT OFF (SM_VIT_SMALL_LANES=n enables n lanes): 4 frames as 4 lanes 5.72 ms against 3.74 ms as one batch, 8 frames as 8
+// lanes 9.9 vs 5.56 -- and with one HOST THREAD per lane (tools/lanes_threads_probe.py: the issue cost taken out) 4 frames still take
+// 3.52 ms: the chip retires ~one dependent launch per 4.7 us ACROSS all queues (740 launches of four concurrent one-frame chains in
+// 3.5 ms), so side-by-side launch chains do not buy latency here; only fewer launches do.
 static int vit_small_lanes(int B) {
     static int max_l = -1, max_b = 8;
     if (max_l < 0) {
-        const char* e = getenv("SM_VIT_SMALL_LANES"); max_l = e ? atoi(e) : 8;
+        const char* e = getenv("SM_VIT_SMALL_LANES"); max_l = e ? atoi(e) : 1;
         const char* mb = getenv("SM_VIT_SMALL_MAX"); if (mb) max_b = atoi(mb);
         if (max_l > 8) max_l = 8;
     }
@@ -660,10 +664,16 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
         if ((rc = sm_vit_cls_rows(x, L.B, S, D, R.cls, R.pos, stream))) return rc;
         if ((rc = sm_norm(x, M, D, D, R.pre_ln_w, R.pre_ln_b, c.vit_eps, 0, x, nullptr, D, stream))) return rc;
     }
+    // LayerNorms ride behind the residual products (sm_linear_t.post_ln_*): out-proj leaves LN2(x), fc2 leaves the NEXT layer's LN1(x),
+    // as the 16-bit operand `xn` of the following product -- fused into the slab pass for a single frame, a separate launch otherwise.
+    // Only the first layer's LN1 is a call of its own.
+    if (c.vit_layers_run > 0) LANES { LV;
+        if ((rc = sm_norm_ex(x, M, D, D, R.vit[0].ln1_w, R.vit[0].ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
+    }
     for (int l = 0; l < c.vit_layers_run; ++l) {
         const sm_model::LayerW& w = R.vit[l];
+        const sm_model::LayerW* wnext = l + 1 < c.vit_layers_run ? &R.vit[l + 1] : nullptr;
         LANES { LV;
-            if ((rc = sm_norm_ex(x, M, D, D, w.ln1_w, w.ln1_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.qkv, xn, SM_X_BF16, M, D);
             a.bias = w.qkv_b;
             a.out_bf16 = w_qkv; a.ldo_bf16 = 3 * D;
@@ -676,10 +686,10 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             sm_linear_t a = lin(m, *w.out, w_ctx, SM_X_BF16, M, D);
             a.bias = w.out_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            a.post_ln_gamma = w.ln2_w; a.post_ln_beta = w.ln2_b; a.post_ln_eps = c.vit_eps; a.post_ln_out = xn; a.post_ln_ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         LANES { LV;
-            if ((rc = sm_norm_ex(x, M, D, D, w.ln2_w, w.ln2_b, c.vit_eps, 0, nullptr, xn, D, od, stream))) return rc;
             sm_linear_t a = lin(m, *w.fc1, xn, SM_X_BF16, M, D);
             a.bias = w.fc1_b; a.act = SM_ACT_QUICK_GELU;
             a.out_bf16 = w_hmid; a.ldo_bf16 = c.vit_mlp;
@@ -689,6 +699,7 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             sm_linear_t a = lin(m, *w.fc2, w_hmid, SM_X_BF16, M, c.vit_mlp);
             a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            if (wnext) { a.post_ln_gamma = wnext->ln1_w; a.post_ln_beta = wnext->ln1_b; a.post_ln_eps = c.vit_eps; a.post_ln_out = xn; a.post_ln_ldo = D; }
             if ((rc = sm_linear(&a, stream))) return rc;
         }
     }

@@ -5,7 +5,7 @@
 
 thread_local char g_sm_err[512] = {0};
 extern "C" const char* sm_last_error(void) { return g_sm_err; }
-extern "C" int sm_abi_version(void) { return 2; }
+extern "C" int sm_abi_version(void) { return 3; }
 
 // ------------------------------------------------------------------------------------------------ profiling hooks
 #include <vector>

@@ -267,3 +267,105 @@ class GatedTokenExchange:
 
     def flush(self) -> Optional[List[torch.Tensor]]:
         return self._collect()
+
+
+# ------------------------------------------------------------------------------------------------ peer-write exchange (C ABI)
+class PeerWriteExchange:
+    """The same tick() / flush() contract as `GatedTokenExchange`, on the library's own exchange (include/streammind_hip.h
+    `sm_comm_*`, csrc/comm.hip): every rank writes its fired rows straight into a hipIpc-mapped mailbox in every peer's HBM over
+    xGMI -- one hop, all links at once, no ring -- and a silent tick moves one 16-byte header per peer: no collective, no host
+    allocation, no host wait (the counts of tick t are read from a pinned mirror while tick t+1 is already posted).
+
+    `torch.distributed` is used ONCE, to move the 64-byte mailbox handles (any backend: gloo or nccl); after that the data path
+    is the C ABI only, so a Level-2 (ctypes) integrator gets the same path without torch.  max_rows bounds the rows one rank
+    can contribute per tick (the connector emits one token per frame: rows = frames of a tick whose gate fired)."""
+
+    def __init__(self, d_model: int, max_rows: int = 64, group=None, dtype: torch.dtype = torch.float32,
+                 device: Optional[torch.device] = None):
+        import ctypes as C
+        from . import _lib
+        self._C, self.lib = C, _lib.load()
+        self.group, self.d_model, self.dtype, self.max_rows = group, d_model, dtype, int(max_rows)
+        self.world, self.rank = tdist.get_world_size(group), tdist.get_rank(group)
+        self.dev = device or torch.device("cuda", torch.cuda.current_device())
+        self.row_bytes = d_model * torch.empty(0, dtype=dtype).element_size()
+        if self.row_bytes % 16:
+            raise ValueError(f"row of {self.row_bytes} bytes: the exchange moves 16-byte words")
+        h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.sm_comm_init(self.rank, self.world, self.max_rows, self.row_bytes, C.byref(h)), "sm_comm_init")
+            self.h = h
+            hb = self.lib.sm_comm_handle_bytes()
+            mine = (C.c_ubyte * hb)()
+            _lib.check(self.lib.sm_comm_export(self.h, mine), "sm_comm_export")
+            comm_dev = self.dev if tdist.get_backend(group) == "nccl" else torch.device("cpu")
+            mine_t = torch.tensor(list(mine), dtype=torch.uint8, device=comm_dev)
+            every = torch.empty(self.world * hb, dtype=torch.uint8, device=comm_dev)
+            tdist.all_gather_into_tensor(every, mine_t, group=group)
+            buf = (C.c_ubyte * (self.world * hb)).from_buffer_copy(bytes(every.cpu().tolist()))
+            _lib.check(self.lib.sm_comm_connect(self.h, buf), "sm_comm_connect")
+        tdist.barrier(group=group)                         # every mailbox is mapped everywhere before the first post
+        # two result sets (tick parity): the payload of tick t is read by the caller while tick t+1 is collected
+        self._payload = [torch.empty(self.world, self.max_rows, d_model, dtype=dtype, device=self.dev) for _ in range(2)]
+        self._counts = (C.c_int32 * self.world)()
+        self._ev = [torch.cuda.Event() for _ in range(2)]
+        self.side = torch.cuda.Stream(self.dev)              # the collect WAITS for the slowest peer: it must not sit in the compute stream
+        self._pending = None                                # parity of the tick posted + collected on the GPU, not yet read on the host
+        self.ticks = self.payload_collectives = 0
+        self.host_wait_s = 0.0
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _post(self, tokens: Optional[torch.Tensor]):
+        n = 0 if tokens is None else int(tokens.shape[0])
+        if n > self.max_rows:
+            raise ValueError(f"{n} rows in one tick, the mailbox was sized for {self.max_rows}")
+        if n:
+            tokens = tokens.to(device=self.dev, dtype=self.dtype).contiguous()
+        par = self.ticks & 1
+        from . import _lib
+        cur = torch.cuda.current_stream(self.dev)
+        _lib.check(self.lib.sm_comm_post(self.h, tokens.data_ptr() if n else None, n, cur.cuda_stream), "sm_comm_post")
+        self.side.wait_stream(cur)                           # post(t) before collect(t); collect(t-1) was host-synchronised in _collect
+        _lib.check(self.lib.sm_comm_collect(self.h, None, self._payload[par].data_ptr(), self.side.cuda_stream), "sm_comm_collect")
+        self._ev[par].record(self.side)
+        self._keep = tokens                                  # the rows stay alive until the post kernel has read them
+        self._pending = par
+
+    def _collect(self) -> Optional[List[torch.Tensor]]:
+        if self._pending is None:
+            return None
+        par, self._pending = self._pending, None
+        import time
+        t0 = time.perf_counter()
+        self._ev[par].synchronize()
+        self.host_wait_s += time.perf_counter() - t0
+        from . import _lib
+        _lib.check(self.lib.sm_comm_host_counts(self.h, par, self._counts), "sm_comm_host_counts")
+        counts = list(self._counts)
+        if max(counts) == 0:
+            return None
+        self.payload_collectives += 1
+        return [self._payload[par][r, :counts[r]] for r in range(self.world)]
+
+    def tick(self, tokens: Optional[torch.Tensor]) -> Optional[List[torch.Tensor]]:
+        prev = self._collect()
+        self._post(tokens)
+        self.ticks += 1
+        return prev
+
+    def flush(self) -> Optional[List[torch.Tensor]]:
+        return self._collect()
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.dev)
+            self.lib.sm_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -425,8 +425,10 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,
            w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
            norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
-           out: Optional[torch.Tensor] = None, fp8_mfma: bool = False, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, fp8_mfma: bool = False, out16: Optional[torch.Tensor] = None,
+           post_ln: Optional[Tuple[torch.Tensor, torch.Tensor, float, torch.Tensor]] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front.
+    post_ln = (gamma, beta, eps, out16 [M, N]): LayerNorm of the finished fp32 rows into `out16` from the same call (sm_linear_t.post_ln_*).
     fp8_mfma (with w_scale): SM_W_FP8_MFMA -- above 16 rows the activations are quantised per row and the product is fp8 x fp8."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32, torch.float16)
@@ -464,5 +466,67 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     else:
         assert out16 is None
         a.out_bf16, a.ldo_bf16 = out.data_ptr(), N
+    if post_ln is not None:
+        g, b, eps, ln_out = post_ln
+        assert out_dtype == torch.float32 and ln_out.shape == out.shape and ln_out.is_contiguous() and ln_out.dtype == (torch.float16 if a_f16 else torch.bfloat16)
+        a.post_ln_gamma, a.post_ln_beta, a.post_ln_eps, a.post_ln_out, a.post_ln_ldo = g.data_ptr(), b.data_ptr(), float(eps), ln_out.data_ptr(), N
     check(lib.sm_linear(C.byref(a), _stream()), "sm_linear")
     return out
+
+
+class JpegDecoder:
+    """Baseline JPEG frames -> RGB u8 [n, H, W, 3] in HBM through the C ABI (include/streammind_hip.h sm_jpeg_*, csrc/jpeg.hip): the
+    bit-serial Huffman stage on host threads (ctypes releases the GIL: frames of a batch decode in parallel), one pinned upload of the
+    coefficient images, inverse DCT + upsampling + colour conversion on the GPU with libjpeg's integer arithmetic -- byte for byte
+    PIL's output.  Frames of one batch share a geometry (a Motion-JPEG clip does).  Raises StreamMindHipError for what the decoder
+    does not implement (progressive, CMYK, ...): the caller keeps its host decoder for those."""
+
+    def __init__(self, threads: int = 8, device: Optional[torch.device] = None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.lib = _lib.load()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.pool = ThreadPoolExecutor(max_workers=max(1, threads))
+        self._pinned = {}            # (n, coef_count) -> (coefs int16 pinned, qt int16 pinned)
+        self.host_decode_s = 0.0     # accumulated wall time of the host (entropy) stage
+        self.frames = 0
+
+    def info(self, jpeg: bytes) -> "_lib.sm_jpeg_info_t":
+        inf = self.lib.sm_jpeg_info.argtypes[2]._type_()
+        check(self.lib.sm_jpeg_info(C.cast(C.c_char_p(jpeg), C.c_void_p), len(jpeg), C.byref(inf)), "sm_jpeg_info")
+        return inf
+
+    def decode(self, jpegs: Sequence[bytes]) -> torch.Tensor:
+        import time
+        n = len(jpegs)
+        assert n >= 1
+        jpegs = [bytes(j) for j in jpegs]
+        inf = self.info(jpegs[0])
+        key = (n, inf.coef_count)
+        if key not in self._pinned:
+            if len(self._pinned) > 4:
+                self._pinned.clear()
+            self._pinned[key] = (torch.empty(n, inf.coef_count, dtype=torch.int16).pin_memory(), torch.empty(n, 3, 64, dtype=torch.int16).pin_memory())
+        coefs, qt = self._pinned[key]
+        cp, qp = coefs.data_ptr(), qt.data_ptr()
+
+        def one(i):
+            return self.lib.sm_jpeg_decode_coefs(C.cast(C.c_char_p(jpegs[i]), C.c_void_p), len(jpegs[i]), C.byref(inf), cp + i * inf.coef_count * 2, qp + i * 3 * 64 * 2)
+
+        t0 = time.perf_counter()
+        rcs = list(self.pool.map(one, range(n))) if n > 1 else [one(0)]
+        self.host_decode_s += time.perf_counter() - t0
+        self.frames += n
+        for i, rc in enumerate(rcs):
+            if rc < 0:        # thread-local error text lives on the worker: decode that frame again here for the message
+                check(one(i), f"sm_jpeg_decode_coefs(frame {i})")
+        with torch.cuda.device(self.device):
+            cd = coefs.to(self.device, non_blocking=True)
+            qd = qt.to(self.device, non_blocking=True)
+            planes = torch.empty(self.lib.sm_jpeg_planes_bytes(C.byref(inf), n), dtype=torch.uint8, device=self.device)
+            rgb = torch.empty(n, inf.height, inf.width, 3, dtype=torch.uint8, device=self.device)
+            check(self.lib.sm_jpeg_reconstruct(cd.data_ptr(), qd.data_ptr(), C.byref(inf), n, planes.data_ptr(), rgb.data_ptr(), _stream()), "sm_jpeg_reconstruct")
+            for t in (cd, qd, planes):
+                t.record_stream(torch.cuda.current_stream(self.device))
+        # the pinned buffers are reused by the next call: the upload has to be done before they are overwritten
+        torch.cuda.current_stream(self.device).synchronize()
+        return rgb

@@ -201,6 +201,21 @@ class MjpegAviVideo:
     def get_batch(self, ids: Sequence[int]) -> _Frames:
         return _Frames(np.stack([self._load(i) for i in ids]))
 
+    def get_batch_gpu(self, ids: Sequence[int], decoder=None):
+        """the same frames as a u8 tensor [n, H, W, 3] ALREADY IN HBM, decoded by the C ABI's JPEG path (host Huffman threads + GPU
+        inverse DCT / upsampling / colour: byte for byte `get_batch`) -- nothing is decoded by PIL, no RGB frame crosses PCIe.  Frames
+        the native decoder does not implement (progressive, CMYK ...) take the PIL path and an upload."""
+        import torch
+        from . import native
+        from ._lib import StreamMindHipError
+        if decoder is None:
+            decoder = self._gpu_decoder = getattr(self, "_gpu_decoder", None) or native.JpegDecoder()
+        chunks = [bytes(self._data[o:o + n]) for o, n in (self._frames[int(i)] for i in ids)]       # raw chunks: implied tables are the decoder's business
+        try:
+            return decoder.decode(chunks)
+        except StreamMindHipError:
+            return torch.from_numpy(self.get_batch(ids).asnumpy()).to(decoder.device)
+
 
 class _DecordVideo:
     def __init__(self, path: str):

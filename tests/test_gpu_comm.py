@@ -1,0 +1,151 @@
+"""The C ABI's gated-token exchange (include/streammind_hip.h sm_comm_*, csrc/comm.hip) with a real second rank: two PROCESSES on
+cuda:0 (the single-GPU box's valid world: each maps the other's mailbox through hipIpcGetMemHandle / hipIpcOpenMemHandle exactly as two
+GPUs of a node would), direct peer writes, silent ticks, ragged counts -- against the reference's allgather_diff_shape semantics
+(/root/reference/streammind/dist.py:122-146: per-rank row counts + each rank's rows) and against the torch.distributed form
+(`GatedTokenExchange` over gloo) on the same schedule.  Integer-exact: the payload is moved, never computed on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rows(rank, tick, n, d, dtype):
+    """what rank `rank` contributes at `tick`: n rows, every element a function of (rank, tick, row, col)"""
+    if n == 0:
+        return None
+    base = torch.arange(n * d, dtype=torch.float32).reshape(n, d) % 251
+    return (base + 1000 * rank + 7 * tick).to(dtype)
+
+
+def _schedule(rank, tick):
+    """rows per tick: mostly silent, ranks fire on different ticks, sometimes together, sometimes the full mailbox"""
+    if tick % 7 == 3 + rank:
+        return 1 + (tick % 5)
+    if tick % 11 == 10:
+        return 16                      # both ranks, the whole mailbox
+    return 0
+
+
+def _worker(rank, world, port, q, dtype_name):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from streammind_amd.dist import PeerWriteExchange, GatedTokenExchange
+        dtype = getattr(torch, dtype_name)
+        d, T = 4096, 40
+        ex = PeerWriteExchange(d, max_rows=16, dtype=dtype)
+        ref = GatedTokenExchange(d, dtype=dtype, device=torch.device("cpu"))
+        ok, fired = True, 0
+
+        def check(tick, got, want):
+            nonlocal ok, fired
+            counts = [_schedule(r, tick) for r in range(world)]
+            if max(counts) == 0:
+                ok &= got is None and want is None
+                return
+            fired += 1
+            ok &= got is not None and want is not None and [int(g.shape[0]) for g in got] == counts == [int(w.shape[0]) for w in want]
+            for r in range(world):
+                if counts[r]:
+                    exp = _rows(r, tick, counts[r], d, dtype)
+                    ok &= torch.equal(got[r].cpu(), exp) and torch.equal(want[r].cpu(), exp)
+
+        for t in range(T):
+            n = _schedule(rank, t)
+            rows = _rows(rank, t, n, d, dtype)
+            got = ex.tick(rows.cuda() if rows is not None else None)          # result of tick t - 1
+            want = ref.tick(rows)
+            if t:
+                check(t - 1, got, want)
+        check(T - 1, ex.flush(), ref.flush())
+        stats = (ex.ticks, ex.payload_collectives, fired)
+        # the blocking form through the raw C ABI: counts on the device, payload padded per rank
+        import ctypes as C
+        from streammind_amd import _lib
+        lib = _lib.load()
+        cnt = torch.full((world,), -7, dtype=torch.int32, device="cuda")
+        pay = torch.zeros(world, 16, d, dtype=dtype, device="cuda")
+        mine = _rows(rank, 99, 2 + rank, d, dtype).cuda()
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.sm_allgather_gated(ex.h, mine.data_ptr(), 2 + rank, cnt.data_ptr(), pay.data_ptr(), st), "sm_allgather_gated")
+        torch.cuda.synchronize()
+        ok &= cnt.cpu().tolist() == [2 + r for r in range(world)]
+        for r in range(world):
+            ok &= torch.equal(pay[r, :2 + r].cpu(), _rows(r, 99, 2 + r, d, dtype))
+        dist.barrier()
+        ex.close()
+        q.put((rank, bool(ok), stats, ""))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:          # noqa: BLE001 -- the parent asserts on the message
+        import traceback
+        q.put((rank, False, None, traceback.format_exc()[-2000:]))
+
+
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float32"])
+def test_peer_write_exchange_two_processes_one_gpu(dtype_name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, dtype_name)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for rank, ok, stats, err in got:
+        assert ok, (rank, stats, err)
+        ticks, payload_ticks, fired = stats
+        assert ticks == 40 and payload_ticks == fired and 0 < fired < 40        # silent ticks moved no payload
+
+
+def test_comm_timeout_is_an_error_not_a_hang():
+    """a peer that never posts: the collect gives up after SM_COMM_TIMEOUT_MS and the host read reports WHICH rank was missing"""
+    import ctypes as C
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, torch
+os.environ["SM_COMM_TIMEOUT_MS"] = "200"
+from streammind_amd import _lib
+lib = _lib.load()
+h = C.c_void_p()
+_lib.check(lib.sm_comm_init(0, 2, 4, 64, C.byref(h)))
+hb = lib.sm_comm_handle_bytes()
+mine = (C.c_ubyte * hb)()
+_lib.check(lib.sm_comm_export(h, mine))
+# "rank 1" is a second mailbox of this very process that nobody ever posts into ... and never posts itself
+h1 = C.c_void_p()
+_lib.check(lib.sm_comm_init(1, 2, 4, 64, C.byref(h1)))
+other = (C.c_ubyte * hb)()
+_lib.check(lib.sm_comm_export(h1, other))
+every = (C.c_ubyte * (2 * hb))(*list(mine), *list(other))
+try:
+    _lib.check(lib.sm_comm_connect(h, every))
+except _lib.StreamMindHipError as e:          # the same process cannot re-open its own allocation through IPC: accepted outcome
+    print("SKIP", e); raise SystemExit(0)
+st = torch.cuda.current_stream().cuda_stream
+_lib.check(lib.sm_comm_post(h, None, 0, st))
+_lib.check(lib.sm_comm_collect(h, None, None, st))
+torch.cuda.synchronize()
+cnt = (C.c_int32 * 2)()
+try:
+    _lib.check(lib.sm_comm_host_counts(h, 0, cnt))
+    print("NOERROR")
+except _lib.StreamMindHipError as e:
+    print("TIMEOUT_REPORTED", e)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "TIMEOUT_REPORTED" in r.stdout and "rank 1 did not post" in r.stdout or "SKIP" in r.stdout, r.stdout[-1000:]

@@ -78,6 +78,32 @@ def test_tiled_gemm(nat, M, N, K, out_dtype):
     assert relerr(y, ref) < (1e-5 if out_dtype == torch.float32 else 5e-3)
 
 
+@pytest.mark.parametrize("M,N,K,f16", [(577, 1024, 1024, False), (577, 1024, 4096, False), (1154, 1024, 4096, True), (16156, 1024, 1024, False), (300, 384, 256, False)])
+def test_linear_post_ln(nat, M, N, K, f16):
+    """sm_linear_t.post_ln_*: the LayerNorm of the finished row behind a residual product (ViT out-proj -> LN2, fc2 -> next LN1).  One
+    frame (577 rows, N = 1024: few tiles) runs it as split-K slabs + ONE slab-sum / bias / residual / LayerNorm pass; many rows and other
+    widths end with the separate norm launch.  Either way: the fp32 rows are the product (1e-5 of fp64 on the same 16-bit operands), and
+    the 16-bit LayerNorm output is BIT FOR BIT what sm_norm_ex writes for those very fp32 rows (same two-pass arithmetic)."""
+    from streammind_amd._lib import load, check, SM_OP_F16, SM_OP_BF16
+    lib = load()
+    dt = torch.float16 if f16 else torch.bfloat16
+    w = rnd((N, K), 1, K ** -0.5).to(dt).float()
+    x = rnd((M, K), 2).to(dt).float()
+    bias, res = rnd((N,), 3, 0.1), rnd((M, N), 4)
+    g, b = 1 + rnd((N,), 5, 0.1), rnd((N,), 6, 0.1)
+    ln_out = torch.empty(M, N, device="cuda", dtype=dt)
+    resg, gg, bg = res.cuda(), g.cuda(), b.cuda()
+    y = nat.linear(x.cuda().to(dt), nat.pack_weight(w.cuda().to(dt)), N, K, bias=bias.cuda(), residual=resg, out=resg,
+                   post_ln=(gg, bg, 1e-5, ln_out))
+    ref = (x.double() @ w.double().t() + bias.double() + res.double()).float()
+    assert relerr(y, ref) < 1e-5
+    want = torch.empty(M, N, device="cuda", dtype=dt)
+    check(lib.sm_norm_ex(y.data_ptr(), M, N, N, gg.data_ptr(), bg.data_ptr(), 1e-5, 0, None, want.data_ptr(), N,
+                         SM_OP_F16 if f16 else SM_OP_BF16, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(ln_out.cpu(), want.cpu())
+    assert relerr(ln_out, O.layer_norm(ref, g, b, 1e-5)) < (2e-3 if f16 else 1e-2)
+
+
 def test_pack_layout(nat):
     """the packed image is the documented permutation of W (integer-exact)."""
     N, K = 40, 70
