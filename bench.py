@@ -557,7 +557,7 @@ def cpu_baseline(n_frames: int = 12) -> dict:
     """the oracle (plain-torch CPU port of the reference arithmetic, fp32) on a bounded sample of the same workload:
     n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 12 frames ~ 10 s of CPU work.
     Plus the other CPU items of SURVEY 8d: BASELINE configs[0] (8 frames through the tower, fp32 and bf16, then the [:, ::12]
-    stride) and Mistral-7B decode tokens/s (4 of 32 layers timed, x8 extrapolated -- flagged)."""
+    stride) and Mistral-7B decode tokens/s (all 32 layers + lm_head when the host has the 29 GB; else 4 layers x8, flagged)."""
     from oracle import streammind_oracle as O
     torch.set_grad_enabled(False)
     cores = usable_cores()
@@ -590,19 +590,42 @@ def cpu_baseline(n_frames: int = 12) -> dict:
                                    "stride_out_frames": int(strided.shape[1]), "note": "CLIPVisionTower arithmetic (oracle port), batch of 8; bf16 = torch CPU autocast"}
     except Exception as e:
         out["config0_8_frames"] = {"error": repr(e)[:200]}
-    try:        # decode: 4 of the 32 Mistral-7B layers (3.5 GB fp32), 8 single-token steps over a 64-token cache
-        lcfg = O.LmCfg(hidden=4096, layers=4, heads=32, kv_heads=8, mlp=14336, vocab=64, eps=1e-5, rope_theta=1e6)
-        Wl = O.make_lm_weights(lcfg, 21)
+    try:        # decode: the WHOLE Mistral-7B (32 layers + final norm + lm_head over 32000 words), single-token steps over a 64-token cache
+        def avail_gb():
+            try:
+                for ln in open("/proc/meminfo"):
+                    if ln.startswith("MemAvailable"):
+                        return int(ln.split()[1]) / 1048576.0
+            except Exception:
+                pass
+            return 0.0
+        full = avail_gb() >= 48.0                       # 7.24 G parameters in fp32 = 29 GB + headroom; else 4 layers, extrapolated and flagged
+        lcfg = O.LmCfg(hidden=4096, layers=32 if full else 4, heads=32, kv_heads=8, mlp=14336, vocab=32000 if full else 64, eps=1e-5, rope_theta=1e6)
+        # timing only: the values are irrelevant, so the weights are tiled copies of one seeded 4 M-element block (a philox fill of 7 G
+        # elements would cost more than the measurement)
+        blk = torch.randn(1 << 22, generator=torch.Generator().manual_seed(21)) * 0.02
+        Wl = {}
+        for name, shape in O.lm_weight_shapes(lcfg, with_embed=False).items():
+            n = 1
+            for d_ in shape:
+                n *= d_
+            Wl[name] = torch.ones(shape) if len(shape) == 1 else blk.repeat((n + blk.numel() - 1) // blk.numel())[:n].reshape(shape)
         cache = O.KVCache()
         O.lm_forward(torch.randn(64, 4096) * 0.1, Wl, lcfg, cache)
         x = torch.randn(1, 4096) * 0.1
         O.lm_forward(x, Wl, lcfg, cache)
+        n_tok = 6 if full else 8
         t0 = time.perf_counter()
-        for _ in range(8):
+        for _ in range(n_tok):
             O.lm_forward(x, Wl, lcfg, cache)
-        t4 = (time.perf_counter() - t0) / 8
-        out["decode_tokens_per_s"] = {"value": round(1.0 / (8 * t4), 3), "extrapolated": True,
-                                      "note": "4 of 32 layers timed (fp32 weights, 64..72-token cache), x8; final norm + lm_head (0.26 G MAC) not included"}
+        t1 = (time.perf_counter() - t0) / n_tok
+        if full:
+            out["decode_tokens_per_s"] = {"value": round(1.0 / t1, 3), "extrapolated": False, "tokens_timed": n_tok,
+                                          "note": "all 32 layers + final norm + lm_head (vocab 32000), fp32 weights (29 GB), 64..72-token cache, oracle lm_forward, torch CPU threads=%d" % cores}
+        else:
+            out["decode_tokens_per_s"] = {"value": round(1.0 / (8 * t1), 3), "extrapolated": True,
+                                          "note": "host has < 48 GB available: 4 of 32 layers timed (fp32 weights, 64..72-token cache), x8; final norm + lm_head not included"}
+        del Wl, cache
     except Exception as e:
         out["decode_tokens_per_s"] = {"error": repr(e)[:200]}
     return out
@@ -723,11 +746,38 @@ def main():
     # gate's own decisions are not a workload): on its fire steps a rank contributes the frame tokens of the segment since its
     # last fire; every tick posts the asynchronous 4-byte-per-rank count word, the payload all-gather runs only for ticks on
     # which some rank fired (streammind_amd.dist.GatedTokenExchange).  An exchange error is a hard failure of the run.
-    ex, seg_start, rows_seen = None, 0, 0
+    ex, seg_start, rows_seen, ex_impl, ex_note = None, 0, 0, None, None
     if dist is not None:
-        from streammind_amd.dist import GatedTokenExchange
-        # payload as bf16: SURVEY 8e sizes the exchange at 2 B per element (the LLM consumes the tokens as 16-bit operands anyway)
-        ex = GatedTokenExchange(cfg.conn_d_model, dtype=torch.bfloat16, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
+        from streammind_amd.dist import GatedTokenExchange, PeerWriteExchange
+        # payload as bf16: SURVEY 8e sizes the exchange at 2 B per element (the LLM consumes the tokens as 16-bit operands anyway).
+        # First choice: the library's own exchange (include/streammind_hip.h sm_comm_*: direct peer writes into hipIpc-mapped mailboxes over
+        # xGMI, silent ticks move a 16-byte header).  It is PROVEN before it is used -- one tick with rank-specific rows, checked on every
+        # rank, all ranks must agree -- and anything short of that (an IPC mapping the platform refuses, a timeout) falls back to the
+        # torch.distributed form (RCCL all-gather on nccl, gloo on CPU) with the reason in the JSON line.  SM_BENCH_EXCHANGE=rccl skips it.
+        want_peer = (not plumbing) and os.environ.get("SM_BENCH_EXCHANGE", "peer") == "peer"
+        ok_t = torch.ones(1, device=cdev, dtype=torch.int32)
+        if want_peer:
+            try:
+                rows_cap = max(64, 10 * B * cps)
+                pex = PeerWriteExchange(cfg.conn_d_model, max_rows=rows_cap, dtype=torch.bfloat16, device=torch.device("cuda", local))
+                probe = (torch.arange(3 * cfg.conn_d_model, device=f"cuda:{local}").reshape(3, -1) % 97 + rank).to(torch.bfloat16)
+                pex.tick(probe)
+                got = pex.flush()
+                good = got is not None and len(got) == dist.get_world_size() and all(
+                    g.shape[0] == 3 and torch.equal(g, (torch.arange(3 * cfg.conn_d_model, device=g.device).reshape(3, -1) % 97 + r).to(torch.bfloat16)) for r, g in enumerate(got))
+                if not good:
+                    raise RuntimeError("self-test payload mismatch")
+                pex.ticks = pex.payload_collectives = 0
+                pex.host_wait_s = 0.0
+            except Exception as e:      # noqa: BLE001 -- recorded, then the collective form takes over
+                ok_t.zero_()
+                ex_note = f"peer-write exchange unavailable on rank {rank}: {e!r}"[:300]
+            dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if want_peer and int(ok_t.item()) == 1:
+            ex, ex_impl = pex, "peer_write (sm_comm_*: hipIpc mailboxes, direct stores over xGMI)"
+        else:
+            ex = GatedTokenExchange(cfg.conn_d_model, dtype=torch.bfloat16, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
+            ex_impl = "torch.distributed all-gather (%s)" % backend
 
     def fires(i):                        # ~ every 9th step per rank, never the same step on two ranks of an 8-GPU node
         return (i % 9) == (rank % 9)
@@ -738,7 +788,7 @@ def main():
         if fires(i):
             T = stream.num_frames
             tok = stream.tokens(seg_start, T - seg_start)
-            tok = tok if cdev == "cuda" else tok.cpu()
+            tok = tok if (cdev == "cuda" or isinstance(ex, PeerWriteExchange)) else tok.cpu()
             seg_start = T
         prev = ex.tick(tok)
         if prev is not None:
@@ -1170,6 +1220,11 @@ def main():
                                    ", one stream per GPU, random-init weights of the true shapes",
                        "frames_per_step": B * cps, "frames_per_call": B, "calls_per_step": cps, "frames_timed_per_gpu": frames_timed, "stream_frames": n_pool, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
+            # flat copies of the figures the legs below hold (a parser that keeps only top-level scalars still sees them)
+            "fp16_tower_frames_per_s": (fp16_tower_leg or {}).get("frames_per_s"),
+            "latency_ms_per_call": dict(zip([f"{b}_frames" for b in (lat_leg or {}).get("frames_per_call", [])], (lat_leg or {}).get("ms_per_call", []))) or None,
+            "decode_tokens_per_s": (dec_leg or {}).get("tokens_per_s"),
+            "decode_hbm_frac": ((dec_leg or {}).get("roofline") or {}).get("frac"),
             "roofline": roof,
             "decode": dec_leg,
             "group_decode": gdec_leg,
@@ -1193,7 +1248,7 @@ def main():
         if per_rank is not None:
             out["per_rank_frames_per_s"] = per_rank          # each rank's own N=1-equivalent rate (its own clock)
             out["gated_token_exchange"] = {"ticks": ex.ticks, "payload_collectives": ex.payload_collectives, "rows_received": rows_seen,
-                                           "host_wait_ms_total": round(ex.host_wait_s * 1e3, 3),
+                                           "host_wait_ms_total": round(ex.host_wait_s * 1e3, 3), "implementation": ex_impl, "fallback_reason": ex_note,
                                            "fire_schedule": "rank r fires on steps i with i % 9 == r % 9 (never two ranks of one node together)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -115,14 +115,21 @@ typedef struct sm_linear_t {
     int op_dtype;
     /* LayerNorm of the FINISHED output row, behind the epilogue ("post-LN"): post_ln_gamma != NULL (with post_ln_beta) asks for
      * post_ln_out[m][0..N) = 16-bit(LN(out_f32[m][:]) * gamma + beta) (op_dtype), the operand of the next product, next to out_f32.
-     * Needs out_f32, remap_in == 0 and no vt.  Where the product runs as split-K slabs (few tiles: one frame through the tower)
-     * the slab sum, bias, residual and the LayerNorm of the row are ONE pass (a wave per row, N == 1024); everywhere else the call
-     * ends with the sm_norm_ex launch the caller would have made -- the same arithmetic (two-pass mean / variance) either way. */
+     * Needs out_f32, remap_in == 0 and no vt.  Where the product runs as split-K slabs -- few tiles (one frame through the tower: a wave
+     * per row, N == 1024) or 17..32 rows on the weight-streaming path (the connector / gate pass: a block per row, N %% 1024 == 0) --
+     * the slab sum, bias, activation, residual and the norm of the row are ONE pass; everywhere else the call ends with the sm_norm_ex
+     * launch the caller would have made (the same two-pass arithmetic either way). */
     const float* post_ln_gamma;
-    const float* post_ln_beta;
+    const float* post_ln_beta;          /* NULL: RMSNorm (gamma * x * rsqrt(mean(x^2) + eps)) instead of LayerNorm                  */
     float post_ln_eps;
-    void* post_ln_out;
+    void* post_ln_out;                  /* 16-bit output [M][post_ln_ldo] or NULL                                                    */
     int post_ln_ldo;
+    float* post_ln_out_f32;             /* fp32 output [M][post_ln_ldo] or NULL (the connector / gate products take fp32 rows)       */
+    int post_ln_act;                    /* SM_ACT_* applied to the normalised value (the connector's leaky_relu(norm_f(.)))          */
+    /* activations with repeated column groups (the event gate's repeat_kv in front of o_proj, seq-len 1: builder.py:553-562):
+     * x_rep > 1: column k of the [M][K] operand is read from x[m][(k / (x_rep * x_rep_dh)) * x_rep_dh + k % x_rep_dh] -- x holds
+     * K / x_rep columns.  Weight-streaming path only (M <= 32, fp32 x); x_rep and x_rep_dh powers of two, x_rep_dh >= 8. */
+    int x_rep, x_rep_dh;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 

@@ -33,6 +33,7 @@ class sm_linear_t(C.Structure):
         ("w_dtype", i32), ("w_scale", vp), ("w2_scale", vp),
         ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32), ("op_dtype", i32),
         ("post_ln_gamma", vp), ("post_ln_beta", vp), ("post_ln_eps", f32), ("post_ln_out", vp), ("post_ln_ldo", i32),
+        ("post_ln_out_f32", vp), ("post_ln_act", i32), ("x_rep", i32), ("x_rep_dh", i32),
     ]
 
 

@@ -93,6 +93,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// LayerNorm of one row held by one wave (D = 256 * NV columns, lane owns columns lane*4 + j*256) for the fused slab-sum + LayerNorm
+// pass of the split-K GEMM (linear.hip): mean, then the sum of squared deviations, in registers -- norm_wave_fixed_kernel's algorithm
+// with the operation sequence pinned (fused multiply-adds written out, nothing left to contraction).  The standalone kernel keeps
+// the code it was validated with in round 3, so the two may differ in the last fp32 bit of an intermediate (a handful of 16-bit
+// outputs one ulp apart: test_linear_post_ln states the bound).
+template <int NV>
+__device__ __forceinline__ void ln_row_stats(const f32x4 (&v)[NV], float eps, float& mu, float& rstd) {
+#pragma clang fp contract(off)
+    constexpr float inv_d = 1.0f / (NV * 256);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    s = wave_sum(s);
+    mu = s * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q = __builtin_fmaf(d, d, q); }
+    q = wave_sum(q);
+    rstd = rsqrtf(__builtin_fmaf(q, inv_d, eps));
+}
+__device__ __forceinline__ float ln_apply(float v, float mu, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    const float t = (v - mu) * rstd;
+    return __builtin_fmaf(t, g, b);
+}
+
 // 1/(1+e^-x) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the ~20-instruction IEEE division;
 // x -> -inf gives rcp(inf) = 0, x -> +inf gives rcp(1) = 1
 __device__ __forceinline__ float sigmoidf_(float x) {

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             if (valid[0]) r.u = *(const u32x4*)(xs + (size_t)i * a.K + kk * 32 + g * 8);
             xh = r.v;
         } else {
-            load_x<XF32, SPLIT, F16>(xrow[mb], kk * 32 + g * 8, valid[mb], xh, xl);
+            load_x<XF32, SPLIT, F16>(xrow[mb], xcol(a, kk * 32 + g * 8), valid[mb], xh, xl);
         }
     };
     auto mfmas = [&](const bf16x8 (&wa)[U], const bf16x8 (&wb)[U], int k0) {
@@ -547,8 +547,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             if (DUAL) q2 = __builtin_nontemporal_load(wp2 + (size_t)kk * 64);
             if constexpr (!NORM) {
                 if constexpr (XF32) {
-                    x.v[0] = *(const f32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 4);
-                    x.v[1] = *(const f32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 4 + 16);
+                    const int kc = xcol(a, kk * 32 + g * 8);
+                    x.v[0] = *(const f32x4*)(xrow[0] + (size_t)kc * 4);
+                    x.v[1] = *(const f32x4*)(xrow[0] + (size_t)kc * 4 + 16);
                 } else {
                     x.v[0] = *(const u32x4*)(xrow[0] + (size_t)(kk * 32 + g * 8) * 2);
                 }
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(LinArgs a, std::cond
             for (int mb = 0; mb < MB; ++mb) {
                 bf16x8 xh[U], xl[U];
     #pragma unroll
-                for (int u = 0; u < U; ++u) load_x<XF32, SPLIT, F16>(xrow[mb], (ks + u * WAVES) * 32 + g * 8, valid[mb], xh[u], xl[u]);
+                for (int u = 0; u < U; ++u) load_x<XF32, SPLIT, F16>(xrow[mb], xcol(a, (ks + u * WAVES) * 32 + g * 8), valid[mb], xh[u], xl[u]);
     #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     acc[mb] = mfma16<F16>(wa[u], xh[u], acc[mb]);
@@ -1039,7 +1040,7 @@ __global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, co
 // then the sum of squared deviations, in registers), and the slab sum / bias / residual order of splitk_reduce_kernel + store4: the
 // two outputs are bit for bit what the two separate launches wrote.  Replaces two dependent launches (~5 us of fixed cost each at
 // this size) and the re-read of the row by one.
-struct PostLn { const float* gamma; const float* beta; float eps; bf16_t* out; int ldo; };
+struct PostLn { const float* gamma; const float* beta; float eps; bf16_t* out; int ldo; float* out_f32; int act; };
 template <int NV>
 __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(LinArgs a, const float* __restrict__ ws, int S, int ldw, PostLn ln) {
     constexpr int D = NV * 256;
@@ -1074,27 +1075,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(LinArgs a, const 
         }
         *(f32x4*)(a.out_f32 + (size_t)row * a.ldo + lane * 4 + j * 256) = v[j];
     }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    s = wave_sum(s);
-    const float mu = s * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float d = v[j][e] - mu; q += d * d; }
-    q = wave_sum(q);
-    const float rstd = rsqrtf(q * (1.0f / D) + ln.eps);
+    float mu, rstd;
+    ln_row_stats<NV>(v, ln.eps, mu, rstd);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane * 4 + j * 256;
         const f32x4 gm = *(const f32x4*)(ln.gamma + c), bt = *(const f32x4*)(ln.beta + c);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rstd * gm[e] + bt[e];
+        for (int e = 0; e < 4; ++e) o[e] = ln_apply(v[j][e], mu, rstd, gm[e], bt[e]);
         *(u32x2*)(ln.out + (size_t)row * ln.ldo + c) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
     }
+}
+
+// The same for the weight-streaming products of 17..32 rows (connector / gate pass; skinny_lds_kernel leaves K-slice slabs): ONE BLOCK
+// per row, one thread per 4 columns (N / 4 <= 1024 threads: every slab load of the row is in flight at once), slab sum in slab order +
+// store4's epilogue (row scale of fp8 weights, bias, activation, residual) -> the fp32 row, then LayerNorm (beta != NULL: mean, then
+// squared deviations) or RMSNorm of the row across the block, optional activation -> fp32 and / or 16-bit.  Replaces
+// splitk_reduce_kernel + a norm launch.
+__global__ __launch_bounds__(1024) void splitk_reduce_norm_rows_kernel(LinArgs a, const float* __restrict__ ws, int S, PostLn ln) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const size_t sstride = (size_t)a.M * a.N;
+    const int c = tid * 4;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = s0 + u < S ? *(const f32x4*)(ws + (size_t)(s0 + u) * sstride + (size_t)m * a.N + c) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < S) acc += t[u];
+    }
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = acc[e];
+        if (a.wscale) t *= a.wscale[c + e];
+        if (a.bias) t += a.bias[c + e];
+        t = apply_act_rt(t, a.act);
+        if (a.residual) t += a.residual[(size_t)m * a.ldr + c + e];
+        v[e] = t;
+    }
+    if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + c) = v;
+    const f32x4 gm = *(const f32x4*)(ln.gamma + c);
+    f32x4 bt = {0, 0, 0, 0};
+    if (ln.beta) bt = *(const f32x4*)(ln.beta + c);
+    const float inv_n = 1.0f / (float)a.N;
+    auto block_sum = [&](float x) {
+        x = wave_sum(x);
+        __syncthreads();
+        if (lane == 0) red[w] = x;
+        __syncthreads();
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += red[i];
+        return tot;
+    };
+    float mu = 0.f, rstd;
+    if (ln.beta) {
+        mu = block_sum((v[0] + v[1]) + (v[2] + v[3])) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mu; q += d * d; }
+        rstd = rsqrtf(block_sum(q) * inv_n + ln.eps);
+    } else {
+        rstd = rsqrtf(block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) * inv_n + ln.eps);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = ln.beta ? (v[e] - mu) * rstd * gm[e] + bt[e] : gm[e] * (v[e] * rstd);
+        o[e] = apply_act_rt(t, ln.act);
+    }
+    if (ln.out_f32) *(f32x4*)(ln.out_f32 + (size_t)m * ln.ldo + c) = o;
+    if (ln.out) *(u32x2*)(ln.out + (size_t)m * ln.ldo + c) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
 }
 
 // per-HIP-stream split-K workspace (grown on demand; steady state allocates nothing)
@@ -1211,7 +1265,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
             xok[it] = m < a.M && ks < ks1;
             xa[it] = f32x4{0, 0, 0, 0}; xb[it] = f32x4{0, 0, 0, 0};
             if (xok[it]) {
-                const char* px = (const char*)a.x + ((size_t)m * a.ldx + (size_t)ks * 32 + (l2 >> 4) * 8) * (XF32 ? 4 : 2);
+                const char* px = (const char*)a.x + ((size_t)m * a.ldx + (size_t)xcol(a, ks * 32 + (l2 >> 4) * 8)) * (XF32 ? 4 : 2);
                 xa[it] = *(const f32x4*)px;                              // bf16 x: the 8 values are the 16 bytes of xa
                 if (XF32) xb[it] = *(const f32x4*)(px + 16);
             }
@@ -1285,7 +1339,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     }
 }
 
-static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st) {
+static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st, const PostLn* ln = nullptr, bool* ln_done = nullptr) {
     const int nb = (a.NRG + 7) / 8;
     static int target = -1;
     if (target < 0) { const char* e = getenv("SM_SKINNY_LDS_BLOCKS"); target = e ? atoi(e) : 256; }
@@ -1316,6 +1370,12 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
 #undef SL
 #undef SLH
     SM_LAUNCH_CHECK();
+    if (ln && !dual && a.remap_in == 0 && (a.N & 255) == 0 && a.N <= 4096 && (a.ldo & 3) == 0 && (!a.residual || (a.ldr & 3) == 0)) {
+        splitk_reduce_norm_rows_kernel<<<a.M, a.N / 4, 0, st>>>(a, ws, S, *ln);
+        SM_LAUNCH_CHECK();
+        *ln_done = true;
+        return SM_OK;
+    }
     const size_t nthr = (size_t)a.M * ((a.N + 3) / 4);
     splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, ws2, S, a.N);
     SM_LAUNCH_CHECK();
@@ -1378,6 +1438,8 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
     a.wscale = w8 ? p->w_scale : nullptr; a.wscale2 = w8 ? p->w2_scale : nullptr;
     a.ngamma = p->norm_gamma; a.neps = p->norm_eps;
     a.f16 = p->op_dtype == SM_OP_F16;
+    a.xr_sh = a.xr_dh_sh = 0;
+    if (p->x_rep > 1) { while ((1 << a.xr_sh) < p->x_rep) ++a.xr_sh; while ((1 << a.xr_dh_sh) < p->x_rep_dh) ++a.xr_dh_sh; }
 }
 
 // the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): 16-bit or fp8 weights, head_dim
@@ -1427,13 +1489,17 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done);
 extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p, "sm_linear: null args");
     if (p->post_ln_gamma)
-        SM_REQUIRE(p->post_ln_beta && p->post_ln_out && p->out_f32 && p->remap_in == 0 && !p->vt && !p->w2 && p->post_ln_ldo >= p->N && (p->post_ln_ldo & 3) == 0,
-                   "sm_linear: post-LN needs gamma, beta, a 16-bit output [M][post_ln_ldo >= N, %% 4 == 0], an fp32 output and plain rows");
+        SM_REQUIRE((p->post_ln_out || p->post_ln_out_f32) && p->out_f32 && p->remap_in == 0 && !p->vt && !p->w2 && p->post_ln_ldo >= p->N && (p->post_ln_ldo & 3) == 0,
+                   "sm_linear: post-norm needs gamma, an output [M][post_ln_ldo >= N, %% 4 == 0] (16-bit and / or fp32), an fp32 product output and plain rows");
+    if (p->x_rep > 1)
+        SM_REQUIRE(p->M <= 32 && p->x_dtype == SM_X_F32 && p->w_dtype == SM_W_BF16 && !p->norm_gamma && (p->x_rep & (p->x_rep - 1)) == 0 && p->x_rep_dh >= 8 &&
+                   (p->x_rep_dh & (p->x_rep_dh - 1)) == 0 && p->K % (p->x_rep * p->x_rep_dh) == 0 && p->ldx >= p->K / p->x_rep,
+                   "sm_linear: x_rep needs the weight-streaming path (M <= 32, fp32 x, 16-bit weights), powers of two, K a multiple of x_rep * x_rep_dh");
     bool ln_done = false;
     int rc = linear_impl(p, stream, &ln_done);
     if (rc || !p->post_ln_gamma || ln_done) return rc;
-    return sm_norm_ex(p->out_f32, p->M, p->N, p->ldo, p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, 0, nullptr, p->post_ln_out, p->post_ln_ldo,
-                      p->op_dtype, stream);
+    return sm_norm_ex(p->out_f32, p->M, p->N, p->ldo, p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, p->post_ln_act, p->post_ln_out_f32, p->post_ln_out,
+                      p->post_ln_ldo, p->op_dtype, stream);
 }
 static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     SM_REQUIRE(p && p->w && p->x, "sm_linear: null w/x");
@@ -1450,7 +1516,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
                "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
     SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
-    SM_REQUIRE(p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
+    SM_REQUIRE(p->x_rep > 1 || p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
     const bool xf32 = p->x_dtype == SM_X_F32;
@@ -1510,8 +1576,12 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         {
             static int use_lds = -1;
             if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
-            if (use_lds && p->M >= lds_min_m && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt)
-                return launch_skinny_lds(a, xf32, split, dual, st);
+            if (use_lds && p->M >= lds_min_m && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt) {
+                static int ln_fuse_rows = -1;
+                if (ln_fuse_rows < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse_rows = e ? atoi(e) : 1; }
+                const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+                return launch_skinny_lds(a, xf32, split, dual, st, (ln_fuse_rows && p->post_ln_gamma && p->out_f32) ? &ln : nullptr, ln_done);
+            }
         }
         if (p->M > 16) {       // fallback for 17..32 rows: two MFMA column blocks share every weight load, activations re-read per block
             if (a.KS >= 32) return launch_skinny<8, 2>(a, xf32, split, dual, st);
@@ -1580,7 +1650,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // the product costs one launch less than GEMM + LayerNorm, so slabs pay even for short K loops (out-proj, K = 1024: 4 k-tiles each)
     static int ln_fuse = -1, ln_smax = 6;
     if (ln_fuse < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse = e ? atoi(e) : 1; const char* m = getenv("SM_POST_LN_SMAX"); if (m) ln_smax = atoi(m); }
-    const bool ln_ok = ln_fuse && p->post_ln_gamma && p->N == 1024 && tiles <= 128 && p->act == SM_ACT_NONE && !w8 && (p->ldo & 3) == 0 &&
+    const bool ln_ok = ln_fuse && p->post_ln_gamma && p->post_ln_beta && p->post_ln_out && !p->post_ln_out_f32 && p->post_ln_act == SM_ACT_NONE && p->N == 1024 && tiles <= 128 && p->act == SM_ACT_NONE && !w8 && (p->ldo & 3) == 0 &&
                        (!p->residual || (p->ldr & 3) == 0) && p->M <= 4096 && ln_smax >= 2;
     if (ln_ok) {
         S = 256 / tiles;
@@ -1618,7 +1688,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         GEMM_LAUNCH(0, b, dim3(tiles, S));
         SM_LAUNCH_CHECK();
         if (ln_ok && S >= 2) {
-            const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo};
+            const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, nullptr, SM_ACT_NONE};
             splitk_reduce_ln_kernel<4><<<cdiv(p->M, 4), 256, 0, st>>>(a, ws, S, p->N, ln);
             SM_LAUNCH_CHECK();
             *ln_done = true;

@@ -25,7 +25,13 @@ struct LinArgs {
     const float* ngamma;        // fused RMSNorm of the activations (weight-streaming path): gamma [K], or nullptr
     float neps;
     int f16;                    // 16-bit operands AND 16-bit outputs are IEEE fp16 instead of bf16 (tiled GEMM path only)
+    int xr_sh, xr_dh_sh;        // repeated column groups of x (sm_linear_t.x_rep): log2(x_rep) (0 = off), log2(x_rep_dh)
 };
+
+// column of the stored x row that operand column k reads (k a multiple of 8: a fragment's 8 columns stay inside one group)
+static __device__ __forceinline__ int xcol(const LinArgs& a, int k) {
+    return a.xr_sh ? (((k >> (a.xr_sh + a.xr_dh_sh)) << a.xr_dh_sh) | (k & ((1 << a.xr_dh_sh) - 1))) : k;
+}
 
 static __device__ __noinline__ float apply_act_rt(float v, int act) { return apply_act(v, act); }
 

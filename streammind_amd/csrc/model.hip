@@ -903,13 +903,19 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
         return a;
     };
     float* tok = S == 1 ? tokdst.p[0] : ws.tokrows.as<float>();     // one stream: PostNet writes straight into its token store
+    // Every norm of the pass rides behind the product that finishes its input row (sm_linear_t.post_ln_*: LayerNorm with beta, RMSNorm
+    // without, optional activation, fp32 out): with 17..32 rows the products run as K-slice slabs and the slab sum, epilogue and norm are
+    // one launch; with fewer rows the call ends with the norm launch that used to be issued here.
+    auto post_norm = [&](sm_linear_t& a, const float* gamma, const float* beta, float eps, int act, float* out) {
+        a.post_ln_gamma = gamma; a.post_ln_beta = beta; a.post_ln_eps = eps; a.post_ln_act = act; a.post_ln_out_f32 = out; a.post_ln_ldo = d;
+    };
     {   // PreNet: leaky_relu(W x + b)                                         builder.py:166-170
         sm_linear_t a = L(W.pre, pooled, c.conn_mm_hidden);
         a.bias = W.pre_b; a.act = SM_ACT_LEAKY_RELU; a.out_f32 = ws.t0.as<float>(); a.ldo = d;
+        // Block: hidden = Mamba(LN(residual)), residual = t0                  block.py:51-67
+        post_norm(a, W.cn_w, W.cn_b, c.conn_eps, 0, ws.u.as<float>());
         if ((rc = sm_linear(&a, stream))) return rc;
     }
-    // Block: hidden = Mamba(LN(residual)), residual = t0                      block.py:51-67
-    if ((rc = sm_norm(ws.t0.as<float>(), M, d, d, W.cn_w, W.cn_b, c.conn_eps, 0, ws.u.as<float>(), nullptr, d, stream))) return rc;
     {   sm_linear_t a = L(W.in_proj, ws.u.as<float>(), d); a.out_f32 = ws.xz.as<float>(); a.ldo = 2 * di;
         if ((rc = sm_linear(&a, stream))) return rc; }
     if ((rc = sm_mamba_conv_step_seg(ws.xz.as<float>(), S, F, di, c.conn_d_conv, conv, W.conv_w, W.conv_b, ws.xc.as<float>(), stream))) return rc;
@@ -922,26 +928,32 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
     if ((rc = sm_mamba_ssm_step_seg(ws.xc.as<float>(), ws.delta.as<float>(), ws.xdbl.as<float>(), xd, R, ws.xz.as<float>(), S, F, di, ds, W.A_log, W.Dp, ssm, ws.y.as<float>(), stream))) return rc;
     {   sm_linear_t a = L(W.out_proj, ws.y.as<float>(), di);
         a.residual = ws.t0.as<float>(); a.ldr = d; a.out_f32 = ws.r.as<float>(); a.ldo = d;       // hidden + residual, ssm.py:83
+        post_norm(a, W.nf_w, W.nf_b, c.conn_eps, SM_ACT_LEAKY_RELU, ws.lnf.as<float>());           // leaky_relu(norm_f(.)) in front of PostNet
         if ((rc = sm_linear(&a, stream))) return rc; }
-    if ((rc = sm_norm(ws.r.as<float>(), M, d, d, W.nf_w, W.nf_b, c.conn_eps, SM_ACT_LEAKY_RELU, ws.lnf.as<float>(), nullptr, d, stream))) return rc;
     {   sm_linear_t a = L(W.post, ws.lnf.as<float>(), d);
         a.bias = W.post_b; a.out_f32 = tok; a.ldo = d;
+        if (c.gate_layers > 0) post_norm(a, W.gate[0].ln1_w, nullptr, c.gate_eps, 0, ws.hn.as<float>());      // the first gate layer's input norm
+        else post_norm(a, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>());
         if ((rc = sm_linear(&a, stream))) return rc; }
     if (S > 1 && (rc = sm_scatter_rows(tok, S, F, d, tokdst, stream))) return rc;
     // ---- gate on each of the M tokens independently (seq-len 1 each; builder.py:553-562)
     const int gdh = c.gate_hidden / c.gate_heads, kvn = c.gate_kv_heads * gdh, qn = c.gate_heads * gdh;
+    const int rep = c.gate_heads / c.gate_kv_heads;
+    // repeat_kv folded into o_proj's operand addressing (sm_linear_t.x_rep) where the kernels read x through it: 16-bit weights, powers of two
+    const bool fold_rep = rep > 1 && (rep & (rep - 1)) == 0 && (gdh & (gdh - 1)) == 0 && gdh >= 8;
     const float* hcur = tok;       // layer 0 reads the token, writes ws.h
     for (int l = 0; l < c.gate_layers; ++l) {
         const sm_model::LayerW& w = W.gate[l];
-        if ((rc = sm_norm(hcur, M, d, d, w.ln1_w, nullptr, c.gate_eps, 0, ws.hn.as<float>(), nullptr, d, stream))) return rc;
         {   sm_linear_t a = L(w.v, ws.hn.as<float>(), d); a.out_f32 = ws.v.as<float>(); a.ldo = kvn;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_repeat_kv(ws.v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, ws.vrep.as<float>(), stream))) return rc;
-        {   sm_linear_t a = L(w.o, ws.vrep.as<float>(), qn);
+        const bool fold = fold_rep && !w.o->fp8;
+        if (!fold && (rc = sm_repeat_kv(ws.v.as<float>(), M, c.gate_kv_heads, c.gate_heads, gdh, ws.vrep.as<float>(), stream))) return rc;
+        {   sm_linear_t a = fold ? L(w.o, ws.v.as<float>(), kvn) : L(w.o, ws.vrep.as<float>(), qn);
+            if (fold) { a.x_rep = rep; a.x_rep_dh = gdh; }
             a.residual = hcur; a.ldr = d; a.out_f32 = ws.h.as<float>(); a.ldo = d;
+            post_norm(a, w.ln2_w, nullptr, c.gate_eps, 0, ws.hn.as<float>());
             if ((rc = sm_linear(&a, stream))) return rc; }
         hcur = ws.h.as<float>();
-        if ((rc = sm_norm(hcur, M, d, d, w.ln2_w, nullptr, c.gate_eps, 0, ws.hn.as<float>(), nullptr, d, stream))) return rc;
         {   const Slot& gu = *w.gu;
             sm_linear_t a = L(w.gu, ws.hn.as<float>(), d);
             a.N = c.gate_mlp;
@@ -951,9 +963,10 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
             if ((rc = sm_linear(&a, stream))) return rc; }
         {   sm_linear_t a = L(w.down, ws.act.as<float>(), c.gate_mlp);
             a.residual = hcur; a.ldr = d; a.out_f32 = ws.h.as<float>(); a.ldo = d;
+            if (l + 1 < c.gate_layers) post_norm(a, W.gate[l + 1].ln1_w, nullptr, c.gate_eps, 0, ws.hn.as<float>());
+            else post_norm(a, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>());
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
-    if ((rc = sm_norm(hcur, M, d, d, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>(), nullptr, d, stream))) return rc;
     float* lg = logits ? logits : ws.logits2.as<float>();
     {   sm_linear_t a = L(W.gate_head, ws.hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
         if ((rc = sm_linear(&a, stream))) return rc; }

@@ -414,12 +414,21 @@ __global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, i
     float stt[8], w[8];
     for (int j = 0; j < dc; ++j) { stt[j] = cs[(size_t)d * dc + j]; w[j] = cw[(size_t)d * dc + j]; }
     const float bias = cb[d];
-    for (int m = m0; m < m0 + F; ++m) {
-        for (int j = 0; j + 1 < dc; ++j) stt[j] = stt[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
-        stt[dc - 1] = xz[(size_t)m * 2 * di + d];
-        float a = 0.f;
-        for (int j = 0; j < dc; ++j) a += stt[j] * w[j];
-        xc[(size_t)m * di + d] = siluf_(a + bias);
+    // the recurrence over a segment's frames is serial, its loads are not: eight frames' inputs are requested together (a load per
+    // step on the critical path made 28 frames cost 28 memory round trips: 32 us per pass)
+    for (int mb = m0; mb < m0 + F; mb += 8) {
+        float xin[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xin[u] = mb + u < m0 + F ? xz[(size_t)(mb + u) * 2 * di + d] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (mb + u >= m0 + F) break;
+            for (int j = 0; j + 1 < dc; ++j) stt[j] = stt[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
+            stt[dc - 1] = xin[u];
+            float a = 0.f;
+            for (int j = 0; j < dc; ++j) a += stt[j] * w[j];
+            xc[(size_t)(mb + u) * di + d] = siluf_(a + bias);
+        }
     }
     for (int j = 0; j < dc; ++j) cs[(size_t)d * dc + j] = stt[j];
 }
@@ -450,18 +459,31 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
     float h[32], A[32];
     for (int n = 0; n < ds; ++n) { h[n] = hst[(size_t)d * ds + n]; A[n] = -__expf(Alog[(size_t)d * ds + n]); }
     const float Dd = Dp[d];
-    for (int m = m0; m < m0 + F; ++m) {
-        const float dt = delta[(size_t)m * di + d];
-        const float xv = xc[(size_t)m * di + d];
-        const float* Bm = xdbl + (size_t)m * ldx + R;
-        const float* Cm = Bm + ds;
-        float acc = 0.f;
-        for (int n = 0; n < ds; ++n) {
-            h[n] = __expf(dt * A[n]) * h[n] + (dt * xv) * Bm[n];
-            acc += h[n] * Cm[n];
+    // serial recurrence, batched loads (see mamba_conv_kernel): four frames' dt / x / z are in flight together (60 us -> per pass of 28 frames
+    // was 28 dependent round trips)
+    for (int mb = m0; mb < m0 + F; mb += 4) {
+        float dtv[4], xvv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = mb + u < m0 + F;
+            dtv[u] = ok ? delta[(size_t)(mb + u) * di + d] : 0.f;
+            xvv[u] = ok ? xc[(size_t)(mb + u) * di + d] : 0.f;
+            zv[u] = ok ? xz[(size_t)(mb + u) * 2 * di + di + d] : 0.f;
         }
-        const float z = xz[(size_t)m * 2 * di + di + d];
-        y[(size_t)m * di + d] = (acc + Dd * xv) * siluf_(z);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (mb + u >= m0 + F) break;
+            const int m = mb + u;
+            const float dt = dtv[u], xv = xvv[u];
+            const float* Bm = xdbl + (size_t)m * ldx + R;
+            const float* Cm = Bm + ds;
+            float acc = 0.f;
+            for (int n = 0; n < ds; ++n) {
+                h[n] = __expf(dt * A[n]) * h[n] + (dt * xv) * Bm[n];
+                acc += h[n] * Cm[n];
+            }
+            y[(size_t)m * di + d] = (acc + Dd * xv) * siluf_(zv[u]);
+        }
     }
     for (int n = 0; n < ds; ++n) hst[(size_t)d * ds + n] = h[n];
 }

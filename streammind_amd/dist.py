@@ -291,20 +291,40 @@ class PeerWriteExchange:
         self.row_bytes = d_model * torch.empty(0, dtype=dtype).element_size()
         if self.row_bytes % 16:
             raise ValueError(f"row of {self.row_bytes} bytes: the exchange moves 16-byte words")
-        h = C.c_void_p()
-        with torch.cuda.device(self.dev):
-            _lib.check(self.lib.sm_comm_init(self.rank, self.world, self.max_rows, self.row_bytes, C.byref(h)), "sm_comm_init")
-            self.h = h
-            hb = self.lib.sm_comm_handle_bytes()
-            mine = (C.c_ubyte * hb)()
-            _lib.check(self.lib.sm_comm_export(self.h, mine), "sm_comm_export")
-            comm_dev = self.dev if tdist.get_backend(group) == "nccl" else torch.device("cpu")
-            mine_t = torch.tensor(list(mine), dtype=torch.uint8, device=comm_dev)
-            every = torch.empty(self.world * hb, dtype=torch.uint8, device=comm_dev)
-            tdist.all_gather_into_tensor(every, mine_t, group=group)
-            buf = (C.c_ubyte * (self.world * hb)).from_buffer_copy(bytes(every.cpu().tolist()))
-            _lib.check(self.lib.sm_comm_connect(self.h, buf), "sm_comm_connect")
-        tdist.barrier(group=group)                         # every mailbox is mapped everywhere before the first post
+        # Collective construction: a rank whose local step fails still takes part in the handle exchange (with a "failed" flag), so the
+        # others raise with it instead of waiting in a collective for a peer that already gave up.
+        comm_dev = self.dev if tdist.get_backend(group) == "nccl" else torch.device("cpu")
+        hb = self.lib.sm_comm_handle_bytes()
+        self.h, err = None, None
+        mine = bytes(hb)
+        try:
+            with torch.cuda.device(self.dev):
+                h = C.c_void_p()
+                _lib.check(self.lib.sm_comm_init(self.rank, self.world, self.max_rows, self.row_bytes, C.byref(h)), "sm_comm_init")
+                self.h = h
+                buf = (C.c_ubyte * hb)()
+                _lib.check(self.lib.sm_comm_export(self.h, buf), "sm_comm_export")
+                mine = bytes(buf)
+        except Exception as e:      # noqa: BLE001
+            err = e
+        mine_t = torch.tensor([0 if err else 1] + list(mine), dtype=torch.uint8, device=comm_dev)
+        every = torch.empty(self.world * (hb + 1), dtype=torch.uint8, device=comm_dev)
+        tdist.all_gather_into_tensor(every, mine_t, group=group)
+        every = every.cpu().reshape(self.world, hb + 1)
+        if not bool(every[:, 0].all()):
+            self.close()
+            raise RuntimeError(f"PeerWriteExchange: mailbox creation failed on rank(s) {[r for r in range(self.world) if not every[r, 0]]}" + (f": {err!r}" if err else ""))
+        try:
+            with torch.cuda.device(self.dev):
+                buf = (C.c_ubyte * (self.world * hb)).from_buffer_copy(bytes(every[:, 1:].reshape(-1).tolist()))
+                _lib.check(self.lib.sm_comm_connect(self.h, buf), "sm_comm_connect")
+        except Exception as e:      # noqa: BLE001
+            err = e
+        okt = torch.tensor([0 if err else 1], dtype=torch.int32, device=comm_dev)
+        tdist.all_reduce(okt, op=tdist.ReduceOp.MIN, group=group)       # also the barrier: every mailbox is mapped everywhere before the first post
+        if int(okt.item()) == 0:
+            self.close()
+            raise RuntimeError("PeerWriteExchange: a rank could not map its peers' mailboxes" + (f": {err!r}" if err else ""))
         # two result sets (tick parity): the payload of tick t is read by the caller while tick t+1 is collected
         self._payload = [torch.empty(self.world, self.max_rows, d_model, dtype=dtype, device=self.dev) for _ in range(2)]
         self._counts = (C.c_int32 * self.world)()

@@ -572,6 +572,24 @@ class Videollama2MistralForCausalLM:
         return torch.tensor([new_ids], dtype=torch.long)
 
     @torch.no_grad()
+    def generate_iter(self, inputs: torch.Tensor, images_or_videos=None, modal_list=None, max_new_tokens: int = 1024, stopping_criteria=None,
+                      do_sample: bool = False, temperature: float = 1.0, top_p: float = 1.0, generator=None):
+        """`generate` as a generator of id chunks, for callers that forward text while it is produced (the serving worker): the
+        native decode loop runs `decode_chunk` greedy steps per host sync and hands each accepted chunk over at once -- no second
+        thread, no queue.  The concatenation of the chunks is `generate`'s result."""
+        if inputs.dim() != 2 or inputs.shape[0] != 1:
+            raise NotImplementedError("generate_iter: batch size 1")
+        if self.native.cfg.llm_layers == 0:
+            raise RuntimeError("perception-only model: no LLM loaded")
+        ids = inputs[0].tolist()
+        if images_or_videos is not None and len(images_or_videos):
+            seq, _, _, _ = self._splice_clips(ids, images_or_videos, modal_list or ["video"], features=False)
+        else:
+            seq = [int(t) for t in ids]
+        sample_kw = dict(do_sample=True, temperature=float(temperature or 1.0), top_p=float(top_p or 1.0), generator=generator) if do_sample else {}
+        yield from self._generate_iter(seq, int(max_new_tokens), stopping_criteria, **sample_kw)
+
+    @torch.no_grad()
     def stream_generate_demo(self, inputs: Optional[torch.Tensor] = None, images_or_videos: Optional[torch.Tensor] = None,
                              modal_list=None, **kwargs):
         """-> (decoded str | None, cls_pred).  Mirrors videollama2_mistral.py:385-439 incl. its error behaviour."""

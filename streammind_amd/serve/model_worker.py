@@ -20,8 +20,7 @@ import time
 import uuid
 from functools import partial
 from io import BytesIO
-from threading import Thread
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -32,6 +31,38 @@ from ..mm_utils import KeywordsStoppingCriteria, process_video, tokenizer_MMODAL
 from ..utils import pretty_print_semaphore, server_error_msg
 
 STREAM_CHECK_MULTIPLE = 20
+
+
+class _WordBoundaryDetokenizer:
+    """ids in, text out, one id at a time: the text decoded so far is released up to the last space (whole words only; everything on a
+    newline or a CJK character, the rest at the end) -- the release rule of the HF text streamer the reference worker reads from
+    (serve/model_worker.py:262-288), so the chunk boundaries on the wire are the reference's for the same ids."""
+
+    def __init__(self, tokenizer):
+        self.tok, self.ids, self.sent = tokenizer, [], 0
+
+    @staticmethod
+    def _cjk(cp: int) -> bool:
+        return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F or
+                0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+    def put(self, tok_id: int) -> str:
+        self.ids.append(tok_id)
+        text = self.tok.decode(self.ids, skip_special_tokens=True)
+        if text.endswith("\n"):
+            piece, self.ids, self.sent = text[self.sent:], [], 0
+        elif text and self._cjk(ord(text[-1])):
+            piece = text[self.sent:]
+            self.sent += len(piece)
+        else:
+            piece = text[self.sent:text.rfind(" ") + 1]
+            self.sent += len(piece)
+        return piece
+
+    def end(self) -> str:
+        piece = self.tok.decode(self.ids, skip_special_tokens=True)[self.sent:] if self.ids else ""
+        self.ids, self.sent = [], 0
+        return piece
 
 
 def load_image_from_base64(image: str):
@@ -147,63 +178,56 @@ class ModelWorker:
 
     @torch.inference_mode()
     def generate_stream(self, params: dict):
-        from transformers import TextIteratorStreamer
         tokenizer, model = self.tokenizer, self.model
-        prompt = params["prompt"]
-        ori_prompt = prompt
-        images_or_videos = params.get("images", None)
-        num_image_tokens = 0
-        image_args = {}
-        modal_token_index = MMODAL_TOKEN_INDEX["IMAGE"]
-        if images_or_videos is not None and len(images_or_videos) and self.is_multimodal:
-            clips, modal_list, replace_token, modal_token_index = self._load_clips(images_or_videos, prompt)
+        ori_prompt = prompt = params["prompt"]
+        media = params.get("images", None)
+        clip_kw, n_visual, modal_index = {}, 0, MMODAL_TOKEN_INDEX["IMAGE"]
+        if media is not None and len(media) and self.is_multimodal:
+            clips, modal_list, placeholder, modal_index = self._load_clips(media, prompt)
             if getattr(model.config, "mm_use_im_start_end", False):
-                replace_token = DEFAULT_IM_START_TOKEN + replace_token + DEFAULT_IM_END_TOKEN
-            prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, replace_token)
-            num_image_tokens = prompt.count(replace_token) * model.get_vision_tower().num_patches
-            image_args = {"images_or_videos": clips, "modal_list": modal_list}
-        temperature = float(params.get("temperature", 1.0))
-        top_p = float(params.get("top_p", 1.0))
-        max_context_length = getattr(model.config, "max_position_embeddings", 2048)
-        max_new_tokens = min(int(params.get("max_new_tokens", 256)), 1024)
+                placeholder = DEFAULT_IM_START_TOKEN + placeholder + DEFAULT_IM_END_TOKEN
+            prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, placeholder)
+            n_visual = prompt.count(placeholder) * model.get_vision_tower().num_patches
+            clip_kw = {"images_or_videos": clips, "modal_list": modal_list}
+        temperature, top_p = float(params.get("temperature", 1.0)), float(params.get("top_p", 1.0))
         stop_str = params.get("stop", None)
-        do_sample = True if temperature > 0.001 else False
-        input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_token_index, return_tensors="pt").unsqueeze(0)
-        stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
-        streamer = TextIteratorStreamer(tokenizer, skip_prompt=True, skip_special_tokens=True, timeout=15)
-        max_new_tokens = min(max_new_tokens, max_context_length - input_ids.shape[-1] - num_image_tokens)
-        if max_new_tokens < 1:
+        input_ids = tokenizer_MMODAL_token(prompt, tokenizer, modal_index, return_tensors="pt").unsqueeze(0)
+        budget = min(int(params.get("max_new_tokens", 256)), 1024,
+                     getattr(model.config, "max_position_embeddings", 2048) - input_ids.shape[-1] - n_visual)
+        if budget < 1:
             yield json.dumps({"text": ori_prompt + "Exceeds max token length. Please start a new conversation, thanks.", "error_code": 0}).encode() + b"\0"
             return
-        failure = []
+        stops = [KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)]
+        # The native decode loop IS the stream: every accepted id (decode_chunk greedy steps per host sync) goes through an incremental
+        # detokeniser and out on the wire from this very generator -- no generate() thread, no streamer queue.  The wire format is the
+        # reference's: one NUL-terminated JSON object per new id with the whole text so far (text is released at word boundaries, as the
+        # reference's streamer releases it), the moderation hook every STREAM_CHECK_MULTIPLE tokens, a trailing stop string trimmed.
+        detok = _WordBoundaryDetokenizer(tokenizer)
+        text, since_check = ori_prompt, 0
 
-        def run():
-            try:
-                with self._lock:
-                    model.generate(inputs=input_ids, do_sample=do_sample, temperature=temperature, top_p=top_p, max_new_tokens=max_new_tokens,
-                                   streamer=streamer, stopping_criteria=[stopping_criteria], use_cache=True, **image_args)
-            except Exception as e:                          # surface in the consumer thread (the reference would time out after 15 s)
-                failure.append(e)
-                streamer.end()
-        thread = Thread(target=run)
-        thread.start()
-        generated_text = ori_prompt
-        token_count = 0
-        for new_text in streamer:
-            generated_text += new_text
-            token_count += len(tokenizer.encode(new_text))
-            if token_count >= STREAM_CHECK_MULTIPLE:
-                msg = self.safety_check(generated_text)
+        def emit(piece):
+            nonlocal text, since_check
+            text += piece
+            since_check += len(tokenizer.encode(piece))
+            if since_check >= STREAM_CHECK_MULTIPLE:
+                since_check = 0
+                msg = self.safety_check(text)
                 if msg:
-                    yield json.dumps({"text": msg, "error_code": 1}).encode() + b"\0"
-                    return
-                token_count = 0
-            if generated_text.endswith(stop_str):
-                generated_text = generated_text[:-len(stop_str)]
-            yield json.dumps({"text": generated_text, "error_code": 0}).encode() + b"\0"
-        thread.join()
-        if failure:
-            raise failure[0]
+                    return json.dumps({"text": msg, "error_code": 1}).encode() + b"\0", True
+            if stop_str and text.endswith(stop_str):
+                text = text[:-len(stop_str)]
+            return json.dumps({"text": text, "error_code": 0}).encode() + b"\0", False
+
+        with self._lock:
+            for chunk in model.generate_iter(input_ids, max_new_tokens=budget, stopping_criteria=stops, do_sample=temperature > 0.001,
+                                             temperature=temperature, top_p=top_p, **clip_kw):
+                for tok_id in chunk:
+                    out, blocked = emit(detok.put(int(tok_id)))
+                    yield out
+                    if blocked:
+                        return
+            out, _ = emit(detok.end())
+            yield out
 
     def generate_stream_gate(self, params: dict):
         try:
@@ -257,15 +281,14 @@ class ModelWorker:
                     closed = self._close_stream(sid)
                 yield json.dumps({"stream_id": sid, "closed": closed, "error_code": 0}).encode() + b"\0"
                 return
-            with self._lock:
-                st = self._stream_state(sid, bool(params.get("reset", False)))
-            fr = params["frames"]
-            if isinstance(fr, dict):
+            fr = params["frames"]                         # decoded BEFORE the registry is touched: lookup / create and every tick of this request
+            if isinstance(fr, dict):                      # are then ONE critical section (a close / reset / eviction cannot land in between)
                 frames = np.frombuffer(base64.b64decode(fr["u8"]), dtype=np.uint8).reshape(fr["shape"])
             else:
                 frames = np.stack([np.asarray(load_image_from_base64(f).convert("RGB")) for f in fr])
             ar = getattr(self.model.config, "image_aspect_ratio", None)
             with self._lock:
+                st = self._stream_state(sid, bool(params.get("reset", False)))
                 for i in range(len(frames)):
                     video = process_video(frames[i:i + 1], self.image_processor, aspect_ratio=ar, num_frames=1)
                     text, st["prompt"] = infer(st["model"], video, "", self.tokenizer, prompt=st["prompt"],
