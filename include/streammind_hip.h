@@ -225,6 +225,10 @@ int sm_llm_attention(const void* q_bf16, const void* kcache, const void* vtcache
                      int KV, int dh, int S_max, void* ctx_bf16, void* stream);
 /* single-token decode attention (flash-decoding: keys split over up to splits_max blocks per KV group, then merged);
  * q bf16 [H*dh] at position pos, cache as above; workspace fp32 [splits_max * H * (dh + 2)]                */
+int sm_llm_attention_window(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max, int window,
+                            void* ctx, void* stream);       /* sm_llm_attention with Mistral's sliding window (keys (p - window, p]); window 0 = none */
+int sm_llm_decode_attention_window(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh, int S_max, int window,
+                                   float* workspace, int splits_max, void* ctx, void* stream);
 int sm_llm_decode_attention(const void* q_bf16, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
                             int S_max, float* workspace, int splits_max, void* ctx_bf16, void* stream);
 /* out[m] = bf16( silu(gu[m][0:F]) * gu[m][F:2F] ) */
@@ -285,6 +289,9 @@ typedef struct sm_config_t {
     int proj_fp16;           /* 1: the same for the connector + event gate: their linear weights are kept as IEEE fp16 and the */
                              /*    fp32 activations enter the products as fp16 hi/lo pairs (gate_precise) -- an fp16 checkpoint */
                              /*    rounded to bf16 would move the gate logits by ~5e-3, five times the 1e-3 bar.  Excludes fp8. */
+    int llm_sliding_window;  /* Mistral `sliding_window` (4096 for Mistral-7B-v0.1): a query at position p attends to keys        */
+                             /*    (p - window, p] -- HF MistralModel's mask; 0 = full causal.  The KV cache stays linear (max_seq  */
+                             /*    positions); prefill and decode attention read only the window.                                  */
 } sm_config_t;
 
 typedef struct sm_model sm_model;

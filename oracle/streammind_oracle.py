@@ -98,6 +98,7 @@ class LmCfg:                        # Mistral decoder (gate: MistralConfig() def
     vocab: int = 32000
     eps: float = 1e-5
     rope_theta: float = 1e6
+    sliding_window: Optional[int] = None     # Mistral-7B-v0.1: 4096 -- HF MistralModel masks keys k <= q - sliding_window (a query sees (q - W, q])
 
     @property
     def head_dim(self): return self.hidden // self.heads
@@ -594,6 +595,8 @@ def lm_forward(embeds: Tensor, W: Dict[str, Tensor], cfg: LmCfg, cache: Optional
         vv = vv.repeat_interleave(rep, dim=1)
         s = torch.einsum("qhd,khd->hqk", q, kk) * (dh ** -0.5)
         mask = torch.arange(S)[None, :] > pos[:, None]
+        if cfg.sliding_window:                                           # transformers MistralModel._update_causal_mask (4.44: modeling_mistral.py)
+            mask = mask | (torch.arange(S)[None, :] <= pos[:, None] - cfg.sliding_window)
         s = s.masked_fill(mask[None], float("-inf"))
         if prec.mode == "mixed":
             m = s.max(-1, keepdim=True).values

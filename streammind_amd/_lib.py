@@ -47,7 +47,7 @@ class sm_config_t(C.Structure):
         ("gate_eps", f32),
         ("llm_hidden", i32), ("llm_layers", i32), ("llm_heads", i32), ("llm_kv_heads", i32), ("llm_mlp", i32),
         ("llm_vocab", i32), ("llm_eps", f32), ("llm_rope_theta", f32),
-        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32), ("llm_fp16", i32), ("proj_fp16", i32),
+        ("max_frames_per_call", i32), ("gate_precise", i32), ("weights_fp8", i32), ("vit_fp16", i32), ("llm_fp16", i32), ("proj_fp16", i32), ("llm_sliding_window", i32),
     ]
 
 
@@ -88,6 +88,8 @@ SIGNATURES = {
     "sm_rope_kv_append": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
     "sm_llm_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sm_llm_decode_attention": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "sm_llm_attention_window": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sm_llm_decode_attention_window": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "sm_swiglu": (i32, [vp, i32, i32, vp, vp]),
     "sm_argmax": (i32, [vp, i32, vp, vp]),
     "sm_model_create": (i32, [C.POINTER(sm_config_t), C.POINTER(vp)]),

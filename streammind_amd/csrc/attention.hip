@@ -25,6 +25,7 @@ struct AttnP {
     const bf16_t* v; long v_bs, v_rs;       // row-major V: [batch][key][...], kv head kvh at column kvh*DH (VROW == true)
     bf16_t* o; long o_bs, o_rs;
     int nq, nk, H, KV, causal, pos0;
+    int window;                              // sliding-window attention (Mistral `sliding_window`): query at position q sees keys (q - window, q]; 0 = all
     float c;                                 // softmax scale * log2(e)
     // flash-decoding (single-token decode): blockIdx.z = key split; partial (unnormalised o, m, l) go to part_*
     int split_len;                           // keys per split (multiple of 64), 0 = no splitting
@@ -100,9 +101,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     if (CAUSAL) {
         int last = p.pos0 + min(qtile * 128 + 127, p.nq - 1) + 1;
         k_end = min(k_end, last);
+        // sliding window: nothing older than the FIRST query row's window is visible to any row of this tile
+        if (p.window > 0) k_begin = max(0, p.pos0 + qtile * 128 - p.window + 1) & ~63;
     }
+    // decode (GROUPQ): the one query row is the newest position nk - 1; with a window the key range starts at nk - window
+    const int dec_lo = (!CAUSAL && p.window > 0) ? max(0, nk - p.window) : 0;
     if (p.split_len) {
-        k_begin = blockIdx.z * p.split_len;
+        k_begin = (dec_lo & ~63) + blockIdx.z * p.split_len;
         k_end = min(k_end, k_begin + p.split_len);
     }
     const bf16_t* kbase = (segm ? (const bf16_t*)p.seg.kc[b] : p.k + b * p.k_bs) + kvh * DH;
@@ -238,11 +243,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 s[1][kb][f] = a1;
             }
         // ---- mask + online softmax (lane-local query = lane & 15)
-        if (CAUSAL || kt0 + 64 > nk) {
+        if (CAUSAL || kt0 + 64 > nk || kt0 < dec_lo) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int qpos = p.pos0 + q0 + qb * 16 + i;
                 const int lim = CAUSAL ? min(nk - 1, qpos) : nk - 1;       // last visible key of this lane's query
+                const int lo = CAUSAL ? (p.window > 0 ? qpos - p.window + 1 : 0) : dec_lo;      // first visible key
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
-                            s[qb][kb][f][r] = key > lim ? -INFINITY : s[qb][kb][f][r];
+                            s[qb][kb][f][r] = (key > lim || key < lo) ? -INFINITY : s[qb][kb][f][r];
                         }
             }
         }
@@ -699,14 +705,15 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     p.vt = (const bf16_t*)vt; p.vt_bs = (long)H * dh * vt_ld; p.vt_hs = (long)dh * vt_ld; p.vt_ld = vt_ld;
     p.v = vt ? nullptr : (const bf16_t*)qkv + 2L * H * dh; p.v_bs = (long)S * ld; p.v_rs = ld;   // vt == NULL: V straight from qkv
     p.o = (bf16_t*)ctx; p.o_bs = (long)S * H * dh; p.o_rs = (long)H * dh;
-    p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0;
+    p.nq = S; p.nk = S; p.H = H; p.KV = H; p.causal = 0; p.pos0 = 0; p.window = 0;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
     return launch_attn(p, B, dh, (hipStream_t)stream, op_dtype == SM_OP_F16);
 }
 
 int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
-                        int dh, int S_max, void* ctx, int f16, void* stream) {
+                        int dh, int S_max, void* ctx, int f16, void* stream, int window) {
+    SM_REQUIRE(window >= 0, "sm_llm_attention: window >= 0");
     SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
     AttnP p;
@@ -716,14 +723,18 @@ int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, 
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
     p.v = nullptr; p.v_bs = 0; p.v_rs = 0;
     p.o = (bf16_t*)ctx; p.o_bs = 0; p.o_rs = (long)H * dh;
-    p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0;
+    p.nq = n; p.nk = pos0 + n; p.H = H; p.KV = KV; p.causal = 1; p.pos0 = pos0; p.window = window;
     p.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     p.split_len = 0; p.part_o = nullptr; p.part_ml = nullptr;
     return launch_attn(p, 1, dh, (hipStream_t)stream, f16 != 0);
 }
 extern "C" int sm_llm_attention(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
                                 int dh, int S_max, void* ctx, void* stream) {
-    return sm_llm_attention_ex(q, kcache, vtcache, n, pos0, H, KV, dh, S_max, ctx, 0, stream);
+    return sm_llm_attention_ex(q, kcache, vtcache, n, pos0, H, KV, dh, S_max, ctx, 0, stream, 0);
+}
+extern "C" int sm_llm_attention_window(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV,
+                                       int dh, int S_max, int window, void* ctx, void* stream) {
+    return sm_llm_attention_ex(q, kcache, vtcache, n, pos0, H, KV, dh, S_max, ctx, 0, stream, window);
 }
 
 
@@ -742,6 +753,7 @@ struct DecAttnP {
     const bf16_t* q; bf16_t* ctx;      // [S][H*128]
     const bf16_t* k; const bf16_t* vt; // single stream (nseg == 0)
     int nk, H, KV, S_max, nseg;
+    int window;                        // 0 = all keys; else the newest `window` keys (the query is the newest position)
     float c;
     SmDecodeSeg seg;
 };
@@ -772,7 +784,8 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
     for (int df = 0; df < 8; ++df) o[df] = f32x4{0, 0, 0, 0};
     float m_run = -INFINITY, l_run = 0.f;
     const int NB = (nk + 31) >> 5;
-    for (int blk0 = wave; blk0 < NB; blk0 += 16) {
+    const int k_lo = p.window > 0 ? max(0, nk - p.window) : 0;          // first visible key
+    for (int blk0 = (k_lo >> 5) + wave; blk0 < NB; blk0 += 16) {
         const bool two = blk0 + 8 < NB;
         bf16x8 kf[2][2][4], vf[2][8];
 #pragma unroll
@@ -802,13 +815,13 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
                 for (int ks = 0; ks < 4; ++ks) acc = mfma16<F16>(kf[u][a][ks], qf[ks], acc);
                 sc[a] = acc;
             }
-            const bool part = key0 + 32 > nk;        // only the last block of the cache carries masked keys
+            const bool part = key0 + 32 > nk || key0 < k_lo;        // only the last block of the cache (and the first of a window) carries masked keys
             if (part) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (key0 + g * 8 + a * 4 + r >= nk) sc[a][r] = -INFINITY;
+                        if (key0 + g * 8 + a * 4 + r >= nk || key0 + g * 8 + a * 4 + r < k_lo) sc[a][r] = -INFINITY;
                 // positions past the cache end may hold anything (a caller-owned cache need not be zeroed): 0 * garbage must stay 0
 #pragma unroll
                 for (int df = 0; df < 8; ++df) {
@@ -885,26 +898,29 @@ static bool decode_attn_fused_ok(int nk, int dh, int S, int KV) {
 // that every CU streams part of the cache, and a tiny kernel merges the partial softmaxes.
 // workspace: fp32 [splits_max * H * (dh + 2)]
 int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
-                               int S_max, float* workspace, int splits_max, void* ctx, int f16, void* stream) {
+                               int S_max, float* workspace, int splits_max, void* ctx, int f16, void* stream, int window) {
+    SM_REQUIRE(window >= 0, "sm_llm_decode_attention: window >= 0");
     SM_REQUIRE(q && kcache && vtcache && ctx && workspace && pos >= 0 && pos < S_max, "sm_llm_decode_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && dh <= 128, "sm_llm_decode_attention: dims");
     const int rep = H / KV, nk = pos + 1;
-    if (decode_attn_fused_ok(nk, dh, 1, KV)) {
+    const int k_lo64 = window > 0 ? (nk - window > 0 ? (nk - window) & ~63 : 0) : 0;      // first key tile that holds a visible key
+    const int nk_eff = nk - k_lo64;                                                      // keys the kernels walk
+    if (decode_attn_fused_ok(nk_eff, dh, 1, KV)) {
         DecAttnP d;
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = (const bf16_t*)kcache; d.vt = (const bf16_t*)vtcache;
-        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = 0; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = 0; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
         SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
         if (f16) decode_attn_kernel<true><<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
         else decode_attn_kernel<false><<<dim3(1, KV), 512, 0, (hipStream_t)stream>>>(d);
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
-    int splits = cdiv(nk, 64);            // one 64-key tile per block while the cache is short: the kernel is a latency chain per tile
+    int splits = cdiv(nk_eff, 64);            // one 64-key tile per block while the cache is short: the kernel is a latency chain per tile
     if (splits > splits_max) splits = splits_max;
-    const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
-    splits = cdiv(nk, split_len);
+    const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
+    splits = cdiv(nk_eff, split_len);
     AttnP p;
-    p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
+    p.nseg = 0; p.part_bs = 0; p.ml_bs = 0; p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = (const bf16_t*)vtcache; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;
@@ -935,14 +951,18 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
 }
 extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
                                        int S_max, float* workspace, int splits_max, void* ctx, void* stream) {
-    return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream);
+    return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream, 0);
+}
+extern "C" int sm_llm_decode_attention_window(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
+                                              int S_max, int window, float* workspace, int splits_max, void* ctx, void* stream) {
+    return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream, window);
 }
 
 // single-token decode attention of S streams in ONE launch pair: stream t's query row block q[t] (H heads) against ITS cache
 // [0, pos[t]]; the key range is cut into the same number of splits for every stream (sized for the longest context; a split
 // that lies beyond a shorter stream's cache contributes weight 0 to the merge)
 int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
-                                int splits_max, void* ctx, int f16, void* stream) {
+                                int splits_max, void* ctx, int f16, void* stream, int window) {
     SM_REQUIRE(q && ctx && workspace && S > 0 && S <= SM_MAX_SEG, "sm_llm_decode_attention_seg: bad args");
     SM_REQUIRE(S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && splits_max >= 1 && splits_max <= 64 && (dh == 64 || dh == 128), "sm_llm_decode_attention_seg: dims");
     const int rep = H / KV;
@@ -951,21 +971,24 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
         SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg: stream %d: bad position / cache", t);
         nk = seg.pos[t] + 1 > nk ? seg.pos[t] + 1 : nk;
     }
-    if (decode_attn_fused_ok(nk, dh, S, KV)) {
+    // with a window every stream walks at most window + 63 keys (its own tile-aligned start is computed in the kernel)
+    const int nk_eff = window > 0 && nk > window + 63 ? window + 63 : nk;
+    if (decode_attn_fused_ok(nk_eff, dh, S, KV)) {
         DecAttnP d;
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
-        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+        d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
         SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
         if (f16) decode_attn_kernel<true><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
         else decode_attn_kernel<false><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
         SM_LAUNCH_CHECK();
         return SM_OK;
     }
-    int splits = cdiv(nk, 64);
+    int splits = cdiv(nk_eff, 64);
     if (splits > splits_max) splits = splits_max;
-    const int split_len = cdiv(cdiv(nk, splits), 64) * 64;
-    splits = cdiv(nk, split_len);
+    const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
+    splits = cdiv(nk_eff, split_len);
     AttnP p;
+    p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = (long)H * dh; p.q_rs = dh;
     p.k = nullptr; p.k_bs = 0; p.k_rs = (long)KV * dh;
     p.vt = nullptr; p.vt_bs = 0; p.vt_hs = (long)dh * S_max; p.vt_ld = S_max;

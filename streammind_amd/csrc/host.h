@@ -38,6 +38,8 @@ int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_db
                           int F, int di, int d_state, const float* A_log, const float* Dp, const SmSegStates& st, float* y,
                           void* stream);
 int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& dst, void* stream);
+int sm_gate_tail(const float* x, int M, int D, int ldx, const float* gamma, float eps, const float* head_w_f32, float* logits, int32_t* decisions, void* stream);   // vecops.hip
+int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* stream);
 
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
 struct SmDecodeSeg { void* kc[SM_MAX_SEG]; void* vtc[SM_MAX_SEG]; int pos[SM_MAX_SEG]; };
@@ -55,12 +57,13 @@ int sm_rope_kv_append_ex(const float* qkv, int n, int pos0, int H, int KV, int d
 int sm_embed_splice_ex(const int32_t* ids, int n, const void* table, const float* tokens, int D, float* out, int f16, int vocab,
                        int n_tok, void* stream);
 int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);
+// window: Mistral's sliding_window (a query at position p sees keys (p - window, p]); 0 = full causal
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
-                                int splits_max, void* ctx_bf16, int f16, void* stream);                           // attention.hip
+                                int splits_max, void* ctx_bf16, int f16, void* stream, int window = 0);           // attention.hip
 int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max,
-                        void* ctx, int f16, void* stream);
+                        void* ctx, int f16, void* stream, int window = 0);
 int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh, int S_max,
-                               float* workspace, int splits_max, void* ctx, int f16, void* stream);
+                               float* workspace, int splits_max, void* ctx, int f16, void* stream, int window = 0);
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
                         int f16, void* stream);
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);

@@ -182,6 +182,7 @@ struct sm_model {
             for (auto ev : kv.second.more_join) (void)hipEventDestroy(ev);
         }
     }
+    DevBuf gate_head_f32;          // the gate's 2-way head as fp32 [2][d] (16-bit checkpoint values widened): operand of the fused gate tail
     // RoPE tables for the LLM
     DevBuf rope_cos, rope_sin;
     int rope_len = 0;
@@ -488,6 +489,10 @@ extern "C" int sm_model_finalize(sm_model* m, void* stream) {
             w.ln1_w = F(p + "input_layernorm.weight"); w.ln2_w = F(p + "post_attention_layernorm.weight");
         }
         R.gate_norm = F("proj.cls_net.cls_model.model.norm.weight"); R.gate_head = S("proj.gate_head");
+        if (!R.gate_head->fp8 && R.gate_head->N == 2 && c.conn_d_model <= 8192 && (c.conn_d_model & 3) == 0) {
+            if ((rc = m->gate_head_f32.alloc((size_t)2 * c.conn_d_model * sizeof(float)))) return rc;
+            if ((rc = sm_unpack_rows_f32(R.gate_head->buf.p, 2, c.conn_d_model, R.gate_head->f16 ? 1 : 0, m->gate_head_f32.as<float>(), stream))) return rc;
+        }
         }
         R.llm.resize(c.llm_layers);
         for (int l = 0; l < c.llm_layers; ++l) {
@@ -942,6 +947,8 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
     // repeat_kv folded into o_proj's operand addressing (sm_linear_t.x_rep) where the kernels read x through it: 16-bit weights, powers of two
     const bool fold_rep = rep > 1 && (rep & (rep - 1)) == 0 && (gdh & (gdh - 1)) == 0 && gdh >= 8;
     const float* hcur = tok;       // layer 0 reads the token, writes ws.h
+    static const bool no_tail = [] { const char* e = getenv("SM_GATE_TAIL"); return e && atoi(e) == 0; }();
+    const bool tail = m->gate_head_f32.p != nullptr && c.gate_layers > 0 && !no_tail;
     for (int l = 0; l < c.gate_layers; ++l) {
         const sm_model::LayerW& w = W.gate[l];
         {   sm_linear_t a = L(w.v, ws.hn.as<float>(), d); a.out_f32 = ws.v.as<float>(); a.ldo = kvn;
@@ -964,10 +971,12 @@ static int conn_gate_pass(sm_model* m, ConnScratch& ws, const float* pooled, int
         {   sm_linear_t a = L(w.down, ws.act.as<float>(), c.gate_mlp);
             a.residual = hcur; a.ldr = d; a.out_f32 = ws.h.as<float>(); a.ldo = d;
             if (l + 1 < c.gate_layers) post_norm(a, W.gate[l + 1].ln1_w, nullptr, c.gate_eps, 0, ws.hn.as<float>());
-            else post_norm(a, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>());
+            else if (!tail) post_norm(a, W.gate_norm, nullptr, c.gate_eps, 0, ws.hfin.as<float>());
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
     float* lg = logits ? logits : ws.logits2.as<float>();
+    if (tail)       // final RMSNorm + 2-way head + decision in one launch (fp32 throughout)
+        return sm_gate_tail(hcur, M, d, d, W.gate_norm, c.gate_eps, m->gate_head_f32.as<float>(), lg, decisions, stream);
     {   sm_linear_t a = L(W.gate_head, ws.hfin.as<float>(), d); a.out_f32 = lg; a.ldo = 2;
         if ((rc = sm_linear(&a, stream))) return rc; }
     if (decisions && (rc = sm_gate_decide(lg, M, decisions, stream))) return rc;
@@ -1166,8 +1175,8 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         }
         if (!fuse_rope && (rc = sm_rope_kv_append_ex(s->qkvf.as<float>(), n, s->kv_len, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), s->qb.p, s->kc[l].p, s->vtc[l].p, s->max_seq, f16, stream))) return rc;
         if (n == 1) {
-            if ((rc = sm_llm_decode_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, f16, stream))) return rc;
-        } else if ((rc = sm_llm_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, f16, stream))) return rc;
+            if ((rc = sm_llm_decode_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, s->kv_len, H, KV, dh, s->max_seq, s->attn_ws.as<float>(), SM_DECODE_SPLITS, s->ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
+        } else if ((rc = sm_llm_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
         {   sm_linear_t a = lin(m, *w.o, s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
             if ((rc = sm_linear(&a, stream))) return rc; }
@@ -1335,7 +1344,7 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             SmDecodeSeg seg;
             for (int t = 0; t < S; ++t) { seg.kc[t] = act[t]->kc[l].p; seg.vtc[t] = act[t]->vtc[l].p; seg.pos[t] = act[t]->kv_len; }
             if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, seg, S_max, f16, stream))) return rc;
-            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, f16, stream))) return rc;
+            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }

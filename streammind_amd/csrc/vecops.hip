@@ -405,13 +405,18 @@ extern "C" int sm_pool_patches(const float* x, int B, int S, int D, float* poole
 
 // ------------------------------------------------------------------------------------------------ mamba step
 // rows are S segments (streams) of F consecutive frames each: blockIdx.y = segment, its recurrent state st.p[segment]
-__global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, int dc, SmSegStates st,
+// DC > 0: d_conv is a compile-time constant (the window and the taps live in registers); DC = 0: run-time width (<= 8) -- with run-time
+// trip counts the two arrays are indexed dynamically and live in scratch memory, which made this kernel 27 us per 28-frame pass
+template <int DC>
+__global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, int dc_rt, SmSegStates st,
                                   const float* __restrict__ cw, const float* __restrict__ cb, float* __restrict__ xc) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= di) return;
+    const int dc = DC > 0 ? DC : dc_rt;
     float* __restrict__ cs = st.p[blockIdx.y];
     const int m0 = blockIdx.y * F;
-    float stt[8], w[8];
+    float stt[DC > 0 ? DC : 8], w[DC > 0 ? DC : 8];
+#pragma unroll
     for (int j = 0; j < dc; ++j) { stt[j] = cs[(size_t)d * dc + j]; w[j] = cw[(size_t)d * dc + j]; }
     const float bias = cb[d];
     // the recurrence over a segment's frames is serial, its loads are not: eight frames' inputs are requested together (a load per
@@ -423,19 +428,23 @@ __global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, i
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (mb + u >= m0 + F) break;
+#pragma unroll
             for (int j = 0; j + 1 < dc; ++j) stt[j] = stt[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
             stt[dc - 1] = xin[u];
             float a = 0.f;
+#pragma unroll
             for (int j = 0; j < dc; ++j) a += stt[j] * w[j];
             xc[(size_t)(mb + u) * di + d] = siluf_(a + bias);
         }
     }
+#pragma unroll
     for (int j = 0; j < dc; ++j) cs[(size_t)d * dc + j] = stt[j];
 }
 int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,
                            const float* conv_b, float* xc, void* stream) {
     SM_REQUIRE(xz && conv_w && conv_b && xc && S > 0 && S <= SM_MAX_SEG && F > 0 && d_conv <= 8, "sm_mamba_conv_step: bad args");
-    mamba_conv_kernel<<<dim3(cdiv(di, 256), S), 256, 0, (hipStream_t)stream>>>(xz, F, di, d_conv, st, conv_w, conv_b, xc);
+    if (d_conv == 4) mamba_conv_kernel<4><<<dim3(cdiv(di, 256), S), 256, 0, (hipStream_t)stream>>>(xz, F, di, d_conv, st, conv_w, conv_b, xc);
+    else mamba_conv_kernel<0><<<dim3(cdiv(di, 256), S), 256, 0, (hipStream_t)stream>>>(xz, F, di, d_conv, st, conv_w, conv_b, xc);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -448,15 +457,19 @@ extern "C" int sm_mamba_conv_step(const float* xz, int M, int di, int d_conv, fl
 }
 
 // thread per channel d, d_state (<= 32) state elements in registers; segments as in mamba_conv_kernel
+// DS > 0: compile-time d_state (state and decay rates in registers); DS = 0: run-time (<= 32; the arrays then live in scratch, see the conv kernel)
+template <int DS>
 __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __restrict__ delta,
                                  const float* __restrict__ xdbl, int ldx, int R, const float* __restrict__ xz, int F, int di,
-                                 int ds, const float* __restrict__ Alog, const float* __restrict__ Dp,
+                                 int ds_rt, const float* __restrict__ Alog, const float* __restrict__ Dp,
                                  SmSegStates st, float* __restrict__ y) {
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= di) return;
+    const int ds = DS > 0 ? DS : ds_rt;
     float* __restrict__ hst = st.p[blockIdx.y];
     const int m0 = blockIdx.y * F;
-    float h[32], A[32];
+    float h[DS > 0 ? DS : 32], A[DS > 0 ? DS : 32];
+#pragma unroll
     for (int n = 0; n < ds; ++n) { h[n] = hst[(size_t)d * ds + n]; A[n] = -__expf(Alog[(size_t)d * ds + n]); }
     const float Dd = Dp[d];
     // serial recurrence, batched loads (see mamba_conv_kernel): four frames' dt / x / z are in flight together (60 us -> per pass of 28 frames
@@ -478,6 +491,7 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
             const float* Bm = xdbl + (size_t)m * ldx + R;
             const float* Cm = Bm + ds;
             float acc = 0.f;
+#pragma unroll
             for (int n = 0; n < ds; ++n) {
                 h[n] = __expf(dt * A[n]) * h[n] + (dt * xv) * Bm[n];
                 acc += h[n] * Cm[n];
@@ -485,6 +499,7 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
             y[(size_t)m * di + d] = (acc + Dd * xv) * siluf_(zv[u]);
         }
     }
+#pragma unroll
     for (int n = 0; n < ds; ++n) hst[(size_t)d * ds + n] = h[n];
 }
 int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_dbl, int ldx, int dt_rank, const float* xz, int S,
@@ -492,8 +507,8 @@ int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_db
                           void* stream) {
     SM_REQUIRE(xc && delta && x_dbl && xz && A_log && Dp && y, "sm_mamba_ssm_step: null arg");
     SM_REQUIRE(S > 0 && S <= SM_MAX_SEG && F > 0 && d_state <= 32, "sm_mamba_ssm_step: d_state <= 32, segments <= %d", SM_MAX_SEG);
-    mamba_ssm_kernel<<<dim3(cdiv(di, 128), S), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, F, di, d_state,
-                                                                              A_log, Dp, st, y);
+    if (d_state == 16) mamba_ssm_kernel<16><<<dim3(cdiv(di, 128), S), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, F, di, d_state, A_log, Dp, st, y);
+    else mamba_ssm_kernel<0><<<dim3(cdiv(di, 128), S), 128, 0, (hipStream_t)stream>>>(xc, delta, x_dbl, ldx, dt_rank, xz, F, di, d_state, A_log, Dp, st, y);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -529,6 +544,73 @@ __global__ void repeat_kv_kernel(const float* v, int M, int KV, int H, int dh, f
 extern "C" int sm_repeat_kv(const float* v, int M, int KV, int H, int dh, float* out, void* stream) {
     SM_REQUIRE(v && out && M > 0 && H % KV == 0, "sm_repeat_kv: bad args");
     repeat_kv_kernel<<<cdiv(M * H * dh, 256), 256, 0, (hipStream_t)stream>>>(v, M, KV, H, dh, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// Tail of the event gate in ONE launch (builder.py:553-562: final RMSNorm of the last hidden state, the 2-way `score` head, then
+// softmax + argmax -- monotone, so a comparison): a block per row; the row lives in registers (D <= 8192), the head weights are the
+// checkpoint's 16-bit values widened to fp32 (head_w [2][D], unpacked once at finalize), everything is fp32 FMA.  Replaces a norm
+// launch, a 2-column weight-streaming product (17 us at 28 rows: one block walks all of K) and the decision launch.
+__global__ __launch_bounds__(256) void gate_tail_kernel(const float* __restrict__ x, int D, int ldx, const float* __restrict__ gamma, float eps,
+                                                        const float* __restrict__ head_w, float* __restrict__ logits, int32_t* __restrict__ dec) {
+    __shared__ float red[3][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* xr = x + (size_t)row * ldx;
+    const int nv = D >> 2;
+    f32x4 v[8], gm[8], w0[8], w1[8];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = tid + j * 256;
+        v[j] = gm[j] = w0[j] = w1[j] = f32x4{0, 0, 0, 0};
+        if (c < nv) {
+            v[j] = *(const f32x4*)(xr + (size_t)c * 4);
+            gm[j] = *(const f32x4*)(gamma + (size_t)c * 4);
+            w0[j] = *(const f32x4*)(head_w + (size_t)c * 4);
+            w1[j] = *(const f32x4*)(head_w + D + (size_t)c * 4);
+        }
+        q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[0][w] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D + eps);
+    float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float hn = gm[j][e] * (v[j][e] * rstd);
+            l0 += hn * w0[j][e];
+            l1 += hn * w1[j][e];
+        }
+    l0 = wave_sum(l0); l1 = wave_sum(l1);
+    if (lane == 0) { red[1][w] = l0; red[2][w] = l1; }
+    __syncthreads();
+    if (tid == 0) {
+        const float a = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), b = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        logits[2 * row] = a; logits[2 * row + 1] = b;
+        if (dec) dec[row] = b > a ? 1 : 0;                 // tie -> index 0, as gate_decide_kernel
+    }
+}
+int sm_gate_tail(const float* x, int M, int D, int ldx, const float* gamma, float eps, const float* head_w_f32, float* logits, int32_t* decisions, void* stream) {
+    SM_REQUIRE(x && gamma && head_w_f32 && logits && M > 0 && D > 0 && D <= 8192 && (D & 3) == 0 && (ldx & 3) == 0, "sm_gate_tail: bad args (D <= 8192, %% 4)");
+    gate_tail_kernel<<<M, 256, 0, (hipStream_t)stream>>>(x, D, ldx, gamma, eps, head_w_f32, logits, decisions);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+// rows of a packed 16-bit weight image (sm_pack_weight layout) widened to fp32 row-major [N][K]
+__global__ void unpack_rows_f32_kernel(const bf16_t* __restrict__ wp, int N, int K, int KS, int f16, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * K) return;
+    const int n = t / K, k = t - n * K;
+    const uint16_t raw = ((const uint16_t*)wp)[packed_index(n, k, KS)];
+    out[t] = f16 ? (float)__builtin_bit_cast(_Float16, raw) : __uint_as_float((uint32_t)raw << 16);
+}
+int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* stream) {
+    SM_REQUIRE(wp && out && N > 0 && K > 0, "sm_unpack_rows_f32: bad args");
+    unpack_rows_f32_kernel<<<cdiv(N * K, 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)wp, N, K, (K + 31) / 32, f16, out);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

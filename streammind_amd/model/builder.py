@@ -136,24 +136,47 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
             over.update(img_mean=tuple(pj["image_mean"]), img_std=tuple(pj["image_std"]))
     if stc:
         over.update(conn_d_state=0, gate_layers=0)          # native model without the Mamba connector / gate (sm_config_t.conn_d_state)
+    # builder.py:150-152, 186-196: the tokenizer comes first because it decides the size of the embedding table -- the patch / start / end
+    # tokens are ADDED to it and the reference then calls resize_token_embeddings(len(tokenizer)), growing embed_tokens and lm_head by
+    # freshly initialised rows (transformers 4.44: normal(0, initializer_range), i.e. unspecified values).  Same here: the native table has
+    # len(tokenizer) rows, the checkpoint fills the rows it has, the new rows get seeded normal(0, initializer_range) values.  A checkpoint
+    # SAVED after the resize already holds its (trained) rows and config.vocab_size says so: then nothing is grown.
+    try:
+        tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+    except Exception:                                       # no slow-tokenizer files: builder.py:150-152 falls back to the fast one too
+        tokenizer = AutoTokenizer.from_pretrained(model_path, model_max_length=2048, padding_side="right", use_fast=True)
+    if cfgj.get("mm_use_im_patch_token", True):
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+    if cfgj.get("mm_use_im_start_end", False):
+        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+    if cfgj.get("sliding_window"):
+        over.update(llm_sliding_window=int(cfgj["sliding_window"]))
+    ckpt_vocab = int(cfgj["vocab_size"])
+    grown_vocab = max(ckpt_vocab, len(tokenizer))
+    if grown_vocab > ckpt_vocab:
+        over.update(llm_vocab=grown_vocab)
     cfg = path_config_from_checkpoint(cfgj, vj, **over)
-    # Mistral's sliding window (4096 for Mistral-7B-v0.1, null for v0.2): the attention kernels are full-causal, which equals
-    # the windowed attention as long as the context stays inside the window -- so the KV capacity is capped at it
+    # Mistral's sliding window (4096 for Mistral-7B-v0.1, null for v0.2): the attention kernels mask it like HF's MistralModel (a query at
+    # position p sees keys (p - window, p]; sm_config_t.llm_sliding_window), so the KV capacity may exceed it.  Default capacity 4096.
     window = cfgj.get("sliding_window")
     max_seq = kwargs.pop("max_seq", None)
     if max_seq is None:
-        max_seq = min(4096, window) if window else 4096
-        max_seq -= max_seq % 64
-    elif window and max_seq > window:
-        raise ValueError(f"max_seq={max_seq} exceeds the checkpoint's sliding_window={window}: the attention kernels are full-causal")
+        max_seq = 4096
+    max_seq -= max_seq % 64
     dev = "cuda:0" if device == "cuda" else device
     nat = NativeModel(cfg, dev)
     proj_sd = {}                                            # STC family: the projector's tensors go to the host-side connector class
+    def grown(k, v):            # resize_token_embeddings on the way in: rows [ckpt_vocab, len(tokenizer)) of the two vocabulary-sized tensors
+        if grown_vocab > v.shape[0] and v.dim() == 2 and (k.endswith("embed_tokens.weight") or k.endswith("lm_head.weight")) and "cls_net" not in k:
+            g = torch.Generator().manual_seed(20240 + (1 if k.endswith("lm_head.weight") else 0))
+            extra = torch.randn(grown_vocab - v.shape[0], v.shape[1], generator=g) * float(cfgj.get("initializer_range", 0.02))
+            return torch.cat([v, extra.to(v.dtype)], dim=0)
+        return v
     for k, v in _checkpoint_tensors(model_path):
         if stc and "mm_projector." in k:
             proj_sd[k.split("mm_projector.", 1)[1]] = v
         else:
-            nat.load_tensor(k, v)
+            nat.load_tensor(k, grown(k, v))
     pbin = os.path.join(model_path, "mm_projector.bin")
     if os.path.exists(pbin):                                # builder.py:141-142 -> load_mm_projector
         for k, v in torch.load(pbin, map_location="cpu", weights_only=True).items():
@@ -171,18 +194,6 @@ def load_pretrained_model(model_path, model_base=None, model_name="VideoLLaMA2-7
     if nat.missing():
         raise ValueError(f"checkpoint incomplete, missing: {nat.missing()[:8]}")
     nat.finalize()
-    try:
-        tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
-    except Exception:                                       # no slow-tokenizer files: builder.py:150-152 falls back to the fast one too
-        tokenizer = AutoTokenizer.from_pretrained(model_path, model_max_length=2048, padding_side="right", use_fast=True)
-    # builder.py:186-191: the patch / start / end tokens are ADDED to the tokenizer; the reference then grows the embedding by
-    # freshly initialised rows (resize_token_embeddings), which no prompt of this path ever indexes -- the native vocabulary
-    # stays the checkpoint's, and an id behind it (a prompt that spells <im_patch> out) is rejected before it reaches the device
-    # (Videollama2MistralForCausalLM._check_ids; the embedding kernel itself reads such a row as zeros)
-    if cfgj.get("mm_use_im_patch_token", True):
-        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
-    if cfgj.get("mm_use_im_start_end", False):
-        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
     image_processor = CLIPImageProcessor.from_pretrained(tower_dir)
     context_len = cfgj.get("max_sequence_length", 2048)                      # builder.py:205-208
     model = Videollama2MistralForCausalLM(nat, max_frames=kwargs.pop("max_frames", 4096), max_seq=max_seq,

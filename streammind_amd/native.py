@@ -62,6 +62,7 @@ class PathConfig:
     vit_fp16: bool = False         # vision-tower operands in IEEE fp16 (the reference demo's precision) instead of bf16
     llm_fp16: bool = False         # the same for the LLM (weights, embedding table, activations, q / KV caches, attention P)
     proj_fp16: bool = False        # the same for the connector + gate weights (activations as fp16 hi/lo pairs in precise mode)
+    llm_sliding_window: int = 0    # Mistral `sliding_window`: a query at position p attends to keys (p - window, p]; 0 = full causal
 
     @property
     def vit_layers_run(self) -> int:
@@ -96,6 +97,7 @@ class PathConfig:
         c.vit_fp16 = int(self.vit_fp16)
         c.llm_fp16 = int(self.llm_fp16)
         c.proj_fp16 = int(self.proj_fp16)
+        c.llm_sliding_window = int(self.llm_sliding_window or 0)
         return c
 
 

@@ -91,7 +91,12 @@ def test_model_init_from_checkpoint_then_reference_stream_loop(tmp_path, gold, l
     assert model.config.mm_projector_type == "mamba" and model.native.cfg.vit_layers_run == TV.layers - 1
     assert sorted(model.native.ignored) != [] or layout.startswith("as_saved")      # q/k of the gate, post_layernorm: never read
     if layout.startswith("hf444"):
-        assert model.max_seq == 4096                  # capped at the checkpoint's sliding window
+        assert model.max_seq == 4096 and model.native.cfg.llm_sliding_window == 4096      # the window is the attention kernels' mask now, not a capacity cap
+    # resize_token_embeddings (builder.py:186-196): <im_patch> was added to the tokenizer and the native table grew with it -- the id indexes
+    # a real (freshly initialised) row, as in the reference, instead of being refused
+    pid = tokenizer.convert_tokens_to_ids("<im_patch>")
+    assert pid == len(tokenizer) - 1 and model.native.cfg.llm_vocab == len(tokenizer) == json.load(open(os.path.join(ck, "config.json")))["vocab_size"] + 1
+    model._check_ids([1, pid, 5])
 
     def to_video(frame_u8):                           # eval/video_score_stream_demo.py:285-287: processor([img], num_frames=1)
         return processor([frame_u8[0].numpy()], num_frames=1)
@@ -120,9 +125,10 @@ def test_loader_errors(tmp_path, gold):
     json.dump(dict(cfg, mm_vision_tower="openai/clip-vit-large-patch14-336"), open(cfgp, "w"))
     with pytest.raises(FileNotFoundError, match="not a local directory"):
         load_pretrained_model(ck, None, "VideoLLaMA2-7B")
-    json.dump(dict(cfg, sliding_window=128), open(cfgp, "w"))
-    with pytest.raises(ValueError, match="sliding_window"):
-        load_pretrained_model(ck, None, "VideoLLaMA2-7B", max_seq=256)
+    json.dump(dict(cfg, sliding_window=128), open(cfgp, "w"))      # a KV capacity beyond the window is legal: the kernels mask the window
+    _, mw, _, _ = load_pretrained_model(ck, None, "VideoLLaMA2-7B", max_seq=256)
+    assert mw.max_seq == 256 and mw.native.cfg.llm_sliding_window == 128
+    del mw
     # a checkpoint that lost one half of a fused pair must not finalize -- even when the other half arrives twice (here:
     # gate_proj of the gate is in model.safetensors AND in mm_projector.bin, its up_proj nowhere)
     from safetensors.torch import load_file, save_file

@@ -284,6 +284,62 @@ def test_decode_attention_split_keys(nat, pos, H, KV, dh):
         assert torch.equal(ctx2, ctx)
 
 
+@pytest.mark.parametrize("pos,W,H,KV,dh", [(10, 64, 32, 8, 128), (63, 64, 32, 8, 128), (64, 64, 32, 8, 128), (200, 64, 32, 8, 128), (1000, 100, 32, 8, 128),
+                                           (4095, 4096, 32, 8, 128), (5000, 4096, 32, 8, 128), (6143, 4096, 32, 8, 128), (3000, 1000, 4, 4, 64), (700, 33, 2, 1, 128)])
+def test_decode_attention_sliding_window(nat, pos, W, H, KV, dh):
+    """Mistral's sliding window at decode time (HF MistralModel: keys k <= p - window are masked, i.e. the query at position p sees the
+    newest `window` keys, itself included): one-launch kernel and key-split + merge, window starting inside / at / before a key tile,
+    contexts beyond the window (the case the checkpoint's sliding_window = 4096 exists for).  bf16 output, 8e-3 of max; with the window
+    at least as long as the context the result is bit for bit the plain call's."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    S_max = 6144
+    g = torch.Generator().manual_seed(pos + W)
+    q = O.bf16_round(torch.randn(H, dh, generator=g))
+    k = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    v = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    qg, kg = q.cuda().bfloat16(), k.cuda().bfloat16()
+    vt = v.permute(1, 2, 0).contiguous().cuda().bfloat16()
+    ws = torch.empty(32 * H * (dh + 2), device="cuda")
+    ctx = torch.empty(H, dh, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.sm_llm_decode_attention_window(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), pos, H, KV, dh, S_max, W, ws.data_ptr(), 32, ctx.data_ptr(), st))
+    lo = max(0, pos - W + 1)
+    rep = H // KV
+    kk, vv = k[lo:pos + 1].repeat_interleave(rep, dim=1), v[lo:pos + 1].repeat_interleave(rep, dim=1)
+    ref = torch.einsum("hk,khd->hd", torch.softmax(torch.einsum("hd,khd->hk", q, kk) * dh ** -0.5, -1), vv)
+    assert relerr(ctx, ref) < 8e-3
+    if W > pos:
+        plain = torch.empty_like(ctx)
+        check(lib.sm_llm_decode_attention(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), pos, H, KV, dh, S_max, ws.data_ptr(), 32, plain.data_ptr(), st))
+        assert torch.equal(plain, ctx)
+
+
+@pytest.mark.parametrize("n,pos0,W,H,KV,dh", [(40, 0, 16, 4, 2, 128), (300, 0, 64, 8, 2, 128), (130, 500, 200, 8, 8, 64), (257, 4000, 4096, 32, 8, 128), (64, 100, 1000, 4, 1, 128)])
+def test_prefill_attention_sliding_window(nat, n, pos0, W, H, KV, dh):
+    """the causal prefill kernel with the window mask: n new queries at positions pos0.. against the cache [0, pos0 + n), each seeing
+    keys (p - W, p].  vs fp32 softmax attention on the same bf16 operands, bf16 output: 8e-3 of max."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    S_max = ((pos0 + n + 63) // 64) * 64
+    g = torch.Generator().manual_seed(n + W)
+    q = O.bf16_round(torch.randn(n, H, dh, generator=g))
+    k = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    v = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    qg, kg = q.reshape(n, H * dh).cuda().bfloat16(), k.cuda().bfloat16()
+    vt = v.permute(1, 2, 0).contiguous().cuda().bfloat16()
+    ctx = torch.empty(n, H * dh, device="cuda", dtype=torch.bfloat16)
+    check(lib.sm_llm_attention_window(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), n, pos0, H, KV, dh, S_max, W, ctx.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    S = pos0 + n
+    rep = H // KV
+    kk, vv = k[:S].repeat_interleave(rep, dim=1), v[:S].repeat_interleave(rep, dim=1)
+    s = torch.einsum("qhd,khd->hqk", q, kk) * dh ** -0.5
+    pos = torch.arange(pos0, pos0 + n)
+    mask = (torch.arange(S)[None, :] > pos[:, None]) | (torch.arange(S)[None, :] <= pos[:, None] - W)
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(s.masked_fill(mask[None], float("-inf")), -1), vv).reshape(n, H * dh)
+    assert relerr(ctx, ref) < 8e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 96), (8, 4096, 4096), (1, 4096, 14336), (16, 288, 8192), (2, 2, 4096)])
 @pytest.mark.parametrize("mode", ["f32_precise", "bf16"])
 def test_skinny_linear_fp8_weights(nat, M, N, K, mode):

@@ -16,7 +16,7 @@ def path_config(vcfg: O.VitCfg, ccfg: O.ConnCfg, gcfg: O.LmCfg, lcfg=None, max_f
         kw.update(llm_layers=0)
     else:
         kw.update(llm_layers=lcfg.layers, llm_heads=lcfg.heads, llm_kv_heads=lcfg.kv_heads, llm_mlp=lcfg.mlp,
-                  llm_vocab=lcfg.vocab, llm_eps=lcfg.eps, llm_rope_theta=lcfg.rope_theta)
+                  llm_vocab=lcfg.vocab, llm_eps=lcfg.eps, llm_rope_theta=lcfg.rope_theta, llm_sliding_window=int(lcfg.sliding_window or 0))
     return PathConfig(**kw)
 
 
