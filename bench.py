@@ -307,6 +307,48 @@ def ingest_leg(B=28, H=720, W=1280, reps=20):
                          "frac": round(byts / dt / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_frame": byts // B}}
 
 
+def jpeg_leg(B=28, H=720, W=1280, quality=85, reps=5):
+    """f2, codec half: B Motion-JPEG frames (720p, 4:2:0, synthetic content encoded once with PIL) -> u8 RGB in HBM.
+    Three rates side by side: PIL / libjpeg-turbo on one host thread (what the reference's loader does per frame), the C ABI's host
+    Huffman stage alone (thread pool), and the whole native path (Huffman threads + pinned upload + GPU IDCT / upsampling / colour).
+    The GPU kernels' own time is reported from HIP events.  The outputs are byte-identical (tests/test_gpu_jpeg.py)."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from streammind_amd import native
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:H, 0:W]
+    jpegs = []
+    for i in range(B):
+        img = np.stack([128 + 100 * np.sin(xx / (9.0 + i)) * np.cos(yy / 7.0), 128 + 110 * np.sin((xx + yy) / 13.0), 255.0 * ((xx // 11 + yy // 5 + i) % 2)], axis=2)
+        img = np.clip(img + rng.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, "JPEG", quality=quality, subsampling=2)
+        jpegs.append(buf.getvalue())
+    t0 = time.perf_counter()
+    for j in jpegs:
+        np.asarray(Image.open(io.BytesIO(j)).convert("RGB"))
+    pil_s = time.perf_counter() - t0
+    threads = min(16, usable_cores())
+    dec = native.JpegDecoder(threads=threads)
+    out = dec.decode(jpegs)                       # warm-up: pinned buffers, kernels
+    ok = bool(np.array_equal(out[0].cpu().numpy(), np.asarray(Image.open(io.BytesIO(jpegs[0])).convert("RGB"))))
+    dec.host_decode_s = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec.decode(jpegs)
+    torch.cuda.synchronize()
+    tot = (time.perf_counter() - t0) / reps
+    host = dec.host_decode_s / reps
+    mb = sum(len(j) for j in jpegs) / 1e6
+    return {"source": f"{B} frames {H}x{W} 4:2:0 q{quality} ({mb / B:.2f} MB per frame)", "byte_identical_to_pil": ok,
+            "pil_1_thread_frames_per_s": round(B / pil_s, 1), "native_frames_per_s": round(B / tot, 1), "native_ms_per_batch": round(tot * 1e3, 2),
+            "host_huffman_stage_frames_per_s": round(B / host, 1), "host_threads": threads,
+            "gpu_side_ms_per_batch": round(max(tot - host, 0.0) * 1e3, 2),
+            "note": "host Huffman is the bound (bit-serial per frame, parallel across frames); upload + IDCT + upsampling + colour are the remainder"}
+
+
 def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens=256, gather=None, overlap=False, chunk=16):
     """BASELINE configs[2] shape: perception of every frame + Mistral-7B replies on SCHEDULED fires (the random-weight
     gate's own decisions are not a workload), each reply = prefill of the new context (KV prefix reuse) + exactly
@@ -878,9 +920,11 @@ def main():
             try:       # the same schedule with the replies on the LLM lane, and what the lane buys a live stream
                 e2e["with_llm_lane"] = e2e_leg(model, stream, cfg, frames, B, overlap=True)
                 e2e["live_stream_overlap"] = live_overlap_leg(model, stream, cfg, frames, B)
-                e2e["note"] = ("frames/s of this schedule is decode-bound: 448 frames cost 0.18 s, the two 256-token replies 2 x 0.78 s, and the second "
-                               "reply's context contains the first, so the replies cannot overlap each other -- the lane hides the perception, "
-                               "not the replies (see live_stream_overlap for the resource-sharing gain)")
+                t_frames = e2e["frames"] / max(total_rate_hint, 1e-9) if (total_rate_hint := float(B * cps * a.steps / dt_local)) else 0.0
+                e2e["note"] = (f"frames/s of this schedule is decode-bound: at this run's perception rate the {e2e['frames']} frames cost about {t_frames:.2f} s of the "
+                               f"{e2e['seconds']:.2f} s, the {e2e['fires']} replies of {e2e['reply_tokens']} tokens the rest, and a later reply's context contains the "
+                               "earlier ones, so the replies cannot overlap each other -- the lane hides the perception, not the replies (see live_stream_overlap "
+                               "for the resource-sharing gain)")
             except Exception as e:
                 e2e["with_llm_lane"] = {"error": repr(e)[:300]}
     if not a.no_decode:                      # second half of the metric: decode tokens/s (outside the timed frame steps)
@@ -914,6 +958,10 @@ def main():
     if world == 1 and not a.no_aux:
         try:
             ing_leg = ingest_leg()
+            try:
+                ing_leg["jpeg_frontend"] = jpeg_leg()
+            except Exception as e:
+                ing_leg["jpeg_frontend"] = {"error": repr(e)[:200]}
         except Exception as e:
             ing_leg = {"error": repr(e)[:200]}
         try:
@@ -1080,7 +1128,7 @@ def main():
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
             # being profiled): the newest committed summary is quoted and its source named
             traffic = traffic_src = None
-            for rnd in ("r03", "r02", "r01"):
+            for rnd in ("r04", "r03", "r02", "r01"):
                 tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic.json")
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
@@ -1090,7 +1138,7 @@ def main():
             ktrace = None
             try:
                 import csv as _csv
-                for rnd in ("r03", "r02"):
+                for rnd in ("r04", "r03", "r02"):
                     kf = os.path.join(ROOT, "profiles", f"{rnd}_bench_steps_kernel_stats.csv")
                     if os.path.exists(kf):
                         rows = [r for r in _csv.DictReader(open(kf)) if r["Name"].startswith(("void gemm256_kernel", "void gemm256p_kernel"))]
@@ -1099,7 +1147,8 @@ def main():
                             av = sum(float(r["TotalDurationNs"]) for r in rows) / n_k * 1e-3
                             fl = vit_linear_flops_per_frame(cfg) * LB / 93.0
                             ktrace = {"avg_launch_us": round(av, 2), "launches": n_k, "frac": round(fl / (av * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                                      "source": f"profiles/{rnd}_bench_steps_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --batch 28 --no-pipeline`, a separate run)"}
+                                      "archived": True,
+                                      "source": f"profiles/{rnd}_bench_steps_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --batch 28 --no-pipeline`: an ARCHIVED earlier run on another box, not this run)"}
                         break
             except Exception:
                 ktrace = None
@@ -1109,7 +1158,7 @@ def main():
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 8 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "kernel_trace": ktrace,
+                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "archived_kernel_trace": ktrace,
                     # the TIMED schedule as a whole against the same peak: every FLOP of a frame's tower (tiled GEMMs + attention, SURVEY
                     # 8d's 366 GFLOP) x the frames timed / the timed wall clock -- what `value` is worth in MFMA terms
                     "whole_step_frac": round((vit_linear_flops_per_frame(cfg) + cfg.vit_layers_run * 4.0 * (cfg.n_patches + 1) ** 2 * cfg.vit_hidden)

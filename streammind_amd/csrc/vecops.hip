@@ -431,10 +431,16 @@ __global__ void mamba_conv_kernel(const float* __restrict__ xz, int F, int di, i
 #pragma unroll
             for (int j = 0; j + 1 < dc; ++j) stt[j] = stt[j + 1];          // torch.roll(shifts=-1); state[..., -1] = x
             stt[dc - 1] = xin[u];
+            // the operation sequence is written out (no contraction left to the optimiser): a frame must get the same bits whether it is the
+            // first or the fifth of its call -- the unrolled copies of this body were contracted differently
             float a = 0.f;
+            {
+#pragma clang fp contract(off)
 #pragma unroll
-            for (int j = 0; j < dc; ++j) a += stt[j] * w[j];
-            xc[(size_t)(mb + u) * di + d] = siluf_(a + bias);
+                for (int j = 0; j < dc; ++j) a = __builtin_fmaf(stt[j], w[j], a);
+                a = a + bias;
+            }
+            xc[(size_t)(mb + u) * di + d] = siluf_(a);
         }
     }
 #pragma unroll
@@ -490,13 +496,18 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
             const float dt = dtv[u], xv = xvv[u];
             const float* Bm = xdbl + (size_t)m * ldx + R;
             const float* Cm = Bm + ds;
-            float acc = 0.f;
+            float acc = 0.f, yv;
+            {   // pinned operation sequence (see mamba_conv_kernel): the same bits for a frame wherever it sits in its call
+#pragma clang fp contract(off)
+                const float dtx = dt * xv;
 #pragma unroll
-            for (int n = 0; n < ds; ++n) {
-                h[n] = __expf(dt * A[n]) * h[n] + (dt * xv) * Bm[n];
-                acc += h[n] * Cm[n];
+                for (int n = 0; n < ds; ++n) {
+                    h[n] = __builtin_fmaf(__expf(dt * A[n]), h[n], dtx * Bm[n]);
+                    acc = __builtin_fmaf(h[n], Cm[n], acc);
+                }
+                yv = __builtin_fmaf(Dd, xv, acc);
             }
-            y[(size_t)m * di + d] = (acc + Dd * xv) * siluf_(zv[u]);
+            y[(size_t)m * di + d] = yv * siluf_(zv[u]);
         }
     }
 #pragma unroll

@@ -343,7 +343,7 @@ class PeerWriteExchange:
             raise ValueError(f"{n} rows in one tick, the mailbox was sized for {self.max_rows}")
         if n:
             tokens = tokens.to(device=self.dev, dtype=self.dtype).contiguous()
-        par = self.ticks & 1
+        par = self.lib.sm_comm_tick(self.h) & 1              # the library's own tick counter: `ticks` below is a statistic callers may reset
         from . import _lib
         cur = torch.cuda.current_stream(self.dev)
         _lib.check(self.lib.sm_comm_post(self.h, tokens.data_ptr() if n else None, n, cur.cuda_stream), "sm_comm_post")
