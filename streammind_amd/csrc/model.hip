@@ -1335,9 +1335,12 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     for (int j = 0; j < n_steps; ++j) {
         // emit the pending token of every stream (out_ids[stream][j], rows of inactive streams untouched) and feed it back
         if ((rc = sm_embed_tokens_seg(tok, S, m->R.embed->buf.p, ld, x, rows, j, f16, stream))) return rc;
+        // RMSNorms ride behind the products that finish their rows (sm_linear_t.post_ln_*): with 17..32 active streams o_proj and down_proj
+        // run as K-slice slabs and the slab sum + residual + the NEXT norm are one launch; with fewer the call ends with the norm launch
+        // that used to be issued here.  Only the first layer's input norm is a launch of its own.
+        if (c.llm_layers > 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
         for (int l = 0; l < c.llm_layers; ++l) {
             const sm_model::LayerW& w = m->R.llm[l];
-            if ((rc = sm_norm_ex(x, S, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
             {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
@@ -1347,8 +1350,8 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+                a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            if ((rc = sm_norm_ex(x, S, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
             {   const Slot& gu = *w.gu;
                 sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.N = c.llm_mlp;
@@ -1358,10 +1361,12 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 if ((rc = sm_linear(&a, stream))) return rc; }
             {   sm_linear_t a = lin(m, *w.down, g->d_actb.p, SM_X_BF16, S, c.llm_mlp);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+                a.post_ln_gamma = l + 1 < c.llm_layers ? m->R.llm[l + 1].ln1_w : m->R.llm_norm;       // the next layer's input norm / the final norm
+                a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }
         }
         for (sm_stream* s : act) s->kv_len += 1;
-        if ((rc = sm_norm_ex(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
+        if (c.llm_layers == 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
         {   sm_linear_t a = lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
             a.out_f32 = g->d_log.as<float>(); a.ldo = V;
             if ((rc = sm_linear(&a, stream))) return rc; }
