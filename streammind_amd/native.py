@@ -428,9 +428,12 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            w2_scale: Optional[torch.Tensor] = None, norm_gamma: Optional[torch.Tensor] = None,
            norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
            out: Optional[torch.Tensor] = None, fp8_mfma: bool = False, out16: Optional[torch.Tensor] = None,
-           post_ln: Optional[Tuple[torch.Tensor, torch.Tensor, float, torch.Tensor]] = None) -> torch.Tensor:
+           post_ln: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], float, torch.Tensor]] = None, post_ln_act: int = 0,
+           x_rep: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front.
-    post_ln = (gamma, beta, eps, out16 [M, N]): LayerNorm of the finished fp32 rows into `out16` from the same call (sm_linear_t.post_ln_*).
+    post_ln = (gamma, beta | None, eps, out [M, N]): LayerNorm (beta given) / RMSNorm of the finished fp32 rows into `out` (16-bit or fp32) from
+    the same call (sm_linear_t.post_ln_*), post_ln_act applied to the normalised value; x_rep = (rep, dh): x holds K / rep columns and column
+    group j of width dh is read rep times (the gate's repeat_kv in front of o_proj).
     fp8_mfma (with w_scale): SM_W_FP8_MFMA -- above 16 rows the activations are quantised per row and the product is fp8 x fp8."""
     lib = _lib.load()
     assert x.is_cuda and x.dim() == 2 and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32, torch.float16)
@@ -445,6 +448,9 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
     a.w, a.w2, a.N, a.K = wp.data_ptr(), _p(w2p), N, K
     a.x, a.x_dtype = x.data_ptr(), (_lib.SM_X_F32 if x.dtype == torch.float32 else _lib.SM_X_BF16)
     a.precise, a.M, a.ldx = int(precise), M, x.shape[1]
+    if x_rep is not None:
+        a.x_rep, a.x_rep_dh = int(x_rep[0]), int(x_rep[1])
+        assert x.shape[1] * a.x_rep == K
     a.bias, a.act = _p(bias), act
     if w_scale is not None:
         a.w_dtype, a.w_scale, a.w2_scale = (_lib.SM_W_FP8_MFMA if fp8_mfma else _lib.SM_W_FP8), w_scale.data_ptr(), _p(w2_scale)
@@ -470,8 +476,13 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
         a.out_bf16, a.ldo_bf16 = out.data_ptr(), N
     if post_ln is not None:
         g, b, eps, ln_out = post_ln
-        assert out_dtype == torch.float32 and ln_out.shape == out.shape and ln_out.is_contiguous() and ln_out.dtype == (torch.float16 if a_f16 else torch.bfloat16)
-        a.post_ln_gamma, a.post_ln_beta, a.post_ln_eps, a.post_ln_out, a.post_ln_ldo = g.data_ptr(), b.data_ptr(), float(eps), ln_out.data_ptr(), N
+        assert out_dtype == torch.float32 and ln_out.shape == out.shape and ln_out.is_contiguous()
+        a.post_ln_gamma, a.post_ln_beta, a.post_ln_eps, a.post_ln_ldo, a.post_ln_act = g.data_ptr(), _p(b), float(eps), N, int(post_ln_act)
+        if ln_out.dtype == torch.float32:
+            a.post_ln_out_f32 = ln_out.data_ptr()
+        else:
+            assert ln_out.dtype == (torch.float16 if a_f16 else torch.bfloat16)
+            a.post_ln_out = ln_out.data_ptr()
     check(lib.sm_linear(C.byref(a), _stream()), "sm_linear")
     return out
 

@@ -110,6 +110,45 @@ def test_linear_post_ln(nat, M, N, K, f16):
     assert relerr(ln_out, O.layer_norm(ref, g, b, 1e-5)) < (2e-3 if f16 else 1e-2)
 
 
+@pytest.mark.parametrize("M", [1, 7, 16, 17, 28, 32])
+@pytest.mark.parametrize("kind", ["rms_f32", "ln_leaky_f32", "rms_bf16"])
+def test_skinny_linear_post_norm(nat, M, kind):
+    """the connector / gate pass's norms behind their products (sm_linear_t.post_ln_*, weight-streaming path): RMSNorm or LayerNorm (+ leaky_relu)
+    of the finished row, fp32 or 16-bit out.  17..32 rows: K-slice slabs + ONE slab-sum / residual / norm launch; fewer rows: the product,
+    then the norm launch.  The fp32 row is the product (3e-5 of fp64: hi/lo activations), the normalised row the oracle's norm of it (2e-5;
+    bf16 out: one rounding)."""
+    N, K = 4096, 4096
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    x, res = rnd((M, K), 2), rnd((M, N), 3)
+    g, b = 1 + rnd((N,), 5, 0.1), rnd((N,), 6, 0.1)
+    ln = kind.startswith("ln")
+    out_dt = torch.bfloat16 if kind.endswith("bf16") else torch.float32
+    nout = torch.empty(M, N, device="cuda", dtype=out_dt)
+    gg, bg, resg = g.cuda(), b.cuda(), res.cuda()
+    y = nat.linear(x.cuda(), nat.pack_weight(w.cuda().bfloat16()), N, K, residual=resg, precise=True,
+                   post_ln=(gg, bg if ln else None, 1e-5, nout), post_ln_act=2 if ln else 0)
+    ref = (x.double() @ w.double().t() + res.double()).float()
+    assert relerr(y, ref) < 3e-5
+    want = O.leaky_relu(O.layer_norm(y.cpu(), g, b, 1e-5)) if ln else O.rms_norm(y.cpu(), g, 1e-5)
+    assert relerr(nout, want) < (8e-3 if out_dt == torch.bfloat16 else 2e-5)
+
+
+@pytest.mark.parametrize("M", [1, 16, 28])
+def test_skinny_linear_repeated_column_groups(nat, M):
+    """sm_linear_t.x_rep: the event gate's repeat_kv folded into o_proj's operand addressing (builder.py:553-562 at seq-len 1: o_proj reads
+    every kv head H / KV times).  Bit for bit the product on the materialised repeat."""
+    KV, rep, dh, N = 8, 4, 128, 4096
+    K = KV * rep * dh
+    w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
+    v = rnd((M, KV * dh), 2)
+    vrep = v.reshape(M, KV, 1, dh).expand(M, KV, rep, dh).reshape(M, K).contiguous()
+    wp = nat.pack_weight(w.cuda().bfloat16())
+    a = nat.linear(v.cuda(), wp, N, K, precise=True, x_rep=(rep, dh))
+    bq = nat.linear(vrep.cuda(), wp, N, K, precise=True)
+    assert torch.equal(a, bq)
+    assert relerr(a, (vrep.double() @ w.double().t()).float()) < 3e-5
+
+
 def test_pack_layout(nat):
     """the packed image is the documented permutation of W (integer-exact)."""
     N, K = 40, 70

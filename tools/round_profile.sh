@@ -5,7 +5,7 @@ set -u
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/round; mkdir -p $O
-timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log > $O/bench_default.json; cut -c1-400 $O/bench_default.json
 # kernel stats of the BENCH STEPS ONLY (no decode / end-to-end / auxiliary legs, no HIP-event bracketing).  Two runs:
 #  (a) the default schedule (56 frames per step, two tower lanes + pipelined gate pass): two kernels share the chip, so a kernel's
@@ -31,4 +31,12 @@ python tools/pmc_traffic_summary.py /tmp/pmc_f /tmp/pmc_w $O/gemm_traffic.json
 rm -rf /tmp/pmc_m
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d /tmp/pmc_m -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
 python tools/pmc_mfma_summary.py /tmp/pmc_m $O/mfma_util.json
+# round 4: the one-frame tick (kernel stats + one tick's launch timeline), the connector + gate pass alone, tick latencies
+for F in 1 4 8; do timeout 300 python tools/tick_bench.py $F 200 2>&1 | tail -1; done > $O/tick_latency.txt; cat $O/tick_latency.txt
+for R in 1 28; do timeout 300 python tools/pass_bench.py $R 200 2>&1 | tail -1; done > $O/pass_bench.txt; cat $O/pass_bench.txt
+rm -rf /tmp/prof_t1; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t1 -- python tools/tick_bench.py 1 200 > $O/tick_b1_profiled.log 2>&1
+cp "$(find /tmp/prof_t1 -name '*kernel_stats.csv' | head -1)" $O/tick_b1_kernel_stats.csv
+python tools/trace_window.py /tmp/prof_t1 preprocess_kernel > $O/tick_b1_timeline.txt 2>&1
+rm -rf /tmp/prof_p28; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_p28 -- python tools/pass_bench.py 28 40 > $O/pass28_profiled.log 2>&1
+python tools/trace_window.py /tmp/prof_p28 gate_tail_kernel > $O/pass28_timeline.txt 2>&1
 head -8 $O/kernel_stats_steps_default.csv | cut -c1-160; head -12 $O/kernel_stats_steps.csv | cut -c1-160; head -8 $O/kernel_stats_decode.csv | cut -c1-160
