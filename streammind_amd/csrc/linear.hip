@@ -1571,6 +1571,19 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             if (fw == 8 && a.KS >= 8 && p->M <= 16) return launch_skinny<8>(a, xf32, split, dual, st);
             if (fw == 16 && a.KS >= 16 && !dual && p->M <= 16) return launch_skinny<16>(a, xf32, split, dual, st);
         }
+        // 17..32 rows, SMALL weights (the gate's V, the connector's x_proj / dt_proj: 1-8 MB): the K-slice kernel + its slab-sum launch are two
+        // launches of ~5 us for ~1 us of traffic; the two-column-block kernel does it in one (activations re-read per block from L2).
+        // MEASURED AND LEFT OFF (SM_SKINNY_DIRECT_MB=n enables it for weights up to n MB): the 28-row connector + gate pass 588 -> 636 us with
+        // n = 12 or 40 -- one block per 16 output rows walking all of K is a longer latency chain than the launch it saves.
+        {
+            static int direct_mb = -1;
+            if (direct_mb < 0) { const char* e = getenv("SM_SKINNY_DIRECT_MB"); direct_mb = e ? atoi(e) : 0; }
+            if (direct_mb > 0 && p->M > 16 && !p->post_ln_gamma && !w8k && (size_t)p->N * p->K * 2 <= (size_t)direct_mb * 1048576 && p->remap_in == 0 && !p->vt) {
+                if (a.KS >= 32) return launch_skinny<8, 2>(a, xf32, split, dual, st);
+                if (a.KS >= 8) return launch_skinny<4, 2>(a, xf32, split, dual, st);
+                return launch_skinny<1, 2>(a, xf32, split, dual, st);
+            }
+        }
         static int lds_min_m = -1;                    // SM_SKINNY_LDS_MINM: smallest M sent to the LDS-shared kernel (tuning)
         if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 17; }
         {
