@@ -1122,7 +1122,11 @@ def main():
         cnt.value, ms.value = gemm_prof
         if cnt.value:
             PB = B * cps if prof_in_timed else LB      # frames per profiled step
-            flops_per_launch = vit_linear_flops_per_frame(cfg) * PB * prof_steps / cnt.value
+            # FLOPs the COUNTED launches execute: with the streaming path's patch-mean algebra (SM_VIT_FC2_MEAN, default on: the last layer's fc2 is
+            # a patch mean + a weight-streaming product, no tiled GEMM) that GEMM is neither launched nor counted, so its FLOPs leave the numerator
+            fc2_mean_on = os.environ.get("SM_VIT_FC2_MEAN", "1") != "0" and PB <= 32 * (2 if lanes == 2 and prof_in_timed else 1)
+            gemm_flops_frame = vit_linear_flops_per_frame(cfg) - (2.0 * (cfg.n_patches + 1) * cfg.vit_mlp * cfg.vit_hidden if fc2_mean_on else 0.0)
+            flops_per_launch = gemm_flops_frame * PB * prof_steps / cnt.value
             avg_s = ms.value * 1e-3 / cnt.value
             ach = flops_per_launch / avg_s / 1e12
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
@@ -1159,6 +1163,7 @@ def main():
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
                     "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "archived_kernel_trace": ktrace,
+                    "whole_step_note": "whole_step_frac prices the reference's 366 GFLOP per frame; 4.8 GFLOP of them (the last layer's fc2) are replaced by a patch mean + a 28-row product",
                     # the TIMED schedule as a whole against the same peak: every FLOP of a frame's tower (tiled GEMMs + attention, SURVEY
                     # 8d's 366 GFLOP) x the frames timed / the timed wall clock -- what `value` is worth in MFMA terms
                     "whole_step_frac": round((vit_linear_flops_per_frame(cfg) + cfg.vit_layers_run * 4.0 * (cfg.n_patches + 1) ** 2 * cfg.vit_hidden)

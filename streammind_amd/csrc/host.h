@@ -39,6 +39,7 @@ int sm_mamba_ssm_step_seg(const float* xc, const float* delta, const float* x_db
                           void* stream);
 int sm_scatter_rows(const float* src, int S, int F, int d, const SmSegStates& dst, void* stream);
 int sm_gate_tail(const float* x, int M, int D, int ldx, const float* gamma, float eps, const float* head_w_f32, float* logits, int32_t* decisions, void* stream);   // vecops.hip
+int sm_pool_patches16(const void* h, int B, int S, int D, float* out, int f16, void* stream);          // vecops.hip: patch mean of a 16-bit matrix
 int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* stream);
 
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value

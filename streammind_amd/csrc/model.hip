@@ -128,7 +128,7 @@ struct sm_model {
     // ViT workspaces, one set per HIP stream the tower is driven on (two streams of one model may then run the tower
     // concurrently on different HIP streams: their kernels fill each other's launch gaps and tails, +7 % aggregate frames/s
     // measured with two 28-frame streams); allocated on the first call of a stream, never afterwards
-    struct VitWs { DevBuf patches, x, xn, qkv, ctx, hmid; };
+    struct VitWs { DevBuf patches, x, xn, qkv, ctx, hmid, hbar; };
     std::map<void*, std::unique_ptr<VitWs>> vit_ws;
     std::mutex ws_mu;
     int S = 0, P = 0, Spad = 0, Kpe = 0, Bmax = 0;
@@ -146,6 +146,7 @@ struct sm_model {
             if ((rc = w->qkv.alloc(rows * 3 * D * 2))) return rc;
             if ((rc = w->ctx.alloc(rows * D * 2))) return rc;
             if ((rc = w->hmid.alloc(rows * c.vit_mlp * 2))) return rc;
+            if ((rc = w->hbar.alloc((size_t)Bmax * c.vit_mlp * 4))) return rc;
             e = std::move(w);
         }
         *out = e.get();
@@ -655,6 +656,7 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
     const int D = c.vit_hidden, H = c.vit_heads, dh = D / H, S = m->S, P = m->P;
     int rc;
     const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
+    static const bool fc2_mean = [] { const char* e = getenv("SM_VIT_FC2_MEAN"); return !e || atoi(e) != 0; }();
 #define LANES for (int li = 0; li < nl; ++li)
 #define LV const VitLaneArgs& L = lanes[li]; const size_t r0 = (size_t)L.f0 * S; float* x = L.ws->x.as<float>() + r0 * D; bf16_t* xn = L.ws->xn.as<bf16_t>() + r0 * D; \
     char* w_patches = (char*)L.ws->patches.p + (size_t)L.f0 * P * m->Kpe * 2; char* w_qkv = (char*)L.ws->qkv.p + r0 * 3 * D * 2; char* w_ctx = (char*)L.ws->ctx.p + r0 * D * 2; \
@@ -701,6 +703,19 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             if ((rc = sm_linear(&a, stream))) return rc;
         }
         LANES { LV;
+            // LAST layer, pooled feature only (the streaming path): pooled = mean_p(x_p + fc2(h_p) + b) = mean_p x_p + fc2(mean_p h_p) + b -- the
+            // 135 GFLOP GEMM of a 28-frame lane becomes a patch mean over h (one pass over 132 MB) and a 28-row weight-streaming product
+            // (exact algebra, fp32 means).  Not when the per-patch features are asked for.  SM_VIT_FC2_MEAN=0: the GEMM (A/B).
+            if (!wnext && fc2_mean && !L.feats && L.B <= 32) {
+                float* hbar = L.ws->hbar.as<float>() + (size_t)L.f0 * c.vit_mlp;
+                if ((rc = sm_pool_patches16(w_hmid, L.B, S, c.vit_mlp, hbar, c.vit_fp16 ? 1 : 0, stream))) return rc;
+                if ((rc = sm_pool_patches(x, L.B, S, D, L.pooled, nullptr, stream))) return rc;
+                sm_linear_t a = lin(m, *w.fc2, hbar, SM_X_F32, L.B, c.vit_mlp);
+                a.precise = 1; a.bias = w.fc2_b;
+                a.residual = L.pooled; a.ldr = D; a.out_f32 = L.pooled; a.ldo = D;
+                if ((rc = sm_linear(&a, stream))) return rc;
+                continue;
+            }
             sm_linear_t a = lin(m, *w.fc2, w_hmid, SM_X_BF16, M, c.vit_mlp);
             a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
@@ -709,6 +724,7 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
         }
     }
     LANES { LV;
+        if (c.vit_layers_run > 0 && fc2_mean && !L.feats && L.B <= 32) continue;         // pooled already written by the last layer (above)
         if ((rc = sm_pool_patches(x, L.B, S, D, L.pooled, L.feats, stream))) return rc;
     }
 #undef LANES

@@ -403,6 +403,43 @@ extern "C" int sm_pool_patches(const float* x, int B, int S, int D, float* poole
     return SM_OK;
 }
 
+// the same mean over the patch rows (CLS dropped) of a 16-bit matrix [B * S][D] -> fp32 [B][D]: the operand of the LAST tower layer's fc2
+// when only the pooled feature is wanted -- mean_p(fc2(h_p)) = fc2(mean_p h_p), SURVEY 7 step 3.  Block = (frame, 128-column slab), a
+// lane owns two columns (one 32-bit load per row), 16 waves split the rows, 8 rows in flight per wave.
+__global__ __launch_bounds__(1024) void pool16_kernel(const bf16_t* __restrict__ h, int S, int D, float* __restrict__ out, int f16) {
+    __shared__ float red[16][128];
+    const int b = blockIdx.y, l = threadIdx.x & 63, c = blockIdx.x * 128 + l * 2, w = threadIdx.x >> 6;
+    const int P = S - 1;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < D) {
+        const bf16_t* hb = h + ((size_t)b * S + 1) * D + c;
+        for (int r0 = w; r0 < P; r0 += 128) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = r0 + u * 16 < P ? *(const uint32_t*)(hb + (size_t)(r0 + u * 16) * D) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (f16) { s0 += (float)__builtin_bit_cast(_Float16, (uint16_t)(v[u] & 0xffffu)); s1 += (float)__builtin_bit_cast(_Float16, (uint16_t)(v[u] >> 16)); }
+                else { s0 += __uint_as_float(v[u] << 16); s1 += __uint_as_float(v[u] & 0xffff0000u); }
+            }
+        }
+    }
+    red[w][2 * l] = s0; red[w][2 * l + 1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][threadIdx.x];
+        out[(size_t)b * D + blockIdx.x * 128 + threadIdx.x] = t / (float)P;
+    }
+}
+int sm_pool_patches16(const void* h, int B, int S, int D, float* out, int f16, void* stream) {
+    SM_REQUIRE(h && out && B > 0 && S > 1 && (D & 1) == 0, "sm_pool_patches16: bad args");
+    pool16_kernel<<<dim3(cdiv(D, 128), B), 1024, 0, (hipStream_t)stream>>>((const bf16_t*)h, S, D, out, f16);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ mamba step
 // rows are S segments (streams) of F consecutive frames each: blockIdx.y = segment, its recurrent state st.p[segment]
 // DC > 0: d_conv is a compile-time constant (the window and the taps live in registers); DC = 0: run-time width (<= 8) -- with run-time

@@ -318,3 +318,24 @@ def stream_frames(video_path, cur_fps: float) -> Iterator[Tuple[int, np.ndarray]
     ids, vr = read_video_stream(video_path, cur_fps)
     for fid in ids:
         yield int(fid), np.asarray(vr[int(fid)].asnumpy())
+
+
+def stream_frames_gpu(video_path, cur_fps: float, batch: int = 28, image_size: int = 336, pad_square: bool = False, decoder=None):
+    """The same stream as `stream_frames`, `batch` sampled frames at a time, ALREADY IN HBM and already at the tower's input size:
+    (frame ids, u8 cuda tensor [n, image_size, image_size, 3]).  For a Motion-JPEG source nothing is decoded by PIL and no RGB frame
+    crosses PCIe: host Huffman threads -> coefficient upload -> GPU inverse DCT / upsampling / colour (`get_batch_gpu`, byte for byte
+    PIL's frames) -> PIL-exact resize / crop (`sm_ingest_frames`); any other source is decoded by its reader and uploaded.  The tensors
+    feed `NativeStream.push_frames` / `StreamingSession` directly."""
+    import torch
+    from . import native
+    ids, vr = read_video_stream(video_path, cur_fps)
+    for k in range(0, len(ids), batch):
+        chunk = [int(i) for i in ids[k:k + batch]]
+        if hasattr(vr, "get_batch_gpu"):
+            fr = vr.get_batch_gpu(chunk, decoder=decoder)
+        else:
+            fr = torch.from_numpy(np.ascontiguousarray(vr.get_batch(chunk).asnumpy())).cuda()
+        if tuple(fr.shape[1:3]) != (image_size, image_size):
+            fr = native.ingest_frames(fr.contiguous(), pad_square, image_size)
+        yield chunk, fr
+

@@ -58,3 +58,22 @@ def test_mjpeg_avi_straight_into_hbm(dec, tmp_path):
     sq = native.ingest_frames(gpu, pad_square=False)
     ref = native.ingest_frames(torch.from_numpy(vr.get_batch(ids).asnumpy()).cuda(), pad_square=False)
     assert torch.equal(sq, ref)
+
+
+def test_stream_frames_gpu_equals_the_host_stream(dec, tmp_path):
+    """video_io.stream_frames_gpu (MJPEG -> HBM -> tower-sized frames, batches) == stream_frames (PIL on the host) + the same ingest"""
+    from tests.test_host_cpu import _write_mjpeg_avi
+    from streammind_amd import video_io, native
+    w, h, n = 352, 288, 31
+    jpegs = [U.encode(U.test_image(w, h, 70 + i), quality=75, subsampling=2) for i in range(n)]
+    _write_mjpeg_avi(tmp_path / "cam.avi", jpegs, w, h, 30, 1)
+    host = list(video_io.stream_frames(str(tmp_path / "cam.avi"), 10))                    # every 3rd frame
+    got_ids, got = [], []
+    for ids, fr in video_io.stream_frames_gpu(str(tmp_path / "cam.avi"), 10, batch=4, decoder=dec):
+        assert fr.is_cuda and fr.dtype == torch.uint8 and tuple(fr.shape[1:]) == (336, 336, 3)
+        got_ids += ids
+        got.append(fr)
+    assert got_ids == [i for i, _ in host]
+    want = native.ingest_frames(torch.from_numpy(np.stack([f for _, f in host])).cuda(), False, 336)
+    assert torch.equal(torch.cat(got), want)
+

@@ -48,7 +48,9 @@ def test_vit_tiny_vs_oracle(tiny):
     one = torch.cat([m.vit_encode(frames[i:i + 1].cuda()) for i in range(5)])
     assert maxdiff(one, pooled) < 1e-3
     three = m.vit_encode(frames[:3].cuda().contiguous())          # 51 token rows / 48 patch rows: tiled GEMM like the batch of 5
-    assert torch.equal(three.cpu(), pooled.cpu()[:3])
+    five = m.vit_encode(frames.cuda())                            # pooled only, like `three`: the last layer's fc2 goes through the patch mean
+    assert torch.equal(three.cpu(), five.cpu()[:3])               # (mean_p fc2(h_p) = fc2(mean_p h_p)); with per-patch features asked for it is the GEMM
+    assert maxdiff(five, pooled) < 1e-4
 
 
 def test_vit_fullwidth_golden(gold):
