@@ -657,6 +657,9 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
     int rc;
     const int od = c.vit_fp16 ? SM_OP_F16 : SM_OP_BF16;      // 16-bit type of every ViT GEMM operand (weights are packed to match)
     static const bool fc2_mean = [] { const char* e = getenv("SM_VIT_FC2_MEAN"); return !e || atoi(e) != 0; }();
+    // tile experiments for the two fp32 + residual shapes (SM_TILE_* values; 0 = sm_linear's own choice)
+    static const int out_tile = [] { const char* e = getenv("SM_VIT_OUT_TILE"); return e ? atoi(e) : 0; }();
+    static const int fc2_tile = [] { const char* e = getenv("SM_VIT_FC2_TILE"); return e ? atoi(e) : 0; }();
 #define LANES for (int li = 0; li < nl; ++li)
 #define LV const VitLaneArgs& L = lanes[li]; const size_t r0 = (size_t)L.f0 * S; float* x = L.ws->x.as<float>() + r0 * D; bf16_t* xn = L.ws->xn.as<bf16_t>() + r0 * D; \
     char* w_patches = (char*)L.ws->patches.p + (size_t)L.f0 * P * m->Kpe * 2; char* w_qkv = (char*)L.ws->qkv.p + r0 * 3 * D * 2; char* w_ctx = (char*)L.ws->ctx.p + r0 * D * 2; \
@@ -693,6 +696,7 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             sm_linear_t a = lin(m, *w.out, w_ctx, SM_X_BF16, M, D);
             a.bias = w.out_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            a.tile_hint = out_tile;
             a.post_ln_gamma = w.ln2_w; a.post_ln_beta = w.ln2_b; a.post_ln_eps = c.vit_eps; a.post_ln_out = xn; a.post_ln_ldo = D;
             if ((rc = sm_linear(&a, stream))) return rc;
         }
@@ -719,6 +723,7 @@ static int vit_body_lanes(sm_model* m, const VitLaneArgs* lanes, int nl) {
             sm_linear_t a = lin(m, *w.fc2, w_hmid, SM_X_BF16, M, c.vit_mlp);
             a.bias = w.fc2_b;
             a.residual = x; a.ldr = D; a.out_f32 = x; a.ldo = D;
+            a.tile_hint = fc2_tile;
             if (wnext) { a.post_ln_gamma = wnext->ln1_w; a.post_ln_beta = wnext->ln1_b; a.post_ln_eps = c.vit_eps; a.post_ln_out = xn; a.post_ln_ldo = D; }
             if ((rc = sm_linear(&a, stream))) return rc;
         }
