@@ -1662,11 +1662,13 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // a post-LN call pays for a second pass anyway (the LayerNorm of the finished rows): as slabs + the fused slab-sum / LayerNorm pass
     // the product costs one launch less than GEMM + LayerNorm, so slabs pay even for short K loops (out-proj, K = 1024: 4 k-tiles each)
     static int ln_fuse = -1, ln_smax = 6;
-    if (ln_fuse < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse = e ? atoi(e) : 1; const char* m = getenv("SM_POST_LN_SMAX"); if (m) ln_smax = atoi(m); }
-    const bool ln_ok = ln_fuse && p->post_ln_gamma && p->post_ln_beta && p->post_ln_out && !p->post_ln_out_f32 && p->post_ln_act == SM_ACT_NONE && p->N == 1024 && tiles <= 128 && p->act == SM_ACT_NONE && !w8 && (p->ldo & 3) == 0 &&
+    static int ln_maxtiles = 128;
+    if (ln_fuse < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse = e ? atoi(e) : 1; const char* m = getenv("SM_POST_LN_SMAX"); if (m) ln_smax = atoi(m);
+                       const char* t = getenv("SM_POST_LN_MAXTILES"); if (t) ln_maxtiles = atoi(t); }
+    const bool ln_ok = ln_fuse && p->post_ln_gamma && p->post_ln_beta && p->post_ln_out && !p->post_ln_out_f32 && p->post_ln_act == SM_ACT_NONE && p->N == 1024 && tiles <= ln_maxtiles && p->act == SM_ACT_NONE && !w8 && (p->ldo & 3) == 0 &&
                        (!p->residual || (p->ldr & 3) == 0) && p->M <= 4096 && ln_smax >= 2;
     if (ln_ok) {
-        S = 256 / tiles;
+        S = tiles <= 128 ? 256 / tiles : 2;
         if (S > ln_smax) S = ln_smax;
         if (S > 8) S = 8;
         while (S > 2 && KTall / S < 4) --S;
