@@ -159,7 +159,7 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
                          "bytes_per_token": weight_bytes + kv_bytes}}
 
 
-def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32), n_ctx=328, n_new=48):
+def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32, 64, 128), n_ctx=328, n_new=48):
     """Batched greedy decode across streams (sm_group_llm_decode): S streams, each with its OWN KV cache and a 328-token context,
     advance together -- one pass over the 14.2 GB of Mistral-7B weights per step for all of them.  Aggregate tokens/s; HBM
     roofline per step = weights once + every stream's KV."""

@@ -31,6 +31,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Per-segment (= per-stream) base pointers handed to kernels BY VALUE: a connector pass covers at most SM_MAX_SEG streams
 // (one weight pass = at most 32 rows), so no device-side pointer table has to be built or uploaded per call.
 #define SM_MAX_SEG 32
+#define SM_GROUP_DECODE_MAX 128     // active streams of one batched decode step (beyond SM_MAX_SEG: tiled GEMMs + chunked per-stream kernels)
 struct SmSegStates { float* p[SM_MAX_SEG]; };
 int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,
                            const float* conv_b, float* xc, void* stream);                                    // vecops.hip

@@ -1101,7 +1101,7 @@ struct sm_stream_group {
     std::vector<sm_stream*> streams;
     ConnScratch w;
     // batched decode scratch (rows = streams), allocated by the first sm_group_llm_decode
-    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
+    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws, d_guf;
     bool d_ready = false;
 };
 
@@ -1331,7 +1331,10 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         if (!active_host || active_host[i]) { act.push_back(g->streams[i]); idx.push_back((int)i); }
     const int S = (int)act.size();
     SM_REQUIRE(S >= 1, "sm_group_llm_decode: no active stream");
-    SM_REQUIRE(S <= (c.weights_fp8 ? 16 : SM_MAX_SEG), "sm_group_llm_decode: %d active streams exceed one weight pass", S);
+    // up to SM_MAX_SEG streams: weight-streaming kernels (one row per stream); beyond that, up to SM_GROUP_DECODE_MAX: the same step with the
+    // linears on the tiled MFMA GEMM (M = streams) -- still ONE pass over the weights per step -- and the per-stream kernels (token gather,
+    // RoPE + KV append, attention, arg-max: per-stream pointers travel by value, SM_MAX_SEG at a time) in chunks
+    SM_REQUIRE(S <= (c.weights_fp8 ? 16 : SM_GROUP_DECODE_MAX), "sm_group_llm_decode: %d active streams exceed one weight pass (%d)", S, c.weights_fp8 ? 16 : SM_GROUP_DECODE_MAX);
     const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh, V = c.llm_vocab;
     int S_max = act[0]->max_seq;
     for (sm_stream* s : act) {
@@ -1341,23 +1344,29 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     }
     int rc = 0;
     if (!g->d_ready) {
-        const size_t R = SM_MAX_SEG;
+        const size_t R = SM_GROUP_DECODE_MAX;
 #define A(buf, bytes) if (!rc) rc = g->buf.alloc(bytes)
         A(d_emb, R * ld * 4); A(d_xnb, R * ld * 2); A(d_qkvf, R * (qn + 2 * kn) * 4); A(d_qb, R * qn * 2); A(d_ctxb, R * qn * 2);
-        A(d_actb, R * c.llm_mlp * 2); A(d_log, R * V * 4); A(d_ws, R * SM_DECODE_SPLITS * H * (dh + 2) * 4);
+        A(d_actb, R * c.llm_mlp * 2); A(d_log, R * V * 4); A(d_ws, (size_t)SM_MAX_SEG * SM_DECODE_SPLITS * H * (dh + 2) * 4);
+        A(d_guf, R * 2 * c.llm_mlp * 4);
 #undef A
         if (rc) return rc;
         g->d_ready = true;
     }
     float* x = g->d_emb.as<float>();
     const int f16 = c.llm_fp16 ? 1 : 0, od = f16 ? SM_OP_F16 : SM_OP_BF16;
-    SmTokPtrs tok, rows;
-    for (int t = 0; t < S; ++t) { tok.p[t] = act[t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[t] * n_steps; }
+    const int NC = cdiv(S, SM_MAX_SEG);                       // chunks of the per-stream kernels
+    auto c0 = [&](int ch) { return ch * SM_MAX_SEG; };
+    auto cn = [&](int ch) { return S - c0(ch) < SM_MAX_SEG ? S - c0(ch) : SM_MAX_SEG; };
     for (int j = 0; j < n_steps; ++j) {
         // emit the pending token of every stream (out_ids[stream][j], rows of inactive streams untouched) and feed it back
-        if ((rc = sm_embed_tokens_seg(tok, S, m->R.embed->buf.p, ld, x, rows, j, f16, stream))) return rc;
+        for (int ch = 0; ch < NC; ++ch) {
+            SmTokPtrs tok, rows;
+            for (int t = 0; t < cn(ch); ++t) { tok.p[t] = act[c0(ch) + t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[c0(ch) + t] * n_steps; }
+            if ((rc = sm_embed_tokens_seg(tok, cn(ch), m->R.embed->buf.p, ld, x + (size_t)c0(ch) * ld, rows, j, f16, stream))) return rc;
+        }
         // RMSNorms ride behind the products that finish their rows (sm_linear_t.post_ln_*): with 17..32 active streams o_proj and down_proj
-        // run as K-slice slabs and the slab sum + residual + the NEXT norm are one launch; with fewer the call ends with the norm launch
+        // run as K-slice slabs and the slab sum + residual + the NEXT norm are one launch; otherwise the call ends with the norm launch
         // that used to be issued here.  Only the first layer's input norm is a launch of its own.
         if (c.llm_layers > 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
         for (int l = 0; l < c.llm_layers; ++l) {
@@ -1365,21 +1374,31 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            SmDecodeSeg seg;
-            for (int t = 0; t < S; ++t) { seg.kc[t] = act[t]->kc[l].p; seg.vtc[t] = act[t]->vtc[l].p; seg.pos[t] = act[t]->kv_len; }
-            if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, seg, S_max, f16, stream))) return rc;
-            if ((rc = sm_llm_decode_attention_seg(g->d_qb.p, seg, S, H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, g->d_ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
+            for (int ch = 0; ch < NC; ++ch) {
+                SmDecodeSeg seg;
+                for (int t = 0; t < cn(ch); ++t) { sm_stream* st = act[c0(ch) + t]; seg.kc[t] = st->kc[l].p; seg.vtc[t] = st->vtc[l].p; seg.pos[t] = st->kv_len; }
+                char* qb = (char*)g->d_qb.p + (size_t)c0(ch) * qn * 2;
+                if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>() + (size_t)c0(ch) * (qn + 2 * kn), cn(ch), H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), qb, seg, S_max, f16, stream))) return rc;
+                if ((rc = sm_llm_decode_attention_seg(qb, seg, cn(ch), H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, (char*)g->d_ctxb.p + (size_t)c0(ch) * qn * 2, f16, stream, c.llm_sliding_window))) return rc;
+            }
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            {   const Slot& gu = *w.gu;
+            if (S <= SM_MAX_SEG) {
+                const Slot& gu = *w.gu;
                 sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.N = c.llm_mlp;
                 if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
                 else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
                 a.out_bf16 = g->d_actb.p; a.ldo_bf16 = c.llm_mlp;
-                if ((rc = sm_linear(&a, stream))) return rc; }
+                if ((rc = sm_linear(&a, stream))) return rc;
+            } else {              // more rows than the dual weight-streaming kernel takes: gate | up as one tiled product, then SwiGLU (as a prefill chunk does)
+                sm_linear_t a = lin(m, *w.gu, g->d_xnb.p, SM_X_BF16, S, ld);
+                a.out_f32 = g->d_guf.as<float>(); a.ldo = 2 * c.llm_mlp;
+                if ((rc = sm_linear(&a, stream))) return rc;
+                if ((rc = sm_swiglu_ex(g->d_guf.as<float>(), S, c.llm_mlp, g->d_actb.p, f16, stream))) return rc;
+            }
             {   sm_linear_t a = lin(m, *w.down, g->d_actb.p, SM_X_BF16, S, c.llm_mlp);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 a.post_ln_gamma = l + 1 < c.llm_layers ? m->R.llm[l + 1].ln1_w : m->R.llm_norm;       // the next layer's input norm / the final norm
@@ -1391,7 +1410,11 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         {   sm_linear_t a = lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
             a.out_f32 = g->d_log.as<float>(); a.ldo = V;
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if ((rc = sm_argmax_rows_seg(g->d_log.as<float>(), S, V, V, tok, stream))) return rc;
+        for (int ch = 0; ch < NC; ++ch) {
+            SmTokPtrs tok;
+            for (int t = 0; t < cn(ch); ++t) tok.p[t] = act[c0(ch) + t]->next_tok.as<int32_t>();
+            if ((rc = sm_argmax_rows_seg(g->d_log.as<float>() + (size_t)c0(ch) * V, cn(ch), V, V, tok, stream))) return rc;
+        }
     }
     // each stream's own "last logits" as sm_llm_decode would have left them
     for (int t = 0; t < S; ++t)
