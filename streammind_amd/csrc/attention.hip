@@ -749,16 +749,18 @@ extern "C" int sm_llm_attention_window(const void* q, const void* kcache, const 
 // round trip per round.  The 8 per-wave partial softmaxes meet in LDS (fp32, 16 KiB) and 512 threads write the merged bf16
 // context.  Same arithmetic as attn_kernel + attn_combine_kernel (scores in the scaled log2 domain, P rounded to bf16 before
 // both the PV product and the row sum); used while the context is short enough for one CU per KV group (the launcher decides).
-struct DecAttnP {
+template <class SEG>
+struct DecAttnPT {
     const bf16_t* q; bf16_t* ctx;      // [S][H*128]
     const bf16_t* k; const bf16_t* vt; // single stream (nseg == 0)
     int nk, H, KV, S_max, nseg;
     int window;                        // 0 = all keys; else the newest `window` keys (the query is the newest position)
     float c;
-    SmDecodeSeg seg;
+    SEG seg;
 };
-template <bool F16>
-__global__ __launch_bounds__(512) void decode_attn_kernel(DecAttnP p) {
+typedef DecAttnPT<SmDecodeSeg> DecAttnP;
+template <bool F16, class P = DecAttnP>
+__global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
     constexpr int DH = 128;
     __shared__ float osh[8][16][DH + 4];
     __shared__ float msh[8][16], lsh[8][16];
@@ -956,6 +958,28 @@ extern "C" int sm_llm_decode_attention(const void* q, const void* kcache, const 
 extern "C" int sm_llm_decode_attention_window(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh,
                                               int S_max, int window, float* workspace, int splits_max, void* ctx, void* stream) {
     return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream, window);
+}
+
+// up to SM_GROUP_DECODE_MAX streams in ONE launch of the one-launch kernel (per-stream pointers: 2.5 KB of kernel arguments).  Returns 1 (not
+// an error) when the longest context is beyond what that kernel is used for: the caller then goes through sm_llm_decode_attention_seg in
+// chunks of SM_MAX_SEG.
+int sm_llm_decode_attention_seg_big(const void* q, const SmDecodeSegBig& seg, int S, int H, int KV, int dh, int S_max, void* ctx, int f16, void* stream, int window) {
+    SM_REQUIRE(q && ctx && S > 0 && S <= SM_GROUP_DECODE_MAX && S_max % 64 == 0 && H % KV == 0 && H / KV <= 16, "sm_llm_decode_attention_seg_big: bad args");
+    int nk = 1;
+    for (int t = 0; t < S; ++t) {
+        SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg_big: stream %d: bad position / cache", t);
+        nk = seg.pos[t] + 1 > nk ? seg.pos[t] + 1 : nk;
+    }
+    const int nk_eff = window > 0 && nk > window + 63 ? window + 63 : nk;
+    if (!decode_attn_fused_ok(nk_eff, dh, S, KV)) return 1;
+    DecAttnPT<SmDecodeSegBig> d;
+    d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
+    d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
+    if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegBig>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+    else decode_attn_kernel<false, DecAttnPT<SmDecodeSegBig>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
 }
 
 // single-token decode attention of S streams in ONE launch pair: stream t's query row block q[t] (H heads) against ITS cache

@@ -44,7 +44,9 @@ int sm_pool_patches16(const void* h, int B, int S, int D, float* out, int f16, v
 int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* stream);
 
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
-struct SmDecodeSeg { void* kc[SM_MAX_SEG]; void* vtc[SM_MAX_SEG]; int pos[SM_MAX_SEG]; };
+template <int N> struct SmDecodeSegT { void* kc[N]; void* vtc[N]; int pos[N]; };
+typedef SmDecodeSegT<SM_MAX_SEG> SmDecodeSeg;
+typedef SmDecodeSegT<SM_GROUP_DECODE_MAX> SmDecodeSegBig;      // every stream of a large batched decode step in ONE launch (2.5 KB of kernel arguments)
 struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
 // epilogue of the decode-step q/k/v product with RoPE + KV append fused in (linear.hip sm_linear_qkv_rope): row i of the
 // activations is stream i's token at seg.pos[i]; q goes out rotated as bf16 [M][H*dh], k rotated into seg.kc[i], v transposed
@@ -62,6 +64,12 @@ int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream
 // window: Mistral's sliding_window (a query at position p sees keys (p - window, p]); 0 = full causal
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
                                 int splits_max, void* ctx_bf16, int f16, void* stream, int window = 0);           // attention.hip
+// the one-launch decode attention / RoPE + KV append for up to SM_GROUP_DECODE_MAX streams; the attention returns SM_EINVAL-free `1` when the
+// contexts are too long for the one-launch kernel (the caller then falls back to chunks of SM_MAX_SEG through the calls above)
+int sm_llm_decode_attention_seg_big(const void* q_bf16, const SmDecodeSegBig& seg, int S, int H, int KV, int dh, int S_max, void* ctx_bf16, int f16,
+                                    void* stream, int window = 0);
+int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
+                              const SmDecodeSegBig& seg, int S_max, int f16, void* stream);                       // vecops.hip
 int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max,
                         void* ctx, int f16, void* stream, int window = 0);
 int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh, int S_max,

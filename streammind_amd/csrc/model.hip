@@ -1374,11 +1374,21 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            for (int ch = 0; ch < NC; ++ch) {
+            bool rope_done = false, attn_done = false;
+            if (NC > 1) {           // all streams in ONE RoPE + append launch and ONE attention launch (pointer packs of SM_GROUP_DECODE_MAX by value)
+                SmDecodeSegBig big;
+                for (int t = 0; t < S; ++t) { big.kc[t] = act[t]->kc[l].p; big.vtc[t] = act[t]->vtc[l].p; big.pos[t] = act[t]->kv_len; }
+                if ((rc = sm_rope_kv_append_seg_big(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, big, S_max, f16, stream))) return rc;
+                rope_done = true;
+                rc = sm_llm_decode_attention_seg_big(g->d_qb.p, big, S, H, KV, dh, S_max, g->d_ctxb.p, f16, stream, c.llm_sliding_window);
+                if (rc < 0) return rc;
+                attn_done = rc == 0;          // 1: contexts too long for the one-launch kernel -> chunks below
+            }
+            for (int ch = 0; ch < NC && !attn_done; ++ch) {
                 SmDecodeSeg seg;
                 for (int t = 0; t < cn(ch); ++t) { sm_stream* st = act[c0(ch) + t]; seg.kc[t] = st->kc[l].p; seg.vtc[t] = st->vtc[l].p; seg.pos[t] = st->kv_len; }
                 char* qb = (char*)g->d_qb.p + (size_t)c0(ch) * qn * 2;
-                if ((rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>() + (size_t)c0(ch) * (qn + 2 * kn), cn(ch), H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), qb, seg, S_max, f16, stream))) return rc;
+                if (!rope_done && (rc = sm_rope_kv_append_seg(g->d_qkvf.as<float>() + (size_t)c0(ch) * (qn + 2 * kn), cn(ch), H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), qb, seg, S_max, f16, stream))) return rc;
                 if ((rc = sm_llm_decode_attention_seg(qb, seg, cn(ch), H, KV, dh, S_max, g->d_ws.as<float>(), SM_DECODE_SPLITS, (char*)g->d_ctxb.p + (size_t)c0(ch) * qn * 2, f16, stream, c.llm_sliding_window))) return rc;
             }
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);

@@ -741,9 +741,10 @@ extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int K
 }
 
 // the same for S streams x one token each: row t = stream t at ITS position, appended to ITS caches
+template <class SEG>
 __global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict__ qkv, int H, int KV, int dh,
                                                          const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-                                                         bf16_t* __restrict__ q, SmDecodeSeg seg, int S_max, int f16) {
+                                                         bf16_t* __restrict__ q, SEG seg, int S_max, int f16) {
     const int t = blockIdx.x, hd = blockIdx.y;
     const int pos = seg.pos[t];
     bf16_t* __restrict__ kc = (bf16_t*)seg.kc[t];
@@ -767,7 +768,14 @@ __global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict
 int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
                           const SmDecodeSeg& seg, int S_max, int f16, void* stream) {
     SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_MAX_SEG, "sm_rope_kv_append_seg: bad args");
-    rope_kv_seg_kernel<<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
+    rope_kv_seg_kernel<SmDecodeSeg><<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
+                              const SmDecodeSegBig& seg, int S_max, int f16, void* stream) {
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_GROUP_DECODE_MAX, "sm_rope_kv_append_seg_big: bad args");
+    rope_kv_seg_kernel<SmDecodeSegBig><<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
