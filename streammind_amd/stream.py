@@ -135,14 +135,17 @@ class StreamingSession:
         a, m = self._active, self.model
         while len(a["chunks"]) < self.lane_depth and a["issued"] < a["budget"]:
             n = min(m.decode_chunk, a["budget"] - a["issued"])
+            # pinned landing buffers and events are allocated ONCE per session (lane_depth + 1 of each: a pinned allocation is a
+            # synchronous hipHostMalloc, this is the hot overlap path) and reused round-robin; a slot is free again once its chunk was taken
+            slot = self._lane_slots[self._lane_next % len(self._lane_slots)]
+            self._lane_next += 1
             with torch.cuda.stream(self._llm):
                 ids = m.stream.decode(n)
-                host = torch.empty(n, dtype=torch.int32).pin_memory()
+                host = slot[0][:n]
                 host.copy_(ids, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._llm)
+                slot[1].record(self._llm)
             a["issued"] += n
-            a["chunks"].append((host, ev, ids))
+            a["chunks"].append((host, slot[1], ids))
 
     def _pump(self, block: bool) -> Iterator[StreamEvent]:
         """advance the lane: start the next queued fire, keep `lane_depth` decode chunks enqueued, take the chunks that have
@@ -232,6 +235,10 @@ class StreamingSession:
         self._fire_q, self._active, self.lane_depth = [], None, max(1, lane_depth)
         if overlap_replies and getattr(self, "_llm", None) is None:
             self._llm = torch.cuda.Stream(self.model.device)
+        if overlap_replies and len(getattr(self, "_lane_slots", ())) != self.lane_depth + 1:
+            self._lane_slots = [(torch.empty(max(1, self.model.decode_chunk), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                                for _ in range(self.lane_depth + 1)]
+        self._lane_next = 0
 
         def batches():
             nonlocal buf
@@ -249,18 +256,24 @@ class StreamingSession:
                 return
             self._fire_q.extend(self._collect(handle, fires_only=True))
             yield from self._pump(block=False)
-        for b in batches():
-            handle = self._issue(b, pipelined=True)
+        try:
+            for b in batches():
+                handle = self._issue(b, pipelined=True)
+                if pending is not None:
+                    yield from collect(pending)
+                elif overlap_replies:
+                    yield from self._pump(block=False)
+                pending = handle
             if pending is not None:
                 yield from collect(pending)
-            elif overlap_replies:
-                yield from self._pump(block=False)
-            pending = handle
-        if pending is not None:
-            yield from collect(pending)
-        if overlap_replies:
-            yield from self._pump(block=True)                 # the stream has ended: finish what the lane still owes
-            torch.cuda.current_stream().wait_stream(self._llm)
+            if overlap_replies:
+                yield from self._pump(block=True)             # the stream has ended: finish what the lane still owes
+        finally:
+            # also when the consumer abandons the generator early: whatever is still in flight on the lane is ordered in front of the
+            # next thing the compute stream does (a later serial feed() / _reply must not race it on the KV cache), the lane's queue is dropped
+            if overlap_replies and getattr(self, "_llm", None) is not None:
+                torch.cuda.current_stream().wait_stream(self._llm)
+            self._fire_q, self._active = [], None
 
 
 class MultiStreamSession:
