@@ -1657,8 +1657,13 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     if (use_w8 < 0) { const char* e = getenv("SM_GEMM_W8"); use_w8 = e ? atoi(e) : 2; }   // 0: 4-wave blocks, 1: 8 waves when blocks <= 256, 2: always
     const int tiles = tiles_m * tiles_n, KTall = a.KS >> 1;
     int S = tiles <= 128 ? 256 / tiles : 1;
-    if (S > 4) S = 4;
-    while (S > 1 && KTall / S < 16) --S;
+    // up to 128 rows (a batched decode step of 33..128 streams: one row tile, the product is a weight stream) more slabs pay: every CU should
+    // pull weights, and a slab of 128 rows is 2 MB (SM_SPLITK_SMALLM_MAX, default 8; 4 = the rule of the larger shapes)
+    static int smallm_max = -1;
+    if (smallm_max < 0) { const char* e = getenv("SM_SPLITK_SMALLM_MAX"); smallm_max = e ? atoi(e) : 8; }
+    const int s_cap = p->M <= 128 ? smallm_max : 4;
+    if (S > s_cap) S = s_cap;
+    while (S > 1 && KTall / S < (p->M <= 128 ? 8 : 16)) --S;
     // a post-LN call pays for a second pass anyway (the LayerNorm of the finished rows): as slabs + the fused slab-sum / LayerNorm pass
     // the product costs one launch less than GEMM + LayerNorm, so slabs pay even for short K loops (out-proj, K = 1024: 4 k-tiles each)
     static int ln_fuse = -1, ln_smax = 6;
