@@ -1714,6 +1714,16 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             *ln_done = true;
             return SM_OK;
         }
+        if (p->post_ln_gamma && ln_fuse && p->M <= 256 && (p->N & 255) == 0 && p->N <= 4096 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) &&
+            p->remap_in == 0 && !a.wscale) {
+            // few rows (a batched decode step of 33..128 streams): the row-block pass of the weight-streaming path -- slab sum, epilogue and the
+            // LayerNorm / RMSNorm of the finished row in one launch (the slabs have the same [S][M][N] layout)
+            const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+            splitk_reduce_norm_rows_kernel<<<p->M, p->N / 4, 0, st>>>(a, ws, S, ln);
+            SM_LAUNCH_CHECK();
+            *ln_done = true;
+            return SM_OK;
+        }
         const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);
         splitk_reduce_kernel<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(a, ws, nullptr, S, p->N);
         SM_LAUNCH_CHECK();
