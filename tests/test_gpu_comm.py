@@ -28,7 +28,7 @@ def _rows(rank, tick, n, d, dtype):
 
 def _schedule(rank, tick):
     """rows per tick: mostly silent, ranks fire on different ticks, sometimes together, sometimes the full mailbox"""
-    if tick % 7 == 3 + rank:
+    if tick % 7 == (3 + rank) % 7:
         return 1 + (tick % 5)
     if tick % 11 == 10:
         return 16                      # both ranks, the whole mailbox
@@ -92,12 +92,13 @@ def _worker(rank, world, port, q, dtype_name):
         q.put((rank, False, None, traceback.format_exc()[-2000:]))
 
 
-@pytest.mark.parametrize("dtype_name", ["bfloat16", "float32"])
-def test_peer_write_exchange_two_processes_one_gpu(dtype_name):
+@pytest.mark.parametrize("dtype_name,world", [("bfloat16", 2), ("float32", 2), ("bfloat16", 4)])
+def test_peer_write_exchange_two_processes_one_gpu(dtype_name, world):
+    """world = 4: four processes on the one GPU (every rank posts into three peers and its own mailbox, collects from four)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, dtype_name)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, dtype_name)) for r in range(world)]
     for p in ps:
         p.start()
     got = [q.get(timeout=300) for _ in ps]
