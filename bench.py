@@ -425,7 +425,7 @@ def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per
 
     def perceive(i):
         stream.push_frames(frames[(i * B) % (n_pool - B + 1):][:B])
-    lane = torch.cuda.Stream()
+    lane = torch.cuda.Stream(priority=int(os.environ.get("SM_LLM_LANE_PRIORITY", "0")))      # -1: high-priority lane (A/B knob)
     # one after the other
     stream.reset(); stream.prefill(ids); stream.decode(8)
     for i in range(2):
