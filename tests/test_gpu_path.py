@@ -1031,6 +1031,41 @@ def test_group_batched_decode_beyond_32_streams(tiny):
             s.close()
 
 
+@pytest.mark.parametrize("lens,window,max_seq", [([60, 75, 110, 20], 48, 192), ([400, 450, 500, 30], 64, 576)])
+def test_group_decode_with_sliding_window_equals_solo(lens, window, max_seq):
+    """the batched decode's attention with Mistral's sliding window: streams whose contexts (60 / 75 / 110 / 20 tokens) lie on both sides of
+    a 48-token window decode together; every stream's ids equal its own windowed solo decode outside near-ties (both one-launch and
+    key-split attention are per-stream windowed: each stream's key walk starts at ITS window)."""
+    import dataclasses
+    from tests.util_models import build_native, conn_gate_weights
+    TLw = dataclasses.replace(TL, sliding_window=window)          # second case: contexts beyond 384 keys -> the key-split kernels, per-stream windows
+    m = build_native(TV, TC, TG, O.make_vit_weights(TV, 1), conn_gate_weights(TC, TG, 2), TLw, O.make_lm_weights(TL, 3))
+    g = torch.Generator().manual_seed(31)
+    n_new = 10
+    ctxs = [torch.randint(3, TL.vocab, (n,), generator=g, dtype=torch.int32).cuda() for n in lens]
+    solo_ids, solo_lg = [], []
+    for c in ctxs:
+        s = m.open_stream(max_frames=8, max_seq=max_seq)
+        s.prefill(c)
+        ids, lgs = [], []
+        for _ in range(n_new):
+            lgs.append(s.logits()[0].cpu())
+            ids.append(int(s.decode(1)[0]))
+        solo_ids.append(ids); solo_lg.append(lgs + [s.logits()[0].cpu()])
+        s.close()
+    streams = [m.open_stream(max_frames=8, max_seq=max_seq) for _ in lens]
+    for s, c in zip(streams, ctxs):
+        s.prefill(c)
+    out = m.open_group(streams).decode(n_new).cpu()
+    for t in range(len(lens)):
+        for j, (a, b) in enumerate(zip(out[t].tolist(), solo_ids[t])):
+            if a != b:
+                assert float(torch.topk(solo_lg[t][j], 2).values.diff().abs()) < 2 * 3e-2, (t, j, out[t].tolist(), solo_ids[t])
+                break
+        else:
+            assert maxdiff(streams[t].logits()[0], solo_lg[t][-1]) < 3e-2
+
+
 def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenizer):
     """MultiStreamSession (group perception + batched decode of the fired streams) against S independent reference-shaped
     loops (`streammind_amd.stream_infer`, one frame per call): per stream the same fire positions, the same prompt growth and the same
