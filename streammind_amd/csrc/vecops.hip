@@ -506,11 +506,22 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
                                  const float* __restrict__ xdbl, int ldx, int R, const float* __restrict__ xz, int F, int di,
                                  int ds_rt, const float* __restrict__ Alog, const float* __restrict__ Dp,
                                  SmSegStates st, float* __restrict__ y) {
+    // B and C of every frame of the segment (2 * d_state floats per frame, the same for all channels) go to LDS once: fetched per step
+    // inside the serial loop they were a memory round trip per frame on the critical path (22 us of a 28-frame pass)
+    __shared__ float bc[SM_MAX_SEG * 64];
+    const int ds = DS > 0 ? DS : ds_rt;
+    const int m0 = blockIdx.y * F;
+    const bool staged = F <= SM_MAX_SEG;
+    if (staged) {
+        for (int t = threadIdx.x; t < F * 2 * ds; t += blockDim.x) {
+            const int f = t / (2 * ds), j = t - f * 2 * ds;
+            bc[f * 64 + j] = xdbl[(size_t)(m0 + f) * ldx + R + j];
+        }
+        __syncthreads();
+    }
     int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= di) return;
-    const int ds = DS > 0 ? DS : ds_rt;
     float* __restrict__ hst = st.p[blockIdx.y];
-    const int m0 = blockIdx.y * F;
     float h[DS > 0 ? DS : 32], A[DS > 0 ? DS : 32];
 #pragma unroll
     for (int n = 0; n < ds; ++n) { h[n] = hst[(size_t)d * ds + n]; A[n] = -__expf(Alog[(size_t)d * ds + n]); }
@@ -531,16 +542,22 @@ __global__ void mamba_ssm_kernel(const float* __restrict__ xc, const float* __re
             if (mb + u >= m0 + F) break;
             const int m = mb + u;
             const float dt = dtv[u], xv = xvv[u];
-            const float* Bm = xdbl + (size_t)m * ldx + R;
-            const float* Cm = Bm + ds;
+            float Bv[DS > 0 ? DS : 32], Cv[DS > 0 ? DS : 32];
+            if (staged) {          // LDS (ds_read, not a generic pointer)
+#pragma unroll
+                for (int n = 0; n < ds; ++n) { Bv[n] = bc[(m - m0) * 64 + n]; Cv[n] = bc[(m - m0) * 64 + ds + n]; }
+            } else {
+#pragma unroll
+                for (int n = 0; n < ds; ++n) { Bv[n] = xdbl[(size_t)m * ldx + R + n]; Cv[n] = xdbl[(size_t)m * ldx + R + ds + n]; }
+            }
             float acc = 0.f, yv;
             {   // pinned operation sequence (see mamba_conv_kernel): the same bits for a frame wherever it sits in its call
 #pragma clang fp contract(off)
                 const float dtx = dt * xv;
 #pragma unroll
                 for (int n = 0; n < ds; ++n) {
-                    h[n] = __builtin_fmaf(__expf(dt * A[n]), h[n], dtx * Bm[n]);
-                    acc = __builtin_fmaf(h[n], Cm[n], acc);
+                    h[n] = __builtin_fmaf(__expf(dt * A[n]), h[n], dtx * Bv[n]);
+                    acc = __builtin_fmaf(h[n], Cv[n], acc);
                 }
                 yv = __builtin_fmaf(Dd, xv, acc);
             }
