@@ -77,3 +77,12 @@ def test_stream_frames_gpu_equals_the_host_stream(dec, tmp_path):
     want = native.ingest_frames(torch.from_numpy(np.stack([f for _, f in host])).cuda(), False, 336)
     assert torch.equal(torch.cat(got), want)
 
+
+
+def test_gpu_decode_equals_golden_g19(dec):
+    """the committed fixture through the HIP kernels: byte for byte the frames recorded from PIL / libjpeg-turbo"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g19_jpeg.npz"))
+    for i in range(int(g["n"])):
+        assert np.array_equal(dec.decode([bytes(g[f"jpeg{i}"])])[0].cpu().numpy(), g[f"rgb{i}"]), i
+    assert np.array_equal(dec.decode([bytes(g["jpeg_bare"])])[0].cpu().numpy(), g["rgb0"])

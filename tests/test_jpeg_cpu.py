@@ -50,3 +50,15 @@ def test_implied_huffman_tables_and_errors(lib):
     q = np.zeros((3, 64), np.uint16)
     rc = lib.sm_jpeg_decode_coefs(tb, len(trunc), C.byref(inf), out.ctypes.data, q.ctypes.data)      # truncated stream: zeros are fed, never a crash
     assert rc in (0, -1, -2, -3)
+
+
+def test_golden_g19_jpeg_fixture(lib):
+    """committed fixture (oracle/make_jpeg_golden.py): JPEG byte strings + the frames PIL / libjpeg-turbo decoded them to when the fixture was
+    minted -- the host entropy decoder + the oracle reproduce them byte for byte, whatever PIL this machine has"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g19_jpeg.npz"))
+    for i in range(int(g["n"])):
+        info, coefs, qt = U.host_coefs(lib, bytes(g[f"jpeg{i}"]))
+        assert np.array_equal(J.reconstruct(coefs, qt, info), g[f"rgb{i}"]), i
+    info, coefs, qt = U.host_coefs(lib, bytes(g["jpeg_bare"]))
+    assert np.array_equal(J.reconstruct(coefs, qt, info), g["rgb0"])
