@@ -115,7 +115,7 @@ typedef struct sm_linear_t {
     int op_dtype;
     /* LayerNorm of the FINISHED output row, behind the epilogue ("post-LN"): post_ln_gamma != NULL (with post_ln_beta) asks for
      * post_ln_out[m][0..N) = 16-bit(LN(out_f32[m][:]) * gamma + beta) (op_dtype), the operand of the next product, next to out_f32.
-     * Needs out_f32, remap_in == 0 and no vt.  Where the product runs as split-K slabs -- few tiles (one frame through the tower: a wave
+     * Needs out_f32 (and out_bf16 == NULL: the fused slab passes do not write it), remap_in == 0 and no vt.  Where the product runs as split-K slabs -- few tiles (one frame through the tower: a wave
      * per row, N == 1024) or 17..32 rows on the weight-streaming path (the connector / gate pass: a block per row, N %% 1024 == 0) --
      * the slab sum, bias, activation, residual and the norm of the row are ONE pass; everywhere else the call ends with the sm_norm_ex
      * launch the caller would have made (the same two-pass arithmetic either way). */
@@ -461,6 +461,11 @@ int sm_jpeg_reconstruct(const int16_t* coefs, const uint16_t* qt, const sm_jpeg_
  *                                                      [world][max_rows][row_bytes] (device, may be NULL): rows [0, count) of each rank
  *   sm_comm_host_counts(parity, counts_out[world])      the same counts from the pinned host mirror of tick parity (t & 1), valid once
  *                                                      `stream` has passed that collect; error if a rank timed out
+ *   sm_comm_poll_counts(parity, counts_out, &missing)   the same read with a timeout as "not yet": 0 + counts, or 1 + the rank that had not
+ *                                                      posted (no error recorded); then
+ *   sm_comm_recollect(counts_out, payload_out, stream)  issues the collect of that same tick again -- ranks fire on different ticks and a
+ *                                                      rank decoding a long reply lags by more than any GPU-side spin should last; the
+ *                                                      caller owns the overall deadline (PeerWriteExchange: 30 min, the process-group default)
  *   sm_allgather_gated(...)                             post + collect of one tick (the blocking form)
  * post and collect alternate (post t, collect t, post t+1, ...); on one HIP stream per rank, or on streams ordered by events.
  * ---------------------------------------------------------------------------------------------- */
@@ -474,6 +479,8 @@ void sm_comm_destroy(sm_comm* c);
 int sm_comm_post(sm_comm* c, const void* rows, int n_rows, void* stream);
 int sm_comm_collect(sm_comm* c, int32_t* counts_out, void* payload_out, void* stream);
 int sm_comm_host_counts(sm_comm* c, int tick_parity, int32_t* counts_out);
+int sm_comm_poll_counts(sm_comm* c, int tick_parity, int32_t* counts_out, int* missing_rank);
+int sm_comm_recollect(sm_comm* c, int32_t* counts_out, void* payload_out, void* stream);
 int sm_allgather_gated(sm_comm* c, const void* rows, int n_rows, int32_t* counts_out, void* payload_out, void* stream);
 int sm_comm_max_rows(sm_comm* c);
 int sm_comm_tick(sm_comm* c);

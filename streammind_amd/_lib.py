@@ -141,6 +141,8 @@ SIGNATURES = {
     "sm_comm_post": (i32, [vp, vp, i32, vp]),
     "sm_comm_collect": (i32, [vp, vp, vp, vp]),
     "sm_comm_host_counts": (i32, [vp, i32, C.POINTER(C.c_int32)]),
+    "sm_comm_poll_counts": (i32, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "sm_comm_recollect": (i32, [vp, vp, vp, vp]),
     "sm_allgather_gated": (i32, [vp, vp, i32, vp, vp, vp]),
     "sm_comm_max_rows": (i32, [vp]),
     "sm_comm_tick": (i32, [vp]),

@@ -49,6 +49,7 @@ struct sm_comm {
     int* host_counts_dev = nullptr;
     unsigned long long posted = 0, collected = 0;
     bool connected = false;
+    bool timed_out = false;                                // sm_comm_poll_counts reported a late peer for the last collect: sm_comm_recollect may re-issue it
     long long timeout_ticks = 0;                           // wall_clock64 ticks (100 MHz) a collect waits for a peer
     ~sm_comm() {
         for (int r = 0; r < (int)peer.size(); ++r)
@@ -182,6 +183,7 @@ extern "C" int sm_comm_post(sm_comm* c, const void* rows, int n_rows, void* stre
     SM_REQUIRE(c && c->connected, "sm_comm_post: not connected (sm_comm_connect first)");
     SM_REQUIRE(n_rows >= 0 && n_rows <= c->max_rows && (n_rows == 0 || rows), "sm_comm_post: n_rows=%d outside [0, %d]", n_rows, c->max_rows);
     SM_REQUIRE(c->posted == c->collected, "sm_comm_post: tick %llu has not been collected yet (post and collect alternate)", c->posted - 1);
+    SM_REQUIRE(!c->timed_out, "sm_comm_post: the collect of tick %llu timed out and was not re-issued (sm_comm_recollect)", c->collected - 1);
     SM_REQUIRE(n_rows == 0 || ((size_t)rows & 15) == 0, "sm_comm_post: rows must be 16-byte aligned");
     CommPeers peers;
     for (int r = 0; r < c->world; ++r) peers.p[r] = c->peer[r];
@@ -214,6 +216,35 @@ extern "C" int sm_comm_host_counts(sm_comm* c, int tick_parity, int32_t* counts_
         SM_FAIL(SM_EHIP, "sm_comm: rank %d did not post in time (rank %d waited %lld ms)", err - 1, c->rank, c->timeout_ticks / 100000LL);
     }
     for (int r = 0; r < c->world; ++r) counts_out[r] = c->host_counts[tick_parity * c->world + r];
+    return SM_OK;
+}
+
+// The same read for callers that treat a timeout as "not yet" (ranks fire on different ticks by design, and a rank that is decoding a
+// long reply lags its peers by more than any sensible GPU-side spin): returns 0 with the counts, or 1 with *missing_rank = the rank that
+// had not posted when the collect gave up -- no error is recorded, and the collect of that tick may be issued AGAIN with
+// sm_comm_recollect (the late payload is still delivered: a peer cannot overwrite the slot before this rank has posted its next tick).
+extern "C" int sm_comm_poll_counts(sm_comm* c, int tick_parity, int32_t* counts_out, int* missing_rank) {
+    SM_REQUIRE(c && counts_out && (tick_parity == 0 || tick_parity == 1), "sm_comm_poll_counts: bad args");
+    const int err = c->host_counts[2 * c->world + tick_parity];
+    if (err) {
+        c->host_counts[2 * c->world + tick_parity] = 0;
+        if (missing_rank) *missing_rank = err - 1;
+        c->timed_out = true;
+        return 1;
+    }
+    for (int r = 0; r < c->world; ++r) counts_out[r] = c->host_counts[tick_parity * c->world + r];
+    return SM_OK;
+}
+
+// Re-issue the collect of the LAST collected tick after sm_comm_poll_counts reported a timeout for it (same outputs, same stream rules).
+extern "C" int sm_comm_recollect(sm_comm* c, int32_t* counts_out, void* payload_out, void* stream) {
+    SM_REQUIRE(c && c->connected, "sm_comm_recollect: not connected");
+    SM_REQUIRE(c->timed_out && c->collected >= 1 && c->collected == c->posted, "sm_comm_recollect: the last collect did not time out (poll it with sm_comm_poll_counts first)");
+    c->timed_out = false;
+    const unsigned long long t = c->collected - 1;
+    comm_collect_kernel<<<c->world, 512, 0, (hipStream_t)stream>>>(c->box, c->slot_bytes, c->world, (int)(t & 1), t + 1, c->max_rows, c->row_bytes, counts_out,
+                                                                   (char*)payload_out, c->host_counts_dev, c->timeout_ticks);
+    SM_LAUNCH_CHECK();
     return SM_OK;
 }
 

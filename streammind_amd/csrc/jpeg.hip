@@ -34,13 +34,17 @@ struct Huff {
     // canonical decode tables (ITU T.81 Annex F.2.2.3): codes of length l lie in [mincode[l], maxcode[l]], valptr[l] indexes vals
     int mincode[17], maxcode[18], valptr[17];
     uint16_t fast[512];                       // 9-bit lookahead: (length << 8) | symbol, 0 = longer code
-    void build() {
+    // false: the code-length counts over-subscribe the code space (a length-l code would exceed 2^l: no prefix code has these
+    // counts -- jdhuff.c rejects the table the same way) or name more than 256 symbols.  An over-subscribed table would index
+    // `fast` far beyond its 512 entries (bits[1] = 255: ~130 KB past the array).
+    bool build() {
         int code = 0, k = 0;
         for (int l = 1; l <= 16; ++l) {
             valptr[l] = k;
             mincode[l] = code;
             code += bits[l];
             k += bits[l];
+            if (code > (1 << l) || k > 256) return false;
             maxcode[l] = bits[l] ? code - 1 : -1;
             code <<= 1;
         }
@@ -50,10 +54,11 @@ struct Huff {
         for (int l = 1; l <= 9; ++l) {
             for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
                 const int lo = code << (9 - l);
-                for (int j = 0; j < (1 << (9 - l)); ++j) fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
+                for (int j = 0; j < (1 << (9 - l)) && lo + j < 512; ++j) fast[lo + j] = (uint16_t)((l << 8) | vals[k]);
             }
             code <<= 1;
         }
+        return true;
     }
 };
 
@@ -144,6 +149,9 @@ static int parse_segments(const uint8_t* d, size_t len, size_t& pos, Parsed& P, 
         const uint8_t* s = d + pos + 4;
         const int n = L - 2;
         if (m == 0xC0 || m == 0xC1) {
+            // one frame header per image: a second SOF between the scans of a multi-scan file would change the geometry under the
+            // coefficient layout fixed after the first SOS (block counts, offsets)
+            SM_REQUIRE(!P.sof, "jpeg: second frame header (SOF%d) inside one image", m - 0xC0);
             SM_REQUIRE(n >= 6 && s[0] == 8, "jpeg: %d-bit samples (8-bit only)", n >= 1 ? s[0] : 0);
             P.height = be16(s + 1); P.width = be16(s + 3); P.ncomp = s[5];
             SM_REQUIRE(P.width > 0 && P.height > 0, "jpeg: empty frame (%d x %d)", P.width, P.height);
@@ -178,7 +186,7 @@ static int parse_segments(const uint8_t* d, size_t len, size_t& pos, Parsed& P, 
                 SM_REQUIRE(cnt <= 256 && o + 17 + cnt <= n, "jpeg: bad Huffman table");
                 memcpy(h.vals, s + o + 17, cnt);
                 h.present = true;
-                h.build();
+                SM_REQUIRE(h.build(), "jpeg: Huffman table class %d id %d over-subscribes its code space", tc, th);
                 o += 17 + cnt;
             }
         } else if (m == 0xDB) {
@@ -251,7 +259,7 @@ static void std_table(Huff& h, const uint8_t* bits, const uint8_t* vals, int nv)
     for (int i = 0; i < 16; ++i) h.bits[i + 1] = bits[i];
     memcpy(h.vals, vals, nv);
     h.present = true;
-    h.build();
+    (void)h.build();        // Annex K.3 tables: valid by construction
 }
 
 // One frame: markers + every scan's entropy-coded segment -> quantised coefficients, natural (row-major) order inside a block,
@@ -315,6 +323,7 @@ extern "C" int sm_jpeg_decode_coefs(const uint8_t* data, size_t len, const sm_jp
                     for (int v = 0; v < bv; ++v)
                         for (int h = 0; h < bh; ++h) {
                             const int bx = x * bh + h, by = y * bv + v;
+                            SM_REQUIRE(bx < I.blocks_x[ci] && by < I.blocks_y[ci], "jpeg: block (%d, %d) outside the component's %d x %d blocks", bx, by, I.blocks_x[ci], I.blocks_y[ci]);
                             int16_t* blk = coefs + I.coef_offset[ci] + ((size_t)by * I.blocks_x[ci] + bx) * 64;
                             int s = huff_decode(br, P.dc[k.td]);
                             SM_REQUIRE(s >= 0 && s <= 11, "jpeg: bad DC code");

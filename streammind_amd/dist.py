@@ -216,23 +216,31 @@ class GatedTokenExchange:
         self.cuda = self.dev.type == "cuda"
         self.side = torch.cuda.Stream(self.dev) if self.cuda else None
         self._pending = None          # (counts host tensor, ready event | work handle, this rank's tokens of that tick)
+        self._bufs = [None, None]
         self.ticks = self.payload_collectives = 0
         self.host_wait_s = 0.0
+
+    def _buffers(self, par: int):
+        """per tick parity, allocated ONCE: pinned count word, device count word + gathered counts, pinned host mirror, event -- the
+        hot tick allocates and pins nothing (round 4 built and pinned three tensors per tick on what may be the only path a real
+        8-GPU run takes).  Two parities: the mirror of tick t is read while tick t + 1 is already posted."""
+        if self._bufs[par] is None:
+            self._bufs[par] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.empty(1, dtype=torch.int32, device=self.dev),
+                               torch.empty(self.world, dtype=torch.int32, device=self.dev), torch.empty(self.world, dtype=torch.int32).pin_memory(),
+                               torch.cuda.Event())
+        return self._bufs[par]
 
     def _post(self, tokens: Optional[torch.Tensor]):
         n = 0 if tokens is None else int(tokens.shape[0])
         if self.cuda:
-            cnt = torch.tensor([n], dtype=torch.int32).pin_memory().to(self.dev, non_blocking=True)
-            counts = torch.empty(self.world, dtype=torch.int32, device=self.dev)
-            host = torch.empty(self.world, dtype=torch.int32).pin_memory()
+            cnt_h, cnt, counts, host, ev = self._buffers(self.ticks & 1)
+            cnt_h[0] = n                          # this parity's previous tick (t - 2) was host-synchronised on its event in _collect: all five are free
+            cnt.copy_(cnt_h, non_blocking=True)
             self.side.wait_stream(torch.cuda.current_stream(self.dev))        # the count upload is ordered before the collective
             with torch.cuda.stream(self.side):
                 tdist.all_gather_into_tensor(counts, cnt, group=self.group)
                 host.copy_(counts, non_blocking=True)
-                ev = torch.cuda.Event()
                 ev.record(self.side)
-            for t in (cnt, counts):
-                t.record_stream(self.side)
             self._pending = (host, ev, tokens)
         else:
             cnt = torch.tensor([n], dtype=torch.int32)
@@ -281,11 +289,16 @@ class PeerWriteExchange:
     can contribute per tick (the connector emits one token per frame: rows = frames of a tick whose gate fired)."""
 
     def __init__(self, d_model: int, max_rows: int = 64, group=None, dtype: torch.dtype = torch.float32,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, timeout_s: float = 1800.0):
         import ctypes as C
         from . import _lib
         self._C, self.lib = C, _lib.load()
         self.group, self.d_model, self.dtype, self.max_rows = group, d_model, dtype, int(max_rows)
+        # how long a tick waits for its slowest peer before it is an error.  The GPU-side collect gives up after SM_COMM_TIMEOUT_MS
+        # (5 s: a spinning kernel must not pin a stream for minutes) -- that is "not yet", not an error: ranks fire on different ticks and
+        # a rank decoding a 1024-token reply lags its peers by more than that, exactly where the reference's allgather simply waits
+        # (process-group timeout: 30 min).  `_collect` re-issues the collect until this deadline; `late_retries` counts the re-issues.
+        self.timeout_s, self.late_retries = float(timeout_s), 0
         self.world, self.rank = tdist.get_world_size(group), tdist.get_rank(group)
         self.dev = device or torch.device("cuda", torch.cuda.current_device())
         self.row_bytes = d_model * torch.empty(0, dtype=dtype).element_size()
@@ -358,11 +371,23 @@ class PeerWriteExchange:
             return None
         par, self._pending = self._pending, None
         import time
-        t0 = time.perf_counter()
-        self._ev[par].synchronize()
-        self.host_wait_s += time.perf_counter() - t0
         from . import _lib
-        _lib.check(self.lib.sm_comm_host_counts(self.h, par, self._counts), "sm_comm_host_counts")
+        t0 = time.perf_counter()
+        missing = self._C.c_int32(-1)
+        while True:
+            self._ev[par].synchronize()
+            rc = _lib.check(self.lib.sm_comm_poll_counts(self.h, par, self._counts, self._C.byref(missing)), "sm_comm_poll_counts")
+            if rc == 0:
+                break
+            # a peer had not posted when the GPU-side wait gave up: the tick is NOT consumed -- collect it again (its payload arrives late,
+            # never lost: the peer cannot reuse the slot before this rank has posted its next tick)
+            if time.perf_counter() - t0 > self.timeout_s:
+                raise RuntimeError(f"PeerWriteExchange: rank {missing.value} did not post tick {self.lib.sm_comm_tick(self.h) - 1} within {self.timeout_s:.0f} s "
+                                   f"(rank {self.rank} re-issued the collect {self.late_retries} times)")
+            self.late_retries += 1
+            _lib.check(self.lib.sm_comm_recollect(self.h, None, self._payload[par].data_ptr(), self.side.cuda_stream), "sm_comm_recollect")
+            self._ev[par].record(self.side)
+        self.host_wait_s += time.perf_counter() - t0
         counts = list(self._counts)
         if max(counts) == 0:
             return None

@@ -176,6 +176,37 @@ class ModelWorker:
             clip = process_video(frames, self.image_processor, aspect_ratio=ar, num_frames=len(frames))
             return [clip], ["video"], DEFAULT_VIDEO_TOKEN, MMODAL_TOKEN_INDEX["VIDEO"]
 
+    # ---- the model lock never waits for a client
+    def _produce_locked(self, body):
+        """Run `body(put, cancelled)` on a producer thread that holds the model lock for exactly as long as the MODEL runs, and hand what
+        it `put`s to the calling generator through a queue: the HTTP response is written outside the lock, so a slow, stalled or gone
+        client holds nothing (round 4 yielded to the wire inside `with self._lock`: one stuck reader blocked every other request; a
+        closed generator now sets `cancelled`, which the body polls between decode chunks / ticks).  The queue is bounded by the
+        request itself (<= 1024 new tokens, <= the frames posted).  Exceptions of the body re-raise in the consumer."""
+        import queue
+        q, cancelled, DONE = queue.Queue(), threading.Event(), object()
+
+        def run():
+            try:
+                with self._lock, torch.inference_mode():
+                    body(q.put, cancelled.is_set)
+                q.put(DONE)
+            except BaseException as e:                      # delivered in-band to the consumer
+                q.put(e)
+
+        t = threading.Thread(target=run, name="streammind-model-producer", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is DONE:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            cancelled.set()                                 # GeneratorExit (client went away) or normal end: the producer stops at its next check
+
     @torch.inference_mode()
     def generate_stream(self, params: dict):
         tokenizer, model = self.tokenizer, self.model
@@ -218,16 +249,21 @@ class ModelWorker:
                 text = text[:-len(stop_str)]
             return json.dumps({"text": text, "error_code": 0}).encode() + b"\0", False
 
-        with self._lock:
+        def decode(put, cancelled):                          # under the model lock, on the producer thread: ids only
             for chunk in model.generate_iter(input_ids, max_new_tokens=budget, stopping_criteria=stops, do_sample=temperature > 0.001,
                                              temperature=temperature, top_p=top_p, **clip_kw):
-                for tok_id in chunk:
-                    out, blocked = emit(detok.put(int(tok_id)))
-                    yield out
-                    if blocked:
-                        return
-            out, _ = emit(detok.end())
-            yield out
+                put([int(t) for t in chunk])
+                if cancelled():
+                    return
+
+        for chunk in self._produce_locked(decode):              # detokenise, moderate and write to the wire OUTSIDE the lock
+            for tok_id in chunk:
+                out, blocked = emit(detok.put(tok_id))
+                yield out
+                if blocked:
+                    return
+        out, _ = emit(detok.end())
+        yield out
 
     def generate_stream_gate(self, params: dict):
         try:
@@ -287,15 +323,19 @@ class ModelWorker:
             else:
                 frames = np.stack([np.asarray(load_image_from_base64(f).convert("RGB")) for f in fr])
             ar = getattr(self.model.config, "image_aspect_ratio", None)
-            with self._lock:
+            def ticks(put, cancelled):                       # lookup / create and every tick of this request are ONE critical section
                 st = self._stream_state(sid, bool(params.get("reset", False)))
                 for i in range(len(frames)):
+                    if cancelled():
+                        return
                     video = process_video(frames[i:i + 1], self.image_processor, aspect_ratio=ar, num_frames=1)
                     text, st["prompt"] = infer(st["model"], video, "", self.tokenizer, prompt=st["prompt"],
                                                max_new_tokens=int(params.get("max_new_tokens", 1024)))
                     st["last_used"] = self._clock()
-                    yield json.dumps({"stream_id": sid, "frames_seen": st["model"].stream.num_frames, "cls_pred": int(text is not None),
-                                      "text": text, "error_code": 0}).encode() + b"\0"
+                    put(json.dumps({"stream_id": sid, "frames_seen": st["model"].stream.num_frames, "cls_pred": int(text is not None),
+                                    "text": text, "error_code": 0}).encode() + b"\0")
+
+            yield from self._produce_locked(ticks)
         except Exception as e:
             print("Caught", type(e).__name__, e)
             yield json.dumps({"text": server_error_msg, "error_code": 1}).encode() + b"\0"

@@ -110,6 +110,76 @@ def test_peer_write_exchange_two_processes_one_gpu(dtype_name, world):
         assert ticks == 40 and payload_ticks == fired and 0 < fired < 40        # silent ticks moved no payload
 
 
+def _worker_big_late(rank, world, port, q, max_rows, late_rank, delay_s):
+    """world processes on cuda:0, fires of up to `max_rows` rows (a 3 s segment at 30 fps is 90 frame tokens; 256+ covers any tick the
+    connector can emit), and -- with SM_COMM_TIMEOUT_MS short -- one rank that posts a tick LATER than the GPU-side wait lasts: its
+    payload must still arrive (the collect is re-issued), nothing is lost, nobody errors."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if late_rank >= 0:
+            os.environ["SM_COMM_TIMEOUT_MS"] = "150"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import time
+        from streammind_amd.dist import PeerWriteExchange
+        d, T, dtype = 4096, 12, torch.bfloat16
+        ex = PeerWriteExchange(d, max_rows=max_rows, dtype=dtype, timeout_s=60.0)
+
+        def sched(r, t):
+            if t % 4 == r % 4:
+                return max_rows if (t + r) % 3 == 0 else 1 + (7 * t + r) % max_rows
+            return 0
+        ok = True
+        for t in range(T):
+            if rank == late_rank and t in (3, 7):
+                time.sleep(delay_s)                                  # this rank "decodes a long reply": its peers' collects time out meanwhile
+            n = sched(rank, t)
+            rows = _rows(rank, t, n, d, dtype)
+            got = ex.tick(rows.cuda() if rows is not None else None)
+            tt = t - 1
+            if t:
+                counts = [sched(r, tt) for r in range(world)]
+                if max(counts) == 0:
+                    ok &= got is None
+                else:
+                    ok &= got is not None and [int(g.shape[0]) for g in got] == counts
+                    for r in range(world):
+                        if counts[r]:
+                            ok &= torch.equal(got[r].cpu(), _rows(r, tt, counts[r], d, dtype))
+        last = ex.flush()
+        counts = [sched(r, T - 1) for r in range(world)]
+        ok &= (last is None) == (max(counts) == 0)
+        retries = ex.late_retries
+        dist.barrier()
+        ex.close()
+        q.put((rank, bool(ok), retries, ""))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:          # noqa: BLE001
+        import traceback
+        q.put((rank, False, None, traceback.format_exc()[-2000:]))
+
+
+@pytest.mark.parametrize("world,max_rows,late_rank", [(8, 256, -1), (2, 64, 1)])
+def test_peer_write_exchange_world8_big_fires_and_a_late_rank(world, max_rows, late_rank):
+    """(8, 256): eight processes on the one GPU -- the node's world size -- with fires of up to 256 rows (2 MB bf16 per peer);
+    (2, 64, late 1): rank 1 sleeps 0.6 s before two of its ticks while the GPU-side wait lasts 0.15 s: rank 0's collect times out,
+    is re-issued (`late_retries` > 0) and the late rows arrive -- a timeout is "not yet", never a lost tick (advisor, round 4)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_big_late, args=(r, world, port, q, max_rows, late_rank, 0.6)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    for rank, ok, retries, err in got:
+        assert ok, (rank, retries, err)
+    if late_rank >= 0:
+        assert sum(r for _, _, r, _ in got) > 0, "the delay never outlasted the GPU-side wait: the retry path was not exercised"
+
+
 def test_comm_timeout_is_an_error_not_a_hang():
     """a peer that never posts: the collect gives up after SM_COMM_TIMEOUT_MS and the host read reports WHICH rank was missing"""
     import ctypes as C

@@ -1,5 +1,5 @@
-"""BASELINE configs[4] names a "hipGraph-captured per-frame gate step".  The product path stays eager (profiles/r04_graph_ab.json:
-replay buys nothing, the step is GPU-bound), but the C ABI must be CAPTURE-SAFE so that a deployment can capture it: no allocation,
+"""BASELINE configs[4] names a "hipGraph-captured per-frame gate step".  The product path stays eager (profiles/r02_graph_ab.json,
+re-measured on this round's kernels in profiles/r05_graph_ab.json by tools/graph_ab.py: replay buys nothing, the step is GPU-bound), but the C ABI must be CAPTURE-SAFE so that a deployment can capture it: no allocation,
 no synchronisation, no host read-back inside a hot call once its HIP stream is warm.  These tests capture the gate step and the
 decode step with hipStreamBeginCapture (torch.cuda.CUDAGraph on the stream the library launches on), replay them, and demand
 results BIT-IDENTICAL to the eager calls."""

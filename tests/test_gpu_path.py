@@ -391,9 +391,11 @@ def test_full_size_perception_vs_fp32_oracle(fullsize):
     """FULL-SIZE silent-frame path (CLIP-ViT-L/14-336, 23 layers, bf16 MFMA) -> connector -> 872 M-parameter gate against
     the fp32 oracle (the arithmetic pinned to the reference): pooled features and gate logits, 2 frames per call (the
     128x128 GEMM).  The connector+gate alone are within 1e-3 of the reference (test_conn_gate_full_size_golden).  End to
-    end, with the bf16-operand ViT in front, the gate logits are asserted at the north-star's 1e-3 (measured 4.3e-4; pooled
-    features 7e-3 on magnitudes up to 27, asserted at 2e-2), and the decisions must agree wherever the oracle margin
-    exceeds twice the tolerance."""
+    end, with the bf16-operand ViT in front, the gate logits are asserted at GATE_TOL_BF16_VIT = 4e-3 -- the FLOOR of a
+    bf16-operand tower against fp32, NOT the north-star's 1e-3 (measured 4.3e-4 on these 2 frames, 2.3e-3 on 28; the 1e-3 bound
+    is asserted against fp32 with the fp16 tower in test_full_size_28_frames_fp16_tower_meets_the_north_star_bound, and against
+    the bf16-mode oracle in test_full_size_28_frames_bf16_tower_vs_bf16_mode_oracle); pooled features 7e-3 on magnitudes up to
+    27, asserted at 2e-2; the decisions must agree wherever the oracle margin exceeds twice the tolerance."""
     m, Wv, Wc, vcfg, ccfg, gcfg = fullsize
     frames = O.synthetic_frames(2, 336, seed=55, scene_len=1)
     s = m.open_stream(max_frames=8, max_seq=64)

@@ -192,3 +192,41 @@ def test_stream_registry_is_bounded(tiny_tokenizer, monkeypatch):
     out = [json.loads(c[:-1]) for c in w.stream_frames({"stream_id": "c", "close": True})]
     assert out == [{"stream_id": "c", "closed": True, "error_code": 0}] and closed == [1, 2, 3] and set(w._stream_models) == {"b"}
     assert [json.loads(c[:-1]) for c in w.stream_frames({"stream_id": "zz", "close": True})][0]["closed"] is False
+
+
+def test_a_stalled_client_does_not_hold_the_model_lock(gold, tiny_tokenizer):
+    """Advisor (round 4, medium): the chunk stream used to be yielded to the wire INSIDE the model lock.  The lock now belongs to a
+    producer thread for as long as the model runs; a reader that stalls after the first chunk (or goes away) holds nothing, and a
+    closed response cancels the producer at its next chunk."""
+    import time
+    g = gold("g15_serving")
+    w = _worker(tiny_tokenizer, str(g["reply"]))
+    req = json.loads(str(g["requests"]))[0]
+    stalled = w.generate_stream_gate(dict(req))
+    first = next(stalled)                               # a client that read one chunk and then stopped reading
+    assert first.endswith(b"\0")
+    deadline = time.time() + 5.0                        # the producer finishes on its own: the lock comes back without the reader
+    while w._lock.locked() and time.time() < deadline:
+        time.sleep(0.01)
+    assert not w._lock.locked()
+    other = [c[:-1].decode() for c in w.generate_stream_gate(dict(req))]        # a second request is served in full meanwhile
+    assert other == json.loads(str(g["chunks"]))[0]
+    stalled.close()                                     # the client disconnects: GeneratorExit, nothing left behind
+    assert not w._lock.locked()
+    # a producer that is still decoding when the client leaves stops at its next chunk
+    seen = []
+
+    class Slow(FakeModel):
+        def generate_iter(self, inputs, **kw):
+            for i in range(0, len(self.ids), 3):
+                seen.append(i)
+                time.sleep(0.02)
+                yield self.ids[i:i + 3]
+
+    w2 = _worker(tiny_tokenizer, str(g["reply"]))
+    w2.model = Slow(w2.model.ids)
+    gen = w2.generate_stream_gate(dict(req))
+    next(gen)
+    gen.close()
+    time.sleep(0.3)
+    assert not w2._lock.locked() and len(seen) < len(range(0, len(w2.model.ids), 3))
