@@ -1626,36 +1626,8 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         if (hint == 256 && ok) bn = 256;
         if (hint == 2561 && ok) bn = 257;
         if (bn) {
-            // "light" row pass behind a post-LN product (SM_LIGHT, see ln_light_kernel in vecops.hip): 1 = the LayerNorm as a 16-register
-            // one-wave kernel that fits beside the OTHER tower lane's GEMM blocks; 2 = the residual add leaves the GEMM's epilogue too
-            // (the product goes to a scratch as fp32, write only; the light pass does x += product, then the LayerNorm of the row)
-            static int light = -1;
-            if (light < 0) { const char* e = getenv("SM_LIGHT"); light = e ? atoi(e) : 0; }
-            const bool light_ok = light > 0 && p->post_ln_gamma && p->post_ln_beta && p->post_ln_out && !p->post_ln_out_f32 && p->post_ln_act == SM_ACT_NONE &&
-                                  p->act == SM_ACT_NONE && (p->N & 511) == 0 && (p->ldo & 3) == 0 && p->remap_in == 0 && !p->vt && !p->out_bf16;
-            if (light_ok && light >= 2 && p->residual == p->out_f32 && p->ldr == p->ldo) {
-                float* prod = nullptr;
-                int rc = splitk_workspace(st, (size_t)p->M * p->N * sizeof(float), &prod);
-                if (rc) return rc;
-                LinArgs b = a;
-                b.out_f32 = prod; b.ldo = p->N; b.residual = nullptr;
-                {
-                    SmProfScope prof(SM_PROF_GEMM, st);
-                    if ((rc = launch_gemm256(b, p->act, bn, st))) return rc;
-                }
-                *ln_done = true;
-                return launch_ln_light(p->out_f32, p->ldo, prod, p->N, nullptr, p->M, p->N, p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, p->post_ln_out,
-                                       p->post_ln_ldo, a.f16, st);
-            }
-            int rc;
-            {
-                SmProfScope prof(SM_PROF_GEMM, st);
-                rc = launch_gemm256(a, p->act, bn, st);
-            }
-            if (rc || !light_ok) return rc;
-            *ln_done = true;
-            return launch_ln_light(p->out_f32, p->ldo, nullptr, 0, nullptr, p->M, p->N, p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, p->post_ln_out, p->post_ln_ldo,
-                                   a.f16, st);
+            SmProfScope prof(SM_PROF_GEMM, st);
+            return launch_gemm256(a, p->act, bn, st);
         }
     }
     SM_REQUIRE((a.KS & 1) == 0, "sm_linear: the 128x128 GEMM needs K padded to a multiple of 64 (K=%d)", p->K);

@@ -102,8 +102,5 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st);      // gemm256.hip (256 x bn tile; a.f16 selects the fp16 build)
 int launch_gemm_fp8(LinArgs& a, hipStream_t st);                            // gemm_fp8.hip (fp8 x fp8 MFMA, activations quantised per row)
 int splitk_workspace(hipStream_t st, size_t bytes, float** out);            // linear.hip: per-HIP-stream fp32 slabs of the split-K kernels
-// vecops.hip: 16-register row pass (x += prod; out = 16-bit LayerNorm(x)) that fits beside the GEMM blocks of another HIP stream
-int launch_ln_light(float* x, int ldx, const float* prod, int ldp, const float* bias, int M, int D, const float* gamma, const float* beta, float eps,
-                    void* out, int ldo, int f16, hipStream_t st);
 int launch_splitk_reduce(const LinArgs& a, const float* ws, int S, int ldw, hipStream_t st);     // ... their fixed-order sum + the real epilogue
 void release_stream_workspaces(hipStream_t st);                             // linear.hip: free the per-stream slabs of a stream about to be destroyed

@@ -195,95 +195,6 @@ __global__ __launch_bounds__(256) void norm_row_block_kernel(const float* __rest
     }
 }
 
-// ------------------------------------------------------------------------------------------------ "light" row pass
-// A 256 x 256 GEMM block (gemm256.hip) holds 2 x 248 of a SIMD's 512 vector registers and 128 of the CU's 160 KiB of LDS: no wave of
-// an ordinary kernel fits beside it, so with two tower lanes the HBM-bound row passes of one lane (residual add, LayerNorm) wait
-// for the other lane's GEMM blocks to LEAVE their CUs, and the matrix pipes idle while they run.  This kernel is built to fit INTO
-// the leftover: one-wave blocks, <= 16 VGPRs, no LDS -- the dispatcher places one on every SIMD that hosts a GEMM block, and
-// the row pass of lane A streams through HBM underneath lane B's k-loops (which use ~1.4 of the 8 TB/s).
-// The price of 16 registers: a row (D floats, lane owns columns lane*4 + j*256) cannot live in registers, so the pass walks it three
-// times -- sum (RES: x += prod + bias on the way, written back), centred sum of squares, normalise -- the re-reads hit L2.
-// Arithmetic: that of ln_row_stats / ln_apply (mean, then centred variance; contraction off), summation order differs from
-// norm_wave_fixed_kernel's by the j-loop only.
-// wave-wide sum in two VGPRs: DPP inside the 16-lane rows (xor 1, xor 2, rotate 4, rotate 8), then the row / half swaps
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));     // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));     // row_ror:8
-    return xor32_sum(xor16_sum(v));
-}
-template <bool RES>
-__global__ __launch_bounds__(64) void ln_light_kernel(float* __restrict__ x, int ldx, const float* __restrict__ prod, int ldp,
-                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps, bf16_t* __restrict__ out, int ldo,
-                                                      int D, float inv_d, int f16) {
-#pragma clang fp contract(off)
-    // every address is a wave-uniform base (SGPRs) + one 32-bit per-lane byte offset: no 64-bit pointers in VGPRs
-    char* const xr = (char*)(x + (size_t)blockIdx.x * ldx);
-    const uint32_t end = (uint32_t)D * 4u;
-    uint32_t off0 = threadIdx.x * 16u;
-    asm volatile("" : "+v"(off0));                 // opaque: the three passes re-derive their offsets from it instead of keeping copies alive
-    float s = 0.f;
-    if (RES) {
-        const char* const pr = (const char*)(prod + (size_t)blockIdx.x * ldp);
-#pragma unroll 1
-        for (uint32_t off = off0; off < end; off += 1024u) {
-            f32x4 v = *(const f32x4*)(xr + off);
-            v += *(const f32x4*)(pr + off);
-            if (bias) v += *(const f32x4*)((const char*)bias + off);
-            *(f32x4*)(xr + off) = v;
-            s += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the row is re-read below: the stores have left this wave
-    } else {
-#pragma unroll 1
-        for (uint32_t off = off0; off < end; off += 2048u) {
-            const f32x4 v0 = *(const f32x4*)(xr + off);
-            const f32x4 v1 = *(const f32x4*)(xr + off + 1024u);
-            s += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-        }
-    }
-    // mean and 1/std are wave-uniform: kept in SGPRs (as VGPR values hipcc splats each over four registers for packed math)
-    const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wave_sum_dpp(s) * inv_d)));
-    float q = 0.f;
-#pragma unroll 1
-    for (uint32_t off = off0; off < end; off += 2048u) {
-        const f32x4 v0 = *(const f32x4*)(xr + off);
-        const f32x4 v1 = *(const f32x4*)(xr + off + 1024u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v0[e] - mu; q = __builtin_fmaf(d, d, q); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v1[e] - mu; q = __builtin_fmaf(d, d, q); }
-    }
-    const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rsqrtf(__builtin_fmaf(wave_sum_dpp(q), inv_d, eps)))));
-    char* const orow = (char*)(out + (size_t)blockIdx.x * ldo);
-#pragma unroll 1
-    for (uint32_t off = off0; off < end; off += 1024u) {
-        f32x4 v = *(const f32x4*)(xr + off);
-        {
-            const f32x4 g = *(const f32x4*)((const char*)gamma + off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((v[e] - mu) * rstd) * g[e];
-        }
-        asm volatile("" : "+v"(v));                 // beta is loaded into the registers gamma has left (no 12-register peak)
-        const f32x4 b = *(const f32x4*)((const char*)beta + off);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
-        *(u32x2*)(orow + (off >> 1)) = u32x2{pack16_rt(v[0], v[1], f16), pack16_rt(v[2], v[3], f16)};
-    }
-}
-// x[m][:] (+= prod[m][:] + bias) and out[m][:] = 16-bit(LayerNorm(x[m][:])), D % 512 == 0; see ln_light_kernel
-int launch_ln_light(float* x, int ldx, const float* prod, int ldp, const float* bias, int M, int D, const float* gamma, const float* beta,
-                    float eps, void* out, int ldo, int f16, hipStream_t st) {
-    SM_REQUIRE(x && gamma && beta && out && M > 0 && D > 0 && (D & 511) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (!prod || (ldp & 3) == 0),
-               "ln_light: D %% 512 == 0, ldx / ldo / ldp %% 4 == 0");
-    if (prod) ln_light_kernel<true><<<M, 64, 0, st>>>(x, ldx, prod, ldp, bias, gamma, beta, eps, (bf16_t*)out, ldo, D, 1.0f / (float)D, f16);
-    else ln_light_kernel<false><<<M, 64, 0, st>>>(x, ldx, nullptr, 0, nullptr, gamma, beta, eps, (bf16_t*)out, ldo, D, 1.0f / (float)D, f16);
-    SM_LAUNCH_CHECK();
-    return SM_OK;
-}
-
 extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps,
                           int post_act, float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream) {
     SM_REQUIRE(x && gamma && (out_f32 || out_bf16), "sm_norm: null arg");

@@ -16,17 +16,8 @@ O=gpurun_out/${TAG:-$STEP}; mkdir -p $O
 case $STEP in
 barrier)      # device-side grid barrier in the price table's forms + the graph-replay boundary slope
   hipcc --offload-arch=gfx950 -O3 -o /tmp/gbx tools/experiments/grid_barrier_xcd_ubench.hip && timeout 300 /tmp/gbx | tee $O/grid_barrier_xcd_ubench.txt ;;
-light_tests)  # the tower tests with the light row pass in both modes
-  for L in 1 2; do SM_LIGHT=$L timeout 1500 python -m pytest tests/test_gpu_path.py tests/test_gpu_gemm256.py tests/test_gpu_ops.py -q -x -m gpu -k "full_size or lanes or vit or post_ln or gemm256" 2>&1 | tail -3 | sed "s/^/SM_LIGHT=$L /"; done | tee $O/light_tests.txt ;;
-light_ab)     # same-box A/B of the default schedule and the single-lane schedule, SM_LIGHT = 0 / 1 / 2, alternating
-  for i in 1 2; do for L in 0 1 2; do
-    SM_LIGHT=$L python bench.py $BENCH_FAST 2>/dev/null | line "default SM_LIGHT=$L"
-    SM_LIGHT=$L python bench.py $BENCH_FAST --batch 28 --no-pipeline 2>/dev/null | line "single-lane SM_LIGHT=$L"
-  done; done | tee $O/light_ab.txt ;;
-light_trace)  # kernel trace of the default schedule with the light pass: do the light kernels run UNDER the other lane's GEMMs?
-  for L in 0 2; do rm -rf /tmp/pl$L; SM_LIGHT=$L rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl$L -- python bench.py --steps 6 --warmup 2 $BENCH_FAST --no-prof > $O/trace_light$L.log 2>&1
-    cp "$(find /tmp/pl$L -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_light$L.csv; cp "$(find /tmp/pl$L -name '*kernel_trace.csv' | head -1)" /tmp/kt_light$L.csv
-    python tools/trace_overlap.py /tmp/kt_light$L.csv > $O/overlap_light$L.txt 2>&1; head -12 $O/kernel_stats_light$L.csv | cut -c1-150; cat $O/overlap_light$L.txt; done ;;
+cores)        # co-residency probe (needs tools/experiments/ln_light_coresident.patch applied): light vs ordinary LayerNorm beside a GEMM of another stream
+  for L in 1 0 1 0; do SM_NORM_LIGHT=$L timeout 600 python tools/coresidency_probe.py 2>&1 | grep -v Warning; done | tee $O/coresidency_probe.txt ;;
 tests)        timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee $O/pytest_gpu_tail.txt ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
