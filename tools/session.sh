@@ -19,6 +19,15 @@ barrier)      # device-side grid barrier in the price table's forms + the graph-
 cores)        # co-residency probe (needs tools/experiments/ln_light_coresident.patch applied): light vs ordinary LayerNorm beside a GEMM of another stream
   for L in 1 0 1 0; do SM_NORM_LIGHT=$L timeout 600 python tools/coresidency_probe.py 2>&1 | grep -v Warning; done | tee $O/coresidency_probe.txt ;;
 tests)        timeout 2700 python -m pytest tests -q -m gpu 2>&1 | tail -5 | tee $O/pytest_gpu_tail.txt ;;
+lnx)          # (needs tools/experiments/ln_exchange_epilogue.patch applied) fused LayerNorm in the 256 x 256 epilogue: operator tests, then same-box A/B of the bench (default schedule and single lane)
+  timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "post_ln" 2>&1 | tail -5 | tee $O/pytest_post_ln.txt
+  for L in 1 0 1 0; do
+    SM_GEMM_LNX=$L timeout 600 python bench.py $BENCH_FAST 2>/dev/null | line "default SM_GEMM_LNX=$L"
+    SM_GEMM_LNX=$L timeout 600 python bench.py $BENCH_FAST --batch 28 --no-pipeline 2>/dev/null | line "single-lane SM_GEMM_LNX=$L"
+  done | tee $O/lnx_ab.txt ;;
+lnxtl)        # (needs the same patch) phase timeline of the fused LayerNorm epilogue
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSM_GEMM_TIMELINE -Istreammind_amd/csrc -Iinclude tools/lnx_timeline.hip -o /tmp/lnxtl && for Z in 1 8 32; do echo "SM_LNX_POLL_SLEEPS=$Z"; SM_LNX_POLL_SLEEPS=$Z timeout 300 /tmp/lnxtl; done | tee $O/lnx_timeline.txt ;;
+graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
 esac
