@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libstreammind_hip.so")
 # A/B builds for tools/ (kernel variants compiled side by side): STREAMMIND_HIP_LIB=/path/to/other.so
 LIB_PATH = os.environ.get("STREAMMIND_HIP_LIB", LIB_PATH)
 
-SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU, SM_ACT_GELU = 0, 1, 2, 3, 4, 5
+SM_ACT_NONE, SM_ACT_QUICK_GELU, SM_ACT_LEAKY_RELU, SM_ACT_SOFTPLUS, SM_ACT_SILU, SM_ACT_GELU, SM_ACT_SWIGLU_DUAL = 0, 1, 2, 3, 4, 5, 6
 SM_X_BF16, SM_X_F32 = 0, 1
 SM_W_BF16, SM_W_FP8, SM_W_FP8_MFMA = 0, 1, 2
 SM_OP_BF16, SM_OP_F16 = 0, 1

@@ -180,6 +180,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int rgg = tile_n * 16 + wave * 2 + j;
+            // SwiGLU-dual: the tile's 16 row groups alternate gate / up groups of the SAME 128 output columns (w = [gate rows | up rows]),
+            // so fragments 2f and 2f + 1 of a wave hold gate and up of the same (row, column) in the same lane and register
+            if constexpr (ACT == SM_ACT_SWIGLU_DUAL) rgg = ((wave * 2 + j) & 1) * (a.NRG >> 1) + tile_n * 8 + ((wave * 2 + j) >> 1);
             if (rgg >= a.NRG) rgg = a.NRG - 1;
             wbase[j] = (const char*)a.w + (size_t)rgg * KS * 1024;
             const int row = (wave * 2 + j) * 16 + (lane >> 2);
@@ -372,7 +375,47 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     const bool vt_tile = a.vt && tile_n * BN >= a.vt_n0;
     const bool fast = ACT >= 0 && a.remap_in == 0 && (tile_n + 1) * BN <= a.N && (a.ldo & 3) == 0 && (a.ldo_bf16 & 3) == 0 &&
                       (a.ldr & 3) == 0;
-    if constexpr (WN == 2 && ACT >= 0) {
+    if constexpr (WN == 2 && ACT == SM_ACT_SWIGLU_DUAL) {
+        // out_bf16[m][tile_n * 128 + c] = 16-bit(silu(gate + b_g) * (up + b_u)): in-lane (fragments 2f / 2f + 1), the 256 x 128 tile staged
+        // as 16-bit ([256 m][128 n], 256-byte rows, 16-byte chunk index XOR (m & 15)) and written 16 B per lane.  The launcher guarantees
+        // full column tiles, 16-byte aligned rows and no other output.
+        static_assert(!M32, "SwiGLU-dual epilogue: 16x16x32 accumulators");
+        const int F = a.N >> 1;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int nl = wn * 64 + f * 16 + g * 4;
+            f32x4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
+            if (a.bias) { bg = *(const f32x4*)(a.bias + tile_n * 128 + nl); bu = *(const f32x4*)(a.bias + F + tile_n * 128 + nl); }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int ml = wm * 64 + mb * 16 + i;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = siluf_(acc[2 * f][mb][j] + bg[j]) * (acc[2 * f + 1][mb][j] + bu[j]);
+                *(u32x2*)(smem + ml * 256 + (((nl >> 3) ^ (ml & 15)) * 16) + (nl & 4) * 2) = u32x2{pack16<F16>(o[0], o[1]), pack16<F16>(o[2], o[3])};
+            }
+        }
+        __syncthreads();
+        TL(3);
+        bf16_t* const __restrict__ ob = a.out_bf16;
+        const int chunk = tid & 15;
+#pragma unroll
+        for (int p0 = 0; p0 < 8; p0 += 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ml = (p0 + u) * 32 + (tid >> 4);
+                v[u] = *(const u32x4*)(smem + ml * 256 + ((chunk ^ (ml & 15)) * 16));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = tile_m * G2_BM + (p0 + u) * 32 + (tid >> 4);
+                if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + tile_n * 128 + chunk * 8, v[u]);
+            }
+        }
+        TL(4);
+        return;
+    } else if constexpr (WN == 2 && ACT >= 0) {
         // bf16-only outputs (qkv, fc1): bias + activation in registers, the WHOLE tile staged as bf16 ([256 m][256 n], 512-byte
         // rows, 16-byte chunk index XOR (m & 31)) and written with 16 B per lane (two whole rows per wave-store): half the
         // store instructions and LDS bytes of the fp32 staging below -- 8-byte stores ran at ~4.7 B/clk/CU, store-issue-bound.
@@ -575,6 +618,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int rgg = tile_n * 16 + wave * 2 + j;
+            if constexpr (ACT == SM_ACT_SWIGLU_DUAL) rgg = ((wave * 2 + j) & 1) * (a.NRG >> 1) + tile_n * 8 + ((wave * 2 + j) >> 1);      // gate / up groups alternate (gemm256_kernel)
             if (rgg >= a.NRG) rgg = a.NRG - 1;
             t.wbase[j] = (const char*)a.w + (size_t)rgg * KS * 1024;
             const int row = (wave * 2 + j) * 16 + (lane >> 2);
@@ -690,7 +734,26 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));
         const int lane_e = tid_e & 63, i_e = lane_e & 15, g_e = lane_e >> 4;
-        uint32_t pk[8][4][2];
+        constexpr bool DUAL = ACT == SM_ACT_SWIGLU_DUAL;      // SwiGLU-dual: fragments 2f / 2f + 1 are gate / up of the same 16 columns -> 4 output fragments per wave
+        constexpr int NPK = DUAL ? 4 : 8, OBN = DUAL ? 128 : 256;
+        uint32_t pk[NPK][4][2];
+        if constexpr (DUAL) {
+            const int F = a.N >> 1;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int nl = wn * 64 + f * 16 + g_e * 4;
+                f32x4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
+                if (a.bias) { bg = *(const f32x4*)(a.bias + cur.tile_n * 128 + nl); bu = *(const f32x4*)(a.bias + F + cur.tile_n * 128 + nl); }
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = siluf_(acc[2 * f][mf][j] + bg[j]) * (acc[2 * f + 1][mf][j] + bu[j]);
+                    pk[f][mf][0] = pack16<F16>(o[0], o[1]);
+                    pk[f][mf][1] = pack16<F16>(o[2], o[3]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int nf = 0; nf < 8; ++nf) {
             const int nl = wn * 128 + nf * 16 + g_e * 4;
@@ -709,6 +772,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
                 pk[nf][mf][1] = pack16<F16>(o[2], o[3]);
             }
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- window passes: pass qn moves columns [32 qn, 32 qn + 32) of both 128-column halves (fragments 2 qn, 2 qn + 1 of
@@ -717,7 +781,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         char* const win = smem + WINDOW;
         bf16_t* const __restrict__ ob = a.out_bf16;
 #pragma unroll
-        for (int qn = 0; qn < 4; ++qn) {
+        for (int qn = 0; qn < NPK / 2; ++qn) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -737,10 +801,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
                 const int row = id >> 3, c = id & 7;
                 const u32x4 v = *(const u32x4*)(win + row * 128 + ((c ^ ((row >> 1) & 7)) * 16));
                 const int m = cur.tile_m * G2_BM + row;
-                const int n = cur.tile_n * BN + (c >> 2) * 128 + qn * 32 + (c & 3) * 8;
+                const int n = cur.tile_n * OBN + (c >> 2) * (OBN / 2) + qn * 32 + (c & 3) * 8;
                 if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + n, v);
             }
-            if (qn < 3) {                                           // the window is free again (the reads were consumed by the stores)
+            if (qn < NPK / 2 - 1) {                                           // the window is free again (the reads were consumed by the stores)
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -759,9 +823,11 @@ template <int WN, bool F16>
 static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persistent = true) {
     constexpr int BN = 128 * WN;
     constexpr int LDS = WN == 2 ? 4 * 32768 : 3 * (BN * 64 + 16384);
-    const int tiles_m = cdiv(a.M, G2_BM), tiles_n = cdiv(a.N, BN);
+    const bool dual = act == SM_ACT_SWIGLU_DUAL;                 // tiles of 256 weight rows = 128 gate + 128 up rows -> 128 output columns (WN == 2 only: launch_gemm256 checks)
+    const int tiles_m = cdiv(a.M, G2_BM), tiles_n = dual ? (a.N >> 1) / 128 : cdiv(a.N, BN);
     static bool attr_set = false;
     if (!attr_set) {
+        if constexpr (WN == 2) SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<SM_ACT_SWIGLU_DUAL, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -791,16 +857,25 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
             if (!attr_p) {
                 SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<0, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
                 SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<1, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+                SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<SM_ACT_SWIGLU_DUAL, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
                 attr_p = true;
             }
         }
         const bool bf16_only = a.out_bf16 && !a.out_f32 && !a.residual && !a.vt && a.remap_in == 0 && (a.ldo_bf16 & 7) == 0 &&
-                               ((uintptr_t)a.out_bf16 & 15) == 0 && (a.N % BN) == 0 && (act == SM_ACT_NONE || act == SM_ACT_QUICK_GELU);
+                               ((uintptr_t)a.out_bf16 & 15) == 0 && (a.N % BN) == 0 && (act == SM_ACT_NONE || act == SM_ACT_QUICK_GELU || dual);
         if (persist && allow_persistent && bf16_only && n_cu >= 8 && (n_cu & 7) == 0 && (nblk & 7) == 0 && nblk > n_cu && (a.KS & 3) == 0 && a.KS >= 8 &&
             (cb == 0 || (nblk >> 3) % tiles_n == 0)) {
             const dim3 pgrid(n_cu);
             if (act == SM_ACT_NONE) gemm256p_kernel<0, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            else if (dual) gemm256p_kernel<SM_ACT_SWIGLU_DUAL, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
             else gemm256p_kernel<1, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            SM_LAUNCH_CHECK();
+            return SM_OK;
+        }
+    }
+    if constexpr (WN == 2) {
+        if (dual) {
+            gemm256_kernel<SM_ACT_SWIGLU_DUAL, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
             SM_LAUNCH_CHECK();
             return SM_OK;
         }

@@ -1156,6 +1156,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_norm_rows_kernel(LinArgs a
 #include <mutex>
 static std::mutex g_ws_mu;
 static std::map<hipStream_t, std::pair<float*, size_t>> g_ws;
+static std::map<hipStream_t, std::pair<float*, size_t>> g_dual_ws;      // fp32 gate | up rows of SwiGLU-dual calls outside the 256 x 256 kernel (sm_linear)
 int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     auto& e = g_ws[st];
@@ -1183,6 +1184,8 @@ void release_stream_workspaces(hipStream_t st) {
         std::lock_guard<std::mutex> lk(g_ws_mu);
         auto w = g_ws.find(st);
         if (w != g_ws.end()) { if (w->second.first) (void)hipFree(w->second.first); g_ws.erase(w); }
+        auto dw = g_dual_ws.find(st);
+        if (dw != g_dual_ws.end()) { if (dw->second.first) (void)hipFree(dw->second.first); g_dual_ws.erase(dw); }
         for (auto& dq : g_dq) {
             auto d = dq.find(st);
             if (d != dq.end()) { if (d->second.first) (void)hipFree(d->second.first); dq.erase(d); }
@@ -1486,8 +1489,59 @@ int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) 
 extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
                           float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);                        // vecops.hip
 static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done);
+int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);           // vecops.hip
+// fp32 [M][2F] gate | up rows of an SM_ACT_SWIGLU_DUAL call that does not run on the 256 x 256 kernel (per HIP stream, grown on demand; not the
+// split-K slabs: the product itself may use those)
+static int dual_workspace(hipStream_t st, size_t bytes, float** out) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto& e = g_dual_ws[st];
+    if (e.second < bytes) {
+        if (e.first) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+        SM_HIP(hipMalloc((void**)&e.first, bytes));
+        e.second = bytes;
+    }
+    *out = e.first;
+    return SM_OK;
+}
+// the tile rule of the LDS-tiled GEMM (linear_impl): 0 = 128 x 128, 256 / 257 = 256 x 256 (257: never persistent), 128 = 256 x 128
+static int gemm_tile_choice(const sm_linear_t* p) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("SM_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
+    const bool ok = !p->vt || p->vt_n0 % 256 == 0;
+    int bn = (ok && t256 >= 192) ? 256 : 0;
+    const int hint = p->tile_hint ? p->tile_hint : force;
+    if (hint == 128) bn = 0;
+    if (hint == 256128 && ok) bn = 128;
+    if (hint == 256 && ok) bn = 256;
+    if (hint == 2561 && ok) bn = 257;
+    return bn;
+}
 extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p, "sm_linear: null args");
+    if (p->act == SM_ACT_SWIGLU_DUAL) {
+        const int F = p->N >> 1;
+        SM_REQUIRE(p->M > 32 && p->x_dtype == SM_X_BF16 && p->out_bf16 && !p->out_f32 && !p->residual && !p->vt && !p->w2 && p->remap_in == 0 && !p->post_ln_gamma &&
+                   !p->norm_gamma && (p->N & 255) == 0 && p->ldo_bf16 >= F,
+                   "sm_linear: SM_ACT_SWIGLU_DUAL needs M > 32, 16-bit x, one [gate | up] weight image with N %% 256 == 0 and a 16-bit output [M][ldo_bf16 >= N / 2] only");
+        static int dual_fuse = -1;                    // SM_SWIGLU_FUSE=0: always the product + the SwiGLU pass (A/B)
+        if (dual_fuse < 0) { const char* e = getenv("SM_SWIGLU_FUSE"); dual_fuse = e ? atoi(e) : 1; }
+        const int bn = gemm_tile_choice(p);
+        const bool w8 = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
+        const bool fp8_mfma = p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && (p->ldx & 7) == 0;
+        const bool fused = dual_fuse && (bn == 256 || bn == 257) && !fp8_mfma && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0 && (!w8 || p->w_scale);
+        if (!fused) {
+            SM_REQUIRE(p->ldo_bf16 == F, "sm_linear: SM_ACT_SWIGLU_DUAL outside the 256 x 256 kernel writes a dense [M][N / 2] output (ldo_bf16=%d)", p->ldo_bf16);
+            float* ws = nullptr;
+            int rc = dual_workspace((hipStream_t)stream, (size_t)p->M * p->N * sizeof(float), &ws);
+            if (rc) return rc;
+            sm_linear_t q = *p;
+            q.act = SM_ACT_NONE; q.out_bf16 = nullptr; q.out_f32 = ws; q.ldo = p->N;
+            bool dummy = false;
+            if ((rc = linear_impl(&q, stream, &dummy))) return rc;
+            return sm_swiglu_ex(ws, p->M, F, p->out_bf16, p->op_dtype == SM_OP_F16 ? 1 : 0, stream);
+        }
+    }
     if (p->post_ln_gamma)
         SM_REQUIRE((p->post_ln_out || p->post_ln_out_f32) && p->out_f32 && !p->out_bf16 && p->remap_in == 0 && !p->vt && !p->w2 && p->post_ln_ldo >= p->N && (p->post_ln_ldo & 3) == 0,
                    "sm_linear: post-norm needs gamma, an output [M][post_ln_ldo >= N, %% 4 == 0] (16-bit and / or fp32), an fp32 product output (out_bf16 is not written by the fused "
@@ -1615,16 +1669,8 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // else 128x128 (two blocks per CU); SM_GEMM_TILE=128|256128|256 overrides (tools/gemm_bench.py).  Measured on the
     // ViT shapes: B=28 frames (M=16156) 739 vs 706 TFLOP/s, B=14 565 vs 654 -> the threshold.
     {
-        static int force = -1;
-        if (force < 0) { const char* e = getenv("SM_GEMM_TILE"); force = e ? atoi(e) : 0; }
-        const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
-        const bool ok = !p->vt || p->vt_n0 % 256 == 0;
-        int bn = (ok && t256 >= 192) ? 256 : 0;
-        const int hint = p->tile_hint ? p->tile_hint : force;
-        if (hint == 128) bn = 0;
-        if (hint == 256128 && ok) bn = 128;
-        if (hint == 256 && ok) bn = 256;
-        if (hint == 2561 && ok) bn = 257;
+        const int bn = gemm_tile_choice(p);
+        SM_REQUIRE(p->act != SM_ACT_SWIGLU_DUAL || bn == 256 || bn == 257, "sm_linear: internal: SwiGLU-dual outside the 256 x 256 kernel");
         if (bn) {
             SmProfScope prof(SM_PROF_GEMM, st);
             return launch_gemm256(a, p->act, bn, st);

@@ -776,7 +776,7 @@ struct sm_stream {
     ConnScratch w;
     // LLM
     std::vector<DevBuf> kc, vtc;
-    DevBuf emb, xnb, qkvf, qb, ctxb, guf, actb, lmlog, next_tok, attn_ws;
+    DevBuf emb, xnb, qkvf, qb, ctxb, actb, lmlog, next_tok, attn_ws;
     int chunk = 0;
     // pipelined perception (sm_stream_push_frames_pipelined): the connector + gate pass of call i runs on this stream's own
     // side HIP stream while the caller's stream already runs the tower of call i+1
@@ -830,7 +830,7 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
         const size_t ch = s->chunk;
         A(emb, ch * ld * 4, false); A(xnb, ch * ld * 2, false);
         A(qkvf, ch * (qn + 2 * kn) * 4, false); A(qb, ch * qn * 2, false); A(ctxb, ch * qn * 2, false);
-        A(guf, ch * 2 * c.llm_mlp * 4, false); A(actb, ch * c.llm_mlp * 2, false);
+        A(actb, ch * c.llm_mlp * 2, false);
         A(lmlog, (size_t)c.llm_vocab * 4, false); A(next_tok, 64, true);
         A(attn_ws, (size_t)SM_DECODE_SPLITS * c.llm_heads * (dh + 2) * 4, false);
         if (!rc && m->rope_len < max_seq) {
@@ -1212,10 +1212,13 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
             a.out_bf16 = s->actb.p; a.ldo_bf16 = c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
         } else {
+            // prefill chunks / teacher-forced rows: act_fn(gate) * up in the epilogue of the gate | up product where the 256 x 256 kernel runs it (>= 192 tiles:
+            // gate and up fragments of a column meet in one lane, 16-bit rows out: no fp32 [n][2 mlp] round trip, no SwiGLU launch); below that
+            // sm_linear runs the product into its own fp32 scratch + the SwiGLU pass, as before
             sm_linear_t a = lin(m, *w.gu, s->xnb.p, SM_X_BF16, n, ld);
-            a.out_f32 = s->guf.as<float>(); a.ldo = 2 * c.llm_mlp;
+            a.act = SM_ACT_SWIGLU_DUAL;
+            a.out_bf16 = s->actb.p; a.ldo_bf16 = c.llm_mlp;
             if ((rc = sm_linear(&a, stream))) return rc;
-            if ((rc = sm_swiglu_ex(s->guf.as<float>(), n, c.llm_mlp, s->actb.p, f16, stream))) return rc;
         }
         {   sm_linear_t a = lin(m, *w.down, s->actb.p, SM_X_BF16, n, c.llm_mlp);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;

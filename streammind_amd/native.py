@@ -473,7 +473,7 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
             a.out_bf16, a.ldo_bf16 = out16.data_ptr(), N
     else:
         assert out16 is None
-        a.out_bf16, a.ldo_bf16 = out.data_ptr(), N
+        a.out_bf16, a.ldo_bf16 = out.data_ptr(), out.shape[1]      # SM_ACT_SWIGLU_DUAL: the caller's [M][N / 2] buffer
     if post_ln is not None:
         g, b, eps, ln_out = post_ln
         assert out_dtype == torch.float32 and ln_out.shape == out.shape and ln_out.is_contiguous()

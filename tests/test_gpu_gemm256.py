@@ -210,3 +210,35 @@ def test_vit_attention_fp16_28_frames(nat):
     e = torch.exp(s - s.max(-1, keepdim=True).values)
     ref = ((e.half().float() @ v) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B * S, D)
     assert relerr(ctx, ref) < 1e-3
+
+
+@pytest.mark.parametrize("M,F,K,f16,bias", [(2048, 3072, 1024, False, False), (2304, 4096, 4096, False, False), (2304, 4096, 1024, True, True), (2000, 3584, 512, False, True),
+                                            (328, 14336, 4096, False, False), (200, 1024, 512, False, False)])
+def test_swiglu_dual_epilogue(M, F, K, f16, bias):
+    """SM_ACT_SWIGLU_DUAL (round 5): MistralMLP's act_fn(gate_proj(x)) * up_proj(x) (transformers MistralMLP.forward, the reference's LLM:
+    videollama2_mistral.py:426-431 -> HF generate) in the EPILOGUE of the fused gate | up product -- the 256 x 256 kernel stages gate and up row groups
+    alternately, so both values of an output element sit in one lane.  One-tile kernel (192 tiles), persistent kernel (288 tiles), ragged last row
+    tile, fp16 operands, bias; (200 rows: the 128 x 128 kernel + the SwiGLU pass inside sm_linear).  The fused rows must equal the unfused arithmetic
+    (fp32 product -> silu(g) * u -> 16 bits) BIT FOR BIT, and that is the fp64 value to 16-bit rounding."""
+    from streammind_amd import native
+    from streammind_amd._lib import SM_ACT_SWIGLU_DUAL
+    dt = torch.float16 if f16 else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(2 * F, K, generator=g) * K ** -0.5).to(dt)
+    x = torch.randn(M, K, generator=g).to(dt)
+    b = (torch.randn(2 * F, generator=g) * 0.1) if bias else None
+    wp = native.pack_weight(w.cuda())
+    xg, bg = x.cuda(), (b.cuda() if bias else None)
+    out = torch.empty(M, F, device="cuda", dtype=dt)
+    native.linear(xg, wp, 2 * F, K, bias=bg, act=SM_ACT_SWIGLU_DUAL, out=out)
+    gu = native.linear(xg, wp, 2 * F, K, bias=bg)                      # the same product as fp32 rows
+    want = (torch.nn.functional.silu(gu[:, :F]) * gu[:, F:])
+    ref64 = (x.double() @ w.double().t() + (b.double() if bias else 0))
+    ref = (torch.nn.functional.silu(ref64[:, :F]) * ref64[:, F:]).float()
+    scale = ref.abs().max().item()
+    assert (out.float().cpu() - ref).abs().max().item() < (2e-3 if f16 else 1.2e-2) * scale
+    # silu on the device is v_exp + v_rcp (1 ulp each), torch's is expf-based: compare against the library's own unfused route bit for bit instead
+    unf = torch.empty(M, F, device="cuda", dtype=dt)
+    native.linear(xg, wp, 2 * F, K, bias=bg, act=SM_ACT_SWIGLU_DUAL, out=unf, tile_hint=128)
+    assert torch.equal(out, unf)
+    assert (unf.float() - want).abs().max().item() < (2e-3 if f16 else 1.2e-2) * scale

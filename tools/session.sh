@@ -27,6 +27,15 @@ lnx)          # (needs tools/experiments/ln_exchange_epilogue.patch applied) fus
   done | tee $O/lnx_ab.txt ;;
 lnxtl)        # (needs the same patch) phase timeline of the fused LayerNorm epilogue
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSM_GEMM_TIMELINE -Istreammind_amd/csrc -Iinclude tools/lnx_timeline.hip -o /tmp/lnxtl && for Z in 1 8 32; do echo "SM_LNX_POLL_SLEEPS=$Z"; SM_LNX_POLL_SLEEPS=$Z timeout 300 /tmp/lnxtl; done | tee $O/lnx_timeline.txt ;;
+gdtrace)      # kernel trace of the grouped decode step at $GD streams (default 128) -> per-kernel us per step
+  rm -rf /tmp/prof_gd; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gd -- python tools/group_decode_bench.py ${GD:-128} > $O/gd_profiled.log 2>&1
+  cp "$(find /tmp/prof_gd -name '*kernel_stats.csv' | head -1)" $O/group_decode${GD:-128}_kernel_stats.csv; tail -2 $O/gd_profiled.log; head -25 $O/group_decode${GD:-128}_kernel_stats.csv | cut -c1-200 ;;
+pftrace)      # kernel trace of a 2048-token prefill (bf16, then fp8 x fp8): tools/prefill_breakdown.py
+  rm -rf /tmp/prof_pf; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_pf -- python tools/decode_bench.py 8 4096 1976 > $O/pf_profiled.log 2>&1
+  python tools/prefill_breakdown.py /tmp/prof_pf | tee $O/prefill2048_breakdown.txt ;;
+dual)         # SwiGLU-dual epilogue: operator test, LLM parity tests, prefill A/B
+  timeout 900 python -m pytest tests/test_gpu_gemm256.py -q -x -k "swiglu" 2>&1 | tail -4
+  for L in 1 0 1 0; do SM_SWIGLU_FUSE=$L timeout 600 python tools/decode_bench.py 8 4096 1976 2>&1 | grep -o "prefill_ms[^,]*, .prefill_tokens_per_s[^,]*" | sed "s/^/SM_SWIGLU_FUSE=$L /"; done | tee $O/dual_ab.txt ;;
 graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
