@@ -167,7 +167,11 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         //        batches of t+2 and t+3 may stay in flight); group 0 first reads step t+1 in interval 2t+2, which opens with
         //        the barrier group 1 reaches from its R(t) with that wait behind it.
         constexpr int STAGE = 32768;
-        const int KS = a.KS;
+        // split-K (gridDim.y slabs; round 5: the N = 4096 products of an LLM prefill chunk leave 64..128 tiles for 256 CUs): slab y multiplies
+        // k-steps [y KS / S, (y + 1) KS / S) and leaves its raw accumulators in out_f32 + y M ldo (the launcher points out_f32 at the slabs, no
+        // bias / residual); a.KS stays the row-group stride of the packed weights
+        const int KS = a.KS / (int)gridDim.y;
+        const int k0 = (int)blockIdx.y * KS;
         // Staging sources as a wave-uniform 64-bit base (scalar registers, advanced on the scalar unit) plus a 32-bit per-lane
         // offset that is fixed for the whole tile: no vector arithmetic per DMA piece.  VALU instructions of the wave that is
         // in its R interval are not free for the OTHER wave of the SIMD: on gfx950 they do not overlap with its MFMAs
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
         // pointers cost came straight out of the M interval (32 MFMAs measured at ~20 clk each instead of 16-17).
         const char* wbase[2];
         const uint32_t woff = lane * 16;
-        const char* const xbase = (const char*)a.x + (size_t)tile_m * G2_BM * a.ldx * 2;
+        const char* const xbase = (const char*)a.x + (size_t)tile_m * G2_BM * a.ldx * 2 + (size_t)k0 * 64;
         uint32_t xoff[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
             // so fragments 2f and 2f + 1 of a wave hold gate and up of the same (row, column) in the same lane and register
             if constexpr (ACT == SM_ACT_SWIGLU_DUAL) rgg = ((wave * 2 + j) & 1) * (a.NRG >> 1) + tile_n * 8 + ((wave * 2 + j) >> 1);
             if (rgg >= a.NRG) rgg = a.NRG - 1;
-            wbase[j] = (const char*)a.w + (size_t)rgg * KS * 1024;
+            wbase[j] = (const char*)a.w + ((size_t)rgg * a.KS + k0) * 1024;
             const int row = (wave * 2 + j) * 16 + (lane >> 2);
             int rl = row;
             if (tile_m * G2_BM + row >= a.M) rl = a.M - 1 - tile_m * G2_BM;
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
     }
     __syncthreads();       // every wave is done reading the staging buffers before the epilogue reuses them
     TL(2);
+    if constexpr (WN == 2) a.out_f32 += (size_t)blockIdx.y * a.M * a.ldo;       // split-K slab of this block (gridDim.y == 1: nothing)
 
     // ---- epilogue in two 128-row halves: waves wm = 2h, 2h+1 stage their accumulators ([128 m][BN n] fp32, 16-byte
     // chunk index XOR (m & 31)), then all waves write whole rows.
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
 }
 
 template <int WN, bool F16>
-static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persistent = true) {
+static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persistent = true, int S = 1) {
     constexpr int BN = 128 * WN;
     constexpr int LDS = WN == 2 ? 4 * 32768 : 3 * (BN * 64 + 16384);
     const bool dual = act == SM_ACT_SWIGLU_DUAL;                 // tiles of 256 weight rows = 128 gate + 128 up rows -> 128 output columns (WN == 2 only: launch_gemm256 checks)
@@ -833,7 +838,8 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
-    const dim3 grid(tiles_m * tiles_n);
+    const dim3 grid(tiles_m * tiles_n, S);              // S > 1 (WN == 2, one-tile kernel only): split-K slabs, see the kernel
+    if (S > 1) allow_persistent = false;
     // blocked tile walk: the XCD's band is walked in SM_GEMM_CG column groups (0 = plain row-major walk; default 3, or the next smaller count that divides the column tiles); needs whole
     // bands per XCD and a group count that divides the column tiles
     static int cg_env = -1;
@@ -889,8 +895,9 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
 
 // bn = 256: one 8-wave block per CU; bn = 128: two independent 4-wave blocks per CU (their phases drift apart, so one
 // block's barriers / epilogue overlap the other's MFMAs)
-int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st) {
+int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st, int S) {
     const bool np = bn == 257;                    // SM_TILE_256_ONE_TILE_PER_BLOCK: never the persistent variant (tests, A/B)
-    if (a.f16) return bn == 128 ? launch_wn<1, true>(a, act, st) : launch_wn<2, true>(a, act, st, !np);
-    return bn == 128 ? launch_wn<1, false>(a, act, st) : launch_wn<2, false>(a, act, st, !np);
+    if (S > 1 && (bn == 128 || act != SM_ACT_NONE || !a.out_f32 || a.out_bf16 || a.residual || a.bias || a.vt || a.remap_in || a.KS % S)) return SM_EINVAL;
+    if (a.f16) return bn == 128 ? launch_wn<1, true>(a, act, st) : launch_wn<2, true>(a, act, st, !np, S);
+    return bn == 128 ? launch_wn<1, false>(a, act, st) : launch_wn<2, false>(a, act, st, !np, S);
 }

@@ -1040,7 +1040,6 @@ __global__ void splitk_reduce_kernel(LinArgs a, const float* __restrict__ ws, co
 // then the sum of squared deviations, in registers), and the slab sum / bias / residual order of splitk_reduce_kernel + store4: the
 // two outputs are bit for bit what the two separate launches wrote.  Replaces two dependent launches (~5 us of fixed cost each at
 // this size) and the re-read of the row by one.
-struct PostLn { const float* gamma; const float* beta; float eps; bf16_t* out; int ldo; float* out_f32; int act; };
 template <int NV>
 __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(LinArgs a, const float* __restrict__ ws, int S, int ldw, PostLn ln) {
     constexpr int D = NV * 256;
@@ -1108,13 +1107,21 @@ __global__ __launch_bounds__(1024) void splitk_reduce_norm_rows_kernel(LinArgs a
             if (s0 + u < S) acc += t[u];
     }
     f32x4 v;
+    // bias / residual / row scales as 16-byte loads (c is a multiple of 4; the residual row needs ldr % 4 == 0, which every caller of this pass
+    // guarantees -- checked here so that an odd stride still takes the element loads): at 2048 rows (prefill chunks) the four element loads per
+    // operand made this pass 39 us for 151 MB
+    const bool vec = (a.ldr & 3) == 0;
+    f32x4 r4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0}, s4 = {1.f, 1.f, 1.f, 1.f};
+    if (a.residual && vec) r4 = *(const f32x4*)(a.residual + (size_t)m * a.ldr + c);
+    if (a.bias) b4 = *(const f32x4*)(a.bias + c);
+    if (a.wscale) s4 = *(const f32x4*)(a.wscale + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float t = acc[e];
-        if (a.wscale) t *= a.wscale[c + e];
-        if (a.bias) t += a.bias[c + e];
-        t = apply_act_rt(t, a.act);
-        if (a.residual) t += a.residual[(size_t)m * a.ldr + c + e];
+        if (a.wscale) t *= s4[e];
+        if (a.bias) t += b4[e];
+        if (a.act != SM_ACT_NONE) t = apply_act_rt(t, a.act);           // (a real call: not for the plain case)
+        if (a.residual) t += vec ? r4[e] : a.residual[(size_t)m * a.ldr + c + e];
         v[e] = t;
     }
     if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + c) = v;
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_norm_rows_kernel(LinArgs a
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float t = ln.beta ? (v[e] - mu) * rstd * gm[e] + bt[e] : gm[e] * (v[e] * rstd);
-        o[e] = apply_act_rt(t, ln.act);
+        o[e] = ln.act != SM_ACT_NONE ? apply_act_rt(t, ln.act) : t;
     }
     if (ln.out_f32) *(f32x4*)(ln.out_f32 + (size_t)m * ln.ldo + c) = o;
     if (ln.out) *(u32x2*)(ln.out + (size_t)m * ln.ldo + c) = u32x2{pack16_rt(o[0], o[1], a.f16), pack16_rt(o[2], o[3], a.f16)};
@@ -1504,9 +1511,10 @@ static int dual_workspace(hipStream_t st, size_t bytes, float** out) {
     return SM_OK;
 }
 // the tile rule of the LDS-tiled GEMM (linear_impl): 0 = 128 x 128, 256 / 257 = 256 x 256 (257: never persistent), 128 = 256 x 128
-static int gemm_tile_choice(const sm_linear_t* p) {
+static int gemm_tile_choice(const sm_linear_t* p, int* hint_out = nullptr) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("SM_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (hint_out) *hint_out = p->tile_hint ? p->tile_hint : force;
     const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
     const bool ok = !p->vt || p->vt_n0 % 256 == 0;
     int bn = (ok && t256 >= 192) ? 256 : 0;
@@ -1669,8 +1677,39 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // else 128x128 (two blocks per CU); SM_GEMM_TILE=128|256128|256 overrides (tools/gemm_bench.py).  Measured on the
     // ViT shapes: B=28 frames (M=16156) 739 vs 706 TFLOP/s, B=14 565 vs 654 -> the threshold.
     {
-        const int bn = gemm_tile_choice(p);
+        int hint = 0;
+        const int bn = gemm_tile_choice(p, &hint);
         SM_REQUIRE(p->act != SM_ACT_SWIGLU_DUAL || bn == 256 || bn == 257, "sm_linear: internal: SwiGLU-dual outside the 256 x 256 kernel");
+        // 64..128 tiles of 256 x 256 with a long K loop and wide rows (the o / down products of an LLM prefill chunk: M = 1024..2048, N = 4096): split-K
+        // slabs on the 256 x 256 kernel so that every CU multiplies (2048 rows, same box: down 275 -> ~215 us, o 85 -> ~77 us against the 128 x 128
+        // kernel's 512 tiles), then ONE pass sums the slabs in slab order, applies bias / activation / residual and -- when the call carries one
+        // -- the RMSNorm / LayerNorm of the finished row (sm_linear_t.post_ln_*).  SM_GEMM256_SPLITK=0: off (A/B)
+        static int sk256 = -1;
+        if (sk256 < 0) { const char* e = getenv("SM_GEMM256_SPLITK"); sk256 = e ? atoi(e) : 1; }
+        const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
+        if (sk256 && bn == 0 && hint == 0 && t256 >= 64 && t256 <= 128 && p->N >= 2048 && (p->N & 255) == 0 && p->K >= 4096 && p->out_f32 && !p->out_bf16 && !p->vt &&
+            p->remap_in == 0 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) && !a.wscale) {
+            int S = 256 / t256;
+            if (S > 4) S = 4;
+            while (S > 1 && a.KS % S) --S;
+            if (S >= 2) {
+                float* ws = nullptr;
+                int rc = splitk_workspace(st, (size_t)S * p->M * p->N * sizeof(float), &ws);
+                if (rc) return rc;
+                LinArgs b = a;
+                b.out_f32 = ws; b.ldo = p->N; b.out_bf16 = nullptr; b.bias = nullptr; b.residual = nullptr; b.act = SM_ACT_NONE;
+                {   SmProfScope prof(SM_PROF_GEMM, st);
+                    if ((rc = launch_gemm256(b, SM_ACT_NONE, 256, st, S))) return rc; }
+                if (p->post_ln_gamma && p->N <= 4096) {
+                    const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+                    splitk_reduce_norm_rows_kernel<<<p->M, p->N / 4, 0, st>>>(a, ws, S, ln);
+                    SM_LAUNCH_CHECK();
+                    *ln_done = true;
+                    return SM_OK;
+                }
+                return launch_splitk_reduce(a, ws, S, p->N, st);
+            }
+        }
         if (bn) {
             SmProfScope prof(SM_PROF_GEMM, st);
             return launch_gemm256(a, p->act, bn, st);

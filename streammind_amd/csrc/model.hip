@@ -1178,7 +1178,11 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         const sm_model::LayerW& w = m->R.llm[l];
         // decode (one row): both RMSNorms ride inside the weight-streaming products that consume them
         const bool fuse_norm = n == 1 && (ld & 31) == 0 && !g_no_fused_norm;
-        if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
+        // chunks of rows (prefill, teacher-forced evaluation): the RMSNorms ride BEHIND the residual products (sm_linear_t.post_ln_*: o_proj leaves
+        // ln2(x), down_proj the next layer's ln1(x) as the 16-bit operand s->xnb) -- one pass with the slab sum where the product runs as split-K
+        // slabs (2048 rows: the 256 x 256 kernel's N = 4096 shapes), the same sm_norm_ex launch as before everywhere else.  Only layer 0's ln1 is a
+        // call of its own.
+        if (!fuse_norm && l == 0 && (rc = sm_norm_ex(x, n, ld, ld, w.ln1_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
         // decode: RoPE + KV append ride in the epilogue of the q/k/v product (no fp32 q/k/v round trip, one launch less per layer)
         const bool fuse_rope = fuse_norm && dh == 128 && ld >= 1024 && !g_no_fused_rope;
         {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, n, ld) : lin(m, *w.qkv, s->xnb.p, SM_X_BF16, n, ld);
@@ -1200,8 +1204,8 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         } else if ((rc = sm_llm_attention_ex(s->qb.p, s->kc[l].p, s->vtc[l].p, n, s->kv_len, H, KV, dh, s->max_seq, s->ctxb.p, f16, stream, c.llm_sliding_window))) return rc;
         {   sm_linear_t a = lin(m, *w.o, s->ctxb.p, SM_X_BF16, n, qn);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+            if (!fuse_norm) { a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = s->xnb.p; a.post_ln_ldo = ld; }
             if ((rc = sm_linear(&a, stream))) return rc; }
-        if (!fuse_norm && (rc = sm_norm_ex(x, n, ld, ld, w.ln2_w, nullptr, c.llm_eps, 0, nullptr, s->xnb.p, ld, od, stream))) return rc;
         if (n <= (c.weights_fp8 == 2 ? 16 : 32)) {   // decode / tiny chunks: SwiGLU fused into the dual weight-streaming kernel (fp8 MFMA mode: above 16 rows the tiled fp8 product)
             const Slot& gu = *w.gu;
             sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, n, ld) : lin(m, gu, s->xnb.p, SM_X_BF16, n, ld);
@@ -1222,6 +1226,7 @@ static int llm_layers(sm_stream* s, int n, void* stream) {
         }
         {   sm_linear_t a = lin(m, *w.down, s->actb.p, SM_X_BF16, n, c.llm_mlp);
             a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
+            if (!fuse_norm && l + 1 < c.llm_layers) { a.post_ln_gamma = m->R.llm[l + 1].ln1_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = s->xnb.p; a.post_ln_ldo = ld; }
             if ((rc = sm_linear(&a, stream))) return rc; }
     }
     s->kv_len += n;

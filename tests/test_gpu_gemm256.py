@@ -242,3 +242,30 @@ def test_swiglu_dual_epilogue(M, F, K, f16, bias):
     native.linear(xg, wp, 2 * F, K, bias=bg, act=SM_ACT_SWIGLU_DUAL, out=unf, tile_hint=128)
     assert torch.equal(out, unf)
     assert (unf.float() - want).abs().max().item() < (2e-3 if f16 else 1.2e-2) * scale
+
+
+@pytest.mark.parametrize("M,N,K,norm", [(2048, 4096, 4096, True), (2048, 4096, 14336, True), (1024, 4096, 4096, False), (1500, 2048, 4096, True)])
+def test_splitk_slabs_on_the_256_tile(nat, M, N, K, norm):
+    """Round 5: 64..128 tiles of 256 x 256 with K >= 4096 and N >= 2048 (the o_proj / down_proj of an LLM prefill chunk: transformers
+    MistralAttention.o_proj / MistralMLP.down_proj at 1024..2048 rows) run as split-K slabs on the 256 x 256 kernel + ONE pass that sums the slabs in slab
+    order, adds the residual (in place) and -- with post_ln -- writes the RMSNorm of the finished row as the next product's 16-bit operand.  fp32 rows
+    1e-5 from fp64 on the same operands; the RMSNorm rows are the oracle's rms_norm of those fp32 rows to 16-bit rounding; tile_hint = 128 (the route
+    these shapes took before) agrees to fp32 summation order."""
+    w = rnd((N, K), 1, K ** -0.5).bfloat16().float()
+    x = rnd((M, K), 2).bfloat16().float()
+    res = rnd((M, N), 4)
+    g = 1 + rnd((N,), 5, 0.1)
+    wp = nat.pack_weight(w.cuda().bfloat16())
+    xg, gg = x.cuda().bfloat16(), g.cuda()
+    ref = (x.double() @ w.double().t() + res.double()).float()
+    outs = []
+    for hint in (0, SM_TILE_128):
+        resg = res.cuda()
+        ln_out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        y = nat.linear(xg, wp, N, K, residual=resg, out=resg, tile_hint=hint, post_ln=(gg, None, 1e-5, ln_out) if norm else None)
+        assert ((y.cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+        if norm:
+            want = O.rms_norm(y.cpu(), g, 1e-5)
+            assert ((ln_out.float().cpu() - want).abs().max() / want.abs().max()).item() < 8e-3
+        outs.append(y.cpu())
+    assert ((outs[0] - outs[1]).abs().max() / ref.abs().max()).item() < 2e-6

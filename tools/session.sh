@@ -33,9 +33,9 @@ gdtrace)      # kernel trace of the grouped decode step at $GD streams (default 
 pftrace)      # kernel trace of a 2048-token prefill (bf16, then fp8 x fp8): tools/prefill_breakdown.py
   rm -rf /tmp/prof_pf; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_pf -- python tools/decode_bench.py 8 4096 1976 > $O/pf_profiled.log 2>&1
   python tools/prefill_breakdown.py /tmp/prof_pf | tee $O/prefill2048_breakdown.txt ;;
-dual)         # SwiGLU-dual epilogue: operator test, LLM parity tests, prefill A/B
-  timeout 900 python -m pytest tests/test_gpu_gemm256.py -q -x -k "swiglu" 2>&1 | tail -4
-  for L in 1 0 1 0; do SM_SWIGLU_FUSE=$L timeout 600 python tools/decode_bench.py 8 4096 1976 2>&1 | grep -o "prefill_ms[^,]*, .prefill_tokens_per_s[^,]*" | sed "s/^/SM_SWIGLU_FUSE=$L /"; done | tee $O/dual_ab.txt ;;
+dual)         # SwiGLU-dual epilogue + split-K slabs on the 256 tile: operator tests, 2048-token prefill A/B ($KNOB = SM_SWIGLU_FUSE | SM_GEMM256_SPLITK)
+  timeout 900 python -m pytest tests/test_gpu_gemm256.py -q -x -k "swiglu or splitk_slabs" 2>&1 | tail -4
+  for L in 1 0 1 0; do env ${KNOB:-SM_SWIGLU_FUSE}=$L timeout 600 python tools/decode_bench.py 8 4096 1976 2>&1 | grep -o "prefill_ms[^,]*, .prefill_tokens_per_s[^,]*" | sed "s/^/${KNOB:-SM_SWIGLU_FUSE}=$L /"; done | tee $O/${KNOB:-SM_SWIGLU_FUSE}_ab.txt ;;
 graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
