@@ -159,6 +159,38 @@ def decode_leg(model, stream, cfg, n_ctx_text=64, n_ctx_frames=256, n_new=128):
                          "bytes_per_token": weight_bytes + kv_bytes}}
 
 
+def prefill_leg(model, cfg, lib, n=2048, reps=3, prof=True):
+    """Mistral-7B prefill of one n-token chunk (bf16): tokens/s and the MFMA roofline -- whole prefill (every launch: GEMMs, attention, RoPE, slab sums)
+    and the tiled GEMM launches alone (HIP events around each launch, sm_prof_*).  FLOPs: 2 per weight per token for the 32 decoder layers
+    (lm_head runs on one row) + 4 S^2/2 d per head for the causal attention."""
+    g = torch.Generator(device="cuda").manual_seed(23)
+    ids = torch.randint(3, cfg.llm_vocab, (n,), generator=g, device="cuda", dtype=torch.int32)
+    st = model.open_stream(max_frames=8, max_seq=max(2048, (n + 63) // 64 * 64))
+    d, L = cfg.conn_d_model, cfg.llm_layers
+    lin_fl = 2.0 * n * L * (2 * d * d + 2 * d * cfg.llm_kv_heads * (d // cfg.llm_heads) + 3 * d * cfg.llm_mlp)
+    att_fl = L * 4.0 * n * n / 2 * d
+    try:
+        st.set_kv_len(0); st.prefill(ids); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st.set_kv_len(0); st.prefill(ids)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out = {"tokens": n, "tokens_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3),
+               "roofline": {"bound": "mfma", "achieved": round((lin_fl + att_fl) / dt / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round((lin_fl + att_fl) / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops": lin_fl + att_fl,
+                            "note": "every launch of the prefill (GEMMs, causal attention, RoPE + KV append, slab sums + RMSNorms); see profiles/r05_prefill2048_breakdown.txt"}}
+        if prof:
+            def run():
+                st.set_kv_len(0); st.prefill(ids)
+            r = class_roofline(lib, 0, run, 1, lin_fl, "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s",
+                               "gemm256_kernel / gemm256p_kernel launches of the prefill (q|k|v, o_proj and down_proj as split-K slabs, gate|up with the SwiGLU epilogue)")
+            out["roofline"]["gemm_launches_only"] = r
+    finally:
+        st.close()
+    return out
+
+
 def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32, 64, 128), n_ctx=328, n_new=48):
     """Batched greedy decode across streams (sm_group_llm_decode): S streams, each with its OWN KV cache and a 328-token context,
     advance together -- one pass over the 14.2 GB of Mistral-7B weights per step for all of them.  Aggregate tokens/s; HBM
@@ -595,9 +627,11 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(n_frames: int = 12) -> dict:
+def cpu_baseline(n_frames: int = 28) -> dict:
     """the oracle (plain-torch CPU port of the reference arithmetic, fp32) on a bounded sample of the same workload:
-    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 12 frames ~ 10 s of CPU work.
+    n_frames x (preprocess + ViT-L/14-336 23 layers + pool + connector step + full-size gate); 28 frames (one lane batch of the headline run) ~ 12-20 s of CPU
+    work.  The same 28 frames and weights then go through the HIP path in ONE call, bf16 tower and fp16 tower: `gate_logits_vs_fp32` = max |HIP - oracle fp32| over the
+    28 x 2 gate logits, measured in this run (north-star bound: 1e-3).
     Plus the other CPU items of SURVEY 8d: BASELINE configs[0] (8 frames through the tower, fp32 and bf16, then the [:, ::12]
     stride) and Mistral-7B decode tokens/s (all 32 layers + lm_head when the host has the 29 GB; else 4 layers x8, flagged)."""
     from oracle import streammind_oracle as O
@@ -612,14 +646,36 @@ def cpu_baseline(n_frames: int = 12) -> dict:
     st = O.ConnState.zeros(ccfg)
     pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[:1]), Wv, vcfg))   # warm-up
     t0 = time.perf_counter()
+    ref_logits = []
     for i in range(n_frames):
         pooled = O.pool_patches(O.vit_features(O.preprocess_frames(frames[i:i + 1]), Wv, vcfg))[0]
         tok = O.connector_step(pooled, st, Wc, ccfg)
-        O.gate_decision(O.gate_logits_shortcut(tok[None], Wc, gcfg)[0])
+        lg_ = O.gate_logits_shortcut(tok[None], Wc, gcfg)[0]
+        O.gate_decision(lg_)
+        ref_logits.append(lg_)
     dt = time.perf_counter() - t0
     out = {"value": n_frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
            "sample": f"{n_frames} frames x (preprocess + CLIP-ViT-L/14-336 23 layers + pool + connector step + 4-layer gate), "
                      f"oracle/streammind_oracle.py fp32, torch CPU threads={cores}"}
+    if torch.cuda.is_available():
+        # the precision statement of the headline, measured here and now: the oracle's fp32 logits of these frames against the HIP path on the same
+        # weights (the oracle as the CHECKER: nothing of it runs in the timed path), bf16-operand tower (the bench's dtype) and fp16-operand tower
+        try:
+            from tests.util_models import build_native
+            ref = torch.stack(ref_logits).float()
+            prec = {"frames": n_frames, "bound": 1e-3, "reference": "oracle fp32 (oracle/streammind_oracle.py, pinned to the reference by tests/golden)"}
+            for key, f16 in (("bf16_tower", False), ("fp16_tower", True)):
+                mp = build_native(vcfg, ccfg, gcfg, Wv, Wc, max_frames_per_call=n_frames, vit_fp16=f16)
+                sp = mp.open_stream(max_frames=n_frames + 4, max_seq=64)
+                lg, _ = sp.push_frames(frames.cuda())
+                prec[key] = float(f"{(lg.float().cpu() - ref).abs().max().item():.3e}")
+                sp.close(); mp.close()
+            prec["note"] = ("bf16 operands (BASELINE configs[1]'s dtype, the headline) sit at the dtype's floor against fp32 -- the oracle's own bf16-rounding mode is 2.8e-3 "
+                            "from its fp32 mode on such frames -- and within 1e-3 of the oracle's bf16 mode (tests/test_gpu_path.py); fp16 operands (vit_fp16, what "
+                            "load_pretrained_model selects for the reference's fp16 checkpoints; `fp16_tower_frames_per_s`) meet the bound against fp32")
+            out["gate_logits_vs_fp32"] = prec
+        except Exception as e:
+            out["gate_logits_vs_fp32"] = {"error": repr(e)[:300]}
     try:        # configs[0]: 8 frames as ONE batch through a1 + a2, then the cached-feature stride (process_clip_encoder.py:75)
         pix = O.preprocess_frames(frames[:8])
         t0 = time.perf_counter(); f32 = O.vit_features(pix, Wv, vcfg); t_f32 = time.perf_counter() - t0
@@ -891,6 +947,16 @@ def main():
         lib.sm_prof_enable(0)
         cnt, ms = C.c_int(), C.c_float()
         _lib.check(lib.sm_prof_read(0, C.byref(cnt), C.byref(ms)))       # synchronises the recorded events; later passes reset them
+        # ... and per product shape (launches carry N << 32 | K as their tag): which of the tower's four GEMM shapes is furthest below the peak
+        shape_raw = {}
+        try:
+            Dv_, Fv_ = cfg.vit_hidden, cfg.vit_mlp
+            for nm, (Ns, Ks) in {"qkv": (3 * Dv_, Dv_), "out_proj": (Dv_, Dv_), "fc1": (Fv_, Dv_), "fc2": (Dv_, Fv_)}.items():
+                c2, m2 = C.c_int(), C.c_float()
+                _lib.check(lib.sm_prof_read_tag(0, (Ns << 32) | Ks, C.byref(c2), C.byref(m2)))
+                shape_raw[nm] = (Ns, Ks, c2.value, m2.value)
+        except Exception as e:
+            shape_raw = {"error": repr(e)[:200]}
         gemm_prof = (cnt.value, ms.value)
     per_rank = None
     if dist is not None:
@@ -941,6 +1007,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dec_leg["tokens_per_s_all_gpus"] = round(float(t.item()), 2)
 
+    pre_leg = None
+    if not a.no_decode and world == 1:
+        try:
+            pre_leg = prefill_leg(model, cfg, lib, prof=bool(prof))
+        except Exception as e:
+            pre_leg = {"error": repr(e)[:200]}
     gdec_leg = None
     if not a.no_decode and world == 1 and not a.no_aux:
         try:
@@ -1132,7 +1204,7 @@ def main():
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
             # being profiled): the newest committed summary is quoted and its source named
             traffic = traffic_src = None
-            for rnd in ("r04", "r03", "r02", "r01"):
+            for rnd in ("r05", "r04", "r03", "r02", "r01"):
                 tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic.json")
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
@@ -1142,7 +1214,7 @@ def main():
             ktrace = None
             try:
                 import csv as _csv
-                for rnd in ("r04", "r03", "r02"):
+                for rnd in ("r05", "r04", "r03", "r02"):
                     kf = os.path.join(ROOT, "profiles", f"{rnd}_bench_steps_kernel_stats.csv")
                     if os.path.exists(kf):
                         rows = [r for r in _csv.DictReader(open(kf)) if r["Name"].startswith(("void gemm256_kernel", "void gemm256p_kernel"))]
@@ -1157,12 +1229,23 @@ def main():
             except Exception:
                 ktrace = None
             big = PB * (cfg.n_patches + 1) >= 192 * 64
+            by_shape = {}
+            if "error" in shape_raw:
+                by_shape = shape_raw
+            else:
+                Mrows = PB * (cfg.n_patches + 1)
+                for nm, (Ns, Ks, c2, m2) in shape_raw.items():
+                    if c2:
+                        us = m2 * 1e3 / c2
+                        tf = 2.0 * Mrows * Ns * Ks / (us * 1e-6) / 1e12
+                        by_shape[nm] = {"N": Ns, "K": Ks, "M": Mrows, "launches": c2, "avg_launch_us": round(us, 2), "tflops": round(tf, 1),
+                                        "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
             roof = {"kernel": "gemm256_kernel / gemm256p_kernel (tiled bf16 MFMA GEMM, 256x256 tile, 4-stage 32-deep LDS ring, 8 waves in two staggered groups; "
                               "persistent tile walk for the multi-tile bf16-output shapes)" if big else
                               "gemm_kernel (tiled bf16 MFMA GEMM, 128x128x64, 8 waves)", "bound": "mfma", "achieved": round(ach, 1),
                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "launches": cnt.value, "profiled_steps": prof_steps, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "archived_kernel_trace": ktrace,
+                    "flops_per_launch": flops_per_launch, "frames_per_profiled_step": PB, "by_shape": by_shape or None, "archived_kernel_trace": ktrace,
                     "whole_step_note": "whole_step_frac prices the reference's 366 GFLOP per frame; 4.8 GFLOP of them (the last layer's fc2) are replaced by a patch mean + a 28-row product",
                     # the TIMED schedule as a whole against the same peak: every FLOP of a frame's tower (tiled GEMMs + attention, SURVEY
                     # 8d's 366 GFLOP) x the frames timed / the timed wall clock -- what `value` is worth in MFMA terms
@@ -1280,7 +1363,10 @@ def main():
             "decode_tokens_per_s": (dec_leg or {}).get("tokens_per_s"),
             "decode_hbm_frac": ((dec_leg or {}).get("roofline") or {}).get("frac"),
             "roofline": roof,
+            "prefill_tokens_per_s": (pre_leg or {}).get("tokens_per_s"),
+            "gate_logits_vs_fp32": None,          # filled from cpu_baseline below (measured in this run on 28 frames)
             "decode": dec_leg,
+            "prefill": pre_leg,
             "group_decode": gdec_leg,
             "end_to_end": e2e,
             "teacher_forced_eval": tf_leg,
@@ -1306,6 +1392,7 @@ def main():
                                            "fire_schedule": "rank r fires on steps i with i % 9 == r % 9 (never two ranks of one node together)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["gate_logits_vs_fp32"] = out["cpu_baseline"].get("gate_logits_vs_fp32")
     if dist is not None:
         dist.destroy_process_group()
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio (seen after the line when stdout is a

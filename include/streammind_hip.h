@@ -496,6 +496,8 @@ int sm_comm_tick(sm_comm* c);
 int sm_prof_enable(int class_mask);
 int sm_prof_reset(void);
 int sm_prof_read(int cls, int* count, float* total_ms);   /* synchronises the recorded events */
+/* the same over the launches recorded with one tag; tiled GEMM launches (class 0) carry ((long long)N << 32) | K of their product */
+int sm_prof_read_tag(int cls, long long tag, int* count, float* total_ms);
 
 #ifdef __cplusplus
 }

@@ -149,6 +149,7 @@ SIGNATURES = {
     "sm_prof_enable": (i32, [i32]),
     "sm_prof_reset": (i32, []),
     "sm_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f32)]),
+    "sm_prof_read_tag": (i32, [i32, C.c_longlong, C.POINTER(i32), C.POINTER(f32)]),
 }
 
 _lib = None

@@ -81,11 +81,11 @@ int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtr
 // Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that
 // class is bracketed by HIP events recorded ON THE LAUNCH STREAM; sm_prof_read() synchronises and sums.
 enum { SM_PROF_GEMM = 0, SM_PROF_SKINNY = 1, SM_PROF_ATTN = 2, SM_PROF_NCLS = 3 };
-void sm_prof_begin_(int cls, hipStream_t st);
+void sm_prof_begin_(int cls, hipStream_t st, long long tag);
 void sm_prof_end_(int cls, hipStream_t st);
 extern int g_sm_prof_mask;
 struct SmProfScope {
     int cls; hipStream_t st; bool on;
-    SmProfScope(int c, hipStream_t s) : cls(c), st(s), on((g_sm_prof_mask >> c) & 1) { if (on) sm_prof_begin_(cls, st); }
+    SmProfScope(int c, hipStream_t s, long long tag = 0) : cls(c), st(s), on((g_sm_prof_mask >> c) & 1) { if (on) sm_prof_begin_(cls, st, tag); }      // tag: sm_prof_read_tag's key
     ~SmProfScope() { if (on) sm_prof_end_(cls, st); }
 };

@@ -1585,7 +1585,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     const bool xf32 = p->x_dtype == SM_X_F32;
     if (p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && (p->ldx & 7) == 0 && !p->precise && !p->w2 && !xf32 && !p->vt && p->remap_in == 0) {
         // fp8 x fp8 on the matrix pipe: activation rows quantised to e4m3, no bf16 expansion of the weights (gemm_fp8.hip)
-        SmProfScope prof(SM_PROF_GEMM, st);
+        SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
         return launch_gemm_fp8(a, st);
     }
     if (w8 && p->M > 16) {
@@ -1680,14 +1680,15 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         int hint = 0;
         const int bn = gemm_tile_choice(p, &hint);
         SM_REQUIRE(p->act != SM_ACT_SWIGLU_DUAL || bn == 256 || bn == 257, "sm_linear: internal: SwiGLU-dual outside the 256 x 256 kernel");
-        // 64..128 tiles of 256 x 256 with a long K loop and wide rows (the o / down products of an LLM prefill chunk: M = 1024..2048, N = 4096): split-K
+        // 64..128 tiles of 256 x 256 with >= 768 rows (whole row tiles: a 128-row batched decode step with N = 28672 also has 112 tiles and stays on the
+        // 128 x 128 kernel), a long K loop and wide rows (the o / down products of an LLM prefill chunk: M = 1024..2048, N = 4096): split-K
         // slabs on the 256 x 256 kernel so that every CU multiplies (2048 rows, same box: down 275 -> ~215 us, o 85 -> ~77 us against the 128 x 128
         // kernel's 512 tiles), then ONE pass sums the slabs in slab order, applies bias / activation / residual and -- when the call carries one
         // -- the RMSNorm / LayerNorm of the finished row (sm_linear_t.post_ln_*).  SM_GEMM256_SPLITK=0: off (A/B)
         static int sk256 = -1;
         if (sk256 < 0) { const char* e = getenv("SM_GEMM256_SPLITK"); sk256 = e ? atoi(e) : 1; }
         const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
-        if (sk256 && bn == 0 && hint == 0 && t256 >= 64 && t256 <= 128 && p->N >= 2048 && (p->N & 255) == 0 && p->K >= 4096 && p->out_f32 && !p->out_bf16 && !p->vt &&
+        if (sk256 && bn == 0 && hint == 0 && p->M >= 768 && t256 >= 64 && t256 <= 128 && p->N >= 2048 && (p->N & 255) == 0 && p->K >= 4096 && p->out_f32 && !p->out_bf16 && !p->vt &&
             p->remap_in == 0 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) && !a.wscale) {
             int S = 256 / t256;
             if (S > 4) S = 4;
@@ -1698,7 +1699,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
                 if (rc) return rc;
                 LinArgs b = a;
                 b.out_f32 = ws; b.ldo = p->N; b.out_bf16 = nullptr; b.bias = nullptr; b.residual = nullptr; b.act = SM_ACT_NONE;
-                {   SmProfScope prof(SM_PROF_GEMM, st);
+                {   SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
                     if ((rc = launch_gemm256(b, SM_ACT_NONE, 256, st, S))) return rc; }
                 if (p->post_ln_gamma && p->N <= 4096) {
                     const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
@@ -1711,7 +1712,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             }
         }
         if (bn) {
-            SmProfScope prof(SM_PROF_GEMM, st);
+            SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
             return launch_gemm256(a, p->act, bn, st);
         }
     }
@@ -1775,7 +1776,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // in situ, its k-loop 0.83 -> 0.41 us per k-tile L2-warm), and loses where the two-stage kernel's second resident block per CU hides
     // prologues and epilogues across rounds (4 / 8 frames per call: 3.88 -> 3.98 / 5.48 -> 5.70 ms)
     const bool ring = use_ring && (wv8 || a.f16) && (tiles * S <= 256 || use_ring == 2);
-    SmProfScope prof(SM_PROF_GEMM, st);
+    SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
 #define GEMM_LAUNCH(ACT, ARGS, GRID)                                                                                         \
     do {                                                                                                                     \
         if (ring && a.f16) gemm_kernel<ACT, 8, true, 4><<<GRID, 512, 4 * GEMM_STAGE_BYTES, st>>>(ARGS, tiles_m, tiles_n);    \

@@ -11,6 +11,7 @@ extern "C" int sm_abi_version(void) { return 3; }
 #include <vector>
 int g_sm_prof_mask = 0;
 static std::vector<hipEvent_t> g_prof_ev[SM_PROF_NCLS];      // begin/end pairs in launch order
+static std::vector<long long> g_prof_tag[SM_PROF_NCLS];      // one tag per pair (tiled GEMM launches: N << 32 | K)
 static size_t g_prof_used[SM_PROF_NCLS] = {0, 0, 0};
 static hipEvent_t prof_next(int cls) {
     if (g_prof_used[cls] == g_prof_ev[cls].size()) {
@@ -20,15 +21,21 @@ static hipEvent_t prof_next(int cls) {
     }
     return g_prof_ev[cls][g_prof_used[cls]++];
 }
-void sm_prof_begin_(int cls, hipStream_t st) { (void)hipEventRecord(prof_next(cls), st); }
+void sm_prof_begin_(int cls, hipStream_t st, long long tag) {
+    const size_t pair = g_prof_used[cls] >> 1;
+    if (g_prof_tag[cls].size() <= pair) g_prof_tag[cls].resize(pair + 1);
+    g_prof_tag[cls][pair] = tag;
+    (void)hipEventRecord(prof_next(cls), st);
+}
 void sm_prof_end_(int cls, hipStream_t st) { (void)hipEventRecord(prof_next(cls), st); }
 extern "C" int sm_prof_enable(int mask) { g_sm_prof_mask = mask; return SM_OK; }
 extern "C" int sm_prof_reset(void) { for (int c = 0; c < SM_PROF_NCLS; ++c) g_prof_used[c] = 0; return SM_OK; }
-extern "C" int sm_prof_read(int cls, int* count, float* total_ms) {
+static int prof_sum(int cls, bool by_tag, long long tag, int* count, float* total_ms) {
     SM_REQUIRE(cls >= 0 && cls < SM_PROF_NCLS && count && total_ms, "sm_prof_read: bad args");
     float tot = 0.f;
     int n = 0;
     for (size_t i = 0; i + 1 < g_prof_used[cls]; i += 2) {
+        if (by_tag && g_prof_tag[cls][i >> 1] != tag) continue;
         SM_HIP(hipEventSynchronize(g_prof_ev[cls][i + 1]));
         float ms = 0.f;
         SM_HIP(hipEventElapsedTime(&ms, g_prof_ev[cls][i], g_prof_ev[cls][i + 1]));
@@ -37,6 +44,8 @@ extern "C" int sm_prof_read(int cls, int* count, float* total_ms) {
     *count = n; *total_ms = tot;
     return SM_OK;
 }
+extern "C" int sm_prof_read(int cls, int* count, float* total_ms) { return prof_sum(cls, false, 0, count, total_ms); }
+extern "C" int sm_prof_read_tag(int cls, long long tag, int* count, float* total_ms) { return prof_sum(cls, true, tag, count, total_ms); }
 
 // ------------------------------------------------------------------------------------------------ norm
 // one wave per row; D <= 16384.  LayerNorm: two-pass (mean, then centred variance) from registers/L1.
