@@ -191,7 +191,7 @@ def prefill_leg(model, cfg, lib, n=2048, reps=3, prof=True):
     return out
 
 
-def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32, 64, 128), n_ctx=328, n_new=48):
+def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32, 64, 128, 256, 512), n_ctx=328, n_new=48):
     """Batched greedy decode across streams (sm_group_llm_decode): S streams, each with its OWN KV cache and a 328-token context,
     advance together -- one pass over the 14.2 GB of Mistral-7B weights per step for all of them.  Aggregate tokens/s; HBM
     roofline per step = weights once + every stream's KV."""
@@ -208,6 +208,7 @@ def group_decode_leg(model, cfg, sizes=(4, 8, 16, 32, 64, 128), n_ctx=328, n_new
         for st in streams:
             st.set_kv_len(n_ctx)                      # every size starts from the same context length
         grp = model.open_group(streams[:S])
+        n_new = n_new if S <= 128 else 24             # 256 / 512 streams: 24 timed steps (a step is 10-20 ms there)
         grp.decode(8)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -413,9 +413,10 @@ int sm_group_size(sm_stream_group* g);
 int sm_group_push_frames(sm_stream_group* g, const uint8_t* frames, int F, float* logits, int32_t* decisions, void* stream);
 /* the same from pooled ViT features fp32 [S][F][vit_hidden] */
 int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int F, float* logits, int32_t* decisions, void* stream);
-/* batched greedy decode: n_steps steps of every ACTIVE stream of the group (active_host[i] != 0; NULL = all; at most 128 active,
+/* batched greedy decode: n_steps steps of every ACTIVE stream of the group (active_host[i] != 0; NULL = all; at most 512 active,
  * 16 with fp8 weights; equal max_seq) in one pass over the LLM weights per step (up to 32 streams: weight-streaming kernels, one row
- * per stream; 33..128: the linears as tiled MFMA GEMMs over all rows, the per-stream kernels 32 streams at a time).  Each active stream must hold a pending token
+ * per stream; 33..512: the linears as tiled MFMA GEMMs over all rows -- M = streams, where decode meets an MFMA roofline at all -- , RoPE + append
+ * and attention in launches of 128 streams, token gather / arg-max 32 streams at a time).  Each active stream must hold a pending token
  * (its own sm_llm_prefill) and continues exactly as sm_llm_decode would: out_ids_dev int32 [S][n_steps] (rows of inactive
  * streams untouched), KV caches, positions, pending tokens and last logits advance per stream.  Replaces S batch-1 HF
  * generate loops (videollama2_mistral.py:426-431; "only support batch size 1"): batch-1 decode is bound by streaming 14.2 GB

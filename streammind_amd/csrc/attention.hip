@@ -960,11 +960,11 @@ extern "C" int sm_llm_decode_attention_window(const void* q, const void* kcache,
     return sm_llm_decode_attention_ex(q, kcache, vtcache, pos, H, KV, dh, S_max, workspace, splits_max, ctx, 0, stream, window);
 }
 
-// up to SM_GROUP_DECODE_MAX streams in ONE launch of the one-launch kernel (per-stream pointers: 2.5 KB of kernel arguments).  Returns 1 (not
+// up to SM_BIG_SEG streams in ONE launch of the one-launch kernel (per-stream pointers: 2.5 KB of kernel arguments).  Returns 1 (not
 // an error) when the longest context is beyond what that kernel is used for: the caller then goes through sm_llm_decode_attention_seg in
 // chunks of SM_MAX_SEG.
 int sm_llm_decode_attention_seg_big(const void* q, const SmDecodeSegBig& seg, int S, int H, int KV, int dh, int S_max, void* ctx, int f16, void* stream, int window) {
-    SM_REQUIRE(q && ctx && S > 0 && S <= SM_GROUP_DECODE_MAX && S_max % 64 == 0 && H % KV == 0 && H / KV <= 16, "sm_llm_decode_attention_seg_big: bad args");
+    SM_REQUIRE(q && ctx && S > 0 && S <= SM_BIG_SEG && S_max % 64 == 0 && H % KV == 0 && H / KV <= 16, "sm_llm_decode_attention_seg_big: bad args");
     int nk = 1;
     for (int t = 0; t < S; ++t) {
         SM_REQUIRE(seg.pos[t] >= 0 && seg.pos[t] < S_max && seg.kc[t] && seg.vtc[t], "sm_llm_decode_attention_seg_big: stream %d: bad position / cache", t);

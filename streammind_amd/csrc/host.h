@@ -31,7 +31,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Per-segment (= per-stream) base pointers handed to kernels BY VALUE: a connector pass covers at most SM_MAX_SEG streams
 // (one weight pass = at most 32 rows), so no device-side pointer table has to be built or uploaded per call.
 #define SM_MAX_SEG 32
-#define SM_GROUP_DECODE_MAX 128     // active streams of one batched decode step (beyond SM_MAX_SEG: tiled GEMMs + chunked per-stream kernels)
+#define SM_GROUP_DECODE_MAX 512     // active streams of one batched decode step (beyond SM_MAX_SEG: tiled GEMMs over all rows + per-stream kernels in packs)
+#define SM_BIG_SEG 128              // streams whose per-stream pointers travel in ONE by-value pack (2.5 KB of kernel arguments)
 struct SmSegStates { float* p[SM_MAX_SEG]; };
 int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,
                            const float* conv_b, float* xc, void* stream);                                    // vecops.hip
@@ -46,7 +47,7 @@ int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* 
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
 template <int N> struct SmDecodeSegT { void* kc[N]; void* vtc[N]; int pos[N]; };
 typedef SmDecodeSegT<SM_MAX_SEG> SmDecodeSeg;
-typedef SmDecodeSegT<SM_GROUP_DECODE_MAX> SmDecodeSegBig;      // every stream of a large batched decode step in ONE launch (2.5 KB of kernel arguments)
+typedef SmDecodeSegT<SM_BIG_SEG> SmDecodeSegBig;      // every stream of a large batched decode step in ONE launch (2.5 KB of kernel arguments)
 struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
 // epilogue of the decode-step q/k/v product with RoPE + KV append fused in (linear.hip sm_linear_qkv_rope): row i of the
 // activations is stream i's token at seg.pos[i]; q goes out rotated as bf16 [M][H*dh], k rotated into seg.kc[i], v transposed
@@ -64,7 +65,7 @@ int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream
 // window: Mistral's sliding_window (a query at position p sees keys (p - window, p]); 0 = full causal
 int sm_llm_decode_attention_seg(const void* q_bf16, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
                                 int splits_max, void* ctx_bf16, int f16, void* stream, int window = 0);           // attention.hip
-// the one-launch decode attention / RoPE + KV append for up to SM_GROUP_DECODE_MAX streams; the attention returns SM_EINVAL-free `1` when the
+// the one-launch decode attention / RoPE + KV append for up to SM_BIG_SEG streams; the attention returns SM_EINVAL-free `1` when the
 // contexts are too long for the one-launch kernel (the caller then falls back to chunks of SM_MAX_SEG through the calls above)
 int sm_llm_decode_attention_seg_big(const void* q_bf16, const SmDecodeSegBig& seg, int S, int H, int KV, int dh, int S_max, void* ctx_bf16, int f16,
                                     void* stream, int window = 0);

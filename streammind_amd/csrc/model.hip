@@ -1101,7 +1101,7 @@ struct sm_stream_group {
     std::vector<sm_stream*> streams;
     ConnScratch w;
     // batched decode scratch (rows = streams), allocated by the first sm_group_llm_decode
-    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws, d_guf;
+    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
     bool d_ready = false;
 };
 
@@ -1356,7 +1356,6 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
 #define A(buf, bytes) if (!rc) rc = g->buf.alloc(bytes)
         A(d_emb, R * ld * 4); A(d_xnb, R * ld * 2); A(d_qkvf, R * (qn + 2 * kn) * 4); A(d_qb, R * qn * 2); A(d_ctxb, R * qn * 2);
         A(d_actb, R * c.llm_mlp * 2); A(d_log, R * V * 4); A(d_ws, (size_t)SM_MAX_SEG * SM_DECODE_SPLITS * H * (dh + 2) * 4);
-        A(d_guf, R * 2 * c.llm_mlp * 4);
 #undef A
         if (rc) return rc;
         g->d_ready = true;
@@ -1383,14 +1382,20 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
             bool rope_done = false, attn_done = false;
-            if (NC > 1) {           // all streams in ONE RoPE + append launch and ONE attention launch (pointer packs of SM_GROUP_DECODE_MAX by value)
-                SmDecodeSegBig big;
-                for (int t = 0; t < S; ++t) { big.kc[t] = act[t]->kc[l].p; big.vtc[t] = act[t]->vtc[l].p; big.pos[t] = act[t]->kv_len; }
-                if ((rc = sm_rope_kv_append_seg_big(g->d_qkvf.as<float>(), S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, big, S_max, f16, stream))) return rc;
-                rope_done = true;
-                rc = sm_llm_decode_attention_seg_big(g->d_qb.p, big, S, H, KV, dh, S_max, g->d_ctxb.p, f16, stream, c.llm_sliding_window);
-                if (rc < 0) return rc;
-                attn_done = rc == 0;          // 1: contexts too long for the one-launch kernel -> chunks below
+            if (NC > 1) {           // SM_BIG_SEG streams per RoPE + append launch and per attention launch (pointer packs by value): 1 pack up to 128 streams, 4 at 512
+                rope_done = attn_done = true;
+                for (int b0 = 0; b0 < S; b0 += SM_BIG_SEG) {
+                    const int bn = S - b0 < SM_BIG_SEG ? S - b0 : SM_BIG_SEG;
+                    SmDecodeSegBig big;
+                    for (int t = 0; t < bn; ++t) { big.kc[t] = act[b0 + t]->kc[l].p; big.vtc[t] = act[b0 + t]->vtc[l].p; big.pos[t] = act[b0 + t]->kv_len; }
+                    char* qb = (char*)g->d_qb.p + (size_t)b0 * qn * 2;
+                    if ((rc = sm_rope_kv_append_seg_big(g->d_qkvf.as<float>() + (size_t)b0 * (qn + 2 * kn), bn, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), qb, big, S_max, f16, stream))) return rc;
+                    if (attn_done) {
+                        rc = sm_llm_decode_attention_seg_big(qb, big, bn, H, KV, dh, S_max, (char*)g->d_ctxb.p + (size_t)b0 * qn * 2, f16, stream, c.llm_sliding_window);
+                        if (rc < 0) return rc;
+                        if (rc == 1) attn_done = false;          // contexts too long for the one-launch kernel -> every stream through the chunks below (RoPE + append are done)
+                    }
+                }
             }
             for (int ch = 0; ch < NC && !attn_done; ++ch) {
                 SmDecodeSeg seg;
@@ -1411,11 +1416,12 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
                 a.out_bf16 = g->d_actb.p; a.ldo_bf16 = c.llm_mlp;
                 if ((rc = sm_linear(&a, stream))) return rc;
-            } else {              // more rows than the dual weight-streaming kernel takes: gate | up as one tiled product, then SwiGLU (as a prefill chunk does)
+            } else {              // more rows than the dual weight-streaming kernel takes: gate | up as one tiled product with act_fn(gate) * up behind it
+                                  // (in the 256 x 256 kernel's epilogue from ~440 streams, a SwiGLU pass inside sm_linear below that), as a prefill chunk does
                 sm_linear_t a = lin(m, *w.gu, g->d_xnb.p, SM_X_BF16, S, ld);
-                a.out_f32 = g->d_guf.as<float>(); a.ldo = 2 * c.llm_mlp;
+                a.act = SM_ACT_SWIGLU_DUAL;
+                a.out_bf16 = g->d_actb.p; a.ldo_bf16 = c.llm_mlp;
                 if ((rc = sm_linear(&a, stream))) return rc;
-                if ((rc = sm_swiglu_ex(g->d_guf.as<float>(), S, c.llm_mlp, g->d_actb.p, f16, stream))) return rc;
             }
             {   sm_linear_t a = lin(m, *w.down, g->d_actb.p, SM_X_BF16, S, c.llm_mlp);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;

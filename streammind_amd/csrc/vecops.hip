@@ -800,7 +800,7 @@ int sm_rope_kv_append_seg(const float* qkv, int S, int H, int KV, int dh, const 
 }
 int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
                               const SmDecodeSegBig& seg, int S_max, int f16, void* stream) {
-    SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_GROUP_DECODE_MAX, "sm_rope_kv_append_seg_big: bad args");
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_BIG_SEG, "sm_rope_kv_append_seg_big: bad args");
     rope_kv_seg_kernel<SmDecodeSegBig><<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;

@@ -993,12 +993,13 @@ def test_group_batched_decode_equals_solo_decode(tiny):
 
 
 def test_group_batched_decode_beyond_32_streams(tiny):
-    """40 and 70 streams in ONE batched decode step (more than the 32 rows the weight-streaming kernels take: the linears run as tiled
-    MFMA GEMMs over all rows, token gather / RoPE + KV append / attention / arg-max 32 streams at a time): every stream's ids equal its own
+    """40, 70, 150 and 300 streams in ONE batched decode step (more than the 32 rows the weight-streaming kernels take: the linears run as tiled
+    MFMA GEMMs over all rows, RoPE + KV append / attention in packs of 128 streams -- one, two and three packs here; round 5: up to 512 streams --,
+    token gather / arg-max 32 streams at a time): every stream's ids equal its own
     solo decode wherever the solo run's top-2 margin exceeds twice the bf16 logit tolerance, last logits within it, KV lengths advance."""
     m, _, _, Wl = tiny
     g = torch.Generator().manual_seed(23)
-    for S in (40, 70):
+    for S in (40, 70, 150, 300):
         lens = [int(v) for v in torch.randint(5, 60, (S,), generator=g)]
         n_new = 6
         ctxs = [torch.randint(3, TL.vocab, (n,), generator=g, dtype=torch.int32).cuda() for n in lens]

@@ -29,7 +29,21 @@ lnxtl)        # (needs the same patch) phase timeline of the fused LayerNorm epi
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSM_GEMM_TIMELINE -Istreammind_amd/csrc -Iinclude tools/lnx_timeline.hip -o /tmp/lnxtl && for Z in 1 8 32; do echo "SM_LNX_POLL_SLEEPS=$Z"; SM_LNX_POLL_SLEEPS=$Z timeout 300 /tmp/lnxtl; done | tee $O/lnx_timeline.txt ;;
 gdtrace)      # kernel trace of the grouped decode step at $GD streams (default 128) -> per-kernel us per step
   rm -rf /tmp/prof_gd; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gd -- python tools/group_decode_bench.py ${GD:-128} > $O/gd_profiled.log 2>&1
-  cp "$(find /tmp/prof_gd -name '*kernel_stats.csv' | head -1)" $O/group_decode${GD:-128}_kernel_stats.csv; tail -2 $O/gd_profiled.log; head -25 $O/group_decode${GD:-128}_kernel_stats.csv | cut -c1-200 ;;
+  cp "$(find /tmp/prof_gd -name '*kernel_stats.csv' | head -1)" $O/group_decode${GD:-128}_kernel_stats.csv; tail -1 $O/gd_profiled.log
+  python tools/trace_window.py /tmp/prof_gd embed_tokens_seg_kernel $(( (${GD:-128} + 31) / 32 )) > $O/group_decode${GD:-128}_step_timeline.txt; python - $O/group_decode${GD:-128}_step_timeline.txt <<'PY'
+import sys, collections, re
+d = collections.defaultdict(lambda: [0.0, 0])
+for ln in open(sys.argv[1]):
+    m = re.match(r"\s*([\d.]+) us  dur\s+([\d.]+)  grid\s+(\S+)x\s*(\S+) wg\s+(\S+)  (.*)", ln)
+    if m:
+        k = m.group(6).split("(")[0].replace("void ", "")[:70]
+        d[k][0] += float(m.group(2)); d[k][1] += 1
+    else:
+        print(ln.strip())
+for k, (t, n) in sorted(d.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {k:72s} n={n:4d} avg {t / n:7.2f} us  total {t:8.1f} us")
+PY
+  ;;
 pftrace)      # kernel trace of a 2048-token prefill (bf16, then fp8 x fp8): tools/prefill_breakdown.py
   rm -rf /tmp/prof_pf; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_pf -- python tools/decode_bench.py 8 4096 1976 > $O/pf_profiled.log 2>&1
   python tools/prefill_breakdown.py /tmp/prof_pf | tee $O/prefill2048_breakdown.txt ;;

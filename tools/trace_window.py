@@ -1,11 +1,12 @@
 """One window of a rocprofv3 --kernel-trace CSV, launch by launch: from the second-to-last to the last launch of a marker kernel.
-    python tools/trace_window.py <trace dir> <marker kernel name substring>"""
+    python tools/trace_window.py <trace dir> <marker kernel name substring> [marker launches per window, default 1]"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if sys.argv[2] in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+a, b = idx[-1 - per], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a + 1:b + 1] if sys.argv[2] != "preprocess_kernel" else rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
