@@ -446,6 +446,60 @@ def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens
             "kv_len_end": stream.kv_len, "replies_on_llm_lane": bool(overlap)}
 
 
+def e2e_multi_leg(model, cfg, frames, S=32, ticks=112, cohorts=4, reply_tokens=256):
+    """BASELINE configs[2] for MANY concurrent streams (the loop of streammind_amd.stream.MultiStreamSession.tick at the native level, with scheduled
+    fires as in e2e_leg): S streams, one frame per stream per tick through ONE ViT batch + one connector / gate pass (sm_group_push_frames); stream i
+    belongs to cohort i % cohorts, a cohort fires every ticks / 2 ticks (the cohorts staggered), every fired stream prefills its own grown context (KV
+    prefix reuse: text + its frame tokens since its last fire), then the cohort's replies are decoded TOGETHER -- one pass over the 14.2 GB of weights
+    per step for all of them (sm_group_llm_decode).  A single stream is decode-bound at ~270 frames/s on this schedule shape (end_to_end.frames_per_s)."""
+    g = torch.Generator(device="cuda").manual_seed(29)
+    streams = [model.open_stream(max_frames=ticks + 8, max_seq=1024) for _ in range(S)]
+    grp = model.open_group(streams)
+    period = ticks // 2
+    ctx = [[torch.randint(3, cfg.llm_vocab, (60,), generator=g, device="cuda", dtype=torch.int32)] for _ in range(S)]
+    seg_start = [0] * S
+    n_pool = frames.shape[0]
+    try:
+        grp.push_frames(frames[:S].contiguous())                           # warm-up tick (workspaces), then start over
+        for st in streams:
+            st.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_frames = n_fires = n_tok = 0
+        t_decode = 0.0
+        for t in range(ticks):
+            off = (t * S) % (n_pool - S + 1)
+            grp.push_frames(frames[off:off + S].contiguous())
+            n_frames += S
+            fired = [i for i in range(S) if (t + 1 + (i % cohorts) * (period // cohorts)) % period == 0]
+            if not fired:
+                continue
+            for i in fired:
+                st = streams[i]
+                T = st.num_frames
+                ctx[i].append(-(torch.arange(seg_start[i], T, device="cuda", dtype=torch.int32) + 1))
+                ctx[i].append(torch.randint(3, cfg.llm_vocab, (6,), generator=g, device="cuda", dtype=torch.int32))
+                st.prefill(torch.cat(ctx[i]).contiguous())
+                ctx[i] = [torch.randint(3, cfg.llm_vocab, (4,), generator=g, device="cuda", dtype=torch.int32)]
+                seg_start[i] = T
+            torch.cuda.synchronize(); td = time.perf_counter()
+            grp.decode(reply_tokens, active=[i in fired for i in range(S)])
+            torch.cuda.synchronize(); t_decode += time.perf_counter() - td
+            n_fires += len(fired)
+            n_tok += reply_tokens * len(fired)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"streams": S, "ticks": ticks, "frames": n_frames, "fires": n_fires, "reply_tokens": reply_tokens, "seconds": round(dt, 4),
+                "frames_per_s": round(n_frames / dt, 2), "reply_tokens_per_s_overall": round(n_tok / dt, 2),
+                "reply_tokens_per_s_while_decoding": round(n_tok / max(t_decode, 1e-9), 2), "streams_per_batched_decode": len(range(0, S, cohorts)),
+                "kv_len_end": streams[0].kv_len,
+                "note": "scheduled fires, EOS disabled (every reply is exactly reply_tokens long); per stream the results are those of its own loop (tests: MultiStreamSession)"}
+    finally:
+        grp.close()
+        for st in streams:
+            st.close()
+
+
 def live_overlap_leg(model, stream, cfg, frames, B, reply_tokens=256, tokens_per_iter=4, n_ctx=328):
     """What the LLM lane buys a LIVE stream: ONE 256-token reply is decoded on the lane while the perception stream keeps encoding
     and gating frames, `tokens_per_iter` decode steps enqueued per perception call of B frames.  Reported: the wall clock of
@@ -987,6 +1041,10 @@ def main():
             try:       # the same schedule with the replies on the LLM lane, and what the lane buys a live stream
                 e2e["with_llm_lane"] = e2e_leg(model, stream, cfg, frames, B, overlap=True)
                 e2e["live_stream_overlap"] = live_overlap_leg(model, stream, cfg, frames, B)
+                try:
+                    e2e["multi_stream"] = e2e_multi_leg(model, cfg, frames, S=min(32, model.cfg.max_frames_per_call))
+                except Exception as e:
+                    e2e["multi_stream"] = {"error": repr(e)[:300]}
                 t_frames = e2e["frames"] / max(total_rate_hint, 1e-9) if (total_rate_hint := float(B * cps * a.steps / dt_local)) else 0.0
                 e2e["note"] = (f"frames/s of this schedule is decode-bound: at this run's perception rate the {e2e['frames']} frames cost about {t_frames:.2f} s of the "
                                f"{e2e['seconds']:.2f} s, the {e2e['fires']} replies of {e2e['reply_tokens']} tokens the rest, and a later reply's context contains the "
