@@ -931,6 +931,21 @@ def main():
         else:
             ex = GatedTokenExchange(cfg.conn_d_model, dtype=torch.bfloat16, device=torch.device("cuda", local) if cdev == "cuda" else torch.device("cpu"))
             ex_impl = "torch.distributed all-gather (%s)" % backend
+        # What the first real multi-GPU run must be diagnosable from (nobody has seen one yet): every rank's device, its hipDeviceCanAccessPeer row, the
+        # exchange it ended up with, its own self-test verdict -- gathered BEFORE the timed loop, printed to stderr at once (a run that then hangs or
+        # dies still leaves it in the log) and carried in the JSON line (gated_token_exchange.ranks)
+        try:
+            me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(local) if cdev == "cuda" else "cpu",
+                  "visible_devices": torch.cuda.device_count() if cdev == "cuda" else 0,
+                  "can_access_peer": ([int(j == local or torch.cuda.can_device_access_peer(local, j)) for j in range(torch.cuda.device_count())] if cdev == "cuda" else None),
+                  "peer_write_self_test": (None if not want_peer else ("ok" if ex_note is None else ex_note)), "exchange": ex_impl,
+                  "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "SM_BENCH_EXCHANGE", "SM_COMM_TIMEOUT_MS", "NCCL_DEBUG") if os.environ.get(k) is not None}}
+            rank_diag = [None] * world
+            dist.all_gather_object(rank_diag, me)
+            if rank == 0:
+                print("[bench] exchange diagnostics before the timed loop: " + json.dumps(rank_diag), file=sys.stderr, flush=True)
+        except Exception as e:      # noqa: BLE001 -- diagnostics must never take the run down
+            rank_diag = [{"error": repr(e)[:200]}]
 
     def fires(i):                        # ~ every 9th step per rank, never the same step on two ranks of an 8-GPU node
         return (i % 9) == (rank % 9)
@@ -1447,7 +1462,7 @@ def main():
         if per_rank is not None:
             out["per_rank_frames_per_s"] = per_rank          # each rank's own N=1-equivalent rate (its own clock)
             out["gated_token_exchange"] = {"ticks": ex.ticks, "payload_collectives": ex.payload_collectives, "rows_received": rows_seen,
-                                           "host_wait_ms_total": round(ex.host_wait_s * 1e3, 3), "implementation": ex_impl, "fallback_reason": ex_note,
+                                           "host_wait_ms_total": round(ex.host_wait_s * 1e3, 3), "implementation": ex_impl, "fallback_reason": ex_note, "ranks": rank_diag,
                                            "fire_schedule": "rank r fires on steps i with i % 9 == r % 9 (never two ranks of one node together)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libstreammind_hip.so")
-SOURCES = ["linear.hip", "gemm256.hip", "gemm_fp8.hip", "attention.hip", "vecops.hip", "ingest.hip", "stc.hip", "comm.hip", "jpeg.hip", "model.hip"]
+SOURCES = ["linear.hip", "gemm256.hip", "wstream.hip", "gemm_fp8.hip", "attention.hip", "vecops.hip", "ingest.hip", "stc.hip", "comm.hip", "jpeg.hip", "model.hip"]
 HEADERS = ["common.h", "host.h", "linear_common.h", os.path.join("..", "..", "include", "streammind_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 

@@ -1525,6 +1525,32 @@ static int gemm_tile_choice(const sm_linear_t* p, int* hint_out = nullptr) {
     if (hint == 2561 && ok) bn = 257;
     return bn;
 }
+// 33..128 rows of 16-bit activations on bf16 / fp16 (or weight-only fp8, expanded) weights: the weight-streaming MFMA kernel (wstream.hip).  Returns the number
+// of K slabs (>= 1) and the k-steps per slab, or 0 when the call does not qualify.  SM_WSTREAM=0: off (the 128 x 128 tiled kernel, A/B)
+static int wstream_slabs(const sm_linear_t* p, int* ksl_out) {
+    static int use_ws = -1;
+    if (use_ws < 0) { const char* e = getenv("SM_WSTREAM"); use_ws = e ? atoi(e) : 1; }
+    const bool dual = p->act == SM_ACT_SWIGLU_DUAL;
+    const int KS = (p->K + 31) / 32, NRG = (p->N + 15) / 16;
+    if (!use_ws || p->M <= 32 || p->M > 128 || p->x_dtype != SM_X_BF16 || p->vt || p->remap_in || p->w2 || p->norm_gamma || p->tile_hint || (p->K & 31) || (p->ldx & 7) ||
+        (KS % 8) || (p->w_dtype == SM_W_FP8_MFMA && (p->K & 127) == 0) || (dual && ((p->N & 31) || (p->ldo_bf16 & 3))) || p->x_rep > 1)
+        return 0;
+    const int nb = dual ? cdiv(NRG >> 1, 4) : cdiv(NRG, 8);
+    // Wide products only (>= 192 column blocks: gate | up as SwiGLU-dual, lm_head): one block per CU streams the whole K loop.  The kernel also runs
+    // narrow products as K slabs (SM_WSTREAM=2 enables: <= 8 slabs of whole register rings) -- measured no faster than the 128 x 128 tiled kernel there
+    // (128 rows, same box: q|k|v 22.6 vs 16.6 us with 8 slabs, 17.0 with 4; o_proj 13.4 vs 13.9; down_proj 30.4 vs 31.0): with MFMAs, fragment reads and
+    // barriers REMOVED the kernel streams at the same 4.5-4.8 TB/s (tools/experiments/wstream_probe.hip), i.e. both kernels sit on what 224-256 CUs pull
+    // through 1-KiB row-group streams, and short slabs pay the ring fill twice
+    int S = 1;
+    if (nb < 192) {
+        if (use_ws < 2 || dual) return 0;
+        for (int s = 8; s >= 2; --s)
+            if (nb * s <= 512 && KS % (8 * s) == 0) { S = s; break; }
+        if (S == 1) return 0;
+    }
+    *ksl_out = KS / S;
+    return S;
+}
 extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p, "sm_linear: null args");
     if (p->act == SM_ACT_SWIGLU_DUAL) {
@@ -1537,7 +1563,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const int bn = gemm_tile_choice(p);
         const bool w8 = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
         const bool fp8_mfma = p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && (p->ldx & 7) == 0;
-        const bool fused = dual_fuse && (bn == 256 || bn == 257) && !fp8_mfma && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0 && (!w8 || p->w_scale);
+        int ksl_ = 0;
+        const bool fused = dual_fuse && !fp8_mfma && (!w8 || p->w_scale) &&
+                           (((bn == 256 || bn == 257) && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0) || wstream_slabs(p, &ksl_) == 1);
         if (!fused) {
             SM_REQUIRE(p->ldo_bf16 == F, "sm_linear: SM_ACT_SWIGLU_DUAL outside the 256 x 256 kernel writes a dense [M][N / 2] output (ldo_bf16=%d)", p->ldo_bf16);
             float* ws = nullptr;
@@ -1673,6 +1701,28 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
 
     SM_REQUIRE(p->ldx % 8 == 0, "sm_linear: bf16 x needs ldx %% 8 == 0");
     SM_REQUIRE(!p->vt || (p->vt_n0 % GEMM_BN == 0 && !p->residual && p->remap_in == 0), "sm_linear: vt_n0 must be a multiple of %d on the GEMM path", GEMM_BN);
+    {   // 33..128 rows: a weight stream (wstream.hip)
+        int ksl = 0;
+        const int S = wstream_slabs(p, &ksl);
+        if (S >= 1) {
+            SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
+            if (S == 1) return launch_wstream(a, st, nullptr, 1, ksl);
+            float* ws = nullptr;
+            int rc = splitk_workspace(st, (size_t)S * p->M * p->N * sizeof(float), &ws);
+            if (rc) return rc;
+            if ((rc = launch_wstream(a, st, ws, S, ksl))) return rc;
+            static int ln_fuse_ws = -1;
+            if (ln_fuse_ws < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse_ws = e ? atoi(e) : 1; }
+            if (p->post_ln_gamma && ln_fuse_ws && (p->N & 255) == 0 && p->N <= 4096 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) && !a.wscale) {
+                const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+                splitk_reduce_norm_rows_kernel<<<p->M, p->N / 4, 0, st>>>(a, ws, S, ln);
+                SM_LAUNCH_CHECK();
+                *ln_done = true;
+                return SM_OK;
+            }
+            return launch_splitk_reduce(a, ws, S, p->N, st);
+        }
+    }
     // tile choice: 256x256 (one 8-wave block per CU, 128 FLOP per L2 byte) once its grid fills >= 3/4 of the chip,
     // else 128x128 (two blocks per CU); SM_GEMM_TILE=128|256128|256 overrides (tools/gemm_bench.py).  Measured on the
     // ViT shapes: B=28 frames (M=16156) 739 vs 706 TFLOP/s, B=14 565 vs 654 -> the threshold.

@@ -102,6 +102,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // LayerNorm / RMSNorm of the finished output row riding behind a product (sm_linear_t.post_ln_*)
 struct PostLn { const float* gamma; const float* beta; float eps; bf16_t* out; int ldo; float* out_f32; int act; };
 int launch_gemm256(const LinArgs& a, int act, int bn, hipStream_t st, int S = 1);      // gemm256.hip (256 x bn tile; a.f16 selects the fp16 build; S > 1: split-K slabs [S][M][ldo] of raw accumulators in out_f32)
+int launch_wstream(const LinArgs& a, hipStream_t st, float* ws, int S, int ksl);      // wstream.hip (33..128 rows: weights straight into register rings, X through LDS by a loader wave)
 int launch_gemm_fp8(LinArgs& a, hipStream_t st);                            // gemm_fp8.hip (fp8 x fp8 MFMA, activations quantised per row)
 int splitk_workspace(hipStream_t st, size_t bytes, float** out);            // linear.hip: per-HIP-stream fp32 slabs of the split-K kernels
 int launch_splitk_reduce(const LinArgs& a, const float* ws, int S, int ldw, hipStream_t st);     // ... their fixed-order sum + the real epilogue

@@ -860,12 +860,26 @@ extern "C" int sm_stream_open(sm_model* m, int max_frames, int max_seq, sm_strea
     return SM_OK;
 }
 
+// the recurrent state is zeroed by a KERNEL, not hipMemsetAsync: captured into a hipGraph (BASELINE configs[4]'s captured per-frame step), the two memset
+// nodes of a full-size reset + one-frame push did not order against the kernels behind them on ROCm 7.2 -- the first replay was right, later replays read the
+// previous replay's state (tools/graph_reset_probe.py: 24576 / 131071 state words off; a reset-only graph and the 16-frame graph were fine).  Kernel nodes are.
+__global__ void zero_states_kernel(u32x4* __restrict__ a, size_t na, u32x4* __restrict__ b, size_t nb) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < na) a[t] = u32x4{0, 0, 0, 0};
+    else if (t - na < nb) b[t - na] = u32x4{0, 0, 0, 0};
+}
 extern "C" int sm_stream_reset(sm_stream* s, void* stream) {
     SM_REQUIRE(s, "sm_stream_reset: null");
     { int jrc = auto_join(s, stream); if (jrc) return jrc; }
     hipStream_t st = (hipStream_t)stream;
-    if (s->conv_state.bytes) SM_HIP(hipMemsetAsync(s->conv_state.p, 0, s->conv_state.bytes, st));
-    if (s->ssm_state.bytes) SM_HIP(hipMemsetAsync(s->ssm_state.p, 0, s->ssm_state.bytes, st));      // none in a model without connector
+    {   // DevBuf allocations are 256-byte aligned and the state sizes are multiples of 16 bytes (d_inner * d_conv / d_state fp32 words, d_inner % 4 == 0)
+        const size_t na = s->conv_state.bytes / 16, nb = s->ssm_state.bytes / 16;      // none in a model without connector
+        SM_REQUIRE(s->conv_state.bytes % 16 == 0 && s->ssm_state.bytes % 16 == 0, "sm_stream_reset: state sizes");
+        if (na + nb) {
+            zero_states_kernel<<<(unsigned)((na + nb + 255) / 256), 256, 0, st>>>((u32x4*)s->conv_state.p, na, (u32x4*)s->ssm_state.p, nb);
+            SM_LAUNCH_CHECK();
+        }
+    }
     s->T = 0; s->kv_len = 0;
     return SM_OK;
 }

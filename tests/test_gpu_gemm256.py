@@ -269,3 +269,52 @@ def test_splitk_slabs_on_the_256_tile(nat, M, N, K, norm):
             assert ((ln_out.float().cpu() - want).abs().max() / want.abs().max()).item() < 8e-3
         outs.append(y.cpu())
     assert ((outs[0] - outs[1]).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(33, 4096, 4096, "res_norm"), (64, 6144, 4096, "plain"), (100, 4096, 14336, "res_norm"), (128, 4096, 4096, "res"),
+                                        (128, 32000, 4096, "bias"), (70, 4096, 1024, "res_f16"), (128, 28672, 4096, "dual"), (40, 7168, 512, "dual_bias")])
+def test_weight_streaming_mfma_33_to_128_rows(nat, M, N, K, kind):
+    """Round 5 (csrc/wstream.hip): 33..128 rows of 16-bit activations -- a batched decode step of 33..128 streams (sm_group_llm_decode, M = streams:
+    the reference decodes one stream at a time, videollama2_mistral.py:426-431) -- as a weight stream: W fragments straight into per-wave register rings,
+    X through LDS by a loader wave, K slabs + the slab pass (with the RMSNorm of the finished row) for narrow products, SwiGLU in the lane for gate | up.
+    fp32 rows 1e-5 from fp64 on the same operands; tile_hint = 128 (the 128 x 128 tiled kernel these calls took before) agrees to summation order;
+    the RMSNorm rows are the oracle's rms_norm of the fp32 rows; the SwiGLU rows agree with the unfused route to summation order.  By default only the
+    WIDE products take this kernel (>= 192 column blocks: gate | up, lm_head -- the two cases of the list with N >= 28672); SM_WSTREAM=2 sends the
+    narrow ones through its K-slab form too (measured no faster than the tiled kernel: csrc/linear.hip), which the remaining cases cover when set."""
+    from streammind_amd._lib import SM_ACT_SWIGLU_DUAL
+    f16 = kind.endswith("f16")
+    dt = torch.float16 if f16 else torch.bfloat16
+    w = rnd((N, K), 1, K ** -0.5).to(dt).float()
+    x = rnd((M, K), 2).to(dt).float()
+    wp = nat.pack_weight(w.cuda().to(dt))
+    xg = x.cuda().to(dt)
+    if kind.startswith("dual"):
+        F = N // 2
+        b = rnd((N,), 3, 0.1) if kind == "dual_bias" else None
+        bg = b.cuda() if b is not None else None
+        out, unf = torch.empty(M, F, device="cuda", dtype=dt), torch.empty(M, F, device="cuda", dtype=dt)
+        nat.linear(xg, wp, N, K, bias=bg, act=SM_ACT_SWIGLU_DUAL, out=out)
+        nat.linear(xg, wp, N, K, bias=bg, act=SM_ACT_SWIGLU_DUAL, out=unf, tile_hint=SM_TILE_128)
+        ref64 = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+        ref = (torch.nn.functional.silu(ref64[:, :F]) * ref64[:, F:]).float()
+        assert (out.float().cpu() - ref).abs().max().item() < 1.2e-2 * ref.abs().max().item()
+        # same fp32 accumulators up to summation order -> the 16-bit rows agree to one ulp on a tiny fraction
+        d = (out.cpu().view(torch.int16).int() - unf.cpu().view(torch.int16).int()).abs()
+        assert (out.float() - unf.float()).abs().max().item() < 1e-2 * ref.abs().max().item() and float((d > 1).float().mean()) < 1e-3
+        return
+    bias = rnd((N,), 3, 0.1) if kind == "bias" else None
+    res = rnd((M, N), 4) if kind.startswith("res") else None
+    g = 1 + rnd((N,), 5, 0.1)
+    ref = (x.double() @ w.double().t() + (bias.double() if bias is not None else 0) + (res.double() if res is not None else 0)).float()
+    outs = []
+    for hint in (0, SM_TILE_128):
+        resg = res.cuda() if res is not None else None
+        ln_out = torch.empty(M, N, device="cuda", dtype=dt) if kind == "res_norm" else None
+        y = nat.linear(xg, wp, N, K, bias=bias.cuda() if bias is not None else None, residual=resg, out=resg, tile_hint=hint,
+                       post_ln=(g.cuda(), None, 1e-5, ln_out) if ln_out is not None else None)
+        assert ((y.cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+        if ln_out is not None:
+            want = O.rms_norm(y.cpu(), g, 1e-5)
+            assert ((ln_out.float().cpu() - want).abs().max() / want.abs().max()).item() < 8e-3
+        outs.append(y.cpu())
+    assert ((outs[0] - outs[1]).abs().max() / ref.abs().max()).item() < 2e-6

@@ -106,3 +106,79 @@ def test_decode_step_captured_and_replayed_is_bit_identical(tiny):
     torch.cuda.synchronize()
     assert int(out[0]) == want_id
     assert torch.equal(cap.logits()[0], want_lg)
+
+
+@pytest.mark.parametrize("B", [1, 16])
+def test_config4_full_size_fp8_weights_captured_step_is_bit_identical(B):
+    """BASELINE configs[4] as ONE thing (round 5): the FULL-SIZE model (CLIP-ViT-L/14-336 tower, 872 M-parameter gate and Mistral-7B, gate + LLM weights in
+    fp8 e4m3 with per-row scales: weights_fp8 = 2) with the per-frame gate step -- sm_stream_reset + sm_stream_push_frames(B frames) -- captured by
+    hipStreamBeginCapture and replayed on fresh frames in the same ring slot: logits, decisions, frame tokens and the recurrent state BIT-IDENTICAL to
+    the eager call; then one fp8-weight Mistral-7B decode step captured at a fixed cache position and replayed: id and pending logits equal the eager
+    step's.  Random weights of the true shapes (the bench's generators: no oracle needed for an identity); the timing A/B of the same captures is
+    tools/graph_ab.py (profiles/r05_graph_ab.json, r05_graph_ab_fp8.json)."""
+    import bench
+    from streammind_amd.native import NativeModel, PathConfig
+    cfg = PathConfig(llm_layers=32, max_frames_per_call=16, weights_fp8=2)
+    m = NativeModel(cfg)
+    bench.random_weights_into(m, cfg, 1)
+    bench.random_llm_weights_into(m, cfg, 2)
+    m.finalize()
+    lib = m.lib
+    frames = bench.synthetic_frames_gpu(3 * B, 336, 1, 0)
+    slot = frames[:B].clone()
+    st = m.open_stream(max_frames=32, max_seq=512)
+    lg = torch.empty(B, 2, device="cuda")
+    dc = torch.empty(B, dtype=torch.int32, device="cuda")
+
+    def step():
+        cs = torch.cuda.current_stream().cuda_stream
+        assert lib.sm_stream_reset(st.h, cs) == 0
+        assert lib.sm_stream_push_frames(st.h, slot.data_ptr(), B, lg.data_ptr(), dc.data_ptr(), cs) == 0
+
+    g, side = _capture(step)
+    ref = m.open_stream(max_frames=32, max_seq=512)
+    for r in range(3):
+        slot.copy_(frames[r * B:(r + 1) * B])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            g.replay()
+        torch.cuda.synchronize()
+        ref.reset()
+        want_lg, want_dc = ref.push_frames(frames[r * B:(r + 1) * B].contiguous())
+        assert torch.isfinite(want_lg).all()
+        ref.reset()
+        again_lg, _ = ref.push_frames(frames[r * B:(r + 1) * B].contiguous())
+        assert torch.equal(again_lg, want_lg), ("eager call not repeatable", r, again_lg, want_lg)
+        assert torch.equal(lg, want_lg) and torch.equal(dc, want_dc), (r, lg, want_lg)
+        tok = torch.empty(B, cfg.conn_d_model, device="cuda")
+        assert lib.sm_stream_read_tokens(st.h, 0, B, tok.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        assert torch.equal(tok, ref.tokens(0, B))
+        for a, b in zip(st.state(), ref.state()):
+            assert torch.equal(a, b)
+    if B == 1:
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        ids = torch.randint(3, cfg.llm_vocab, (200,), generator=gen, device="cuda", dtype=torch.int32)
+        eager, cap, warm = (m.open_stream(max_frames=8, max_seq=512) for _ in range(3))
+        for s_ in (eager, cap):
+            s_.prefill(ids)
+            s_.decode(3)
+        kv0 = eager.kv_len
+        want_id = int(eager.decode(1)[0])
+        want_lg = eager.logits()[0].clone()
+        out = torch.zeros(1, dtype=torch.int32, device="cuda")
+        side2 = torch.cuda.Stream()
+        with torch.cuda.stream(side2):
+            warm.prefill(ids)
+            warm.decode(2)
+        torch.cuda.synchronize()
+        gph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side2):
+            with torch.cuda.graph(gph, stream=side2):
+                assert lib.sm_llm_decode(cap.h, 1, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert cap.kv_len == kv0 + 1
+        with torch.cuda.stream(side2):
+            gph.replay()
+        torch.cuda.synchronize()
+        assert int(out[0]) == want_id and torch.equal(cap.logits()[0], want_lg)
+    m.close()

@@ -22,7 +22,8 @@ import bench                                                    # noqa: E402
 from streammind_amd.native import NativeModel, PathConfig       # noqa: E402
 
 torch.set_grad_enabled(False)
-cfg = PathConfig(llm_layers=32, max_frames_per_call=28)
+FP8 = os.environ.get("FP8", "0") == "1"        # BASELINE configs[4]: gate + LLM weights in fp8 (weights_fp8 = 2), 16 frames per gate pass
+cfg = PathConfig(llm_layers=32, max_frames_per_call=28, weights_fp8=2 if FP8 else 0)
 model = NativeModel(cfg)
 bench.random_weights_into(model, cfg, 1)
 bench.random_llm_weights_into(model, cfg, 2)
@@ -97,5 +98,5 @@ for B in (1, 28):
         return f
     out.append(ab(f"per-frame gate step: {B} frame(s) through ViT + connector + gate (sm_stream_push_frames)", mk_push, 30 if B == 1 else 10))
 
-print(json.dumps({"tool": "tools/graph_ab.py", "note": "min over 5 interleaved rounds, microseconds per issue; graph = torch.cuda.CUDAGraph replay of the "
+print(json.dumps({"tool": "tools/graph_ab.py", "weights": "fp8 e4m3 gate + LLM (weights_fp8 = 2)" if FP8 else "bf16", "note": "min over 5 interleaved rounds, microseconds per issue; graph = torch.cuda.CUDAGraph replay of the "
                   "identical launch sequence on a side stream", "results": out}, indent=1))

@@ -50,7 +50,9 @@ pftrace)      # kernel trace of a 2048-token prefill (bf16, then fp8 x fp8): too
 dual)         # SwiGLU-dual epilogue + split-K slabs on the 256 tile: operator tests, 2048-token prefill A/B ($KNOB = SM_SWIGLU_FUSE | SM_GEMM256_SPLITK)
   timeout 900 python -m pytest tests/test_gpu_gemm256.py -q -x -k "swiglu or splitk_slabs" 2>&1 | tail -4
   for L in 1 0 1 0; do env ${KNOB:-SM_SWIGLU_FUSE}=$L timeout 600 python tools/decode_bench.py 8 4096 1976 2>&1 | grep -o "prefill_ms[^,]*, .prefill_tokens_per_s[^,]*" | sed "s/^/${KNOB:-SM_SWIGLU_FUSE}=$L /"; done | tee $O/${KNOB:-SM_SWIGLU_FUSE}_ab.txt ;;
-graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json ;;
+graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json
+  FP8=1 timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab_fp8.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab_fp8.json
+  timeout 900 python -m pytest tests/test_gpu_graph.py -q 2>&1 | tail -3 ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
 esac
