@@ -32,7 +32,7 @@ extern "C" {
 #define SM_ACT_SOFTPLUS 3   /* F.softplus on dt: mamba_simple.py:238                           */
 #define SM_ACT_SILU 4
 #define SM_ACT_GELU 5       /* nn.GELU() exact (erf): build_mlp of the STC readout builder.py:566-571 */
-#define SM_ACT_SWIGLU_DUAL 6 /* sm_linear only, 16-bit x, M > 32: w = [gate rows | up rows] (N = 2F, F %% 128 == 0, the layout of the fused gate|up image),
+#define SM_ACT_SWIGLU_DUAL 6 /* sm_linear only, 16-bit x, M > 16 (fewer rows: the dual weight-streaming kernel, w2): w = [gate rows | up rows] (N = 2F, F %% 128 == 0, the layout of the fused gate|up image),
                               * out_bf16[m][0..F) = 16-bit(silu(gate + bias[c]) * (up + bias[F + c])) -- MistralMLP's act_fn(gate_proj(x)) * up_proj(x) in the
                               * product's epilogue (the 256 x 256 kernel pairs gate / up fragments in one lane); elsewhere the product + sm_swiglu */
 

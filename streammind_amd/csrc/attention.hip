@@ -32,6 +32,8 @@ struct AttnP {
     float* part_o;                           // [splits][H][nq][DH] fp32
     float* part_ml;                          // [splits][H][nq][2]  (running max in scaled-log2 domain source units, l)
     int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
+    int pair;                                // causal prefill: a block runs query tiles t and nqt - 1 - t one after the other (nqt even): every block walks nqt + 1 key-tile units
+                                             // instead of 1 .. nqt (the whole grid is resident at once, so the launch lasted as long as its heaviest tile)
     // batched decode (GROUPQ, blockIdx.x = stream): per-stream caches and key counts; nseg == 0: single stream (k / vt / nk above)
     int nseg;
     long part_bs, ml_bs;                     // per-stream strides of part_o / part_ml (floats)
@@ -56,17 +58,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     // Block -> (query tile, head, batch).  In the tiled (non-split) mode the grid is 1-D and remapped so that all the
     // query tiles of one (batch, head) -- which stream the same K/V -- run on the SAME XCD (block L runs on XCD L % 8):
     // measured without it, each of the 5 q-tiles of a ViT head fetched its K/V through a different L2 (FETCH_SIZE 5x).
-    int h, b, qtile;
+    int h, b, qtile0;
     if (GROUPQ) {
-        h = blockIdx.y; b = blockIdx.x; qtile = 0;          // b: stream index of a batched decode (grid.x == 1 otherwise)
+        h = blockIdx.y; b = blockIdx.x; qtile0 = 0;         // b: stream index of a batched decode (grid.x == 1 otherwise)
     } else {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-        const int grp = (j / p.nqt) * 8 + xcd;
-        qtile = j % p.nqt;
+        const int nqt_g = (CAUSAL && p.pair) ? p.nqt >> 1 : p.nqt;
+        const int grp = (j / nqt_g) * 8 + xcd;
+        qtile0 = j % nqt_g;
         if (grp >= p.H * p.nbatch) return;
         h = grp % p.H; b = grp / p.H;
     }
     const int kvh = h / (p.H / p.KV);
+    const int npass = (CAUSAL && !GROUPQ && p.pair) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int qtile = pass ? qtile0 : (npass == 2 ? p.nqt - 1 - qtile0 : qtile0);      // the heavy tile first
+    if (pass) __syncthreads();                  // every wave is done with the LDS tiles of the first pass
     const int q0 = qtile * 128 + wave * 32;
     const bool segm = GROUPQ && p.nseg > 0;
     const int nk = segm ? p.seg.pos[b] + 1 : p.nk;
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
             }
         }
     }
+  }     // pass
 }
 
 // ------------------------------------------------------------------------------------------------ ViT fast path
@@ -670,7 +678,11 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
 static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
     if (p.v && dh == 64) p.nqt = cdiv(p.nq, VIT_ATTN_WAVES * 32);
-    dim3 grid(cdiv(p.H * B, 8) * 8 * p.nqt);
+    // causal prefill with an even number (>= 4) of query tiles: tiles t and nqt - 1 - t share a block (SM_ATTN_PAIR=0: off, A/B)
+    static int pair_on = -1;
+    if (pair_on < 0) { const char* e = getenv("SM_ATTN_PAIR"); pair_on = e ? atoi(e) : 1; }
+    p.pair = (pair_on && p.causal && !p.v && !p.split_len && p.nqt >= 4 && (p.nqt & 1) == 0) ? 1 : 0;
+    dim3 grid(cdiv(p.H * B, 8) * 8 * (p.pair ? p.nqt >> 1 : p.nqt));
     SmProfScope prof(SM_PROF_ATTN, st);
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
     SM_REQUIRE(!(p.v && p.causal), "attention: row-major V is the non-causal (ViT) mode");
@@ -698,6 +710,7 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     SM_REQUIRE(qkv && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
     SM_REQUIRE(!vt || (vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64), "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
     AttnP p;
+    p.pair = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     const long ld = 3L * H * dh;
     p.q = (const bf16_t*)qkv; p.q_bs = (long)S * ld; p.q_rs = ld;
@@ -717,6 +730,7 @@ int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, 
     SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
     AttnP p;
+    p.pair = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = (long)H * dh;
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
@@ -922,6 +936,7 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
     const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
     splits = cdiv(nk_eff, split_len);
     AttnP p;
+    p.pair = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0; p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
@@ -1012,6 +1027,7 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
     const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
     splits = cdiv(nk_eff, split_len);
     AttnP p;
+    p.pair = 0;
     p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = (long)H * dh; p.q_rs = dh;
     p.k = nullptr; p.k_bs = 0; p.k_rs = (long)KV * dh;

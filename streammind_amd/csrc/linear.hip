@@ -1555,9 +1555,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     SM_REQUIRE(p, "sm_linear: null args");
     if (p->act == SM_ACT_SWIGLU_DUAL) {
         const int F = p->N >> 1;
-        SM_REQUIRE(p->M > 32 && p->x_dtype == SM_X_BF16 && p->out_bf16 && !p->out_f32 && !p->residual && !p->vt && !p->w2 && p->remap_in == 0 && !p->post_ln_gamma &&
+        SM_REQUIRE(p->M > 16 && p->x_dtype == SM_X_BF16 && p->out_bf16 && !p->out_f32 && !p->residual && !p->vt && !p->w2 && p->remap_in == 0 && !p->post_ln_gamma &&
                    !p->norm_gamma && (p->N & 255) == 0 && p->ldo_bf16 >= F,
-                   "sm_linear: SM_ACT_SWIGLU_DUAL needs M > 32, 16-bit x, one [gate | up] weight image with N %% 256 == 0 and a 16-bit output [M][ldo_bf16 >= N / 2] only");
+                   "sm_linear: SM_ACT_SWIGLU_DUAL needs M > 16, 16-bit x, one [gate | up] weight image with N %% 256 == 0 and a 16-bit output [M][ldo_bf16 >= N / 2] only");
         static int dual_fuse = -1;                    // SM_SWIGLU_FUSE=0: always the product + the SwiGLU pass (A/B)
         if (dual_fuse < 0) { const char* e = getenv("SM_SWIGLU_FUSE"); dual_fuse = e ? atoi(e) : 1; }
         const int bn = gemm_tile_choice(p);
