@@ -573,3 +573,43 @@ def test_torch_library_ops_call_the_native_kernels(nat):
     assert torch.equal(lg, lg2) and torch.equal(dc, dc2) and s1.num_frames == 3 and int(st) == 1
     pooled = ops.pool_rows(torch.randn(3, 16, 128, device="cuda"))
     assert pooled.shape == (3, 128)
+
+
+@pytest.mark.parametrize("n,pos0", [(100, 37), (64, 0), (31, 5), (2048, 0)])
+def test_rope_kv_append_rows_and_tiles(n, pos0):
+    """sm_rope_kv_append (HF MistralRotaryEmbedding + apply_rotary_pos_emb, rotate_half convention, then the KV-cache append of
+    transformers' DynamicCache.update: the reference reaches both through videollama2_mistral.py:426-431): q rotated to 16-bit rows, k rotated into
+    the cache row of ITS position, v into the TRANSPOSED cache.  31 rows take the row kernel, 64 / 100 (ragged, unaligned position) / 2048 the tile
+    kernel of round 5 (64 tokens x one head per block, V^T through an LDS transpose): fp32 arithmetic a c - b s / b c + a s with ONE rounding --
+    within one 16-bit ulp of the torch statement on every element (fma contraction), v exact, untouched cache rows stay untouched."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    H, KV, dh, S_max = 32, 8, 128, 2304
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(n, (H + 2 * KV) * dh, generator=g)
+    half = dh // 2
+    inv = 1.0 / (1e6 ** (torch.arange(0, dh, 2).float() / dh))
+    ang = torch.arange(S_max).float()[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q = torch.full((n, H * dh), 7.0, dtype=torch.bfloat16, device="cuda")
+    kc = torch.full((S_max, KV * dh), 7.0, dtype=torch.bfloat16, device="cuda")
+    vtc = torch.full((KV, dh, S_max), 7.0, dtype=torch.bfloat16, device="cuda")
+    qg, cg, sg = qkv.cuda(), cos.cuda(), sin.cuda()
+    check(lib.sm_rope_kv_append(qg.data_ptr(), n, pos0, H, KV, dh, cg.data_ptr(), sg.data_ptr(), q.data_ptr(), kc.data_ptr(), vtc.data_ptr(), S_max,
+                                torch.cuda.current_stream().cuda_stream))
+    x = qkv.view(n, H + 2 * KV, dh)
+    c, s_ = cos[pos0:pos0 + n, None, :], sin[pos0:pos0 + n, None, :]
+    a, b = x[:, :H + KV, :half], x[:, :H + KV, half:]
+    rot = torch.cat([a * c - b * s_, b * c + a * s_], dim=-1)
+    want_q = rot[:, :H].reshape(n, H * dh)
+    want_k = rot[:, H:].reshape(n, KV * dh)
+    def ulps(got, want):
+        gi, wi = got.cpu().view(torch.int16).int(), want.bfloat16().view(torch.int16).int()
+        return int((gi - wi).abs().max()), float(((gi - wi) != 0).float().mean())
+    for got, want in ((q, want_q), (kc[pos0:pos0 + n], want_k)):
+        mx, frac = ulps(got, want)
+        assert mx <= 1 and frac < 2e-2, (mx, frac)
+    want_v = x[:, H + KV:, :].permute(1, 2, 0).bfloat16()                                # [KV][dh][n]
+    assert torch.equal(vtc[:, :, pos0:pos0 + n].cpu(), want_v)
+    assert bool((kc[:pos0] == 7).all()) and bool((kc[pos0 + n:] == 7).all())
+    assert bool((vtc[:, :, :pos0] == 7).all()) and bool((vtc[:, :, pos0 + n:] == 7).all())

@@ -4,7 +4,7 @@
 set -u
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/round; mkdir -p $O
+O=gpurun_out/round; mkdir -p $O; export TAG=round
 timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log > $O/bench_default.json; cut -c1-400 $O/bench_default.json
 # kernel stats of the BENCH STEPS ONLY (no decode / end-to-end / auxiliary legs, no HIP-event bracketing).  Two runs:
@@ -40,3 +40,21 @@ python tools/trace_window.py /tmp/prof_t1 preprocess_kernel > $O/tick_b1_timelin
 rm -rf /tmp/prof_p28; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_p28 -- python tools/pass_bench.py 28 40 > $O/pass28_profiled.log 2>&1
 python tools/trace_window.py /tmp/prof_p28 gate_tail_kernel > $O/pass28_timeline.txt 2>&1
 head -8 $O/kernel_stats_steps_default.csv | cut -c1-160; head -12 $O/kernel_stats_steps.csv | cut -c1-160; head -8 $O/kernel_stats_decode.csv | cut -c1-160
+# round 5: the LLM side -- 2048-token prefill (kernel stats + per-kernel breakdown), the batched decode step at 128 and 512 streams (one-step timelines),
+# and the tile-walk A/B of the dominant GEMM's fabric traffic (SM_GEMM_CG = column groups per XCD band: 0 = plain row-major walk)
+rm -rf /tmp/prof_pf; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pf -- python tools/decode_bench.py 8 4096 1976 > $O/pf_profiled.log 2>&1
+cp "$(find /tmp/prof_pf -name '*kernel_stats.csv' | head -1)" $O/prefill_kernel_stats.csv
+python tools/prefill_breakdown.py /tmp/prof_pf > $O/prefill2048_breakdown.txt; cat $O/prefill2048_breakdown.txt
+for GD in 128 512; do TAG=round GD=$GD bash tools/session.sh gdtrace > /dev/null 2>&1; tail -12 $O/group_decode${GD}_step_timeline.txt | head -0; done
+for CG in 0 3; do
+  rm -rf /tmp/pmc_f$CG; SM_GEMM_CG=$CG rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f$CG -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+  rm -rf /tmp/pmc_w$CG; SM_GEMM_CG=$CG rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w$CG -- python bench.py --batch 28 --no-pipeline --steps 3 --warmup 1 --stream-frames 112 --no-cpu-baseline --no-decode --no-prof --no-aux > /dev/null 2>&1
+  python tools/pmc_traffic_summary.py /tmp/pmc_f$CG /tmp/pmc_w$CG $O/gemm_traffic_cg$CG.json
+  SM_GEMM_CG=$CG timeout 600 python bench.py --batch 28 --no-pipeline --no-cpu-baseline --no-decode --no-aux --no-e2e --no-fp8 2>/dev/null | grep '^{"metric"' > $O/bench_single_lane_cg$CG.json
+done
+python - <<'PY'
+import json
+for cg in (0, 3):
+    t = json.load(open(f"gpurun_out/round/gemm_traffic_cg{cg}.json")); b = json.loads(open(f"gpurun_out/round/bench_single_lane_cg{cg}.json").read())
+    print(f"SM_GEMM_CG={cg}: hbm bytes per GEMM launch {t.get('hbm_bytes_per_launch')}, single-lane frames/s {b['value']}, gemm avg launch us {b['roofline']['avg_launch_us']}")
+PY
