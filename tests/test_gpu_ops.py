@@ -581,7 +581,7 @@ def test_rope_kv_append_rows_and_tiles(n, pos0):
     transformers' DynamicCache.update: the reference reaches both through videollama2_mistral.py:426-431): q rotated to 16-bit rows, k rotated into
     the cache row of ITS position, v into the TRANSPOSED cache.  31 rows take the row kernel, 64 / 100 (ragged, unaligned position) / 2048 the tile
     kernel of round 5 (64 tokens x one head per block, V^T through an LDS transpose): fp32 arithmetic a c - b s / b c + a s with ONE rounding --
-    within one 16-bit ulp of the torch statement on every element (fma contraction), v exact, untouched cache rows stay untouched."""
+    within one 16-bit ulp of the torch statement (fma contraction; absolute 2e-6 where the rotation cancels), v exact, untouched cache rows stay untouched."""
     from streammind_amd._lib import load, check
     lib = load()
     H, KV, dh, S_max = 32, 8, 128, 2304
@@ -603,12 +603,12 @@ def test_rope_kv_append_rows_and_tiles(n, pos0):
     rot = torch.cat([a * c - b * s_, b * c + a * s_], dim=-1)
     want_q = rot[:, :H].reshape(n, H * dh)
     want_k = rot[:, H:].reshape(n, KV * dh)
-    def ulps(got, want):
-        gi, wi = got.cpu().view(torch.int16).int(), want.bfloat16().view(torch.int16).int()
-        return int((gi - wi).abs().max()), float(((gi - wi) != 0).float().mean())
     for got, want in ((q, want_q), (kc[pos0:pos0 + n], want_k)):
-        mx, frac = ulps(got, want)
-        assert mx <= 1 and frac < 2e-2, (mx, frac)
+        # one 16-bit ulp (2^-8 relative) -- except where a c - b s cancels: there the fused multiply-add of the kernel and torch's two roundings differ by
+        # fp32 epsilon of the OPERANDS (1e-7 absolute on O(1) inputs), many ulps of a result that is itself ~1e-6
+        err = (got.float().cpu() - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -7 + 2e-6).all()), float((err - want.abs() * 2.0 ** -7).max())
+        assert float((got.cpu() != want.bfloat16()).float().mean()) < 2e-2
     want_v = x[:, H + KV:, :].permute(1, 2, 0).bfloat16()                                # [KV][dh][n]
     assert torch.equal(vtc[:, :, pos0:pos0 + n].cpu(), want_v)
     assert bool((kc[:pos0] == 7).all()) and bool((kc[pos0 + n:] == 7).all())
