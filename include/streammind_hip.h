@@ -445,6 +445,36 @@ int sm_jpeg_info(const uint8_t* data, size_t len, sm_jpeg_info_t* info);
  * per component).  want != NULL: fail unless the frame has that geometry (frames of one clip share it). */
 int sm_jpeg_decode_coefs(const uint8_t* data, size_t len, const sm_jpeg_info_t* want, int16_t* coefs, uint16_t* qt);
 size_t sm_jpeg_planes_bytes(const sm_jpeg_info_t* info, int n_frames);
+/* Entropy decode ON THE GPU for frames with restart intervals (round 5).  A restart interval (DRI: `restart` MCUs, RSTn markers between them) starts
+ * byte-aligned with its DC predictors reset, i.e. it decodes independently of everything in front of it: one GPU lane per interval (a 720p 4:2:0 frame with
+ * one interval per MCU row = 45 lanes; a batch of 28 frames = 1260), markers found by a parallel scan of the segment, the same ITU T.81 F.2.2 decode as
+ * sm_jpeg_decode_coefs with the tables in LDS, on a copy of the interval's bytes with the stuffed zeros removed (one wave per interval).  Frames WITHOUT restart markers stay on the host path (sm_jpeg_scan_prepare says so).
+ *   sm_jpeg_scan_prepare(data, len, want, scan)   host: markers only (no entropy decode) -> where the entropy-coded segment lies, DRI, the canonical Huffman
+ *                                                 decode tables and the quantisation tables of the frame's ONE interleaved scan (or its one grey scan);
+ *                                                 SM_EINVAL naming the reason for anything else (no DRI, per-component scans, progressive, ...)
+ *   sm_jpeg_entropy_decode(bytes, bytes_total, offsets, scans, info, n, coefs, qt, status, stream)
+ *                                                 device: bytes = the n files back to back (device copy, each file 16-byte aligned, 32 bytes of padding behind
+ *                                                 the last), offsets[n] = each file's first byte,
+ *                                                 scans[n] = the prepared scans (device copy) -> coefs int16 [n][coef_count] and qt uint16 [n][3][64] exactly
+ *                                                 as sm_jpeg_decode_coefs leaves them; status int32 [n]: 0 or the first error of the frame (1 bad code,
+ *                                                 2 run past the block, 3 missing / misnumbered RSTn, 4 segment ends early) -- the caller reads it after `stream`. */
+typedef struct sm_jpeg_huff_t {       /* canonical decode table, device-friendly (T.81 F.2.2.3) */
+    uint16_t fast[512];               /* 9-bit look-ahead: (length << 8) | symbol, 0 = longer code */
+    int32_t maxcode[18];              /* largest code of each length (-1: none), [17] = sentinel */
+    int32_t valoff[17];               /* valptr[l] - mincode[l] */
+    uint8_t vals[256];
+} sm_jpeg_huff_t;
+typedef struct sm_jpeg_scan_t {
+    uint32_t scan_offset, scan_len;   /* entropy-coded segment inside the file (bytes); scan_len runs to the end of the file */
+    int32_t restart;                  /* MCUs per restart interval (> 0) */
+    int32_t n_intervals;
+    int32_t ncomp;
+    uint16_t qt[3][64];               /* per component, natural order */
+    sm_jpeg_huff_t dc[3], ac[3];      /* per component */
+} sm_jpeg_scan_t;
+int sm_jpeg_scan_prepare(const uint8_t* data, size_t len, const sm_jpeg_info_t* want, sm_jpeg_scan_t* scan);
+int sm_jpeg_entropy_decode(const uint8_t* bytes_dev, size_t bytes_total, const uint32_t* offsets_dev, const sm_jpeg_scan_t* scans_dev, const sm_jpeg_info_t* info, int n_frames,
+                           int16_t* coefs_dev, uint16_t* qt_dev, int32_t* status_dev, void* stream);
 /* device: coefs [n][coef_count], qt [n][3][64] -> rgb u8 [n][height][width][3]; planes: scratch of sm_jpeg_planes_bytes bytes */
 int sm_jpeg_reconstruct(const int16_t* coefs, const uint16_t* qt, const sm_jpeg_info_t* info, int n_frames, uint8_t* planes, uint8_t* rgb, void* stream);
 

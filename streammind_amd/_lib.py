@@ -51,6 +51,15 @@ class sm_config_t(C.Structure):
     ]
 
 
+class sm_jpeg_huff_t(C.Structure):
+    _fields_ = [("fast", C.c_uint16 * 512), ("maxcode", C.c_int32 * 18), ("valoff", C.c_int32 * 17), ("vals", C.c_uint8 * 256)]
+
+
+class sm_jpeg_scan_t(C.Structure):
+    _fields_ = [("scan_offset", C.c_uint32), ("scan_len", C.c_uint32), ("restart", C.c_int32), ("n_intervals", C.c_int32), ("ncomp", C.c_int32),
+                ("qt", (C.c_uint16 * 64) * 3), ("dc", sm_jpeg_huff_t * 3), ("ac", sm_jpeg_huff_t * 3)]
+
+
 class sm_jpeg_info_t(C.Structure):
     _fields_ = [("width", i32), ("height", i32), ("ncomp", i32), ("hs", i32 * 3), ("vs", i32 * 3), ("mcu_w", i32), ("mcu_h", i32),
                 ("mcus_x", i32), ("mcus_y", i32), ("blocks_x", i32 * 3), ("blocks_y", i32 * 3), ("coef_offset", i32 * 3), ("coef_count", i32)]
@@ -133,6 +142,8 @@ SIGNATURES = {
     "sm_jpeg_decode_coefs": (i32, [vp, sz, C.POINTER(sm_jpeg_info_t), vp, vp]),
     "sm_jpeg_planes_bytes": (sz, [C.POINTER(sm_jpeg_info_t), i32]),
     "sm_jpeg_reconstruct": (i32, [vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp]),
+    "sm_jpeg_scan_prepare": (i32, [vp, sz, C.POINTER(sm_jpeg_info_t), C.POINTER(sm_jpeg_scan_t)]),
+    "sm_jpeg_entropy_decode": (i32, [vp, sz, vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp, vp]),
     "sm_comm_handle_bytes": (i32, []),
     "sm_comm_init": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
     "sm_comm_export": (i32, [vp, vp]),

@@ -28,6 +28,9 @@ namespace {
 const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+__device__ const uint8_t kZigzagDev[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
 struct Huff {
     bool present = false;
     uint8_t bits[17] = {0}, vals[256] = {0};
@@ -357,6 +360,297 @@ extern "C" int sm_jpeg_decode_coefs(const uint8_t* data, size_t len, const sm_jp
         if (rc) return rc;
     }
     for (int c = 0; c < P.ncomp; ++c) memcpy(qt + 64 * c, P.qt[P.comp[c].tq], 64 * sizeof(uint16_t));
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ entropy decode on the GPU (restart intervals)
+// Markers only: the frame's geometry, tables and where its ONE scan's entropy-coded bytes lie.  The decode itself is jpeg_huff_kernel below.
+extern "C" int sm_jpeg_scan_prepare(const uint8_t* data, size_t len, const sm_jpeg_info_t* want, sm_jpeg_scan_t* out) {
+    SM_REQUIRE(data && out && len >= 4 && data[0] == 0xFF && data[1] == 0xD8, "sm_jpeg_scan_prepare: not a JPEG (no SOI)");
+    Parsed P;
+    size_t pos = 2;
+    int sc[3], sn = 0;
+    int rc = parse_segments(data, len, pos, P, false, sc, &sn);
+    if (rc) return rc;
+    sm_jpeg_info_t I;
+    fill_info(P, &I);
+    if (want)
+        SM_REQUIRE(want->width == I.width && want->height == I.height && want->ncomp == I.ncomp && want->hs[0] == I.hs[0] && want->vs[0] == I.vs[0] &&
+                   want->coef_count == I.coef_count, "sm_jpeg_scan_prepare: frame is %dx%d/%d comps/%dx%d sampling, the batch was opened as %dx%d/%d/%dx%d",
+                   I.width, I.height, I.ncomp, I.hs[0], I.vs[0], want->width, want->height, want->ncomp, want->hs[0], want->vs[0]);
+    SM_REQUIRE(P.restart > 0, "jpeg: no restart interval (DRI): the entropy-coded segment is one serial stream, host path");
+    SM_REQUIRE(sn == P.ncomp, "jpeg: %d of %d components in the first scan (per-component scans: host path)", sn, P.ncomp);
+    for (int i = 0; i < sn; ++i) SM_REQUIRE(sc[i] == i, "jpeg: scan component order (host path)");
+    memset(out, 0, sizeof(*out));
+    for (int c = 0; c < P.ncomp; ++c) {
+        const Comp& k = P.comp[c];
+        if (!P.dc[k.td].present) { SM_REQUIRE(k.td < 2, "jpeg: DC table %d undefined", k.td); std_table(P.dc[k.td], k.td ? kStdDcChrBits : kStdDcLumBits, kStdDcVals, 12); }
+        if (!P.ac[k.ta].present) { SM_REQUIRE(k.ta < 2, "jpeg: AC table %d undefined", k.ta); std_table(P.ac[k.ta], k.ta ? kStdAcChrBits : kStdAcLumBits, k.ta ? kStdAcChrVals : kStdAcLumVals, 162); }
+        SM_REQUIRE(P.qt_present[k.tq], "jpeg: quantisation table %d undefined", k.tq);
+        memcpy(out->qt[c], P.qt[k.tq], 64 * sizeof(uint16_t));
+        for (int t = 0; t < 2; ++t) {
+            const Huff& h = t ? P.ac[k.ta] : P.dc[k.td];
+            sm_jpeg_huff_t& d = t ? out->ac[c] : out->dc[c];
+            memcpy(d.fast, h.fast, sizeof(d.fast));
+            for (int l = 1; l <= 16; ++l) { d.maxcode[l] = h.maxcode[l]; d.valoff[l] = h.valptr[l] - h.mincode[l]; }
+            d.maxcode[0] = -1; d.maxcode[17] = 0x7fffffff; d.valoff[0] = 0;
+            memcpy(d.vals, h.vals, 256);
+        }
+    }
+    out->scan_offset = (uint32_t)pos; out->scan_len = (uint32_t)(len - pos);
+    out->restart = P.restart; out->ncomp = P.ncomp;
+    out->n_intervals = (I.mcus_x * I.mcus_y + P.restart - 1) / P.restart;
+    SM_REQUIRE(out->n_intervals <= 4096, "jpeg: %d restart intervals per frame (the GPU index keeps 4096: host path)", out->n_intervals);
+    return SM_OK;
+}
+
+#define JH_MAX_INT 4096            // restart intervals per frame the index kernel keeps (sm_jpeg_scan_prepare refuses frames with more)
+// Start of every restart interval: interval 0 at the scan's first byte, interval k behind the k-th RSTn marker.  One block per frame; every thread
+// counts the markers of its contiguous chunk, an LDS scan ranks them, a second walk writes the offsets in order.  Also checks the marker numbering
+// (RST(k mod 8) ends interval k) and that exactly n_intervals - 1 markers exist.
+__global__ __launch_bounds__(1024) void jpeg_rst_index_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets,
+                                                              const sm_jpeg_scan_t* __restrict__ scans, uint32_t* __restrict__ starts, int32_t* __restrict__ status) {
+    __shared__ int cnt[1024];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    const uint8_t* d = bytes + offsets[f] + sc.scan_offset;
+    const uint32_t n = sc.scan_len;
+    const uint32_t per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    int c = 0;
+    for (uint32_t p = lo; p < hi; ++p)
+        if (d[p] == 0xFF && p + 1 < n && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7) ++c;
+    cnt[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                      // inclusive scan
+        const int v = tid >= o ? cnt[tid - o] : 0;
+        __syncthreads();
+        cnt[tid] += v;
+        __syncthreads();
+    }
+    int rank = cnt[tid] - c;                                  // markers in front of this thread's chunk
+    uint32_t* st = starts + (size_t)f * JH_MAX_INT;
+    if (tid == 0) st[0] = 0;
+    bool bad = false;
+    for (uint32_t p = lo; p < hi; ++p)
+        if (d[p] == 0xFF && p + 1 < n && d[p + 1] >= 0xD0 && d[p + 1] <= 0xD7) {
+            if (d[p + 1] != 0xD0 + (rank & 7)) bad = true;
+            ++rank;
+            if (rank < JH_MAX_INT) st[rank] = p + 2;
+        }
+    if (bad || (tid == 1023 && cnt[1023] != sc.n_intervals - 1)) atomicCAS(&status[f], 0, 3);
+}
+
+// Unstuffing, one WAVE per restart interval: the interval's bytes (from its start to the marker that ends it) are copied without the zero that follows every
+// data 0xFF, in place of the raw bytes' own range of a second buffer (the clean image is never longer than the raw one); 64 bytes per step, ranks by ballot.
+// lens[f][iv] = clean length.  The decode lanes then read a plain bit stream: no per-byte marker / stuffing checks in their loop.
+__global__ __launch_bounds__(256) void jpeg_unstuff_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                           const uint32_t* __restrict__ starts, uint8_t* __restrict__ clean, uint32_t* __restrict__ lens) {
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
+    const int iv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const sm_jpeg_scan_t& sc = scans[f];
+    if (iv >= sc.n_intervals || iv >= JH_MAX_INT) return;
+    const uint32_t* st = starts + (size_t)f * JH_MAX_INT;
+    const uint32_t lo = st[iv], hi = iv + 1 < sc.n_intervals ? st[iv + 1] - 2 : sc.scan_len;       // (the RSTn marker itself is not data)
+    const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
+    uint8_t* dst = clean + offsets[f] + sc.scan_offset + lo;
+    uint32_t out = 0;
+    bool ended = false;
+    for (uint32_t p0 = lo; p0 < hi && !ended; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        const bool in = p < hi;
+        const uint32_t b = in ? src[p] : 0u;
+        const uint32_t prev = (in && p > lo) ? src[p - 1] : 0u;
+        const uint32_t next = (in && p + 1 < hi) ? src[p + 1] : 0u;
+        // a marker inside the range (0xFF followed by neither 0x00 nor the end of the range: EOI behind the last interval) ends the data
+        const bool is_marker = in && b == 0xFF && p + 1 < hi && next != 0x00;
+        const unsigned long long mk = __ballot(is_marker);
+        const int first_mk = mk ? __ffsll((long long)mk) - 1 : 64;
+        const bool keep = in && lane < first_mk && !(b == 0x00 && prev == 0xFF);
+        const unsigned long long kb = __ballot(keep);
+        if (keep) dst[out + __popcll(kb & ((1ull << lane) - 1))] = (uint8_t)b;
+        out += __popcll(kb);
+        ended = mk != 0;
+    }
+    if (lane == 0) lens[(size_t)f * JH_MAX_INT + iv] = out;
+}
+
+// One lane per restart interval (T.81 F.2.2: DC difference + AC run/size codes, receive + extend), tables of the frame in LDS.  ONE uniform loop: every
+// trip decodes one Huffman symbol (+ its value bits) for every live lane -- no nested data-dependent loops, so the lanes of a wave, which sit at different
+// coefficients of different blocks, still execute the same instructions (the first form, a transliteration of the host decoder with its refill / AC /
+// long-code loops, spent ~5500 clk per symbol on one wave per SIMD: 31.5 ms for 28 frames of 720p).  The bit window is refilled 32 bits at a time from the
+// unstuffed image (one unaligned dword, prefetched one word ahead); codes longer than 9 bits take an unrolled scan of the length classes.
+struct JhGeom { int mcus_x, mcus_y, ncomp, hs[3], vs[3], blocks_x[3], coef_offset[3], coef_count; };
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                       const uint32_t* __restrict__ starts, const uint32_t* __restrict__ lens, JhGeom g, int16_t* __restrict__ coefs,
+                                                       uint16_t* __restrict__ qt, int32_t* __restrict__ status) {
+    __shared__ sm_jpeg_huff_t tab[6];                          // dc[0..2], ac[0..2] of this frame
+    __shared__ uint8_t zz[64];
+    const int f = blockIdx.y, lane = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    if ((int)blockIdx.x * 64 >= sc.n_intervals) return;         // (the grid covers the largest interval count of the geometry)
+    {
+        const uint32_t* src = (const uint32_t*)sc.dc;          // dc[3] and ac[3] are contiguous in sm_jpeg_scan_t
+        uint32_t* dst = (uint32_t*)tab;
+        for (int w = lane; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += 64) dst[w] = src[w];
+        zz[lane] = kZigzagDev[lane];
+        if (blockIdx.x == 0)
+            for (int w = lane; w < 3 * 64; w += 64) qt[(size_t)f * 192 + w] = sc.qt[w / 64][w % 64];
+    }
+    __syncthreads();
+    const int iv = blockIdx.x * 64 + lane;
+    bool live = iv < sc.n_intervals && iv < JH_MAX_INT && status[f] != 3;
+    const uint8_t* src = clean + offsets[f] + sc.scan_offset + (live ? starts[(size_t)f * JH_MAX_INT + iv] : 0u);
+    const uint32_t len = live ? lens[(size_t)f * JH_MAX_INT + iv] : 0u;
+    int16_t* cf = coefs + (size_t)f * g.coef_count;
+    const int total = g.mcus_x * g.mcus_y;
+    int mcu = iv * sc.restart;
+    const int mcu_end = mcu + sc.restart < total ? mcu + sc.restart : total;
+    live = live && mcu < mcu_end;
+    // blocks of an MCU in scan order: component ci, block b of its bh x bv
+    const int nb0 = g.ncomp > 1 ? g.hs[0] * g.vs[0] : 1, nbm = g.ncomp > 1 ? nb0 + 2 : 1;       // blocks per MCU (chroma components are 1 x 1)
+    int bi = 0;                                                 // block index inside the MCU
+    int k = 0;                                                  // next coefficient (zig-zag); 0 = the DC symbol comes next
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int16_t* blk = cf;
+    int ci = 0;
+    // MCU position kept incrementally (no integer division in the loop); luma blocks of an MCU: bh in {1, 2} columns
+    int mx = live ? mcu % g.mcus_x : 0, my = live ? mcu / g.mcus_x : 0;
+    const int bh0 = g.ncomp > 1 ? g.hs[0] : 1, bv0 = g.ncomp > 1 ? g.vs[0] : 1;
+    const sm_jpeg_huff_t* hdc = &tab[0];
+    const sm_jpeg_huff_t* hac = &tab[3];
+    auto locate = [&]() {
+        ci = bi < nb0 ? 0 : bi - nb0 + 1;
+        const int bcol = ci == 0 ? (bh0 == 2 ? (bi & 1) : 0) : 0, brow = ci == 0 ? (bh0 == 2 ? (bi >> 1) : bi) : 0;
+        const int bx = ci == 0 ? mx * bh0 + bcol : mx, by = ci == 0 ? my * bv0 + brow : my;
+        const int bxn = ci == 0 ? g.blocks_x[0] : (ci == 1 ? g.blocks_x[1] : g.blocks_x[2]);
+        const int co = ci == 0 ? g.coef_offset[0] : (ci == 1 ? g.coef_offset[1] : g.coef_offset[2]);
+        blk = cf + co + ((size_t)by * bxn + bx) * 64;
+        hdc = &tab[ci]; hac = &tab[3 + ci];
+    };
+    if (live) locate();
+    // bit window: `n` valid bits at the bottom of acc; words are consumed big-endian from the clean bytes, zeros behind the interval's end
+    uint64_t acc = 0;
+    int n = 0;
+    uint32_t bp = 0;
+    auto load_word = [&](uint32_t at) -> uint32_t {
+        uint32_t v = 0;
+        if (at < len) {
+            v = __builtin_bswap32(*(const uint32_t*)(src + at));        // unaligned dword; reads <= 3 bytes past the interval: inside the (padded) image
+            if (at + 4 > len) v &= 0xFFFFFFFFu << (8 * (at + 4 - len));
+        }
+        return v;
+    };
+    uint32_t nextw = load_word(0);
+    int err = 0;
+    while (__any(live)) {
+        if (live) {
+            if (n < 32) { acc = (acc << 32) | nextw; n += 32; bp += 4; nextw = load_word(bp); }
+            const sm_jpeg_huff_t& h = *(k == 0 ? hdc : hac);
+            const uint32_t look = (uint32_t)(acc >> (n - 16)) & 0xFFFFu;
+            const uint32_t fe = h.fast[look >> 7];
+            int clen = fe >> 8, sym = fe & 0xFF;
+            if (fe == 0) {
+                // a code of 10..16 bits: the seven length classes' largest codes are read together (independent LDS reads), the shortest matching
+                // length wins, then ONE offset and ONE symbol read (as dependent reads per length this was ~2000 clk whenever any lane took it)
+                int mc[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) mc[q] = h.maxcode[10 + q];
+                clen = 17;
+#pragma unroll
+                for (int q = 6; q >= 0; --q) {
+                    const int c = (int)(look >> (6 - q));
+                    if (mc[q] >= 0 && c <= mc[q]) clen = 10 + q;
+                }
+                if (clen <= 16) sym = h.vals[((int)(look >> (16 - clen)) + h.valoff[clen]) & 255];
+            }
+            if (clen > 16) { err = 1; live = false; }
+            n -= clen;
+            const int size = k == 0 ? sym : (sym & 15), run = k == 0 ? 0 : (sym >> 4);
+            int val = 0;
+            if (size) {
+                val = (int)((acc >> (n - size)) & ((1u << size) - 1));
+                n -= size;
+                val = val < (1 << (size - 1)) ? val - (1 << size) + 1 : val;
+            }
+            if (k == 0) {
+                if (sym > 11) { err = 1; live = false; }
+                int pr = ci == 0 ? pred0 : (ci == 1 ? pred1 : pred2);
+                pr += val;
+                if (ci == 0) pred0 = pr; else if (ci == 1) pred1 = pr; else pred2 = pr;
+                blk[0] = (int16_t)pr;
+                k = 1;
+            } else if (size == 0) {
+                k = run == 15 ? k + 16 : 64;
+            } else {
+                k += run;
+                if (k > 63) { err = 2; live = false; }
+                else blk[zz[k]] = (int16_t)val;
+                ++k;
+            }
+            if (k >= 64 && live) {                              // next block / MCU
+                k = 0;
+                if (++bi == nbm) {
+                    bi = 0;
+                    if (++mcu == mcu_end) live = false;
+                    if (++mx == g.mcus_x) { mx = 0; ++my; }
+                }
+                if (live) locate();
+            }
+        }
+    }
+    if (err) atomicCAS(&status[f], 0, err);
+}
+
+__global__ void jpeg_zero_kernel(u32x4* __restrict__ p, size_t n16, int32_t* __restrict__ status, int n_frames) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n16) p[t] = u32x4{0, 0, 0, 0};
+    if (t < (size_t)n_frames) status[t] = 0;
+}
+
+// per-HIP-stream index of interval starts (n_frames x JH_MAX_INT words, grown on demand)
+#include <map>
+#include <mutex>
+static std::mutex g_jh_mu;
+struct JhWs { uint32_t* starts = nullptr; uint32_t* lens = nullptr; size_t frames = 0; uint8_t* clean = nullptr; size_t clean_bytes = 0; };
+static std::map<hipStream_t, JhWs> g_jh_ws;
+extern "C" int sm_jpeg_entropy_decode(const uint8_t* bytes, size_t bytes_total, const uint32_t* offsets, const sm_jpeg_scan_t* scans, const sm_jpeg_info_t* info, int n_frames,
+                                      int16_t* coefs, uint16_t* qt, int32_t* status, void* stream) {
+    SM_REQUIRE(bytes && bytes_total > 0 && offsets && scans && info && coefs && qt && status && n_frames >= 1, "sm_jpeg_entropy_decode: null arg / no frames");
+    SM_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->coef_count > 0 && (((size_t)info->coef_count * 2) % 16) == 0 && ((uintptr_t)coefs & 15) == 0,
+               "sm_jpeg_entropy_decode: bad info / unaligned coefficient image");
+    hipStream_t st = (hipStream_t)stream;
+    JhWs ws;
+    {
+        std::lock_guard<std::mutex> lk(g_jh_mu);
+        JhWs& e = g_jh_ws[st];
+        if (e.frames < (size_t)n_frames) {
+            if (e.starts) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.starts); (void)hipFree(e.lens); e.starts = e.lens = nullptr; e.frames = 0; }
+            SM_HIP(hipMalloc((void**)&e.starts, (size_t)n_frames * JH_MAX_INT * sizeof(uint32_t)));
+            SM_HIP(hipMalloc((void**)&e.lens, (size_t)n_frames * JH_MAX_INT * sizeof(uint32_t)));
+            e.frames = n_frames;
+        }
+        if (e.clean_bytes < bytes_total + 64) {
+            if (e.clean) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.clean); e.clean = nullptr; e.clean_bytes = 0; }
+            SM_HIP(hipMalloc((void**)&e.clean, bytes_total + 64));
+            e.clean_bytes = bytes_total + 64;
+        }
+        ws = e;
+    }
+    const size_t n16 = (size_t)n_frames * info->coef_count * 2 / 16;
+    jpeg_zero_kernel<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>((u32x4*)coefs, n16, status, n_frames);
+    SM_LAUNCH_CHECK();
+    jpeg_rst_index_kernel<<<n_frames, 1024, 0, st>>>(bytes, offsets, scans, ws.starts, status);
+    SM_LAUNCH_CHECK();
+    // the interval count of a frame is in its scan struct (device); the grids cover the largest possible count for this geometry: one interval per MCU
+    const int max_iv = info->mcus_x * info->mcus_y < JH_MAX_INT ? info->mcus_x * info->mcus_y : JH_MAX_INT;
+    jpeg_unstuff_kernel<<<dim3(cdiv(max_iv, 4), n_frames), 256, 0, st>>>(bytes, offsets, scans, ws.starts, ws.clean, ws.lens);
+    SM_LAUNCH_CHECK();
+    JhGeom g;
+    memset(&g, 0, sizeof(g));
+    g.mcus_x = info->mcus_x; g.mcus_y = info->mcus_y; g.ncomp = info->ncomp; g.coef_count = info->coef_count;
+    for (int c = 0; c < info->ncomp; ++c) { g.hs[c] = info->hs[c]; g.vs[c] = info->vs[c]; g.blocks_x[c] = info->blocks_x[c]; g.coef_offset[c] = info->coef_offset[c]; }
+    jpeg_huff_kernel<<<dim3(cdiv(max_iv, 64), n_frames), 64, 0, st>>>(ws.clean, offsets, scans, ws.starts, ws.lens, g, coefs, qt, status);
+    SM_LAUNCH_CHECK();
     return SM_OK;
 }
 

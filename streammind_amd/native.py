@@ -502,18 +502,70 @@ class JpegDecoder:
         self._pinned = {}            # (n, coef_count) -> (coefs int16 pinned, qt int16 pinned)
         self.host_decode_s = 0.0     # accumulated wall time of the host (entropy) stage
         self.frames = 0
+        self.gpu_entropy_frames = 0  # frames whose entropy-coded segment was decoded on the GPU (restart intervals)
 
     def info(self, jpeg: bytes) -> "_lib.sm_jpeg_info_t":
         inf = self.lib.sm_jpeg_info.argtypes[2]._type_()
         check(self.lib.sm_jpeg_info(C.cast(C.c_char_p(jpeg), C.c_void_p), len(jpeg), C.byref(inf)), "sm_jpeg_info")
         return inf
 
-    def decode(self, jpegs: Sequence[bytes]) -> torch.Tensor:
+    def _decode_gpu_entropy(self, jpegs, inf) -> Optional[torch.Tensor]:
+        """Frames WITH restart intervals: markers on the host (sm_jpeg_scan_prepare: no entropy decode), the files uploaded as they are, one GPU lane per
+        restart interval (sm_jpeg_entropy_decode), then the same reconstruction.  None when a frame does not qualify (no DRI, per-component scans, ...)
+        or the device reports a malformed segment: the caller then takes the host path, whose error text names the reason."""
+        n = len(jpegs)
+        tot = sum((len(j) + 15) // 16 * 16 for j in jpegs)
+        ssz = C.sizeof(_lib.sm_jpeg_scan_t)
+        # pinned staging (grown on demand, reused): the files as they are, their offsets, the prepared scans
+        st = getattr(self, "_ent_stage", None)
+        if st is None or st[0].numel() < tot + 32 or st[1].numel() < n * ssz or st[2].numel() < n:
+            st = (torch.empty(max(tot + 32, 1 << 20), dtype=torch.uint8).pin_memory(), torch.empty(max(n, 32) * ssz, dtype=torch.uint8).pin_memory(),
+                  torch.empty(max(n, 32), dtype=torch.int32).pin_memory())
+            self._ent_stage = st
+        blob, sc_host, offs = st
+        scans = (_lib.sm_jpeg_scan_t * n).from_address(sc_host.data_ptr())
+        pos = 0
+        for i, j in enumerate(jpegs):
+            if self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(scans[i])) < 0:
+                return None
+            C.memmove(blob.data_ptr() + pos, j, len(j))
+            offs[i] = pos
+            pos += (len(j) + 15) // 16 * 16
+        with torch.cuda.device(self.device):
+            bd = blob[:tot + 32].to(self.device, non_blocking=True)
+            sd = sc_host[:n * ssz].to(self.device, non_blocking=True)
+            od = offs[:n].to(self.device, non_blocking=True)
+            cd = torch.empty(n, inf.coef_count, dtype=torch.int16, device=self.device)
+            qd = torch.empty(n, 3, 64, dtype=torch.int16, device=self.device)
+            status = torch.empty(n, dtype=torch.int32, device=self.device)
+            check(self.lib.sm_jpeg_entropy_decode(bd.data_ptr(), tot, od.data_ptr(), sd.data_ptr(), C.byref(inf), n, cd.data_ptr(), qd.data_ptr(), status.data_ptr(), _stream()),
+                  "sm_jpeg_entropy_decode")
+            planes = torch.empty(self.lib.sm_jpeg_planes_bytes(C.byref(inf), n), dtype=torch.uint8, device=self.device)
+            rgb = torch.empty(n, inf.height, inf.width, 3, dtype=torch.uint8, device=self.device)
+            check(self.lib.sm_jpeg_reconstruct(cd.data_ptr(), qd.data_ptr(), C.byref(inf), n, planes.data_ptr(), rgb.data_ptr(), _stream()), "sm_jpeg_reconstruct")
+            if int(status.abs().max().item()) != 0:          # (also the sync that lets the pinned staging buffers be reused)
+                return None
+        self.gpu_entropy_frames += n
+        return rgb
+
+    def decode(self, jpegs: Sequence[bytes], entropy: str = "auto") -> torch.Tensor:
+        """entropy: "auto" = on the GPU when every frame of the batch carries restart intervals, else on host threads; "host" / "gpu" force one
+        ("gpu" raises when a frame does not qualify)."""
         import time
         n = len(jpegs)
-        assert n >= 1
+        assert n >= 1 and entropy in ("auto", "host", "gpu")
         jpegs = [bytes(j) for j in jpegs]
         inf = self.info(jpegs[0])
+        if entropy != "host":
+            rgb = self._decode_gpu_entropy(jpegs, inf)
+            if rgb is not None:
+                self.frames += n
+                return rgb
+            if entropy == "gpu":
+                sc = _lib.sm_jpeg_scan_t()
+                for i, j in enumerate(jpegs):
+                    check(self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(sc)), f"sm_jpeg_scan_prepare(frame {i})")
+                raise _lib.StreamMindHipError("sm_jpeg_entropy_decode: the device reported a malformed entropy-coded segment")
         key = (n, inf.coef_count)
         if key not in self._pinned:
             if len(self._pinned) > 4:

@@ -86,3 +86,71 @@ def test_gpu_decode_equals_golden_g19(dec):
     for i in range(int(g["n"])):
         assert np.array_equal(dec.decode([bytes(g[f"jpeg{i}"])])[0].cpu().numpy(), g[f"rgb{i}"]), i
     assert np.array_equal(dec.decode([bytes(g["jpeg_bare"])])[0].cpu().numpy(), g["rgb0"])
+
+
+RST_CASES = [   # (w, h, gray, save kwargs): restart intervals of one MCU row / of N MCUs (Pillow's restart_marker_rows / restart_marker_blocks)
+    (1280, 720, False, dict(quality=85, subsampling=2, restart_marker_rows=1)),
+    (336, 336, False, dict(quality=75, subsampling=2, restart_marker_blocks=5)),
+    (336, 336, False, dict(quality=90, subsampling=0, restart_marker_rows=1)),
+    (333, 217, False, dict(quality=60, subsampling=1, restart_marker_blocks=3)),
+    (47, 33, False, dict(quality=95, subsampling=2, restart_marker_blocks=1)),
+    (200, 120, True, dict(quality=80, restart_marker_rows=2)),
+    (640, 480, False, dict(quality=30, subsampling=2, restart_marker_blocks=11, optimize=True)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RST_CASES)))
+def test_gpu_entropy_decode_of_restart_intervals(dec, case):
+    """Round 5 (f2, the verdict's item 9): frames WITH restart intervals have their entropy-coded segment decoded ON THE GPU -- markers on the host
+    (sm_jpeg_scan_prepare), one lane per restart interval (sm_jpeg_entropy_decode), the same reconstruction.  Coefficients and quantisation tables equal
+    the host decoder's word for word, the RGB frame equals PIL / libjpeg-turbo byte for byte (what decord hands the reference loop:
+    eval/video_score_stream_demo.py:216-225); the host path on the same file agrees."""
+    w, h, gray, kw = RST_CASES[case]
+    b = U.encode(U.test_image(w, h, 300 + case, gray), **kw)
+    before = dec.gpu_entropy_frames
+    got = dec.decode([b], entropy="gpu")[0].cpu().numpy()
+    assert dec.gpu_entropy_frames == before + 1
+    want = U.pil_decode(b)
+    assert got.shape == want.shape and np.array_equal(got, want), f"{int((got != want).sum())} bytes differ"
+    assert np.array_equal(dec.decode([b], entropy="host")[0].cpu().numpy(), want)
+    # the coefficient image itself against the host decoder
+    from streammind_amd import _lib
+    inf = dec.info(b)
+    sc = _lib.sm_jpeg_scan_t()
+    _lib.check(dec.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf), C.byref(sc)))
+    blob = torch.frombuffer(bytearray(b + bytes(32)), dtype=torch.uint8).cuda()
+    sd = torch.frombuffer(bytearray(bytes(sc)), dtype=torch.uint8).cuda()
+    od = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cd = torch.full((inf.coef_count,), 77, dtype=torch.int16, device="cuda")
+    qd = torch.empty(3, 64, dtype=torch.int16, device="cuda")
+    stt = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+    _lib.check(dec.lib.sm_jpeg_entropy_decode(blob.data_ptr(), len(b), od.data_ptr(), sd.data_ptr(), C.byref(inf), 1, cd.data_ptr(), qd.data_ptr(), stt.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+    info, coefs, qt = U.host_coefs(dec.lib, b)
+    assert int(stt[0]) == 0
+    assert np.array_equal(cd.cpu().numpy(), np.asarray(coefs).reshape(-1))
+    nc = 1 if gray else 3
+    assert np.array_equal(qd.cpu().numpy().astype(np.uint16)[:nc], np.asarray(qt).reshape(3, 64)[:nc])
+
+
+def test_gpu_entropy_decode_batch_fallback_and_corruption(dec):
+    """28 frames of 720p with one restart interval per MCU row in ONE call (1260 lanes); a batch with a frame that has no restart markers goes to the
+    host threads as a whole ("auto") and is refused by "gpu" with the reason; a corrupted segment (marker numbering broken) is reported, never decoded wrong."""
+    frames = [U.encode(U.test_image(1280, 720, 500 + i), quality=70 + i % 20, subsampling=2, restart_marker_rows=1) for i in range(28)]
+    before = dec.gpu_entropy_frames
+    got = dec.decode(frames).cpu().numpy()
+    assert dec.gpu_entropy_frames == before + 28
+    for i in (0, 13, 27):
+        assert np.array_equal(got[i], U.pil_decode(frames[i])), i
+    plain = U.encode(U.test_image(1280, 720, 1), quality=80, subsampling=2)
+    mixed = [frames[0], plain]
+    before = dec.gpu_entropy_frames
+    both = dec.decode(mixed).cpu().numpy()
+    assert dec.gpu_entropy_frames == before and np.array_equal(both[1], U.pil_decode(plain))
+    with pytest.raises(Exception, match="no restart interval"):
+        dec.decode(mixed, entropy="gpu")
+    bad = bytearray(frames[1])
+    k = bad.index(b"\xff\xd1")              # RST1 -> RST3: the numbering check of the index kernel
+    bad[k + 1] = 0xD3
+    with pytest.raises(Exception):
+        dec.decode([bytes(bad)], entropy="gpu")

@@ -114,3 +114,25 @@ def test_hostile_streams_are_refused_not_crashed(lib):
         for _ in range(int(rng.integers(1, 4))):
             m[int(rng.integers(2, len(m)))] = int(rng.integers(0, 256))
         _decode_rc(lib, bytes(m))
+
+
+def test_scan_prepare_is_markers_only_and_says_why_not():
+    """sm_jpeg_scan_prepare (the host half of the GPU entropy decode): restart interval, interval count, segment offset and tables of a frame with restart
+    markers; files without DRI, progressive files and per-component scans are refused with the reason (the caller keeps the host decoder)."""
+    import ctypes as C
+    from streammind_amd import _lib
+    lib = _lib.load()
+    img = U.test_image(200, 120, 3)
+    b = U.encode(img, quality=85, subsampling=2, restart_marker_rows=1)
+    inf = _lib.sm_jpeg_info_t()
+    _lib.check(lib.sm_jpeg_info(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf)))
+    sc = _lib.sm_jpeg_scan_t()
+    _lib.check(lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf), C.byref(sc)))
+    assert sc.restart == inf.mcus_x and sc.n_intervals == inf.mcus_y and sc.ncomp == 3
+    assert b[sc.scan_offset - 2 - 12:sc.scan_offset - 12] == b"\xff\xda" and sc.scan_offset + sc.scan_len == len(b)
+    assert b.count(b"\xff\xd0") + sum(b.count(bytes([0xFF, 0xD0 + i])) for i in range(1, 8)) == sc.n_intervals - 1
+    # luminance DC table of Annex K / libjpeg: the 2-bit code 00 is category 0
+    assert sc.dc[0].fast[0] >> 8 == 2 and sc.dc[0].fast[0] & 0xFF == 0
+    for bad, why in ((U.encode(img, quality=85), b"no restart interval"), (U.encode(img, quality=85, progressive=True), b"not baseline")):
+        assert lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(bad), C.c_void_p), len(bad), None, C.byref(sc)) < 0
+        assert why in lib.sm_last_error(), lib.sm_last_error()
