@@ -515,7 +515,7 @@ class JpegDecoder:
         or the device reports a malformed segment: the caller then takes the host path, whose error text names the reason."""
         n = len(jpegs)
         tot = sum((len(j) + 15) // 16 * 16 for j in jpegs)
-        ssz = C.sizeof(_lib.sm_jpeg_scan_t)
+        ssz = C.sizeof(self.lib.sm_jpeg_scan_prepare.argtypes[3]._type_)
         # pinned staging (grown on demand, reused): the files as they are, their offsets, the prepared scans
         st = getattr(self, "_ent_stage", None)
         if st is None or st[0].numel() < tot + 32 or st[1].numel() < n * ssz or st[2].numel() < n:
@@ -523,7 +523,7 @@ class JpegDecoder:
                   torch.empty(max(n, 32), dtype=torch.int32).pin_memory())
             self._ent_stage = st
         blob, sc_host, offs = st
-        scans = (_lib.sm_jpeg_scan_t * n).from_address(sc_host.data_ptr())
+        scans = (self.lib.sm_jpeg_scan_prepare.argtypes[3]._type_ * n).from_address(sc_host.data_ptr())
         pos = 0
         for i, j in enumerate(jpegs):
             if self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(scans[i])) < 0:
@@ -562,7 +562,7 @@ class JpegDecoder:
                 self.frames += n
                 return rgb
             if entropy == "gpu":
-                sc = _lib.sm_jpeg_scan_t()
+                sc = self.lib.sm_jpeg_scan_prepare.argtypes[3]._type_()
                 for i, j in enumerate(jpegs):
                     check(self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(sc)), f"sm_jpeg_scan_prepare(frame {i})")
                 raise _lib.StreamMindHipError("sm_jpeg_entropy_decode: the device reported a malformed entropy-coded segment")

@@ -116,7 +116,7 @@ def test_gpu_entropy_decode_of_restart_intervals(dec, case):
     # the coefficient image itself against the host decoder
     from streammind_amd import _lib
     inf = dec.info(b)
-    sc = _lib.sm_jpeg_scan_t()
+    sc = dec.lib.sm_jpeg_scan_prepare.argtypes[3]._type_()
     _lib.check(dec.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf), C.byref(sc)))
     blob = torch.frombuffer(bytearray(b + bytes(32)), dtype=torch.uint8).cuda()
     sd = torch.frombuffer(bytearray(bytes(sc)), dtype=torch.uint8).cuda()

@@ -124,9 +124,9 @@ def test_scan_prepare_is_markers_only_and_says_why_not():
     lib = _lib.load()
     img = U.test_image(200, 120, 3)
     b = U.encode(img, quality=85, subsampling=2, restart_marker_rows=1)
-    inf = _lib.sm_jpeg_info_t()
+    inf = lib.sm_jpeg_info.argtypes[2]._type_()               # (the structure classes of the library object's own signatures: the ABI test re-imports the module)
     _lib.check(lib.sm_jpeg_info(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf)))
-    sc = _lib.sm_jpeg_scan_t()
+    sc = lib.sm_jpeg_scan_prepare.argtypes[3]._type_()
     _lib.check(lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.byref(inf), C.byref(sc)))
     assert sc.restart == inf.mcus_x and sc.n_intervals == inf.mcus_y and sc.ncomp == 3
     assert b[sc.scan_offset - 2 - 12:sc.scan_offset - 12] == b"\xff\xda" and sc.scan_offset + sc.scan_len == len(b)
