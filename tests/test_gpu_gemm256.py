@@ -318,3 +318,30 @@ def test_weight_streaming_mfma_33_to_128_rows(nat, M, N, K, kind):
             assert ((ln_out.float().cpu() - want).abs().max() / want.abs().max()).item() < 8e-3
         outs.append(y.cpu())
     assert ((outs[0] - outs[1]).abs().max() / ref.abs().max()).item() < 2e-6
+
+
+def test_round5_kernels_repeat_bit_for_bit(nat):
+    """Race screen of the round-5 kernels: the weight-streaming MFMA kernel (two loader waves hand LDS stages to four consumer waves through raw barriers
+    with hand-counted waits), the split-K slabs on the 256 x 256 kernel + the slab pass, and the SwiGLU epilogue of the persistent kernel, each launched 40
+    times on the same inputs -- every result must equal the first bit for bit (any difference = a synchronisation bug)."""
+    from streammind_amd._lib import SM_ACT_SWIGLU_DUAL
+    g = 1 + rnd((4096,), 5, 0.1)
+    cases = []
+    w = rnd((28672, 4096), 1, 4096 ** -0.5).bfloat16().cuda(); x = rnd((128, 4096), 2).bfloat16().cuda()
+    wp = nat.pack_weight(w)
+    cases.append(("wstream dual 128 rows", lambda: nat.linear(x, wp, 28672, 4096, act=SM_ACT_SWIGLU_DUAL, out=torch.empty(128, 14336, device="cuda", dtype=torch.bfloat16))))
+    x70 = rnd((70, 4096), 3).bfloat16().cuda()
+    cases.append(("wstream 70 rows", lambda: nat.linear(x70, wp, 28672, 4096)))
+    w2 = rnd((4096, 14336), 4, 14336 ** -0.5).bfloat16().cuda(); x2 = rnd((2048, 14336), 5).bfloat16().cuda(); res = rnd((2048, 4096), 6).cuda()
+    wp2 = nat.pack_weight(w2)
+    def slabs():
+        ln = torch.empty(2048, 4096, device="cuda", dtype=torch.bfloat16)
+        y = nat.linear(x2, wp2, 4096, 14336, residual=res, post_ln=(g.cuda(), None, 1e-5, ln))
+        return torch.cat([y.view(torch.int32), ln.view(torch.int16).int()], dim=1)
+    cases.append(("split-K slabs on the 256 tile + slab / residual / RMSNorm pass", slabs))
+    x3 = rnd((2304, 4096), 7).bfloat16().cuda()
+    cases.append(("persistent SwiGLU epilogue", lambda: nat.linear(x3, wp, 28672, 4096, act=SM_ACT_SWIGLU_DUAL, out=torch.empty(2304, 14336, device="cuda", dtype=torch.bfloat16))))
+    for name, fn in cases:
+        first = fn().clone()
+        for it in range(40):
+            assert torch.equal(fn(), first), (name, it)
