@@ -183,7 +183,10 @@ def load() -> C.CDLL:
     # binds to the SAME runtime instance torch allocates device memory and streams from.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    older = os.environ.get("STREAMMIND_HIP_LIB_OLDER") == "1"      # A/B runs against the library of an EARLIER revision (tools/build_base.sh): entry points it lacks are skipped
     for name, (res, args) in SIGNATURES.items():
+        if older and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
