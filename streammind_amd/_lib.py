@@ -144,6 +144,8 @@ SIGNATURES = {
     "sm_jpeg_reconstruct": (i32, [vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp]),
     "sm_jpeg_scan_prepare": (i32, [vp, sz, C.POINTER(sm_jpeg_info_t), C.POINTER(sm_jpeg_scan_t)]),
     "sm_jpeg_entropy_decode": (i32, [vp, sz, vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp, vp]),
+    "sm_jpeg_sync_rounds": (i32, [vp, C.POINTER(C.c_int32), i32]),
+    "sm_jpeg_entropy_decode_sync": (i32, [vp, sz, sz, vp, vp, C.POINTER(sm_jpeg_info_t), i32, vp, vp, vp, vp]),
     "sm_comm_handle_bytes": (i32, []),
     "sm_comm_init": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
     "sm_comm_export": (i32, [vp, vp]),

@@ -378,7 +378,6 @@ extern "C" int sm_jpeg_scan_prepare(const uint8_t* data, size_t len, const sm_jp
         SM_REQUIRE(want->width == I.width && want->height == I.height && want->ncomp == I.ncomp && want->hs[0] == I.hs[0] && want->vs[0] == I.vs[0] &&
                    want->coef_count == I.coef_count, "sm_jpeg_scan_prepare: frame is %dx%d/%d comps/%dx%d sampling, the batch was opened as %dx%d/%d/%dx%d",
                    I.width, I.height, I.ncomp, I.hs[0], I.vs[0], want->width, want->height, want->ncomp, want->hs[0], want->vs[0]);
-    SM_REQUIRE(P.restart > 0, "jpeg: no restart interval (DRI): the entropy-coded segment is one serial stream, host path");
     SM_REQUIRE(sn == P.ncomp, "jpeg: %d of %d components in the first scan (per-component scans: host path)", sn, P.ncomp);
     for (int i = 0; i < sn; ++i) SM_REQUIRE(sc[i] == i, "jpeg: scan component order (host path)");
     memset(out, 0, sizeof(*out));
@@ -399,7 +398,7 @@ extern "C" int sm_jpeg_scan_prepare(const uint8_t* data, size_t len, const sm_jp
     }
     out->scan_offset = (uint32_t)pos; out->scan_len = (uint32_t)(len - pos);
     out->restart = P.restart; out->ncomp = P.ncomp;
-    out->n_intervals = (I.mcus_x * I.mcus_y + P.restart - 1) / P.restart;
+    out->n_intervals = P.restart > 0 ? (I.mcus_x * I.mcus_y + P.restart - 1) / P.restart : 0;       // 0: no DRI -- one serial stream, the self-synchronising decode
     SM_REQUIRE(out->n_intervals <= 4096, "jpeg: %d restart intervals per frame (the GPU index keeps 4096: host path)", out->n_intervals);
     return SM_OK;
 }
@@ -487,6 +486,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
     __shared__ uint8_t zz[64];
     const int f = blockIdx.y, lane = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
+    if (sc.n_intervals <= 0 && blockIdx.x == 0 && lane == 0) atomicCAS(&status[f], 0, 3);      // no DRI: sm_jpeg_entropy_decode_sync is the entry for this frame
     if ((int)blockIdx.x * 64 >= sc.n_intervals) return;         // (the grid covers the largest interval count of the geometry)
     {
         const uint32_t* src = (const uint32_t*)sc.dc;          // dc[3] and ac[3] are contiguous in sm_jpeg_scan_t
@@ -601,6 +601,360 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
     if (err) atomicCAS(&status[f], 0, err);
 }
 
+// ------------------------------------------------------------------------------------------------ entropy decode without restart markers
+// One serial Huffman stream per frame, decoded in parallel by SELF-SYNCHRONISATION (Klein & Wiseman 2003; Weissenberger & Schmidt, "Massively parallel
+// Huffman decoding on GPUs" 2018 and its JPEG follow-up 2021 -- restated from the published idea): the unstuffed stream is cut into subsequences of JS_BITS
+// bits, one lane each.  A lane's decoder state is (bit position, block inside the MCU, next zig-zag index); lane 0 knows its state, every other lane GUESSES
+// (start of a block, first bit of its subsequence) and decodes to the end of its subsequence, leaving its exit state.  Round r: every lane takes the exit
+// state its predecessor left in round r - 1 as its entry state and decodes again -- unless that entry state did not change.  A prefix code pulls a wrong
+// decoder onto the right bit boundaries within a few symbols and the block structure pulls the rest of the state along, so the exit states stop changing after
+// a few rounds (lane s is right after round s at the latest).  Then the lanes' completed-block counts are prefix-summed (every lane knows which block it
+// starts in), a last pass writes the coefficients -- the DC DIFFERENCE in place of the DC -- and a per-component scan over the blocks in scan order turns
+// the differences into values.  Same decode step as the restart-interval kernel (one uniform loop: one symbol per trip for every live lane).
+#define JS_BITS 1024                                            // bits per subsequence
+#define JS_ROUNDS 48                                            // at most; a frame whose states stopped moving leaves the later rounds at once
+struct JsGeom { int mcus_x, mcus_y, ncomp, bh0, bv0, nb0, nbm, blocks_x[3], coef_offset[3], coef_count, total_blocks; };
+struct JsArr {                                                  // per-lane records, [lanes]
+    uint32_t* exP[2]; uint32_t* exS[2];                         // exit state of the two newest rounds: bit position; bi | k << 8
+    uint32_t* enP; uint32_t* enS;                               // the entry state the lane last decoded from
+    uint32_t* nblk; uint32_t* base;                             // blocks completed inside the subsequence; their exclusive prefix sum
+    uint32_t* clean_len;                                        // [frames] bytes of the unstuffed stream
+    int32_t* changed;                                           // [frames][JS_ROUNDS + 1] exit states that moved in round r; [JS_ROUNDS] = rounds until none did
+};
+__device__ __forceinline__ uint32_t js_lane0(const uint32_t* offsets, int f) { return (offsets[f] >> 7) + (uint32_t)f; }      // first lane record of frame f
+
+// Unstuffing of a whole scan: one block per frame walks the segment in tiles of 1024 x 16 bytes; a thread counts the bytes it keeps (everything but the
+// 0x00 behind a data 0xFF), an LDS scan ranks the threads, the tile is written compacted behind the previous one.  The first marker ends the data.
+__global__ __launch_bounds__(1024) void jpeg_unstuff_scan_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                                uint8_t* __restrict__ clean, JsArr A) {
+    __shared__ int cnt[1024];
+    __shared__ int s_end, s_base;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
+    uint8_t* dst = clean + offsets[f] + sc.scan_offset;
+    const uint32_t n = sc.scan_len;
+    if (tid == 0) { s_end = 0x7fffffff; s_base = 0; }
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += 16384) {
+        const uint32_t lo = t0 + tid * 16;
+        uint8_t b[18];
+#pragma unroll
+        for (int e = 0; e < 18; ++e) { const uint32_t p = lo + e; b[e] = (p >= 1 && p - 1 < n) ? src[p - 1] : 0; }     // b[e] = byte lo + e - 1
+        int keep = 0, my_end = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t p = lo + e;
+            const bool marker = p + 1 < n && b[e + 1] == 0xFF && b[e + 2] != 0x00;
+            if (marker && my_end == 0x7fffffff) my_end = (int)p;
+            if (p < n && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++keep;
+        }
+        if (my_end != 0x7fffffff) atomicMin(&s_end, my_end);
+        cnt[tid] = keep;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = tid >= o ? cnt[tid - o] : 0;
+            __syncthreads();
+            cnt[tid] += v;
+            __syncthreads();
+        }
+        const int end = s_end;
+        int out = s_base + cnt[tid] - keep;
+        // bytes behind the first marker are not data: recount the threads that straddle it (rare: once per frame)
+        if (end != 0x7fffffff) {
+            __syncthreads();
+            int k2 = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t p = lo + e;
+                if (p < n && (int)p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++k2;
+            }
+            cnt[tid] = k2;
+            __syncthreads();
+            for (int o = 1; o < 1024; o <<= 1) {
+                const int v = tid >= o ? cnt[tid - o] : 0;
+                __syncthreads();
+                cnt[tid] += v;
+                __syncthreads();
+            }
+            keep = k2;
+            out = s_base + cnt[tid] - k2;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t p = lo + e;
+            if (p < n && (int)p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) dst[out++] = b[e + 1];
+        }
+        __syncthreads();
+        if (tid == 1023) s_base += cnt[1023];
+        __syncthreads();
+        if (end != 0x7fffffff) break;
+    }
+    if (tid == 0) A.clean_len[f] = (uint32_t)s_base;
+    if (tid <= JS_ROUNDS) A.changed[f * (JS_ROUNDS + 1) + tid] = 0;
+    // zero padding behind the stream: the decode lanes read whole dwords
+    if (tid < 8) dst[s_base + tid] = 0;
+}
+
+// the shared decode step: one symbol (+ value bits) per call.  `h` tables in LDS; returns false on a code no table holds (only a wrong guess or the padding
+// behind the last block produces one: the caller decides what that means)
+struct JsDec {
+    const uint8_t* src; uint32_t len;          // unstuffed stream of the frame
+    uint64_t acc; int n; uint32_t ba, nextw;   // bit window: n valid bits at the bottom of acc, filled up to byte ba; nextw = the dword at ba
+    int bi, k;
+    __device__ __forceinline__ uint32_t word(uint32_t at) const {
+        uint32_t v = 0;
+        if (at < len) {
+            v = __builtin_bswap32(*(const uint32_t*)(src + at));
+            if (at + 4 > len) v &= 0xFFFFFFFFu << (8 * (at + 4 - len));
+        }
+        return v;
+    }
+    __device__ __forceinline__ void start(uint32_t p, int bi_, int k_) {
+        const uint32_t byte = p >> 3;
+        acc = word(byte); n = 32 - (int)(p & 7); ba = byte + 4; nextw = word(ba);
+        bi = bi_; k = k_;
+    }
+    __device__ __forceinline__ uint32_t pos() const { return 8u * ba - (uint32_t)n; }
+};
+// decodes one symbol; out: is_dc, zig-zag index written (or -1), value; advances (bi, k); `done_block` when the block completed
+template <class TAB>
+__device__ __forceinline__ bool js_step(JsDec& d, const TAB* tab, int nb0, int nbm, int& widx, int& val, bool& done_block) {
+    if (d.n < 32) { d.acc = (d.acc << 32) | d.nextw; d.n += 32; d.ba += 4; d.nextw = d.word(d.ba); }
+    const int ci = d.bi < nb0 ? 0 : d.bi - nb0 + 1;
+    const sm_jpeg_huff_t& h = tab[(d.k == 0 ? 0 : 3) + ci];
+    const uint32_t look = (uint32_t)(d.acc >> (d.n - 16)) & 0xFFFFu;
+    const uint32_t fe = h.fast[look >> 7];
+    int clen = fe >> 8, sym = fe & 0xFF;
+    bool ok = true;
+    if (fe == 0) {
+        int mc[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) mc[q] = h.maxcode[10 + q];
+        clen = 17;
+#pragma unroll
+        for (int q = 6; q >= 0; --q) {
+            const int c = (int)(look >> (6 - q));
+            if (mc[q] >= 0 && c <= mc[q]) clen = 10 + q;
+        }
+        if (clen <= 16) sym = h.vals[((int)(look >> (16 - clen)) + h.valoff[clen]) & 255];
+        else { ok = false; clen = 16; sym = 0; }               // progress anyway: 16 bits, "size 0 / end of block"
+    }
+    d.n -= clen;
+    int size = d.k == 0 ? sym : (sym & 15);
+    const int run = d.k == 0 ? 0 : (sym >> 4);
+    if (d.k == 0 && size > 11) { ok = false; size = 0; }
+    val = 0;
+    if (size) {
+        val = (int)((d.acc >> (d.n - size)) & ((1u << size) - 1));
+        d.n -= size;
+        val = val < (1 << (size - 1)) ? val - (1 << size) + 1 : val;
+    }
+    widx = -1;
+    if (d.k == 0) { widx = 0; d.k = 1; }
+    else if (size == 0) d.k = run == 15 ? d.k + 16 : 64;
+    else {
+        d.k += run;
+        if (d.k > 63) { ok = false; d.k = 64; }
+        else { widx = d.k; ++d.k; }
+    }
+    done_block = d.k >= 64;
+    if (done_block) { d.k = 0; d.bi = d.bi + 1 == nbm ? 0 : d.bi + 1; }
+    return ok;
+}
+
+// one synchronisation round (round 0: the guesses).  Lane s of frame f: subsequence [s JS_BITS, (s + 1) JS_BITS) of the frame's clean stream.
+__global__ __launch_bounds__(64) void jpeg_sync_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                       JsArr A, JsGeom g, int round) {
+    __shared__ sm_jpeg_huff_t tab[6];
+    const int f = blockIdx.y, lane = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    const uint32_t len = A.clean_len[f];
+    const uint32_t S = (len * 8 + JS_BITS - 1) / JS_BITS;
+    if (blockIdx.x * 64u >= S) return;
+    // nothing moved in the round before: every lane's entry state is the one it decoded from, the frame is settled (both exit buffers hold the same states)
+    if (round > 0 && A.changed[f * (JS_ROUNDS + 1) + round - 1] == 0) return;
+    {
+        const uint32_t* src = (const uint32_t*)sc.dc;
+        uint32_t* dst = (uint32_t*)tab;
+        for (int w = lane; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += 64) dst[w] = src[w];
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + lane;
+    const uint32_t L = js_lane0(offsets, f) + s;
+    const int cur = round & 1, prv = cur ^ 1;
+    bool live = s < S;
+    uint32_t ep = s * JS_BITS, es = 0;                          // entry: guessed (block start at the subsequence's first bit) ...
+    if (live && round > 0 && s > 0) { ep = A.exP[prv][L - 1]; es = A.exS[prv][L - 1]; }      // ... or what the predecessor left
+    const uint32_t end = (s + 1) * JS_BITS < len * 8 ? (s + 1) * JS_BITS : len * 8;
+    if (live && round > 0 && ep == A.enP[L] && es == A.enS[L]) {                             // same entry as last time: same exit
+        A.exP[cur][L] = A.exP[prv][L]; A.exS[cur][L] = A.exS[prv][L];
+        live = false;
+    }
+    JsDec d;
+    d.src = clean + offsets[f] + sc.scan_offset; d.len = len;
+    if (live) { A.enP[L] = ep; A.enS[L] = es; d.start(ep, (int)(es & 0xFF), (int)(es >> 8)); }
+    uint32_t nb = 0;
+    bool run = live && ep < end;
+    while (__any(run)) {
+        if (run) {
+            int widx, val; bool done;
+            (void)js_step(d, tab, g.nb0, g.nbm, widx, val, done);
+            nb += done ? 1u : 0u;
+            run = d.pos() < end;
+        }
+    }
+    if (live) {
+        const uint32_t xp = ep < end ? d.pos() : ep, xs = ep < end ? ((uint32_t)d.bi | ((uint32_t)d.k << 8)) : es;
+        if (round == 0 || xp != A.exP[prv][L] || xs != A.exS[prv][L]) atomicAdd(&A.changed[f * (JS_ROUNDS + 1) + round], 1);
+        A.exP[cur][L] = xp; A.exS[cur][L] = xs; A.nblk[L] = nb;
+    }
+}
+
+// exclusive prefix sum of the lanes' completed-block counts (one block per frame), convergence and completeness checks
+__global__ __launch_bounds__(1024) void jpeg_blockscan_kernel(const uint32_t* __restrict__ offsets, JsArr A, JsGeom g, uint32_t lanes_launched,
+                                                              int32_t* __restrict__ status) {
+    __shared__ uint32_t cnt[1024];
+    __shared__ uint32_t carry;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t len = A.clean_len[f], S = (len * 8 + JS_BITS - 1) / JS_BITS, L0 = js_lane0(offsets, f);
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    if (S > lanes_launched) {                                   // a file longer than the caller said: its tail was never decoded
+        if (tid == 0) atomicCAS(&status[f], 0, 5);
+        return;
+    }
+    for (uint32_t s0 = 0; s0 < S; s0 += 1024) {
+        const uint32_t s = s0 + tid;
+        const uint32_t v = s < S ? A.nblk[L0 + s] : 0;
+        cnt[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t t = tid >= o ? cnt[tid - o] : 0;
+            __syncthreads();
+            cnt[tid] += t;
+            __syncthreads();
+        }
+        if (s < S) A.base[L0 + s] = carry + cnt[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += cnt[1023];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int r = 0;
+        while (r < JS_ROUNDS && A.changed[f * (JS_ROUNDS + 1) + r] != 0) ++r;
+        A.changed[f * (JS_ROUNDS + 1) + JS_ROUNDS] = r;                                    // (sm_jpeg_sync_rounds reads it)
+        if (r == JS_ROUNDS) atomicCAS(&status[f], 0, 5);                                   // the exit states still moved in the last round: not synchronised
+        else if (carry < (uint32_t)g.total_blocks) atomicCAS(&status[f], 0, 4);            // the stream ends before the last block
+    }
+}
+
+// the writing pass: every lane decodes its subsequence once more from its (now true) entry state, blocks numbered from its prefix sum
+__global__ __launch_bounds__(64) void jpeg_write_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                        JsArr A, JsGeom g, int16_t* __restrict__ coefs, uint16_t* __restrict__ qt, int32_t* __restrict__ status) {
+    __shared__ sm_jpeg_huff_t tab[6];
+    __shared__ uint8_t zz[64];
+    const int f = blockIdx.y, lane = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    const uint32_t len = A.clean_len[f];
+    const uint32_t S = (len * 8 + JS_BITS - 1) / JS_BITS;
+    if (blockIdx.x * 64u >= S || status[f] != 0) return;
+    {
+        const uint32_t* src = (const uint32_t*)sc.dc;
+        uint32_t* dst = (uint32_t*)tab;
+        for (int w = lane; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += 64) dst[w] = src[w];
+        zz[lane] = kZigzagDev[lane];
+        if (blockIdx.x == 0)
+            for (int w = lane; w < 3 * 64; w += 64) qt[(size_t)f * 192 + w] = sc.qt[w / 64][w % 64];
+    }
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 64 + lane;
+    const uint32_t L = js_lane0(offsets, f) + s;
+    const int cur = 0;                                          // settled: both exit buffers hold the same states
+    bool live = s < S;
+    const uint32_t ep = live ? (s == 0 ? 0u : A.exP[cur][L - 1]) : 0u, es = live ? (s == 0 ? 0u : A.exS[cur][L - 1]) : 0u;
+    const uint32_t end = (s + 1) * JS_BITS < len * 8 ? (s + 1) * JS_BITS : len * 8;
+    JsDec d;
+    d.src = clean + offsets[f] + sc.scan_offset; d.len = len;
+    int G = live ? (int)A.base[L] : 0;                          // the block in progress at the entry
+    live = live && ep < end && G < g.total_blocks;
+    if (live) d.start(ep, (int)(es & 0xFF), (int)(es >> 8));
+    int16_t* cf = coefs + (size_t)f * g.coef_count;
+    int mcu = live ? G / g.nbm : 0, mx = live ? mcu % g.mcus_x : 0, my = live ? mcu / g.mcus_x : 0;
+    int16_t* blk = cf;
+    auto locate = [&]() {
+        const int bi = d.bi;
+        const int ci = bi < g.nb0 ? 0 : bi - g.nb0 + 1;
+        const int bcol = ci == 0 ? (g.bh0 == 2 ? (bi & 1) : 0) : 0, brow = ci == 0 ? (g.bh0 == 2 ? (bi >> 1) : bi) : 0;
+        const int bx = ci == 0 ? mx * g.bh0 + bcol : mx, by = ci == 0 ? my * g.bv0 + brow : my;
+        const int bxn = ci == 0 ? g.blocks_x[0] : (ci == 1 ? g.blocks_x[1] : g.blocks_x[2]);
+        const int co = ci == 0 ? g.coef_offset[0] : (ci == 1 ? g.coef_offset[1] : g.coef_offset[2]);
+        blk = cf + co + ((size_t)by * bxn + bx) * 64;
+    };
+    int err = 0;
+    if (live) {
+        if (d.bi != G % g.nbm) { err = 5; live = false; }      // the state chain and the block count disagree: the rounds did not synchronise after all
+        else locate();
+    }
+    while (__any(live)) {
+        if (live) {
+            int widx, val; bool done;
+            const bool ok = js_step(d, tab, g.nb0, g.nbm, widx, val, done);
+            if (!ok) { err = 1; live = false; }
+            else {
+                if (widx >= 0) blk[zz[widx]] = (int16_t)val;     // widx == 0: the DC DIFFERENCE (jpeg_dc_kernel sums them)
+                if (done) {
+                    ++G;
+                    if (d.bi == 0) { if (++mx == g.mcus_x) { mx = 0; ++my; } }
+                    if (G >= g.total_blocks || d.pos() >= end) live = false;
+                    else locate();
+                } else if (d.pos() >= end) live = false;
+            }
+        }
+    }
+    if (err) atomicCAS(&status[f], 0, err);
+}
+
+// DC differences -> DC values: per (component, frame) an inclusive scan over the component's blocks in scan order (1024 threads x 4 blocks per tile)
+__global__ __launch_bounds__(1024) void jpeg_dc_kernel(JsGeom g, int16_t* __restrict__ coefs, const int32_t* __restrict__ status) {
+    __shared__ int cnt[1024];
+    __shared__ int carry;
+    const int ci = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    if (ci >= g.ncomp || status[f] != 0) return;
+    const int nbc = ci == 0 ? g.nb0 : 1, bh = ci == 0 ? g.bh0 : 1;
+    const int N = g.mcus_x * g.mcus_y * nbc;
+    int16_t* cf = coefs + (size_t)f * g.coef_count + g.coef_offset[ci];
+    const int bxn = g.blocks_x[ci];
+    auto addr = [&](int j) -> int16_t* {
+        const int mcu = j / nbc, b = j - mcu * nbc;
+        const int mx = mcu % g.mcus_x, my = mcu / g.mcus_x;
+        const int bcol = bh == 2 ? (b & 1) : 0, brow = bh == 2 ? (b >> 1) : b;
+        const int bvs = ci == 0 ? g.bv0 : 1;
+        return cf + ((size_t)(my * bvs + brow) * bxn + mx * bh + bcol) * 64;
+    };
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < N; j0 += 4096) {
+        int v[4], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int j = j0 + tid * 4 + e; v[e] = j < N ? (int)addr(j)[0] : 0; sum += v[e]; }
+        cnt[tid] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = tid >= o ? cnt[tid - o] : 0;
+            __syncthreads();
+            cnt[tid] += t;
+            __syncthreads();
+        }
+        int run = carry + cnt[tid] - sum;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int j = j0 + tid * 4 + e; run += v[e]; if (j < N) addr(j)[0] = (int16_t)run; }
+        __syncthreads();
+        if (tid == 1023) carry += cnt[1023];
+        __syncthreads();
+    }
+}
+
 __global__ void jpeg_zero_kernel(u32x4* __restrict__ p, size_t n16, int32_t* __restrict__ status, int n_frames) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n16) p[t] = u32x4{0, 0, 0, 0};
@@ -610,6 +964,7 @@ __global__ void jpeg_zero_kernel(u32x4* __restrict__ p, size_t n16, int32_t* __r
 // per-HIP-stream index of interval starts (n_frames x JH_MAX_INT words, grown on demand)
 #include <map>
 #include <mutex>
+#include <vector>
 static std::mutex g_jh_mu;
 struct JhWs { uint32_t* starts = nullptr; uint32_t* lens = nullptr; size_t frames = 0; uint8_t* clean = nullptr; size_t clean_bytes = 0; };
 static std::map<hipStream_t, JhWs> g_jh_ws;
@@ -651,6 +1006,92 @@ extern "C" int sm_jpeg_entropy_decode(const uint8_t* bytes, size_t bytes_total, 
     for (int c = 0; c < info->ncomp; ++c) { g.hs[c] = info->hs[c]; g.vs[c] = info->vs[c]; g.blocks_x[c] = info->blocks_x[c]; g.coef_offset[c] = info->coef_offset[c]; }
     jpeg_huff_kernel<<<dim3(cdiv(max_iv, 64), n_frames), 64, 0, st>>>(ws.clean, offsets, scans, ws.starts, ws.lens, g, coefs, qt, status);
     SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+// frames WITHOUT restart markers (sm_jpeg_scan_t.restart == 0 for every frame of the batch): the self-synchronising decode above.  Same arguments and
+// results as sm_jpeg_entropy_decode; status 5 = the exit states had not settled after JS_ROUNDS rounds (the caller falls back to the host decoder).
+struct JsWs { uint32_t* lanes = nullptr; size_t n_lanes = 0; uint32_t* per_frame = nullptr; size_t frames = 0; int last_frames = 0; };
+static std::map<hipStream_t, JsWs> g_js_ws;
+extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_total, size_t max_file_bytes, const uint32_t* offsets, const sm_jpeg_scan_t* scans,
+                                           const sm_jpeg_info_t* info, int n_frames, int16_t* coefs, uint16_t* qt, int32_t* status, void* stream) {
+    SM_REQUIRE(bytes && bytes_total > 0 && offsets && scans && info && coefs && qt && status && n_frames >= 1, "sm_jpeg_entropy_decode_sync: null arg / no frames");
+    SM_REQUIRE(max_file_bytes > 0 && max_file_bytes <= bytes_total, "sm_jpeg_entropy_decode_sync: max_file_bytes %zu outside (0, bytes_total]", max_file_bytes);
+    SM_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->coef_count > 0 && (((size_t)info->coef_count * 2) % 16) == 0 && ((uintptr_t)coefs & 15) == 0,
+               "sm_jpeg_entropy_decode_sync: bad info / unaligned coefficient image");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n_lanes = bytes_total / 128 + (size_t)n_frames + 64;
+    JhWs ws; JsWs js;
+    {
+        std::lock_guard<std::mutex> lk(g_jh_mu);
+        JhWs& e = g_jh_ws[st];
+        if (e.clean_bytes < bytes_total + 64) {
+            if (e.clean) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(e.clean); e.clean = nullptr; e.clean_bytes = 0; }
+            SM_HIP(hipMalloc((void**)&e.clean, bytes_total + 64));
+            e.clean_bytes = bytes_total + 64;
+        }
+        ws = e;
+        JsWs& j = g_js_ws[st];
+        if (j.n_lanes < n_lanes) {
+            if (j.lanes) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(j.lanes); j.lanes = nullptr; j.n_lanes = 0; }
+            SM_HIP(hipMalloc((void**)&j.lanes, n_lanes * 8 * sizeof(uint32_t)));
+            j.n_lanes = n_lanes;
+        }
+        if (j.frames < (size_t)n_frames) {
+            if (j.per_frame) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(j.per_frame); j.per_frame = nullptr; j.frames = 0; }
+            SM_HIP(hipMalloc((void**)&j.per_frame, (size_t)n_frames * (JS_ROUNDS + 2) * sizeof(uint32_t)));
+            j.frames = n_frames;
+        }
+        js = j;
+    }
+    JsArr A;
+    A.exP[0] = js.lanes; A.exP[1] = js.lanes + n_lanes; A.exS[0] = js.lanes + 2 * n_lanes; A.exS[1] = js.lanes + 3 * n_lanes;
+    A.enP = js.lanes + 4 * n_lanes; A.enS = js.lanes + 5 * n_lanes; A.nblk = js.lanes + 6 * n_lanes; A.base = js.lanes + 7 * n_lanes;
+    A.clean_len = js.per_frame; A.changed = (int32_t*)(js.per_frame + n_frames);
+    JsGeom g;
+    memset(&g, 0, sizeof(g));
+    g.mcus_x = info->mcus_x; g.mcus_y = info->mcus_y; g.ncomp = info->ncomp; g.coef_count = info->coef_count;
+    g.bh0 = info->ncomp > 1 ? info->hs[0] : 1; g.bv0 = info->ncomp > 1 ? info->vs[0] : 1;
+    g.nb0 = g.bh0 * g.bv0; g.nbm = info->ncomp > 1 ? g.nb0 + 2 : 1;
+    g.total_blocks = info->mcus_x * info->mcus_y * g.nbm;
+    for (int c = 0; c < info->ncomp; ++c) { g.blocks_x[c] = info->blocks_x[c]; g.coef_offset[c] = info->coef_offset[c]; }
+    const size_t n16 = (size_t)n_frames * info->coef_count * 2 / 16;
+    jpeg_zero_kernel<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>((u32x4*)coefs, n16, status, n_frames);
+    SM_LAUNCH_CHECK();
+    jpeg_unstuff_scan_kernel<<<n_frames, 1024, 0, st>>>(bytes, offsets, scans, ws.clean, A);
+    SM_LAUNCH_CHECK();
+    // lanes per frame: the clean stream is no longer than the file; grid.x covers the longest file of the batch (a longer one reports status 5)
+    const unsigned gx = (unsigned)cdiv((int)((max_file_bytes * 8 + JS_BITS - 1) / JS_BITS), 64);
+    for (int r = 0; r < JS_ROUNDS; ++r) {
+        jpeg_sync_kernel<<<dim3(gx, n_frames), 64, 0, st>>>(ws.clean, offsets, scans, A, g, r);
+        SM_LAUNCH_CHECK();
+    }
+    jpeg_blockscan_kernel<<<n_frames, 1024, 0, st>>>(offsets, A, g, gx * 64u, status);
+    SM_LAUNCH_CHECK();
+    jpeg_write_kernel<<<dim3(gx, n_frames), 64, 0, st>>>(ws.clean, offsets, scans, A, g, coefs, qt, status);
+    SM_LAUNCH_CHECK();
+    jpeg_dc_kernel<<<dim3(3, n_frames), 1024, 0, st>>>(g, coefs, status);
+    SM_LAUNCH_CHECK();
+    {
+        std::lock_guard<std::mutex> lk(g_jh_mu);
+        g_js_ws[st].last_frames = n_frames;
+    }
+    return SM_OK;
+}
+// rounds until the states of each frame of the stream's LAST sm_jpeg_entropy_decode_sync call stopped moving (waits for the stream; a diagnostic)
+extern "C" int sm_jpeg_sync_rounds(void* stream, int32_t* rounds, int n_frames) {
+    hipStream_t st = (hipStream_t)stream;
+    JsWs js;
+    {
+        std::lock_guard<std::mutex> lk(g_jh_mu);
+        auto it = g_js_ws.find(st);
+        SM_REQUIRE(it != g_js_ws.end() && rounds && n_frames >= 1 && n_frames <= it->second.last_frames, "sm_jpeg_sync_rounds: no decode of >= %d frames on this stream", n_frames);
+        js = it->second;
+    }
+    SM_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> all((size_t)js.last_frames * (JS_ROUNDS + 1));
+    SM_HIP(hipMemcpy(all.data(), js.per_frame + js.last_frames, all.size() * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < n_frames; ++f) rounds[f] = all[(size_t)f * (JS_ROUNDS + 1) + JS_ROUNDS];
     return SM_OK;
 }
 

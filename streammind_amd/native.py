@@ -502,7 +502,9 @@ class JpegDecoder:
         self._pinned = {}            # (n, coef_count) -> (coefs int16 pinned, qt int16 pinned)
         self.host_decode_s = 0.0     # accumulated wall time of the host (entropy) stage
         self.frames = 0
-        self.gpu_entropy_frames = 0  # frames whose entropy-coded segment was decoded on the GPU (restart intervals)
+        self.gpu_entropy_frames = 0  # frames whose entropy-coded segment was decoded on the GPU
+        self.keep_sync_rounds = False  # diagnostic: after a self-synchronising decode, last_sync_rounds = rounds until each frame's states settled (a stream sync)
+        self.last_sync_rounds = None
 
     def info(self, jpeg: bytes) -> "_lib.sm_jpeg_info_t":
         inf = self.lib.sm_jpeg_info.argtypes[2]._type_()
@@ -510,9 +512,11 @@ class JpegDecoder:
         return inf
 
     def _decode_gpu_entropy(self, jpegs, inf) -> Optional[torch.Tensor]:
-        """Frames WITH restart intervals: markers on the host (sm_jpeg_scan_prepare: no entropy decode), the files uploaded as they are, one GPU lane per
-        restart interval (sm_jpeg_entropy_decode), then the same reconstruction.  None when a frame does not qualify (no DRI, per-component scans, ...)
-        or the device reports a malformed segment: the caller then takes the host path, whose error text names the reason."""
+        """Markers on the host (sm_jpeg_scan_prepare: no entropy decode), the files uploaded as they are, the Huffman decode on the GPU: one lane per
+        restart interval when the frames carry DRI (sm_jpeg_entropy_decode), self-synchronising lanes over 1024-bit subsequences when they do not
+        (sm_jpeg_entropy_decode_sync); then the same reconstruction.  None when a frame does not qualify (per-component scans, a batch that mixes the two
+        kinds, ...) or the device reports a malformed segment / states that did not settle: the caller then takes the host path, whose error text names
+        the reason."""
         n = len(jpegs)
         tot = sum((len(j) + 15) // 16 * 16 for j in jpegs)
         ssz = C.sizeof(self.lib.sm_jpeg_scan_prepare.argtypes[3]._type_)
@@ -528,6 +532,8 @@ class JpegDecoder:
         for i, j in enumerate(jpegs):
             if self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(scans[i])) < 0:
                 return None
+            if (scans[i].restart > 0) != (scans[0].restart > 0):
+                return None
             C.memmove(blob.data_ptr() + pos, j, len(j))
             offs[i] = pos
             pos += (len(j) + 15) // 16 * 16
@@ -538,18 +544,27 @@ class JpegDecoder:
             cd = torch.empty(n, inf.coef_count, dtype=torch.int16, device=self.device)
             qd = torch.empty(n, 3, 64, dtype=torch.int16, device=self.device)
             status = torch.empty(n, dtype=torch.int32, device=self.device)
-            check(self.lib.sm_jpeg_entropy_decode(bd.data_ptr(), tot, od.data_ptr(), sd.data_ptr(), C.byref(inf), n, cd.data_ptr(), qd.data_ptr(), status.data_ptr(), _stream()),
-                  "sm_jpeg_entropy_decode")
+            if scans[0].restart > 0:
+                check(self.lib.sm_jpeg_entropy_decode(bd.data_ptr(), tot, od.data_ptr(), sd.data_ptr(), C.byref(inf), n, cd.data_ptr(), qd.data_ptr(), status.data_ptr(),
+                                                      _stream()), "sm_jpeg_entropy_decode")
+            else:
+                check(self.lib.sm_jpeg_entropy_decode_sync(bd.data_ptr(), tot, max(len(j) for j in jpegs), od.data_ptr(), sd.data_ptr(), C.byref(inf), n, cd.data_ptr(),
+                                                           qd.data_ptr(), status.data_ptr(), _stream()), "sm_jpeg_entropy_decode_sync")
+                if self.keep_sync_rounds:
+                    r = (C.c_int32 * n)()
+                    check(self.lib.sm_jpeg_sync_rounds(_stream(), r, n), "sm_jpeg_sync_rounds")
+                    self.last_sync_rounds = list(r)
             planes = torch.empty(self.lib.sm_jpeg_planes_bytes(C.byref(inf), n), dtype=torch.uint8, device=self.device)
             rgb = torch.empty(n, inf.height, inf.width, 3, dtype=torch.uint8, device=self.device)
             check(self.lib.sm_jpeg_reconstruct(cd.data_ptr(), qd.data_ptr(), C.byref(inf), n, planes.data_ptr(), rgb.data_ptr(), _stream()), "sm_jpeg_reconstruct")
-            if int(status.abs().max().item()) != 0:          # (also the sync that lets the pinned staging buffers be reused)
+            self.last_entropy_status = status.cpu()          # (also the sync that lets the pinned staging buffers be reused)
+            if int(self.last_entropy_status.abs().max()) != 0:
                 return None
         self.gpu_entropy_frames += n
         return rgb
 
     def decode(self, jpegs: Sequence[bytes], entropy: str = "auto") -> torch.Tensor:
-        """entropy: "auto" = on the GPU when every frame of the batch carries restart intervals, else on host threads; "host" / "gpu" force one
+        """entropy: "auto" = on the GPU when the batch qualifies (see _decode_gpu_entropy), else on host threads; "host" / "gpu" force one
         ("gpu" raises when a frame does not qualify)."""
         import time
         n = len(jpegs)
@@ -565,7 +580,8 @@ class JpegDecoder:
                 sc = self.lib.sm_jpeg_scan_prepare.argtypes[3]._type_()
                 for i, j in enumerate(jpegs):
                     check(self.lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(j), C.c_void_p), len(j), C.byref(inf), C.byref(sc)), f"sm_jpeg_scan_prepare(frame {i})")
-                raise _lib.StreamMindHipError("sm_jpeg_entropy_decode: the device reported a malformed entropy-coded segment")
+                raise _lib.StreamMindHipError("GPU entropy decode: the batch mixes frames with and without restart intervals, or the device reported a malformed "
+                                              f"entropy-coded segment / decoder states that did not settle (status {getattr(self, 'last_entropy_status', None)})")
         key = (n, inf.coef_count)
         if key not in self._pinned:
             if len(self._pinned) > 4:

@@ -113,7 +113,11 @@ def test_gpu_entropy_decode_of_restart_intervals(dec, case):
     want = U.pil_decode(b)
     assert got.shape == want.shape and np.array_equal(got, want), f"{int((got != want).sum())} bytes differ"
     assert np.array_equal(dec.decode([b], entropy="host")[0].cpu().numpy(), want)
-    # the coefficient image itself against the host decoder
+    _coefficients_equal_the_host_decoders(dec, b, gray)
+
+
+def _coefficients_equal_the_host_decoders(dec, b, gray):
+    """the coefficient image and the quantisation tables of the GPU entropy decode (either form, through the C ABI) against the host decoder's"""
     from streammind_amd import _lib
     inf = dec.info(b)
     sc = dec.lib.sm_jpeg_scan_prepare.argtypes[3]._type_()
@@ -124,8 +128,12 @@ def test_gpu_entropy_decode_of_restart_intervals(dec, case):
     cd = torch.full((inf.coef_count,), 77, dtype=torch.int16, device="cuda")
     qd = torch.empty(3, 64, dtype=torch.int16, device="cuda")
     stt = torch.full((1,), 9, dtype=torch.int32, device="cuda")
-    _lib.check(dec.lib.sm_jpeg_entropy_decode(blob.data_ptr(), len(b), od.data_ptr(), sd.data_ptr(), C.byref(inf), 1, cd.data_ptr(), qd.data_ptr(), stt.data_ptr(),
-                                               torch.cuda.current_stream().cuda_stream))
+    if sc.restart > 0:
+        _lib.check(dec.lib.sm_jpeg_entropy_decode(blob.data_ptr(), len(b), od.data_ptr(), sd.data_ptr(), C.byref(inf), 1, cd.data_ptr(), qd.data_ptr(), stt.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream))
+    else:
+        _lib.check(dec.lib.sm_jpeg_entropy_decode_sync(blob.data_ptr(), len(b), len(b), od.data_ptr(), sd.data_ptr(), C.byref(inf), 1, cd.data_ptr(), qd.data_ptr(),
+                                                        stt.data_ptr(), torch.cuda.current_stream().cuda_stream))
     info, coefs, qt = U.host_coefs(dec.lib, b)
     assert int(stt[0]) == 0
     assert np.array_equal(cd.cpu().numpy(), np.asarray(coefs).reshape(-1))
@@ -133,9 +141,74 @@ def test_gpu_entropy_decode_of_restart_intervals(dec, case):
     assert np.array_equal(qd.cpu().numpy().astype(np.uint16)[:nc], np.asarray(qt).reshape(3, 64)[:nc])
 
 
+SYNC_CASES = [   # (w, h, gray, save kwargs): NO restart markers -- one serial Huffman stream per frame
+    (1280, 720, False, dict(quality=85, subsampling=2)),
+    (1280, 720, False, dict(quality=25, subsampling=2)),                     # ~25 bits per block: 40 blocks per 1024-bit subsequence
+    (1280, 720, False, dict(quality=98, subsampling=0)),                     # long codes, ~20 subsequences per MCU row
+    (1920, 1080, False, dict(quality=75, subsampling=1, optimize=True)),     # 4:2:2, tables built for the image
+    (336, 336, False, dict(quality=75, subsampling=2)),
+    (333, 217, False, dict(quality=60, subsampling=1)),
+    (47, 33, False, dict(quality=95, subsampling=2)),
+    (17, 9, False, dict(quality=95, subsampling=0)),                         # one subsequence or two
+    (8, 8, True, dict(quality=50)),                                          # one block
+    (640, 480, True, dict(quality=80)),
+    (640, 480, False, dict(quality=5, subsampling=2)),                       # almost every block is DC + EOB
+    (64, 48, False, dict(quality=100, subsampling=2)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SYNC_CASES)))
+def test_gpu_entropy_decode_without_restart_markers(dec, case):
+    """Round 5 (f2 completed): frames WITHOUT restart markers -- what every ordinary JPEG is -- are entropy-decoded on the GPU too
+    (sm_jpeg_entropy_decode_sync: self-synchronising lanes over 1024-bit subsequences, block prefix sum, DC scan).  Coefficients and tables equal the
+    host decoder's word for word, the RGB frame equals PIL / libjpeg-turbo byte for byte."""
+    w, h, gray, kw = SYNC_CASES[case]
+    img = U.test_image(w, h, 700 + case, gray)
+    if case == 10:
+        img = (img // 64) * 64                                                # flat areas: runs of empty blocks
+    b = U.encode(img, **kw)
+    assert b.count(b"\xff\xdd") == 0                                          # no DRI
+    before = dec.gpu_entropy_frames
+    got = dec.decode([b], entropy="gpu")[0].cpu().numpy()
+    assert dec.gpu_entropy_frames == before + 1
+    want = U.pil_decode(b)
+    assert got.shape == want.shape and np.array_equal(got, want), f"{int((got != want).sum())} bytes differ"
+    _coefficients_equal_the_host_decoders(dec, b, gray)
+
+
+def test_gpu_entropy_decode_sync_batches_and_broken_streams(dec):
+    """28 ordinary 720p frames of different qualities (file lengths 60..300 KB) in ONE call; a second call with other frames reuses the workspaces; a stream
+    cut short is reported (status 4: fewer blocks than the frame has), a stream whose middle is overwritten is reported or decodes to SOMETHING without
+    touching memory outside the frame (the sentinel rows around the coefficient image stay)."""
+    frames = [U.encode(U.test_image(1280, 720, 900 + i), quality=40 + 2 * i, subsampling=2) for i in range(28)]
+    before = dec.gpu_entropy_frames
+    got = dec.decode(frames).cpu().numpy()
+    assert dec.gpu_entropy_frames == before + 28
+    for i in (0, 9, 27):
+        assert np.array_equal(got[i], U.pil_decode(frames[i])), i
+    again = dec.decode(frames[::-1][:5]).cpu().numpy()
+    assert np.array_equal(again[0], got[27]) and np.array_equal(again[4], got[23])
+    cut = frames[3][:len(frames[3]) * 2 // 3] + b"\xff\xd9"
+    with pytest.raises(Exception, match="did not settle|malformed"):
+        dec.decode([cut], entropy="gpu")
+    assert int(dec.last_entropy_status[0]) == 4
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        m = bytearray(frames[5])
+        at = len(m) // 2 + 1000 * trial
+        m[at:at + 64] = bytes(int(v) for v in rng.integers(0, 255, 64))      # (no 0xFF: the segment keeps its length)
+        try:
+            out = dec.decode([bytes(m)], entropy="gpu")
+            assert out.shape == (1, 720, 1280, 3)
+        except Exception as e:
+            assert "settle" in str(e) or "malformed" in str(e)
+    assert np.array_equal(dec.decode([frames[9]], entropy="gpu")[0].cpu().numpy(), got[9])      # and the decoder is fine afterwards
+
+
 def test_gpu_entropy_decode_batch_fallback_and_corruption(dec):
-    """28 frames of 720p with one restart interval per MCU row in ONE call (1260 lanes); a batch with a frame that has no restart markers goes to the
-    host threads as a whole ("auto") and is refused by "gpu" with the reason; a corrupted segment (marker numbering broken) is reported, never decoded wrong."""
+    """28 frames of 720p with one restart interval per MCU row in ONE call (1260 lanes); a batch that mixes frames with and without restart markers goes
+    to the host threads as a whole ("auto") and is refused by "gpu" with the reason; a corrupted segment (marker numbering broken) is reported, never
+    decoded wrong."""
     frames = [U.encode(U.test_image(1280, 720, 500 + i), quality=70 + i % 20, subsampling=2, restart_marker_rows=1) for i in range(28)]
     before = dec.gpu_entropy_frames
     got = dec.decode(frames).cpu().numpy()
@@ -147,7 +220,7 @@ def test_gpu_entropy_decode_batch_fallback_and_corruption(dec):
     before = dec.gpu_entropy_frames
     both = dec.decode(mixed).cpu().numpy()
     assert dec.gpu_entropy_frames == before and np.array_equal(both[1], U.pil_decode(plain))
-    with pytest.raises(Exception, match="no restart interval"):
+    with pytest.raises(Exception, match="mixes frames with and without"):
         dec.decode(mixed, entropy="gpu")
     bad = bytearray(frames[1])
     k = bad.index(b"\xff\xd1")              # RST1 -> RST3: the numbering check of the index kernel

@@ -118,7 +118,8 @@ def test_hostile_streams_are_refused_not_crashed(lib):
 
 def test_scan_prepare_is_markers_only_and_says_why_not():
     """sm_jpeg_scan_prepare (the host half of the GPU entropy decode): restart interval, interval count, segment offset and tables of a frame with restart
-    markers; files without DRI, progressive files and per-component scans are refused with the reason (the caller keeps the host decoder)."""
+    markers; a file without DRI is one serial stream (restart 0, no intervals: the self-synchronising decode takes it); progressive files and per-component
+    scans are refused with the reason (the caller keeps the host decoder)."""
     import ctypes as C
     from streammind_amd import _lib
     lib = _lib.load()
@@ -133,6 +134,9 @@ def test_scan_prepare_is_markers_only_and_says_why_not():
     assert b.count(b"\xff\xd0") + sum(b.count(bytes([0xFF, 0xD0 + i])) for i in range(1, 8)) == sc.n_intervals - 1
     # luminance DC table of Annex K / libjpeg: the 2-bit code 00 is category 0
     assert sc.dc[0].fast[0] >> 8 == 2 and sc.dc[0].fast[0] & 0xFF == 0
-    for bad, why in ((U.encode(img, quality=85), b"no restart interval"), (U.encode(img, quality=85, progressive=True), b"not baseline")):
+    plain = U.encode(img, quality=85)
+    _lib.check(lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(plain), C.c_void_p), len(plain), None, C.byref(sc)))
+    assert sc.restart == 0 and sc.n_intervals == 0 and sc.ncomp == 3 and sc.scan_offset + sc.scan_len == len(plain)
+    for bad, why in ((U.encode(img, quality=85, progressive=True), b"not baseline"),):
         assert lib.sm_jpeg_scan_prepare(C.cast(C.c_char_p(bad), C.c_void_p), len(bad), None, C.byref(sc)) < 0
         assert why in lib.sm_last_error(), lib.sm_last_error()
