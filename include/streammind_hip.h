@@ -476,13 +476,14 @@ int sm_jpeg_scan_prepare(const uint8_t* data, size_t len, const sm_jpeg_info_t* 
 int sm_jpeg_entropy_decode(const uint8_t* bytes_dev, size_t bytes_total, const uint32_t* offsets_dev, const sm_jpeg_scan_t* scans_dev, const sm_jpeg_info_t* info, int n_frames,
                            int16_t* coefs_dev, uint16_t* qt_dev, int32_t* status_dev, void* stream);
 /* The same for frames WITHOUT restart markers (restart == 0 in every frame's scan): the one serial Huffman stream of a frame is cut into subsequences of
- * 1024 bits, one GPU lane each; the lanes find their decoder states by self-synchronisation (up to 48 rounds: every lane decodes from the state its predecessor
- * left in the round before, until no state moves), a prefix sum numbers the blocks, a last pass writes the coefficients and a scan turns the DC differences
- * into values.  max_file_bytes: the longest file of the batch (bounds the lanes per frame).  status as above, plus 5 = the states had not settled (the
- * caller decodes that batch on the host). */
+ * 1024 bits, one GPU lane each.  A lane decodes its subsequence from a guessed decoder state and keeps a record (entry state, exit state, blocks completed);
+ * in every round the lanes whose record does not enter where their predecessor's exits decode again from there and follow the stream downstream until they
+ * reach an exit state already on record (a prefix code synchronises).  When the records chain (at most 32 rounds, usually 2-4) a prefix sum numbers the
+ * blocks, a last pass writes the coefficients and a scan turns the DC differences into values.  max_file_bytes: the longest file of the batch (bounds the
+ * lanes per frame).  status as above, plus 5 = the records did not chain (the caller decodes that batch on the host). */
 int sm_jpeg_entropy_decode_sync(const uint8_t* bytes_dev, size_t bytes_total, size_t max_file_bytes, const uint32_t* offsets_dev, const sm_jpeg_scan_t* scans_dev,
                                 const sm_jpeg_info_t* info, int n_frames, int16_t* coefs_dev, uint16_t* qt_dev, int32_t* status_dev, void* stream);
-/* diagnostic: rounds until the decoder states of each frame of this stream's LAST sm_jpeg_entropy_decode_sync call stopped moving (waits for the stream) */
+/* diagnostic: rounds until the records of each frame of this stream's LAST sm_jpeg_entropy_decode_sync call chained (waits for the stream) */
 int sm_jpeg_sync_rounds(void* stream, int32_t* rounds_host, int n_frames);
 /* device: coefs [n][coef_count], qt [n][3][64] -> rgb u8 [n][height][width][3]; planes: scratch of sm_jpeg_planes_bytes bytes */
 int sm_jpeg_reconstruct(const int16_t* coefs, const uint16_t* qt, const sm_jpeg_info_t* info, int n_frames, uint8_t* planes, uint8_t* rgb, void* stream);

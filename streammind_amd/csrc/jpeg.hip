@@ -612,115 +612,135 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
 // starts in), a last pass writes the coefficients -- the DC DIFFERENCE in place of the DC -- and a per-component scan over the blocks in scan order turns
 // the differences into values.  Same decode step as the restart-interval kernel (one uniform loop: one symbol per trip for every live lane).
 #define JS_BITS 1024                                            // bits per subsequence
-#define JS_ROUNDS 48                                            // at most; a frame whose states stopped moving leaves the later rounds at once
+#define JS_ROUNDS 16                                            // at most; a frame whose records chain leaves the later rounds at once
 struct JsGeom { int mcus_x, mcus_y, ncomp, bh0, bv0, nb0, nbm, blocks_x[3], coef_offset[3], coef_count, total_blocks; };
-struct JsArr {                                                  // per-lane records, [lanes]
-    uint32_t* exP[2]; uint32_t* exS[2];                         // exit state of the two newest rounds: bit position; bi | k << 8
-    uint32_t* enP; uint32_t* enS;                               // the entry state the lane last decoded from
-    uint32_t* nblk; uint32_t* base;                             // blocks completed inside the subsequence; their exclusive prefix sum
+struct JsArr {
+    uint64_t* rec;                                              // [lanes] one record per subsequence (layout below)
+    uint32_t* base;                                             // [lanes] exclusive prefix sum of the records' completed blocks
     uint32_t* clean_len;                                        // [frames] bytes of the unstuffed stream
-    int32_t* changed;                                           // [frames][JS_ROUNDS + 1] exit states that moved in round r; [JS_ROUNDS] = rounds until none did
+    int32_t* raw_end;                                           // [frames] raw position of the first marker behind the data
+    uint32_t* tile_cnt;                                         // [frames][tiles_max] bytes every 4096-byte tile of the raw segment keeps
+    int32_t* changed;                                           // [frames][JS_ROUNDS + 1] lanes that had work in round r; [JS_ROUNDS] = rounds until none had
 };
 __device__ __forceinline__ uint32_t js_lane0(const uint32_t* offsets, int f) { return (offsets[f] >> 7) + (uint32_t)f; }      // first lane record of frame f
 
-// Unstuffing of a whole scan: one block per frame walks the segment in tiles of 1024 x 16 bytes; a thread counts the bytes it keeps (everything but the
-// 0x00 behind a data 0xFF), an LDS scan ranks the threads, the tile is written compacted behind the previous one.  The first marker ends the data.
-__global__ __launch_bounds__(1024) void jpeg_unstuff_scan_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
-                                                                uint8_t* __restrict__ clean, JsArr A) {
-    __shared__ int cnt[1024];
-    __shared__ int s_end, s_base;
-    const int f = blockIdx.x, tid = threadIdx.x;
+// Unstuffing of a whole scan, two launches over (tiles of 4096 bytes, frames): every tile counts the bytes it keeps (everything but the 0x00 behind a data
+// 0xFF) and reports the first marker it sees; then every tile sums the counts of the tiles before it, ranks its own threads and writes its bytes compacted
+// at that place.  The first marker ends the data (the tile that holds it writes the stream's length).  The clean stream starts 16-byte aligned.
+#define JS_TILE 4096
+__device__ __forceinline__ uint32_t js_clean_at(const uint32_t* offsets, const sm_jpeg_scan_t& sc, int f) { return offsets[f] + (sc.scan_offset & ~15u); }
+__device__ __forceinline__ void js_tile_bytes(const uint8_t* src, uint32_t n, uint32_t lo, uint8_t (&b)[18]) {                   // b[e] = byte lo + e - 1
+#pragma unroll
+    for (int e = 0; e < 18; ++e) { const uint32_t p = lo + e; b[e] = (p >= 1 && p - 1 < n) ? src[p - 1] : 0; }
+}
+__global__ __launch_bounds__(256) void jpeg_unstuff_count_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                                 JsArr A, int tiles_max) {
+    __shared__ int cnt[4];
+    const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
-    const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
-    uint8_t* dst = clean + offsets[f] + sc.scan_offset;
     const uint32_t n = sc.scan_len;
-    if (tid == 0) { s_end = 0x7fffffff; s_base = 0; }
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n; t0 += 16384) {
-        const uint32_t lo = t0 + tid * 16;
-        uint8_t b[18];
+    if ((uint32_t)t * JS_TILE >= n) return;
+    const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
+    const uint32_t lo = (uint32_t)t * JS_TILE + tid * 16;
+    uint8_t b[18];
+    js_tile_bytes(src, n, lo, b);
+    int keep = 0, my_end = 0x7fffffff;
 #pragma unroll
-        for (int e = 0; e < 18; ++e) { const uint32_t p = lo + e; b[e] = (p >= 1 && p - 1 < n) ? src[p - 1] : 0; }     // b[e] = byte lo + e - 1
-        int keep = 0, my_end = 0x7fffffff;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t p = lo + e;
-            const bool marker = p + 1 < n && b[e + 1] == 0xFF && b[e + 2] != 0x00;
-            if (marker && my_end == 0x7fffffff) my_end = (int)p;
-            if (p < n && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++keep;
-        }
-        if (my_end != 0x7fffffff) atomicMin(&s_end, my_end);
-        cnt[tid] = keep;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = tid >= o ? cnt[tid - o] : 0;
-            __syncthreads();
-            cnt[tid] += v;
-            __syncthreads();
-        }
-        const int end = s_end;
-        int out = s_base + cnt[tid] - keep;
-        // bytes behind the first marker are not data: recount the threads that straddle it (rare: once per frame)
-        if (end != 0x7fffffff) {
-            __syncthreads();
-            int k2 = 0;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t p = lo + e;
-                if (p < n && (int)p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++k2;
-            }
-            cnt[tid] = k2;
-            __syncthreads();
-            for (int o = 1; o < 1024; o <<= 1) {
-                const int v = tid >= o ? cnt[tid - o] : 0;
-                __syncthreads();
-                cnt[tid] += v;
-                __syncthreads();
-            }
-            keep = k2;
-            out = s_base + cnt[tid] - k2;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t p = lo + e;
-            if (p < n && (int)p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) dst[out++] = b[e + 1];
-        }
-        __syncthreads();
-        if (tid == 1023) s_base += cnt[1023];
-        __syncthreads();
-        if (end != 0x7fffffff) break;
+    for (int e = 15; e >= 0; --e) {
+        const uint32_t p = lo + e;
+        if (p + 1 < n && b[e + 1] == 0xFF && b[e + 2] != 0x00) my_end = (int)p;
+        if (p < n && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++keep;
     }
-    if (tid == 0) A.clean_len[f] = (uint32_t)s_base;
-    if (tid <= JS_ROUNDS) A.changed[f * (JS_ROUNDS + 1) + tid] = 0;
-    // zero padding behind the stream: the decode lanes read whole dwords
-    if (tid < 8) dst[s_base + tid] = 0;
+    if (my_end != 0x7fffffff) atomicMin(&A.raw_end[f], my_end);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) keep += __shfl_xor(keep, o);
+    if ((tid & 63) == 0) cnt[tid >> 6] = keep;
+    __syncthreads();
+    if (tid == 0) A.tile_cnt[(size_t)f * tiles_max + t] = (uint32_t)(cnt[0] + cnt[1] + cnt[2] + cnt[3]);
+}
+__global__ __launch_bounds__(256) void jpeg_unstuff_write_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                                 uint8_t* __restrict__ clean, JsArr A, int tiles_max) {
+    __shared__ int part[4];
+    __shared__ int wsum[4];
+    const int f = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+    const sm_jpeg_scan_t& sc = scans[f];
+    const uint32_t n = sc.scan_len;
+    const int end = A.raw_end[f] < (int)n ? A.raw_end[f] : (int)n;                  // raw bytes [0, end) are data
+    if ((int)((uint32_t)t * JS_TILE) >= end && !(end == 0 && t == 0)) return;
+    const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
+    uint8_t* dst = clean + js_clean_at(offsets, sc, f);
+    int before = 0;                                                                // kept bytes of the tiles before this one (all of them wholly data)
+    for (int i = tid; i < t; i += 256) before += (int)A.tile_cnt[(size_t)f * tiles_max + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
+    if ((tid & 63) == 0) part[tid >> 6] = before;
+    const uint32_t lo = (uint32_t)t * JS_TILE + tid * 16;
+    uint8_t b[18];
+    js_tile_bytes(src, n, lo, b);
+    int keep = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int p = (int)lo + e;
+        if (p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) ++keep;
+    }
+    int incl = keep;                                                               // inclusive scan inside the wave, then over the four waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((tid & 63) >= o) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    before = part[0] + part[1] + part[2] + part[3];
+    int wbase = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    int out = before + wbase + incl - keep;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int p = (int)lo + e;
+        if (p < end && !(b[e + 1] == 0x00 && b[e] == 0xFF)) dst[out++] = b[e + 1];
+    }
+    if (tid == 255 && (int)((uint32_t)(t + 1) * JS_TILE) >= end) A.clean_len[f] = (uint32_t)(before + wsum[0] + wsum[1] + wsum[2] + wsum[3]);      // the last tile of data
 }
 
 // the shared decode step: one symbol (+ value bits) per call.  `h` tables in LDS; returns false on a code no table holds (only a wrong guess or the padding
 // behind the last block produces one: the caller decides what that means)
 struct JsDec {
-    const uint8_t* src; uint32_t len;          // unstuffed stream of the frame
-    uint64_t acc; int n; uint32_t ba, nextw;   // bit window: n valid bits at the bottom of acc, filled up to byte ba; nextw = the dword at ba
+    const uint32_t* src; uint32_t len;         // unstuffed stream of the frame (16-byte aligned), its length in bytes
+    const uint32_t* win; uint32_t w0, nw;      // the block's window of it in LDS: dwords [w0, w0 + nw), big-endian already, zeros behind the stream's end,
+                                               // 33 words per 32 (lanes read at a stride of one subsequence: the skew spreads them over the banks)
+    uint64_t acc; int n; uint32_t wn, nextw;   // bit window: n valid bits at the bottom of acc, filled up to dword wn; nextw = dword wn
     int bi, k;
-    __device__ __forceinline__ uint32_t word(uint32_t at) const {
-        uint32_t v = 0;
-        if (at < len) {
-            v = __builtin_bswap32(*(const uint32_t*)(src + at));
-            if (at + 4 > len) v &= 0xFFFFFFFFu << (8 * (at + 4 - len));
+    __device__ __forceinline__ uint32_t word(uint32_t w) const {
+        const uint32_t i = w - w0;
+        if (i < nw) return win[i + (i >> 5)];
+        uint32_t v = 0;                        // (a lane that followed the stream out of the window)
+        if (w * 4 < len) {
+            v = __builtin_bswap32(src[w]);
+            if (w * 4 + 4 > len) v &= 0xFFFFFFFFu << (8 * (w * 4 + 4 - len));
         }
         return v;
     }
     __device__ __forceinline__ void start(uint32_t p, int bi_, int k_) {
-        const uint32_t byte = p >> 3;
-        acc = word(byte); n = 32 - (int)(p & 7); ba = byte + 4; nextw = word(ba);
+        const uint32_t w = p >> 5;
+        acc = word(w); n = 32 - (int)(p & 31); wn = w + 1; nextw = word(wn);
         bi = bi_; k = k_;
     }
-    __device__ __forceinline__ uint32_t pos() const { return 8u * ba - (uint32_t)n; }
+    __device__ __forceinline__ uint32_t pos() const { return 32u * wn - (uint32_t)n; }
 };
+// the block's window of the clean stream into LDS: dwords [w0, w0 + nw) of `src`
+__device__ __forceinline__ void js_stage(uint32_t* win, const uint32_t* src, uint32_t len, uint32_t w0, uint32_t nw, int tid, int nthreads) {
+    for (uint32_t i = tid; i < nw; i += nthreads) {
+        const uint32_t w = w0 + i;
+        uint32_t v = 0;
+        if (w * 4 < len) {
+            v = __builtin_bswap32(src[w]);
+            if (w * 4 + 4 > len) v &= 0xFFFFFFFFu << (8 * (w * 4 + 4 - len));
+        }
+        win[i + (i >> 5)] = v;
+    }
+}
 // decodes one symbol; out: is_dc, zig-zag index written (or -1), value; advances (bi, k); `done_block` when the block completed
 template <class TAB>
 __device__ __forceinline__ bool js_step(JsDec& d, const TAB* tab, int nb0, int nbm, int& widx, int& val, bool& done_block) {
-    if (d.n < 32) { d.acc = (d.acc << 32) | d.nextw; d.n += 32; d.ba += 4; d.nextw = d.word(d.ba); }
+    if (d.n < 32) { d.acc = (d.acc << 32) | d.nextw; d.n += 32; d.wn += 1; d.nextw = d.word(d.wn); }
     const int ci = d.bi < nb0 ? 0 : d.bi - nb0 + 1;
     const sm_jpeg_huff_t& h = tab[(d.k == 0 ? 0 : 3) + ci];
     const uint32_t look = (uint32_t)(d.acc >> (d.n - 16)) & 0xFFFFu;
@@ -763,62 +783,94 @@ __device__ __forceinline__ bool js_step(JsDec& d, const TAB* tab, int nb0, int n
     return ok;
 }
 
-// one synchronisation round (round 0: the guesses).  Lane s of frame f: subsequence [s JS_BITS, (s + 1) JS_BITS) of the frame's clean stream.
-__global__ __launch_bounds__(64) void jpeg_sync_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
-                                                       JsArr A, JsGeom g, int round) {
+// One record per subsequence, ONE 64-bit word (written and read whole, so a record is always a true statement "decoding this subsequence from ENTRY leaves
+// EXIT after NBLK completed blocks"):  bits 0-14 exit state, 15-23 blocks completed, 24-38 entry state; a state = bit offset past the subsequence's first bit
+// (0..30: a symbol is at most 31 bits) | block inside the MCU << 5 | next zig-zag index << 8.  All ones = no record yet.
+// The frame is decoded when the records CHAIN: record[0] enters at (0, 0, 0) and record[s] enters where record[s - 1] exits.
+#define JS_CHAIN 64                                             // subsequences a lane follows downstream in one round
+__device__ __forceinline__ uint32_t js_exit(uint64_t r) { return (uint32_t)r & 0x7FFFu; }
+__device__ __forceinline__ uint32_t js_nblk(uint64_t r) { return (uint32_t)(r >> 15) & 0x1FFu; }
+__device__ __forceinline__ uint32_t js_entry(uint64_t r) { return (uint32_t)(r >> 24) & 0x7FFFu; }
+__device__ __forceinline__ uint64_t js_pack(uint32_t entry, uint32_t exit, uint32_t nb) { return (uint64_t)exit | ((uint64_t)nb << 15) | ((uint64_t)entry << 24); }
+__device__ __forceinline__ uint64_t js_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void js_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void jpeg_sync_init_kernel(JsArr A, size_t n_lanes, int n_frames) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_lanes) A.rec[i] = ~0ull;
+    if (i < (size_t)n_frames) { A.raw_end[i] = 0x7fffffff; A.clean_len[i] = 0; }
+    if (i < (size_t)n_frames * (JS_ROUNDS + 1)) A.changed[i] = 0;
+}
+
+// One relaxation round.  Lane s looks at its record: if it enters where record[s - 1] exits, nothing to do.  Otherwise it decodes subsequence s from that
+// state, stores the record, and FOLLOWS the stream into s + 1, s + 2, ... (the decoder simply keeps going), replacing their records, until the exit state it
+// reaches is the one already on record there -- from that point the downstream records were derived from the same state -- or JS_CHAIN subsequences.
+// Round 0: no records, every lane starts from the guess (start of an MCU at its first bit) and follows into its successor, which is where most guesses have
+// synchronised.  Lanes race on the records they replace; every record is true by itself, only the chaining can be left broken, and the next round's lanes
+// see exactly that.  A round in which no lane had anything to do proves the chain (jpeg_blockscan_kernel and the writing pass check it once more).
+#define JS_TPB 256                                              // lanes (subsequences) per block
+#define JS_AHEAD 32                                             // subsequences behind the block's own that its window holds (a lane following the stream)
+__global__ __launch_bounds__(JS_TPB) void jpeg_sync_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                           JsArr A, JsGeom g, int round) {
     __shared__ sm_jpeg_huff_t tab[6];
-    const int f = blockIdx.y, lane = threadIdx.x;
+    __shared__ uint32_t win[(JS_TPB + JS_AHEAD) * 33];
+    const int f = blockIdx.y, tid = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
     const uint32_t len = A.clean_len[f];
     const uint32_t S = (len * 8 + JS_BITS - 1) / JS_BITS;
-    if (blockIdx.x * 64u >= S) return;
-    // nothing moved in the round before: every lane's entry state is the one it decoded from, the frame is settled (both exit buffers hold the same states)
-    if (round > 0 && A.changed[f * (JS_ROUNDS + 1) + round - 1] == 0) return;
+    if (blockIdx.x * (uint32_t)JS_TPB >= S) return;
+    if (round > 0 && A.changed[f * (JS_ROUNDS + 1) + round - 1] == 0) return;       // the round before found the chain whole
+    const uint32_t s = blockIdx.x * JS_TPB + tid;
+    uint64_t* rec = A.rec + js_lane0(offsets, f);
+    bool live = s < S;
+    uint32_t entry = 0;
+    if (live && s > 0) entry = round == 0 ? 0u : js_exit(js_load(rec + s - 1));
+    if (live && round > 0 && js_entry(js_load(rec + s)) == entry) live = false;
+    if (!__syncthreads_or(live)) return;
+    JsDec d;
+    d.src = (const uint32_t*)(clean + js_clean_at(offsets, sc, f)); d.len = len;
+    d.win = win; d.w0 = blockIdx.x * JS_TPB * (JS_BITS / 32); d.nw = (JS_TPB + JS_AHEAD) * (JS_BITS / 32);
     {
         const uint32_t* src = (const uint32_t*)sc.dc;
         uint32_t* dst = (uint32_t*)tab;
-        for (int w = lane; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += 64) dst[w] = src[w];
+        for (int w = tid; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += JS_TPB) dst[w] = src[w];
+        js_stage(win, d.src, len, d.w0, d.nw, tid, JS_TPB);
     }
     __syncthreads();
-    const uint32_t s = blockIdx.x * 64 + lane;
-    const uint32_t L = js_lane0(offsets, f) + s;
-    const int cur = round & 1, prv = cur ^ 1;
-    bool live = s < S;
-    uint32_t ep = s * JS_BITS, es = 0;                          // entry: guessed (block start at the subsequence's first bit) ...
-    if (live && round > 0 && s > 0) { ep = A.exP[prv][L - 1]; es = A.exS[prv][L - 1]; }      // ... or what the predecessor left
-    const uint32_t end = (s + 1) * JS_BITS < len * 8 ? (s + 1) * JS_BITS : len * 8;
-    if (live && round > 0 && ep == A.enP[L] && es == A.enS[L]) {                             // same entry as last time: same exit
-        A.exP[cur][L] = A.exP[prv][L]; A.exS[cur][L] = A.exS[prv][L];
-        live = false;
-    }
-    JsDec d;
-    d.src = clean + offsets[f] + sc.scan_offset; d.len = len;
-    if (live) { A.enP[L] = ep; A.enS[L] = es; d.start(ep, (int)(es & 0xFF), (int)(es >> 8)); }
-    uint32_t nb = 0;
-    bool run = live && ep < end;
-    while (__any(run)) {
-        if (run) {
+    if (live) atomicAdd(&A.changed[f * (JS_ROUNDS + 1) + round], 1);
+    uint32_t j = s, nb = 0, chain = 0;
+    uint32_t end = (j + 1) * JS_BITS < len * 8 ? (j + 1) * JS_BITS : len * 8;
+    if (live) d.start(s * JS_BITS + (entry & 31), (int)((entry >> 5) & 7), (int)(entry >> 8));
+    while (__any(live)) {
+        if (live) {
             int widx, val; bool done;
             (void)js_step(d, tab, g.nb0, g.nbm, widx, val, done);
             nb += done ? 1u : 0u;
-            run = d.pos() < end;
+            if (d.pos() >= end) {                                // subsequence j is behind the decoder
+                const uint32_t exit = (d.pos() - end) | ((uint32_t)d.bi << 5) | ((uint32_t)d.k << 8);
+                const uint64_t old = js_load(rec + j);
+                // (its own subsequence: if the record it started from has been replaced meanwhile, the result is stale -- leave it to the lane that did that)
+                const bool stale = j == s && s > 0 && round > 0 && js_exit(js_load(rec + s - 1)) != entry;
+                if (!stale) js_store(rec + j, js_pack(entry, exit, nb));
+                if (stale || js_exit(old) == exit || j + 1 >= S || ++chain >= JS_CHAIN) live = false;
+                else {
+                    ++j; entry = exit; nb = 0;                   // the exit state counts from the next subsequence's first bit: its entry state as it is
+                    end = (j + 1) * JS_BITS < len * 8 ? (j + 1) * JS_BITS : len * 8;
+                }
+            }
         }
-    }
-    if (live) {
-        const uint32_t xp = ep < end ? d.pos() : ep, xs = ep < end ? ((uint32_t)d.bi | ((uint32_t)d.k << 8)) : es;
-        if (round == 0 || xp != A.exP[prv][L] || xs != A.exS[prv][L]) atomicAdd(&A.changed[f * (JS_ROUNDS + 1) + round], 1);
-        A.exP[cur][L] = xp; A.exS[cur][L] = xs; A.nblk[L] = nb;
     }
 }
 
-// exclusive prefix sum of the lanes' completed-block counts (one block per frame), convergence and completeness checks
+// exclusive prefix sum of the records' completed-block counts (one block per frame); is the chain whole, does it hold all the frame's blocks
 __global__ __launch_bounds__(1024) void jpeg_blockscan_kernel(const uint32_t* __restrict__ offsets, JsArr A, JsGeom g, uint32_t lanes_launched,
                                                               int32_t* __restrict__ status) {
     __shared__ uint32_t cnt[1024];
     __shared__ uint32_t carry;
+    __shared__ int broken;
     const int f = blockIdx.x, tid = threadIdx.x;
     const uint32_t len = A.clean_len[f], S = (len * 8 + JS_BITS - 1) / JS_BITS, L0 = js_lane0(offsets, f);
-    if (tid == 0) carry = 0;
+    if (tid == 0) { carry = 0; broken = 0; }
     __syncthreads();
     if (S > lanes_launched) {                                   // a file longer than the caller said: its tail was never decoded
         if (tid == 0) atomicCAS(&status[f], 0, 5);
@@ -826,7 +878,12 @@ __global__ __launch_bounds__(1024) void jpeg_blockscan_kernel(const uint32_t* __
     }
     for (uint32_t s0 = 0; s0 < S; s0 += 1024) {
         const uint32_t s = s0 + tid;
-        const uint32_t v = s < S ? A.nblk[L0 + s] : 0;
+        uint32_t v = 0;
+        if (s < S) {
+            const uint64_t r = A.rec[L0 + s];
+            v = js_nblk(r);
+            if (js_entry(r) != (s == 0 ? 0u : js_exit(A.rec[L0 + s - 1]))) broken = 1;
+        }
         cnt[tid] = v;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
@@ -844,41 +901,45 @@ __global__ __launch_bounds__(1024) void jpeg_blockscan_kernel(const uint32_t* __
         int r = 0;
         while (r < JS_ROUNDS && A.changed[f * (JS_ROUNDS + 1) + r] != 0) ++r;
         A.changed[f * (JS_ROUNDS + 1) + JS_ROUNDS] = r;                                    // (sm_jpeg_sync_rounds reads it)
-        if (r == JS_ROUNDS) atomicCAS(&status[f], 0, 5);                                   // the exit states still moved in the last round: not synchronised
+        if (broken) atomicCAS(&status[f], 0, 5);                                           // JS_ROUNDS rounds did not mend the chain
         else if (carry < (uint32_t)g.total_blocks) atomicCAS(&status[f], 0, 4);            // the stream ends before the last block
     }
 }
 
-// the writing pass: every lane decodes its subsequence once more from its (now true) entry state, blocks numbered from its prefix sum
-__global__ __launch_bounds__(64) void jpeg_write_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
-                                                        JsArr A, JsGeom g, int16_t* __restrict__ coefs, uint16_t* __restrict__ qt, int32_t* __restrict__ status) {
+// the writing pass: every lane decodes its subsequence once more from its record's entry state, blocks numbered from the prefix sum; what it finds has to be
+// the record again (exit state, blocks)
+__global__ __launch_bounds__(JS_TPB) void jpeg_write_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
+                                                            JsArr A, JsGeom g, int16_t* __restrict__ coefs, uint16_t* __restrict__ qt, int32_t* __restrict__ status) {
     __shared__ sm_jpeg_huff_t tab[6];
+    __shared__ uint32_t win[(JS_TPB + 1) * 33];
     __shared__ uint8_t zz[64];
-    const int f = blockIdx.y, lane = threadIdx.x;
+    const int f = blockIdx.y, tid = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
     const uint32_t len = A.clean_len[f];
     const uint32_t S = (len * 8 + JS_BITS - 1) / JS_BITS;
-    if (blockIdx.x * 64u >= S || status[f] != 0) return;
+    if (blockIdx.x * (uint32_t)JS_TPB >= S || status[f] != 0) return;
+    JsDec d;
+    d.src = (const uint32_t*)(clean + js_clean_at(offsets, sc, f)); d.len = len;
+    d.win = win; d.w0 = blockIdx.x * JS_TPB * (JS_BITS / 32); d.nw = (JS_TPB + 1) * (JS_BITS / 32);
     {
         const uint32_t* src = (const uint32_t*)sc.dc;
         uint32_t* dst = (uint32_t*)tab;
-        for (int w = lane; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += 64) dst[w] = src[w];
-        zz[lane] = kZigzagDev[lane];
-        if (blockIdx.x == 0)
-            for (int w = lane; w < 3 * 64; w += 64) qt[(size_t)f * 192 + w] = sc.qt[w / 64][w % 64];
+        for (int w = tid; w < (int)(6 * sizeof(sm_jpeg_huff_t) / 4); w += JS_TPB) dst[w] = src[w];
+        if (tid < 64) zz[tid] = kZigzagDev[tid];
+        if (blockIdx.x == 0 && tid < 3 * 64) qt[(size_t)f * 192 + tid] = sc.qt[tid / 64][tid % 64];
+        js_stage(win, d.src, len, d.w0, d.nw, tid, JS_TPB);
     }
     __syncthreads();
-    const uint32_t s = blockIdx.x * 64 + lane;
+    const uint32_t s = blockIdx.x * JS_TPB + tid;
     const uint32_t L = js_lane0(offsets, f) + s;
-    const int cur = 0;                                          // settled: both exit buffers hold the same states
     bool live = s < S;
-    const uint32_t ep = live ? (s == 0 ? 0u : A.exP[cur][L - 1]) : 0u, es = live ? (s == 0 ? 0u : A.exS[cur][L - 1]) : 0u;
+    const uint64_t mine = live ? A.rec[L] : 0ull;
+    const uint32_t entry = js_entry(mine);
     const uint32_t end = (s + 1) * JS_BITS < len * 8 ? (s + 1) * JS_BITS : len * 8;
-    JsDec d;
-    d.src = clean + offsets[f] + sc.scan_offset; d.len = len;
     int G = live ? (int)A.base[L] : 0;                          // the block in progress at the entry
-    live = live && ep < end && G < g.total_blocks;
-    if (live) d.start(ep, (int)(es & 0xFF), (int)(es >> 8));
+    const bool check = live;                                    // (lanes behind the frame's last block have nothing to write, their records still hold)
+    live = live && G < g.total_blocks;
+    if (live) d.start(s * JS_BITS + (entry & 31), (int)((entry >> 5) & 7), (int)(entry >> 8));
     int16_t* cf = coefs + (size_t)f * g.coef_count;
     int mcu = live ? G / g.nbm : 0, mx = live ? mcu % g.mcus_x : 0, my = live ? mcu / g.mcus_x : 0;
     int16_t* blk = cf;
@@ -892,8 +953,10 @@ __global__ __launch_bounds__(64) void jpeg_write_kernel(const uint8_t* __restric
         blk = cf + co + ((size_t)by * bxn + bx) * 64;
     };
     int err = 0;
+    uint32_t nb = 0;
+    bool whole = false;                                         // decoded to the subsequence's end
     if (live) {
-        if (d.bi != G % g.nbm) { err = 5; live = false; }      // the state chain and the block count disagree: the rounds did not synchronise after all
+        if (d.bi != G % g.nbm) { err = 5; live = false; }      // the state chain and the block count disagree
         else locate();
     }
     while (__any(live)) {
@@ -904,13 +967,18 @@ __global__ __launch_bounds__(64) void jpeg_write_kernel(const uint8_t* __restric
             else {
                 if (widx >= 0) blk[zz[widx]] = (int16_t)val;     // widx == 0: the DC DIFFERENCE (jpeg_dc_kernel sums them)
                 if (done) {
-                    ++G;
+                    ++G; ++nb;
                     if (d.bi == 0) { if (++mx == g.mcus_x) { mx = 0; ++my; } }
-                    if (G >= g.total_blocks || d.pos() >= end) live = false;
+                    if (d.pos() >= end) { live = false; whole = true; }
+                    else if (G >= g.total_blocks) live = false;
                     else locate();
-                } else if (d.pos() >= end) live = false;
+                } else if (d.pos() >= end) { live = false; whole = true; }
             }
         }
+    }
+    if (check && whole && !err) {
+        const uint32_t exit = (d.pos() - end) | ((uint32_t)d.bi << 5) | ((uint32_t)d.k << 8);
+        if (exit != js_exit(mine) || nb != js_nblk(mine)) err = 5;
     }
     if (err) atomicCAS(&status[f], 0, err);
 }
@@ -962,6 +1030,7 @@ __global__ void jpeg_zero_kernel(u32x4* __restrict__ p, size_t n16, int32_t* __r
 }
 
 // per-HIP-stream index of interval starts (n_frames x JH_MAX_INT words, grown on demand)
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -1010,7 +1079,7 @@ extern "C" int sm_jpeg_entropy_decode(const uint8_t* bytes, size_t bytes_total, 
 }
 
 // frames WITHOUT restart markers (sm_jpeg_scan_t.restart == 0 for every frame of the batch): the self-synchronising decode above.  Same arguments and
-// results as sm_jpeg_entropy_decode; status 5 = the exit states had not settled after JS_ROUNDS rounds (the caller falls back to the host decoder).
+// results as sm_jpeg_entropy_decode; status 5 = the records did not chain after JS_ROUNDS rounds (the caller falls back to the host decoder).
 struct JsWs { uint32_t* lanes = nullptr; size_t n_lanes = 0; uint32_t* per_frame = nullptr; size_t frames = 0; int last_frames = 0; };
 static std::map<hipStream_t, JsWs> g_js_ws;
 extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_total, size_t max_file_bytes, const uint32_t* offsets, const sm_jpeg_scan_t* scans,
@@ -1021,6 +1090,8 @@ extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_to
                "sm_jpeg_entropy_decode_sync: bad info / unaligned coefficient image");
     hipStream_t st = (hipStream_t)stream;
     const size_t n_lanes = bytes_total / 128 + (size_t)n_frames + 64;
+    const int tiles_max = (int)((max_file_bytes + JS_TILE - 1) / JS_TILE);
+    const size_t per_frame_words = (size_t)n_frames * (JS_ROUNDS + 3 + (size_t)tiles_max);       // clean_len, raw_end, changed[JS_ROUNDS + 1], tile_cnt[tiles_max]
     JhWs ws; JsWs js;
     {
         std::lock_guard<std::mutex> lk(g_jh_mu);
@@ -1034,20 +1105,20 @@ extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_to
         JsWs& j = g_js_ws[st];
         if (j.n_lanes < n_lanes) {
             if (j.lanes) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(j.lanes); j.lanes = nullptr; j.n_lanes = 0; }
-            SM_HIP(hipMalloc((void**)&j.lanes, n_lanes * 8 * sizeof(uint32_t)));
+            SM_HIP(hipMalloc((void**)&j.lanes, n_lanes * 3 * sizeof(uint32_t)));
             j.n_lanes = n_lanes;
         }
-        if (j.frames < (size_t)n_frames) {
+        if (j.frames < per_frame_words) {
             if (j.per_frame) { SM_HIP(hipStreamSynchronize(st)); (void)hipFree(j.per_frame); j.per_frame = nullptr; j.frames = 0; }
-            SM_HIP(hipMalloc((void**)&j.per_frame, (size_t)n_frames * (JS_ROUNDS + 2) * sizeof(uint32_t)));
-            j.frames = n_frames;
+            SM_HIP(hipMalloc((void**)&j.per_frame, per_frame_words * sizeof(uint32_t)));
+            j.frames = per_frame_words;
         }
         js = j;
     }
     JsArr A;
-    A.exP[0] = js.lanes; A.exP[1] = js.lanes + n_lanes; A.exS[0] = js.lanes + 2 * n_lanes; A.exS[1] = js.lanes + 3 * n_lanes;
-    A.enP = js.lanes + 4 * n_lanes; A.enS = js.lanes + 5 * n_lanes; A.nblk = js.lanes + 6 * n_lanes; A.base = js.lanes + 7 * n_lanes;
-    A.clean_len = js.per_frame; A.changed = (int32_t*)(js.per_frame + n_frames);
+    A.rec = (uint64_t*)js.lanes; A.base = js.lanes + 2 * n_lanes;
+    A.clean_len = js.per_frame; A.raw_end = (int32_t*)(js.per_frame + n_frames); A.changed = (int32_t*)(js.per_frame + 2 * n_frames);
+    A.tile_cnt = js.per_frame + (size_t)n_frames * (JS_ROUNDS + 3);
     JsGeom g;
     memset(&g, 0, sizeof(g));
     g.mcus_x = info->mcus_x; g.mcus_y = info->mcus_y; g.ncomp = info->ncomp; g.coef_count = info->coef_count;
@@ -1058,17 +1129,24 @@ extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_to
     const size_t n16 = (size_t)n_frames * info->coef_count * 2 / 16;
     jpeg_zero_kernel<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>((u32x4*)coefs, n16, status, n_frames);
     SM_LAUNCH_CHECK();
-    jpeg_unstuff_scan_kernel<<<n_frames, 1024, 0, st>>>(bytes, offsets, scans, ws.clean, A);
-    SM_LAUNCH_CHECK();
-    // lanes per frame: the clean stream is no longer than the file; grid.x covers the longest file of the batch (a longer one reports status 5)
-    const unsigned gx = (unsigned)cdiv((int)((max_file_bytes * 8 + JS_BITS - 1) / JS_BITS), 64);
-    for (int r = 0; r < JS_ROUNDS; ++r) {
-        jpeg_sync_kernel<<<dim3(gx, n_frames), 64, 0, st>>>(ws.clean, offsets, scans, A, g, r);
+    {
+        const size_t n_init = std::max(n_lanes, (size_t)n_frames * (JS_ROUNDS + 1));
+        jpeg_sync_init_kernel<<<(unsigned)((n_init + 255) / 256), 256, 0, st>>>(A, n_lanes, n_frames);
         SM_LAUNCH_CHECK();
     }
-    jpeg_blockscan_kernel<<<n_frames, 1024, 0, st>>>(offsets, A, g, gx * 64u, status);
+    jpeg_unstuff_count_kernel<<<dim3(tiles_max, n_frames), 256, 0, st>>>(bytes, offsets, scans, A, tiles_max);
     SM_LAUNCH_CHECK();
-    jpeg_write_kernel<<<dim3(gx, n_frames), 64, 0, st>>>(ws.clean, offsets, scans, A, g, coefs, qt, status);
+    jpeg_unstuff_write_kernel<<<dim3(tiles_max, n_frames), 256, 0, st>>>(bytes, offsets, scans, ws.clean, A, tiles_max);
+    SM_LAUNCH_CHECK();
+    // lanes per frame: the clean stream is no longer than the file; grid.x covers the longest file of the batch (a longer one reports status 5)
+    const unsigned gx = (unsigned)cdiv((int)((max_file_bytes * 8 + JS_BITS - 1) / JS_BITS), JS_TPB);
+    for (int r = 0; r < JS_ROUNDS; ++r) {
+        jpeg_sync_kernel<<<dim3(gx, n_frames), JS_TPB, 0, st>>>(ws.clean, offsets, scans, A, g, r);
+        SM_LAUNCH_CHECK();
+    }
+    jpeg_blockscan_kernel<<<n_frames, 1024, 0, st>>>(offsets, A, g, gx * (unsigned)JS_TPB, status);
+    SM_LAUNCH_CHECK();
+    jpeg_write_kernel<<<dim3(gx, n_frames), JS_TPB, 0, st>>>(ws.clean, offsets, scans, A, g, coefs, qt, status);
     SM_LAUNCH_CHECK();
     jpeg_dc_kernel<<<dim3(3, n_frames), 1024, 0, st>>>(g, coefs, status);
     SM_LAUNCH_CHECK();
@@ -1090,7 +1168,7 @@ extern "C" int sm_jpeg_sync_rounds(void* stream, int32_t* rounds, int n_frames) 
     }
     SM_HIP(hipStreamSynchronize(st));
     std::vector<int32_t> all((size_t)js.last_frames * (JS_ROUNDS + 1));
-    SM_HIP(hipMemcpy(all.data(), js.per_frame + js.last_frames, all.size() * 4, hipMemcpyDeviceToHost));
+    SM_HIP(hipMemcpy(all.data(), js.per_frame + 2 * (size_t)js.last_frames, all.size() * 4, hipMemcpyDeviceToHost));
     for (int f = 0; f < n_frames; ++f) rounds[f] = all[(size_t)f * (JS_ROUNDS + 1) + JS_ROUNDS];
     return SM_OK;
 }
