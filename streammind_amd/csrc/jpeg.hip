@@ -611,7 +611,11 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(const uint8_t* __restrict
 // a few rounds (lane s is right after round s at the latest).  Then the lanes' completed-block counts are prefix-summed (every lane knows which block it
 // starts in), a last pass writes the coefficients -- the DC DIFFERENCE in place of the DC -- and a per-component scan over the blocks in scan order turns
 // the differences into values.  Same decode step as the restart-interval kernel (one uniform loop: one symbol per trip for every live lane).
-#define JS_BITS 1024                                            // bits per subsequence
+#ifndef JS_LOG
+#define JS_LOG 10
+#endif
+#define JS_BITS (1 << JS_LOG)                                   // bits per subsequence
+#define JS_WLOG (JS_LOG - 5)                                    // log2 of its dwords
 #define JS_ROUNDS 16                                            // at most; a frame whose records chain leaves the later rounds at once
 struct JsGeom { int mcus_x, mcus_y, ncomp, bh0, bv0, nb0, nbm, blocks_x[3], coef_offset[3], coef_count, total_blocks; };
 struct JsArr {
@@ -622,7 +626,7 @@ struct JsArr {
     uint32_t* tile_cnt;                                         // [frames][tiles_max] bytes every 4096-byte tile of the raw segment keeps
     int32_t* changed;                                           // [frames][JS_ROUNDS + 1] lanes that had work in round r; [JS_ROUNDS] = rounds until none had
 };
-__device__ __forceinline__ uint32_t js_lane0(const uint32_t* offsets, int f) { return (offsets[f] >> 7) + (uint32_t)f; }      // first lane record of frame f
+__device__ __forceinline__ uint32_t js_lane0(const uint32_t* offsets, int f) { return (offsets[f] >> (JS_LOG - 3)) + (uint32_t)f; }      // first lane record of frame f
 
 // Unstuffing of a whole scan, two launches over (tiles of 4096 bytes, frames): every tile counts the bytes it keeps (everything but the 0x00 behind a data
 // 0xFF) and reports the first marker it sees; then every tile sums the counts of the tiles before it, ranks its own threads and writes its bytes compacted
@@ -705,12 +709,12 @@ __global__ __launch_bounds__(256) void jpeg_unstuff_write_kernel(const uint8_t* 
 struct JsDec {
     const uint32_t* src; uint32_t len;         // unstuffed stream of the frame (16-byte aligned), its length in bytes
     const uint32_t* win; uint32_t w0, nw;      // the block's window of it in LDS: dwords [w0, w0 + nw), big-endian already, zeros behind the stream's end,
-                                               // 33 words per 32 (lanes read at a stride of one subsequence: the skew spreads them over the banks)
+                                               // one pad word per subsequence (lanes read at a stride of one subsequence: the skew spreads them over the banks)
     uint64_t acc; int n; uint32_t wn, nextw;   // bit window: n valid bits at the bottom of acc, filled up to dword wn; nextw = dword wn
     int bi, k;
     __device__ __forceinline__ uint32_t word(uint32_t w) const {
         const uint32_t i = w - w0;
-        if (i < nw) return win[i + (i >> 5)];
+        if (i < nw) return win[i + (i >> JS_WLOG)];
         uint32_t v = 0;                        // (a lane that followed the stream out of the window)
         if (w * 4 < len) {
             v = __builtin_bswap32(src[w]);
@@ -734,7 +738,7 @@ __device__ __forceinline__ void js_stage(uint32_t* win, const uint32_t* src, uin
             v = __builtin_bswap32(src[w]);
             if (w * 4 + 4 > len) v &= 0xFFFFFFFFu << (8 * (w * 4 + 4 - len));
         }
-        win[i + (i >> 5)] = v;
+        win[i + (i >> JS_WLOG)] = v;
     }
 }
 // decodes one symbol; out: is_dc, zig-zag index written (or -1), value; advances (bi, k); `done_block` when the block completed
@@ -813,7 +817,7 @@ __global__ void jpeg_sync_init_kernel(JsArr A, size_t n_lanes, int n_frames) {
 __global__ __launch_bounds__(JS_TPB) void jpeg_sync_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
                                                            JsArr A, JsGeom g, int round) {
     __shared__ sm_jpeg_huff_t tab[6];
-    __shared__ uint32_t win[(JS_TPB + JS_AHEAD) * 33];
+    __shared__ uint32_t win[(JS_TPB + JS_AHEAD) * (JS_BITS / 32 + 1)];
     const int f = blockIdx.y, tid = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
     const uint32_t len = A.clean_len[f];
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(1024) void jpeg_blockscan_kernel(const uint32_t* __
 __global__ __launch_bounds__(JS_TPB) void jpeg_write_kernel(const uint8_t* __restrict__ clean, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
                                                             JsArr A, JsGeom g, int16_t* __restrict__ coefs, uint16_t* __restrict__ qt, int32_t* __restrict__ status) {
     __shared__ sm_jpeg_huff_t tab[6];
-    __shared__ uint32_t win[(JS_TPB + 1) * 33];
+    __shared__ uint32_t win[(JS_TPB + 1) * (JS_BITS / 32 + 1)];
     __shared__ uint8_t zz[64];
     const int f = blockIdx.y, tid = threadIdx.x;
     const sm_jpeg_scan_t& sc = scans[f];
@@ -1089,7 +1093,7 @@ extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_to
     SM_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->coef_count > 0 && (((size_t)info->coef_count * 2) % 16) == 0 && ((uintptr_t)coefs & 15) == 0,
                "sm_jpeg_entropy_decode_sync: bad info / unaligned coefficient image");
     hipStream_t st = (hipStream_t)stream;
-    const size_t n_lanes = bytes_total / 128 + (size_t)n_frames + 64;
+    const size_t n_lanes = bytes_total / (JS_BITS / 8) + (size_t)n_frames + 64;
     const int tiles_max = (int)((max_file_bytes + JS_TILE - 1) / JS_TILE);
     const size_t per_frame_words = (size_t)n_frames * (JS_ROUNDS + 3 + (size_t)tiles_max);       // clean_len, raw_end, changed[JS_ROUNDS + 1], tile_cnt[tiles_max]
     JhWs ws; JsWs js;
