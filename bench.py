@@ -387,12 +387,15 @@ def jpeg_leg(B=28, H=720, W=1280, quality=85, reps=5):
         for name, batch in (("batch", jpegs), ("batch_x4", jpegs * 4)):
             dec.decode(batch, entropy="gpu")
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
+            ts = []                                   # every call timed by itself (a synchronise per call): the median is the rate, the maximum is shown
+            for _ in range(2 * reps + 1):             # (one full-bench run had a 5-call mean of 8 ms where every other run, before and after, has 2.0-2.2)
+                t0 = time.perf_counter()
                 dec.decode(batch, entropy="gpu")
-            torch.cuda.synchronize()
-            t_ = (time.perf_counter() - t0) / reps
-            sync_ent[name] = {"frames": len(batch), "gpu_entropy_frames_per_s": round(len(batch) / t_, 1), "ms_per_batch": round(t_ * 1e3, 2)}
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t_ = sorted(ts)[len(ts) // 2]
+            sync_ent[name] = {"frames": len(batch), "gpu_entropy_frames_per_s": round(len(batch) / t_, 1), "ms_per_batch": round(t_ * 1e3, 2),
+                              "ms_per_batch_max": round(max(ts) * 1e3, 2), "calls_timed": len(ts)}
         sync_ent["host_threads_busy_gpu_path"] = 1
     except Exception as e:
         sync_ent = {"error": repr(e)[:300]}
@@ -1187,11 +1190,11 @@ def main():
         # the same step with the tower's operands in IEEE fp16 (vit_fp16: the reference demo's precision, model/builder.py:54;
         # gate logits 1.3e-4 from the fp32 oracle at this batch instead of bf16's 2.3e-3 -- tests/test_gpu_path.py)
         try:
-            cfg16 = PathConfig(llm_layers=0, max_frames_per_call=LB, vit_fp16=True)
+            cfg16 = PathConfig(llm_layers=0, max_frames_per_call=B, vit_fp16=True)
             m16 = NativeModel(cfg16, f"cuda:{local}")
             random_weights_into(m16, cfg16, seed=1234)
             m16.finalize()
-            s16 = m16.open_stream(max_frames=LB * 24, max_seq=64)
+            s16 = m16.open_stream(max_frames=2 * LB * 24 + 64, max_seq=64)
             for i in range(3):
                 s16.push_frames(frames[i * LB:(i + 1) * LB])
             torch.cuda.synchronize()
@@ -1201,7 +1204,23 @@ def main():
             torch.cuda.synchronize()
             d16 = (time.perf_counter() - t1) / 16
             fp16_tower_leg = {"frames_per_s": round(LB / d16, 1), "frames_per_step": LB, "ms_per_step": round(d16 * 1e3, 3),
-                              "note": "vit_fp16=1: tower GEMM / attention operands in IEEE fp16 (same MFMA rate), everything else as the `single_lane_plain` row of `pipelined`"}
+                              "note": "vit_fp16=1: tower GEMM / attention operands in IEEE fp16 (same MFMA rate), everything else as the `single_lane_plain` row of `pipelined`; "
+                                      "headline_schedule: the schedule `value` is measured on (same frames per call, tower lanes, pipelined gate pass)"}
+            # ... and on the headline's own schedule, so that the mode that meets the 1e-3 bound against fp32 has a number comparable with `value`
+            call16 = s16.push_frames_pipelined if a.pipeline else s16.push_frames
+            s16.reset()
+            for i in range(2):
+                call16(frames[i * B:(i + 1) * B])
+            s16.join()
+            torch.cuda.synchronize()
+            n16 = 8
+            t1 = time.perf_counter()
+            for i in range(n16):
+                call16(frames[(i * B) % (n_pool - B + 1):][:B])
+            s16.join()
+            torch.cuda.synchronize()
+            dh16 = (time.perf_counter() - t1) / n16
+            fp16_tower_leg["headline_schedule"] = {"frames_per_s": round(B / dh16, 1), "frames_per_step": B, "ms_per_step": round(dh16 * 1e3, 3)}
             s16.close(); m16.close()
         except Exception as e:
             fp16_tower_leg = {"error": repr(e)[:200]}
@@ -1500,7 +1519,7 @@ def main():
                        "frames_per_step": B * cps, "frames_per_call": B, "calls_per_step": cps, "frames_timed_per_gpu": frames_timed, "stream_frames": n_pool, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             # flat copies of the figures the legs below hold (a parser that keeps only top-level scalars still sees them)
-            "fp16_tower_frames_per_s": (fp16_tower_leg or {}).get("frames_per_s"),
+            "fp16_tower_frames_per_s": ((fp16_tower_leg or {}).get("headline_schedule") or {}).get("frames_per_s", (fp16_tower_leg or {}).get("frames_per_s")),
             "latency_ms_per_call": dict(zip([f"{b}_frames" for b in (lat_leg or {}).get("frames_per_call", [])], (lat_leg or {}).get("ms_per_call", []))) or None,
             "decode_tokens_per_s": (dec_leg or {}).get("tokens_per_s"),
             "decode_hbm_frac": ((dec_leg or {}).get("roofline") or {}).get("frac"),
