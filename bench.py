@@ -517,12 +517,17 @@ def e2e_leg(model, stream, cfg, frames, B, n_steps=8, fire_every=4, reply_tokens
             "kv_len_end": stream.kv_len, "replies_on_llm_lane": bool(overlap)}
 
 
-def e2e_multi_leg(model, cfg, frames, S=32, ticks=112, cohorts=4, reply_tokens=256):
+def e2e_multi_leg(model, cfg, frames, S=32, ticks=112, cohorts=4, reply_tokens=256, continuous=False, chunk=8):
     """BASELINE configs[2] for MANY concurrent streams (the loop of streammind_amd.stream.MultiStreamSession.tick at the native level, with scheduled
     fires as in e2e_leg): S streams, one frame per stream per tick through ONE ViT batch + one connector / gate pass (sm_group_push_frames); stream i
     belongs to cohort i % cohorts, a cohort fires every ticks / 2 ticks (the cohorts staggered), every fired stream prefills its own grown context (KV
     prefix reuse: text + its frame tokens since its last fire), then the cohort's replies are decoded TOGETHER -- one pass over the 14.2 GB of weights
-    per step for all of them (sm_group_llm_decode).  A single stream is decode-bound at ~270 frames/s on this schedule shape (end_to_end.frames_per_s)."""
+    per step for all of them (sm_group_llm_decode).  A single stream is decode-bound at ~270 frames/s on this schedule shape (end_to_end.frames_per_s).
+
+    continuous (MultiStreamSession(continuous=True) at the native level): replies stay in flight across ticks -- a tick is the perception pass of all S streams
+    plus `chunk` decode steps of every stream that is replying at that moment, so the cohorts' replies (started ticks apart, each 256 steps long) share
+    their weight passes and no stream's frames wait for another stream's reply; same fires, same contexts, same number of reply tokens.  chunk = 8: a
+    decode step of 8..32 streams takes 3.5-4.3 ms, so 8 steps are what fits into one 33 ms frame interval of a 30 fps source next to the perception pass."""
     g = torch.Generator(device="cuda").manual_seed(29)
     streams = [model.open_stream(max_frames=ticks + 8, max_seq=1024) for _ in range(S)]
     grp = model.open_group(streams)
@@ -538,31 +543,64 @@ def e2e_multi_leg(model, cfg, frames, S=32, ticks=112, cohorts=4, reply_tokens=2
         t0 = time.perf_counter()
         n_frames = n_fires = n_tok = 0
         t_decode = 0.0
+        batch_sum = batch_n = 0
+        left, waiting = {}, [[] for _ in range(S)]          # continuous: reply tokens a stream still owes; fires that wait behind its running reply
         for t in range(ticks):
             off = (t * S) % (n_pool - S + 1)
             grp.push_frames(frames[off:off + S].contiguous())
             n_frames += S
             fired = [i for i in range(S) if (t + 1 + (i % cohorts) * (period // cohorts)) % period == 0]
+
+            def start(i, T):                       # the stream's grown context up to frame T behind its cached prefix, then it is replying
+                ctx[i].append(-(torch.arange(seg_start[i], T, device="cuda", dtype=torch.int32) + 1))
+                ctx[i].append(torch.randint(3, cfg.llm_vocab, (6,), generator=g, device="cuda", dtype=torch.int32))
+                streams[i].prefill(torch.cat(ctx[i]).contiguous())
+                ctx[i] = [torch.randint(3, cfg.llm_vocab, (4,), generator=g, device="cuda", dtype=torch.int32)]
+                seg_start[i] = T
+            if continuous:
+                for i in fired:
+                    if i in left:
+                        waiting[i].append(streams[i].num_frames)
+                    else:
+                        start(i, streams[i].num_frames); left[i] = reply_tokens
+                n_fires += len(fired)
+
+                def round_():
+                    nonlocal n_tok, t_decode, batch_sum, batch_n
+                    if not left:
+                        return
+                    n = min([chunk] + list(left.values()))
+                    torch.cuda.synchronize(); td = time.perf_counter()
+                    grp.decode(n, active=[i in left for i in range(S)])
+                    torch.cuda.synchronize(); t_decode += time.perf_counter() - td
+                    n_tok += n * len(left); batch_sum += n * len(left); batch_n += n
+                    for i in list(left):
+                        left[i] -= n
+                        if left[i] == 0:
+                            del left[i]
+                            if waiting[i]:
+                                start(i, waiting[i].pop(0)); left[i] = reply_tokens
+                round_()
+                if t == ticks - 1:
+                    while left:
+                        round_()
+                continue
             if not fired:
                 continue
             for i in fired:
-                st = streams[i]
-                T = st.num_frames
-                ctx[i].append(-(torch.arange(seg_start[i], T, device="cuda", dtype=torch.int32) + 1))
-                ctx[i].append(torch.randint(3, cfg.llm_vocab, (6,), generator=g, device="cuda", dtype=torch.int32))
-                st.prefill(torch.cat(ctx[i]).contiguous())
-                ctx[i] = [torch.randint(3, cfg.llm_vocab, (4,), generator=g, device="cuda", dtype=torch.int32)]
-                seg_start[i] = T
+                start(i, streams[i].num_frames)
             torch.cuda.synchronize(); td = time.perf_counter()
             grp.decode(reply_tokens, active=[i in fired for i in range(S)])
             torch.cuda.synchronize(); t_decode += time.perf_counter() - td
             n_fires += len(fired)
             n_tok += reply_tokens * len(fired)
+            batch_sum += reply_tokens * len(fired); batch_n += reply_tokens
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         return {"streams": S, "ticks": ticks, "frames": n_frames, "fires": n_fires, "reply_tokens": reply_tokens, "seconds": round(dt, 4),
                 "frames_per_s": round(n_frames / dt, 2), "reply_tokens_per_s_overall": round(n_tok / dt, 2),
-                "reply_tokens_per_s_while_decoding": round(n_tok / max(t_decode, 1e-9), 2), "streams_per_batched_decode": len(range(0, S, cohorts)),
+                "reply_tokens_per_s_while_decoding": round(n_tok / max(t_decode, 1e-9), 2), "streams_per_decode_step_mean": round(batch_sum / max(batch_n, 1), 1),
+                "replies_in_flight_across_ticks": bool(continuous), "decode_steps_per_tick": chunk if continuous else None,
                 "kv_len_end": streams[0].kv_len,
                 "note": "scheduled fires, EOS disabled (every reply is exactly reply_tokens long); per stream the results are those of its own loop (tests: MultiStreamSession)"}
     finally:
@@ -1131,6 +1169,10 @@ def main():
                     e2e["multi_stream"] = e2e_multi_leg(model, cfg, frames, S=min(32, model.cfg.max_frames_per_call))
                 except Exception as e:
                     e2e["multi_stream"] = {"error": repr(e)[:300]}
+                try:       # the same streams, fires and replies with the replies in flight across ticks (MultiStreamSession(continuous=True))
+                    e2e["multi_stream_continuous"] = e2e_multi_leg(model, cfg, frames, S=min(32, model.cfg.max_frames_per_call), continuous=True)
+                except Exception as e:
+                    e2e["multi_stream_continuous"] = {"error": repr(e)[:300]}
                 t_frames = e2e["frames"] / max(total_rate_hint, 1e-9) if (total_rate_hint := float(B * cps * a.steps / dt_local)) else 0.0
                 e2e["note"] = (f"frames/s of this schedule is decode-bound: at this run's perception rate the {e2e['frames']} frames cost about {t_frames:.2f} s of the "
                                f"{e2e['seconds']:.2f} s, the {e2e['fires']} replies of {e2e['reply_tokens']} tokens the rest, and a later reply's context contains the "

@@ -289,7 +289,14 @@ class MultiStreamSession:
     reply ids are the greedy ids of the same logits up to fp32 summation order).  `models`: one
     Videollama2MistralForCausalLM per stream, all built on the SAME NativeModel."""
 
-    def __init__(self, models, tokenizer, max_new_tokens: int = 1024, decode_chunk: int = 16):
+    def __init__(self, models, tokenizer, max_new_tokens: int = 1024, decode_chunk: int = 16, continuous: bool = False):
+        """continuous=False: a tick returns when the replies it started are complete (every stream waits for them: the lock-step form).
+        continuous=True: replies stay IN FLIGHT across ticks -- a tick is one perception pass for every stream plus `decode_chunk` decode steps of all
+        the streams that are replying at that moment, whichever tick started them (one weight pass per step for all of them: a reply of 256 tokens no
+        longer stops the other streams' frames for 256 steps, and replies started ticks apart share their weight passes); a stream that fires again
+        while it is still replying gets that reply right behind the running one, on the frame interval it fired at.  Perception does not depend on the
+        replies (the gate reads the connector state only), so per stream the events are those of the lock-step form -- they are handed out by the tick
+        in which they complete; `flush()` finishes what is in flight."""
         assert len(models) >= 1 and all(m.native is models[0].native for m in models), "the streams must share one NativeModel"
         self.models, self.tok = list(models), tokenizer
         self.native = models[0].native
@@ -297,6 +304,9 @@ class MultiStreamSession:
         self.max_new, self.chunk = max_new_tokens, decode_chunk
         self.prompts: List[Optional[str]] = [None] * len(models)
         self.stats = StreamStats()
+        self.continuous = continuous
+        self._replying = {}                                # stream index -> state of the reply in flight
+        self._pending = [[] for _ in models]               # stream index -> frame positions of fires that wait for the running reply
 
     def _initial_prompt(self) -> str:
         from .conversation import conv_templates
@@ -314,36 +324,62 @@ class MultiStreamSession:
         self.last_gate_logits = logits[:, 0]
         self.stats.frames += S
         fired = [i for i, d in enumerate(dec_host) if d == 1]
+        self.stats.fires += len(fired)
+        if self.continuous:
+            for i in fired:
+                upto = self.models[i].stream.num_frames
+                if i in self._replying:
+                    self._pending[i].append(upto)            # behind the running reply (its text belongs to this one's prompt)
+                else:
+                    self._start_reply(i, upto)
+            return self._decode_round(self.chunk)
         if not fired:
             return []
-        self.stats.fires += len(fired)
         # ---- every fired stream: its own splice + prefill (prompt growth and KV prefix reuse as in the single-stream loop)
-        state = {}
         for i in fired:
-            m = self.models[i]
-            if self.prompts[i] is None:
-                self.prompts[i] = self._initial_prompt()
-            upto = m.stream.num_frames
-            m.interval_id_list.append(upto)
-            input_ids = tokenizer_MMODAL_token(self.prompts[i], self.tok, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
-            seq = m._expand(input_ids[0].tolist())
-            budget = m._begin_generate(seq, self.max_new)
-            state[i] = {"seq_len": len(seq), "budget": budget, "out": [], "crit": [KeywordsStoppingCriteria(["</s>"], self.tok, input_ids)],
-                        "upto": upto}
-        # ---- all of them decode together
-        active = set(fired)
-        while active:
-            n = min([self.chunk] + [state[i]["budget"] - len(state[i]["out"]) for i in active])
-            ids = self.group.decode(n, active=[i in active for i in range(S)]).cpu().tolist()
-            for i in list(active):
-                st = state[i]
-                _, done = self.models[i]._accept_tokens(st["out"], ids[i], st["seq_len"], st["crit"])
-                if done or len(st["out"]) >= st["budget"]:
-                    active.discard(i)
+            self._start_reply(i, self.models[i].stream.num_frames)
+        # ---- all of them decode together, to the end
         events = []
-        for i in fired:
-            st = state[i]
-            text = self.tok.batch_decode([st["out"]], skip_special_tokens=True)[0].strip()
-            self.prompts[i] += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
-            events.append((i, StreamEvent(st["upto"], text, st["out"])))
+        while self._replying:
+            events += self._decode_round(self.chunk)
+        events.sort(key=lambda e: fired.index(e[0]))
+        return events
+
+    def _start_reply(self, i: int, upto: int) -> None:
+        m = self.models[i]
+        if self.prompts[i] is None:
+            self.prompts[i] = self._initial_prompt()
+        m.interval_id_list.append(upto)
+        input_ids = tokenizer_MMODAL_token(self.prompts[i], self.tok, MMODAL_TOKEN_INDEX["VIDEO"], return_tensors="pt").unsqueeze(0)
+        seq = m._expand(input_ids[0].tolist())
+        budget = m._begin_generate(seq, self.max_new)
+        self._replying[i] = {"seq_len": len(seq), "budget": budget, "out": [], "crit": [KeywordsStoppingCriteria(["</s>"], self.tok, input_ids)], "upto": upto}
+
+    def _decode_round(self, steps: int) -> List[Tuple[int, StreamEvent]]:
+        """up to `steps` decode steps of every reply in flight (one sm_group_llm_decode call: one weight pass per step for all of them); the replies
+        that complete are closed (prompt growth as video_score_stream_demo.py:124) and a fire that waited behind one starts right away"""
+        if not self._replying:
+            return []
+        S = len(self.models)
+        active = sorted(self._replying)
+        n = min([steps] + [self._replying[i]["budget"] - len(self._replying[i]["out"]) for i in active])
+        ids = self.group.decode(n, active=[i in self._replying for i in range(S)]).cpu().tolist()
+        events = []
+        for i in active:
+            st = self._replying[i]
+            _, done = self.models[i]._accept_tokens(st["out"], ids[i], st["seq_len"], st["crit"])
+            if done or len(st["out"]) >= st["budget"]:
+                del self._replying[i]
+                text = self.tok.batch_decode([st["out"]], skip_special_tokens=True)[0].strip()
+                self.prompts[i] += " " + text + " </s>[INST] <video>\n [/INST]"          # video_score_stream_demo.py:124
+                events.append((i, StreamEvent(st["upto"], text, st["out"])))
+                if self._pending[i]:
+                    self._start_reply(i, self._pending[i].pop(0))
+        return events
+
+    def flush(self) -> List[Tuple[int, StreamEvent]]:
+        """continuous mode: decode until no reply is in flight (end of the streams) -> the events that completed"""
+        events = []
+        while self._replying:
+            events += self._decode_round(self.chunk)
         return events

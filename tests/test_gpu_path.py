@@ -1100,6 +1100,23 @@ def test_multi_stream_session_equals_independent_infer_loops(tiny, tiny_tokenize
         assert got[s] == ref_events[s]
         assert (sess.prompts[s] or O.initial_prompt()) == (ref_prompts[s] or O.initial_prompt()) or sess.prompts[s] is None
     assert sess.stats.frames == S * T
+    # continuous form: replies stay in flight across ticks (2 decode steps per tick, replies of up to 6 tokens span three ticks, a stream that fires
+    # again meanwhile gets its reply behind the running one); per stream the SAME events, handed out by the tick in which they complete (or by flush)
+    models = [Videollama2MistralForCausalLM(m, max_frames=32, max_seq=512, eos_token_id=tiny_tokenizer.eos_token_id) for _ in range(S)]
+    cont = MultiStreamSession(models, tiny_tokenizer, max_new_tokens=6, decode_chunk=2, continuous=True)
+    got_c = [[] for _ in range(S)]
+    in_flight_across_ticks = 0
+    for t in range(T):
+        for i, e in cont.tick(frames[:, t]):
+            got_c[i].append((e.frame_index, e.text))
+        in_flight_across_ticks += len(cont._replying)
+    for i, e in cont.flush():
+        got_c[i].append((e.frame_index, e.text))
+    assert in_flight_across_ticks > 0 and not cont._replying and not any(cont._pending)
+    for s in range(S):
+        assert got_c[s] == ref_events[s], (s, got_c[s], ref_events[s])
+        assert (cont.prompts[s] or O.initial_prompt()) == (ref_prompts[s] or O.initial_prompt()) or cont.prompts[s] is None
+    assert cont.stats.frames == S * T and cont.stats.fires == sess.stats.fires
 
 
 def test_two_tower_lanes_equal_two_calls_and_the_stream_path():
