@@ -1533,6 +1533,14 @@ def main():
                     fp8_leg["group_decode_16_streams"] = {"tokens_per_s": g8["tokens_per_s"][0], "ms_per_step": g8["ms_per_step"][0]}
                 except Exception as e:
                     fp8_leg["group_decode_16_streams"] = {"error": repr(e)[:200]}
+                try:      # 32 streams on the weight-only fp8 image (mode 1: the 17..32-row weight-streaming kernel reads fp8 and shares the rows through LDS)
+                    m8.set_fp8_mode(1)
+                    g8 = group_decode_leg(m8, cfg8, sizes=(32,))
+                    fp8_leg["group_decode_32_streams_weight_only"] = {"tokens_per_s": g8["tokens_per_s"][0], "ms_per_step": g8["ms_per_step"][0]}
+                except Exception as e:
+                    fp8_leg["group_decode_32_streams_weight_only"] = {"error": repr(e)[:200]}
+                finally:
+                    m8.set_fp8_mode(2)
             fp8_leg["roofline"]["bytes_per_token"] = fp8_leg["roofline"]["bytes_per_token"] / 2 + 0.0
             fp8_leg["roofline"]["achieved"] = round(fp8_leg["roofline"]["bytes_per_token"] * fp8_leg["tokens_per_s"] / 1e9, 1)
             fp8_leg["roofline"]["frac"] = round(fp8_leg["roofline"]["achieved"] / HBM_PEAK_GBS, 4)

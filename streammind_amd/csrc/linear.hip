@@ -1245,7 +1245,9 @@ static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual,
 // K slice: the x chunk (8 k-steps = 256 k, both 16-row column blocks) is converted once per block into B-fragment order in
 // LDS (hi and, in precise mode, lo) and every wave multiplies it with its own weight rows; the K slices of the grid's second
 // dimension are summed by splitk_reduce_kernel (fixed order), which also applies the epilogue.
-template <bool XF32, bool SPLIT, bool DUAL, bool F16 = false>
+// W8: weight-only fp8 (the packed image of pack_fp8_kernel: 16 bytes per lane = two k-steps), expanded to bf16 in registers -- half the weight bytes of
+// the stream; the row scales stay in the epilogue of the slab pass (store4 / the norm pass), as for <= 16 rows.
+template <bool XF32, bool SPLIT, bool DUAL, bool F16 = false, bool W8 = false>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __restrict__ ws, float* __restrict__ ws2, int ks_per_split) {
     constexpr int KC = 8;                                   // k-steps per staged chunk
     __shared__ __attribute__((aligned(16))) bf16x8 xs[2][SPLIT ? 2 : 1][KC * 2 * 64];      // [buf][hi/lo][(ks, mb, lane)]
@@ -1257,6 +1259,9 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     const int ks0 = blockIdx.y * ks_per_split, ks1 = min(ks0 + ks_per_split, KS);
     const bf16x8* wp = a.w + (size_t)(wave_on ? rg : 0) * KS * 64 + lane;
     const bf16x8* wp2 = DUAL ? a.w2 + (size_t)(wave_on ? rg : 0) * KS * 64 + lane : nullptr;
+    const int KSP = (KS + 1) >> 1;                                 // fp8 image: pairs of k-steps
+    const u32x4* wq = (const u32x4*)a.w + (size_t)(wave_on ? rg : 0) * KSP * 64 + lane;
+    const u32x4* wq2 = DUAL ? (const u32x4*)a.w2 + (size_t)(wave_on ? rg : 0) * KSP * 64 + lane : nullptr;
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 
     // fill item = (ks_local, mb, lane'): 8 consecutive k of row mb*16 + (lane' & 15) -> one 16-byte B fragment (x2 in split mode).
@@ -1294,28 +1299,46 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     };
     // weights of chunk c+1 are requested before chunk c is multiplied (two register sets), the x chunk c+1 is converted into
     // the other LDS buffer meanwhile: one barrier per chunk, HBM latency hidden behind the previous chunk
-    bf16x8 wa[2][KC], wb[2][KC];
+    bf16x8 wa[2][W8 ? 1 : KC], wb[2][W8 ? 1 : KC];
+    u32x4 qa[2][W8 ? KC / 2 : 1], qb[2][W8 ? KC / 2 : 1];          // fp8: one 16-byte load per lane = k-steps 2j and 2j + 1 (slices start at even k-steps)
     auto load_w = [&](int kb, int set) {
+        if constexpr (W8) {
 #pragma unroll
-        for (int u = 0; u < KC; ++u) {
-            const int ks = min(kb + u, ks1 - 1);
-            wa[set][u] = __builtin_nontemporal_load(wp + (size_t)ks * 64);
-            if (DUAL) wb[set][u] = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+            for (int u = 0; u < KC / 2; ++u) {
+                const int kp = min(kb + 2 * u, ks1 - 1) >> 1;
+                qa[set][u] = __builtin_nontemporal_load(wq + (size_t)kp * 64);
+                if (DUAL) qb[set][u] = __builtin_nontemporal_load(wq2 + (size_t)kp * 64);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KC; ++u) {
+                const int ks = min(kb + u, ks1 - 1);
+                wa[set][u] = __builtin_nontemporal_load(wp + (size_t)ks * 64);
+                if (DUAL) wb[set][u] = __builtin_nontemporal_load(wp2 + (size_t)ks * 64);
+            }
         }
     };
     auto compute = [&](int kb, int buf, int set) {
 #pragma unroll
         for (int u = 0; u < KC; ++u) {
             if (kb + u >= ks1) break;
+            bf16x8 w0, w1;
+            if constexpr (W8) {
+                w0 = fp8x8_to_bf16(qa[set][u >> 1][(u & 1) * 2], qa[set][u >> 1][(u & 1) * 2 + 1]);
+                if (DUAL) w1 = fp8x8_to_bf16(qb[set][u >> 1][(u & 1) * 2], qb[set][u >> 1][(u & 1) * 2 + 1]);
+            } else {
+                w0 = wa[set][u];
+                if (DUAL) w1 = wb[set][u];
+            }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 const bf16x8 xh = xs[buf][0][(u * 2 + mb) * 64 + lane];
-                acc[mb] = mfma16<F16>(wa[set][u], xh, acc[mb]);
-                if (DUAL) acc2[mb] = mfma16<F16>(wb[set][u], xh, acc2[mb]);
+                acc[mb] = mfma16<F16>(w0, xh, acc[mb]);
+                if (DUAL) acc2[mb] = mfma16<F16>(w1, xh, acc2[mb]);
                 if (SPLIT) {
                     const bf16x8 xl = xs[buf][SPLIT ? 1 : 0][(u * 2 + mb) * 64 + lane];
-                    acc[mb] = mfma16<F16>(wa[set][u], xl, acc[mb]);
-                    if (DUAL) acc2[mb] = mfma16<F16>(wb[set][u], xl, acc2[mb]);
+                    acc[mb] = mfma16<F16>(w0, xl, acc[mb]);
+                    if (DUAL) acc2[mb] = mfma16<F16>(w1, xl, acc2[mb]);
                 }
             }
         }
@@ -1349,7 +1372,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     }
 }
 
-static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st, const PostLn* ln = nullptr, bool* ln_done = nullptr) {
+static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st, const PostLn* ln = nullptr, bool* ln_done = nullptr, bool w8 = false) {
     const int nb = (a.NRG + 7) / 8;
     static int target = -1;
     if (target < 0) { const char* e = getenv("SM_SKINNY_LDS_BLOCKS"); target = e ? atoi(e) : 256; }
@@ -1366,7 +1389,13 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
     const dim3 grid(nb, S);
 #define SL(XF, SP, DU) skinny_lds_kernel<XF, SP, DU><<<grid, 512, 0, st>>>(a, ws, ws2, per)
 #define SLH(XF, SP, DU) skinny_lds_kernel<XF, SP, DU, true><<<grid, 512, 0, st>>>(a, ws, ws2, per)
-    if (a.f16) {           // fp16 operands (weights fp16; activations fp16, or an fp16 hi/lo pair in precise mode)
+#define SL8(XF, SP, DU) skinny_lds_kernel<XF, SP, DU, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per)
+    if (w8) {              // weight-only fp8 (bf16 operands)
+        if (xf32) {
+            if (split) { if (dual) SL8(true, true, true); else SL8(true, true, false); }
+            else       { if (dual) SL8(true, false, true); else SL8(true, false, false); }
+        } else { if (dual) SL8(false, false, true); else SL8(false, false, false); }
+    } else if (a.f16) {    // fp16 operands (weights fp16; activations fp16, or an fp16 hi/lo pair in precise mode)
         if (xf32) {
             if (split) { if (dual) SLH(true, true, true); else SLH(true, true, false); }
             else       { if (dual) SLH(true, false, true); else SLH(true, false, false); }
@@ -1379,6 +1408,7 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
     }
 #undef SL
 #undef SLH
+#undef SL8
     SM_LAUNCH_CHECK();
     if (ln && !dual && a.remap_in == 0 && (a.N & 255) == 0 && a.N <= 4096 && (a.ldo & 3) == 0 && (!a.residual || (a.ldr & 3) == 0)) {
         splitk_reduce_norm_rows_kernel<<<a.M, a.N / 4, 0, st>>>(a, ws, S, *ln);
@@ -1616,7 +1646,11 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
         return launch_gemm_fp8(a, st);
     }
-    if (w8 && p->M > 16) {
+    // 17..32 rows on fp8 weights: the LDS-shared weight-streaming kernel reads the fp8 image itself (same conditions as its bf16 dispatch below)
+    static int w8_lds_on = -1;
+    if (w8_lds_on < 0) { const char* e = getenv("SM_FP8_LDS"); w8_lds_on = e ? atoi(e) : 1; }
+    const bool w8_lds = w8 && w8_lds_on && p->M > 16 && p->M <= 32 && !p->norm_gamma && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt;
+    if (w8 && p->M > 16 && !w8_lds) {
         // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
         // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes
         const void *d0 = nullptr, *d1 = nullptr;
@@ -1627,7 +1661,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         if (p->w2) a.w2 = (const bf16x8*)d1;
         a.wscale = a.wscale2 = nullptr;
     }
-    const bool w8k = w8 && p->M <= 16;            // fp8 kernels in use
+    const bool w8k = w8 && (p->M <= 16 || w8_lds);            // fp8 kernels in use
     if (p->M <= 32) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
@@ -1644,6 +1678,12 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             if (a.KS >= 32) return launch_skinny_norm<8>(a, dual, w8k, st);
             if (a.KS >= 8) return launch_skinny_norm<4>(a, dual, w8k, st);
             return launch_skinny_norm<1>(a, dual, w8k, st);
+        }
+        if (w8_lds) {
+            static int ln_fuse8 = -1;
+            if (ln_fuse8 < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse8 = e ? atoi(e) : 1; }
+            const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+            return launch_skinny_lds(a, xf32, split, dual, st, (ln_fuse8 && p->post_ln_gamma && p->out_f32) ? &ln : nullptr, ln_done, true);
         }
         if (w8k) {
             static int f8w = -1;                      // SM_FP8_WAVES=4|8|16: tuning override for the fp8 weight-streaming kernels

@@ -1033,10 +1033,10 @@ extern "C" int sm_stream_push_pooled(sm_stream* s, const float* pooled, int M, f
 
 extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M, float* logits, int32_t* decisions, void* stream) {
     SM_REQUIRE(s && frames && M >= 1 && M <= s->m->Bmax, "sm_stream_push_frames: M=%d outside [1, max_frames_per_call=%d]", M, s ? s->m->Bmax : 0);
-    // one ViT batch, then the connector+gate in frame order, at most 32 frames (16 with fp8 weights) per weight pass
+    // one ViT batch, then the connector+gate in frame order, at most 32 frames per weight pass
     int rc = sm_vit_encode(s->m, frames, M, s->w.pooled.as<float>(), nullptr, nullptr, stream);
     if (rc) return rc;
-    const int cap = s->m->c.weights_fp8 ? 16 : 32;
+    const int cap = s->m->c.weights_fp8 == 2 ? 16 : 32;       // (weight-only fp8 too: the 17..32-row weight-streaming kernel reads the fp8 image; the fp8 x fp8 mode keeps 16: its gate rows are never quantised)
     const int parts = cdiv(M, cap), per = cdiv(M, parts);
     for (int i = 0; i < M; i += per) {
         const int n = M - i < per ? M - i : per;
@@ -1074,7 +1074,7 @@ extern "C" int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* fram
     if (rc) return rc;
     SM_HIP(hipEventRecord(s->ev_vit, st));
     SM_HIP(hipStreamWaitEvent(s->side, s->ev_vit, 0));
-    const int cap = m->c.weights_fp8 ? 16 : 32;
+    const int cap = m->c.weights_fp8 == 2 ? 16 : 32;
     const int parts = cdiv(M, cap), per = cdiv(M, parts);
     const int d = m->c.conn_d_model;
     for (int i = 0; i < M; i += per) {
@@ -1141,7 +1141,7 @@ extern "C" int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int
     SM_REQUIRE(g && pooled && F >= 1, "sm_group_push_pooled: bad args");
     sm_model* m = g->m;
     const int S = (int)g->streams.size(), d = m->c.conn_d_model;
-    const int cap = m->c.weights_fp8 ? 16 : 32;
+    const int cap = m->c.weights_fp8 == 2 ? 16 : 32;
     SM_REQUIRE(F <= cap, "sm_group_push_pooled: %d frames per stream exceed one weight pass (%d rows)", F, cap);
     for (int i = 0; i < S; ++i)
         SM_REQUIRE(g->streams[i]->T + F <= g->streams[i]->max_frames, "sm_group_push_pooled: token store of stream %d full (%d + %d > %d)", i,
@@ -1356,7 +1356,9 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     // up to SM_MAX_SEG streams: weight-streaming kernels (one row per stream); beyond that, up to SM_GROUP_DECODE_MAX: the same step with the
     // linears on the tiled MFMA GEMM (M = streams) -- still ONE pass over the weights per step -- and the per-stream kernels (token gather,
     // RoPE + KV append, attention, arg-max: per-stream pointers travel by value, SM_MAX_SEG at a time) in chunks
-    SM_REQUIRE(S <= (c.weights_fp8 ? 16 : SM_GROUP_DECODE_MAX), "sm_group_llm_decode: %d active streams exceed one weight pass (%d)", S, c.weights_fp8 ? 16 : SM_GROUP_DECODE_MAX);
+    // (fp8 weights: the weight-streaming kernels read the fp8 image up to 32 rows; beyond that a product would expand it to bf16 per call)
+    SM_REQUIRE(S <= (c.weights_fp8 == 2 ? 16 : c.weights_fp8 ? SM_MAX_SEG : SM_GROUP_DECODE_MAX), "sm_group_llm_decode: %d active streams exceed one weight pass (%d)", S,
+               c.weights_fp8 == 2 ? 16 : c.weights_fp8 ? SM_MAX_SEG : SM_GROUP_DECODE_MAX);
     const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh, V = c.llm_vocab;
     int S_max = act[0]->max_seq;
     for (sm_stream* s : act) {
