@@ -1649,7 +1649,9 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // 17..32 rows on fp8 weights: the LDS-shared weight-streaming kernel reads the fp8 image itself (same conditions as its bf16 dispatch below)
     static int w8_lds_on = -1;
     if (w8_lds_on < 0) { const char* e = getenv("SM_FP8_LDS"); w8_lds_on = e ? atoi(e) : 1; }
-    const bool w8_lds = w8 && w8_lds_on && p->M > 16 && p->M <= 32 && !p->norm_gamma && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt;
+    // (N < 4 -- the gate head's two rows -- too: every slab store of such a product takes the element path, and the bf16 expansion it would fall back to
+    //  rounds q * s to bf16: 4e-3 on the gate logits where the streamed image gives 3e-5)
+    const bool w8_lds = w8 && w8_lds_on && p->M > 16 && p->M <= 32 && !p->norm_gamma && ((p->N & 3) == 0 || p->N < 4) && a.KS >= 8 && p->remap_in == 0 && !p->vt;
     if (w8 && p->M > 16 && !w8_lds) {
         // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
         // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes

@@ -114,6 +114,7 @@ struct Slot {            // one tensor the path reads
     bool complete() const { return loaded == (parts >= 32 ? 0xffffffffu : (1u << parts) - 1u); }
     int Klogical = 0;    // > 0: checkpoint K (the packed image pads it to K); patch embedding only
     bool fp8 = false;    // packed as fp8 + per-row scales (weights_fp8 mode, gate + LLM linears)
+    bool wo = false;     // fp8 slot that is weight-only in EVERY fp8 mode (the gate: its rows are never quantised, so a pass of 17..32 rows streams the fp8 image)
     bool f16 = false;    // packed image holds IEEE fp16 instead of bf16 (vit_fp16 mode, ViT linears)
     DevBuf scale;        // fp32 [N]
 };
@@ -343,8 +344,10 @@ extern "C" int sm_model_create(const sm_config_t* cfg, sm_model** out) {
             if (kv.second.kind == 1 && kv.first.rfind("proj.", 0) == 0) kv.second.f16 = true;
     if (c.weights_fp8)
         for (auto& kv : m->slots)
-            if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head"))
+            if (kv.second.kind == 1 && (kv.first.rfind("proj.cls_net.", 0) == 0 || kv.first.rfind("llm.", 0) == 0 || kv.first == "proj.gate_head")) {
                 kv.second.fp8 = true;
+                kv.second.wo = kv.first.rfind("llm.", 0) != 0;
+            }
     *out = m;
     return SM_OK;
 }
@@ -522,7 +525,7 @@ static sm_linear_t lin(const sm_model* m, const Slot& w, const void* x, int x_dt
     sm_linear_t a;
     memset(&a, 0, sizeof(a));
     a.w = w.buf.p; a.N = w.N; a.K = w.K; a.x = x; a.x_dtype = x_dtype; a.M = M; a.ldx = ldx;
-    if (w.fp8) { a.w_dtype = m->c.weights_fp8 == 2 ? SM_W_FP8_MFMA : SM_W_FP8; a.w_scale = w.scale.as<float>(); }
+    if (w.fp8) { a.w_dtype = m->c.weights_fp8 == 2 && !w.wo ? SM_W_FP8_MFMA : SM_W_FP8; a.w_scale = w.scale.as<float>(); }
     if (w.f16) a.op_dtype = SM_OP_F16;
     return a;
 }
@@ -1036,7 +1039,7 @@ extern "C" int sm_stream_push_frames(sm_stream* s, const uint8_t* frames, int M,
     // one ViT batch, then the connector+gate in frame order, at most 32 frames per weight pass
     int rc = sm_vit_encode(s->m, frames, M, s->w.pooled.as<float>(), nullptr, nullptr, stream);
     if (rc) return rc;
-    const int cap = s->m->c.weights_fp8 == 2 ? 16 : 32;       // (weight-only fp8 too: the 17..32-row weight-streaming kernel reads the fp8 image; the fp8 x fp8 mode keeps 16: its gate rows are never quantised)
+    const int cap = 32;       // (fp8 weights too: the 17..32-row weight-streaming kernel reads the fp8 image; the gate is weight-only in both fp8 modes)
     const int parts = cdiv(M, cap), per = cdiv(M, parts);
     for (int i = 0; i < M; i += per) {
         const int n = M - i < per ? M - i : per;
@@ -1074,7 +1077,7 @@ extern "C" int sm_stream_push_frames_pipelined(sm_stream* s, const uint8_t* fram
     if (rc) return rc;
     SM_HIP(hipEventRecord(s->ev_vit, st));
     SM_HIP(hipStreamWaitEvent(s->side, s->ev_vit, 0));
-    const int cap = m->c.weights_fp8 == 2 ? 16 : 32;
+    const int cap = 32;
     const int parts = cdiv(M, cap), per = cdiv(M, parts);
     const int d = m->c.conn_d_model;
     for (int i = 0; i < M; i += per) {
@@ -1141,7 +1144,7 @@ extern "C" int sm_group_push_pooled(sm_stream_group* g, const float* pooled, int
     SM_REQUIRE(g && pooled && F >= 1, "sm_group_push_pooled: bad args");
     sm_model* m = g->m;
     const int S = (int)g->streams.size(), d = m->c.conn_d_model;
-    const int cap = m->c.weights_fp8 == 2 ? 16 : 32;
+    const int cap = 32;
     SM_REQUIRE(F <= cap, "sm_group_push_pooled: %d frames per stream exceed one weight pass (%d rows)", F, cap);
     for (int i = 0; i < S; ++i)
         SM_REQUIRE(g->streams[i]->T + F <= g->streams[i]->max_frames, "sm_group_push_pooled: token store of stream %d full (%d + %d > %d)", i,

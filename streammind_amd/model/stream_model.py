@@ -161,7 +161,7 @@ class Video_Mamba_seq:
         check(nat.lib.sm_pool_rows(x.data_ptr(), _DT[x.dtype], t, l, d, pooled.data_ptr(), _stream()), "sm_pool_rows")
         s = nat.open_stream(max_frames=t, max_seq=64)
         logits = None
-        cap = 16 if nat.cfg.weights_fp8 == 2 else 32
+        cap = 32
         all_logits = []
         for i in range(0, t, cap):
             logits, _ = s.push_pooled(pooled[i:i + cap].contiguous())
@@ -271,7 +271,7 @@ class Videollama2MistralForCausalLM:
         nat, cfg = self.native, self.native.cfg
         logits = None
         tick_logits = []
-        step = min(16 if cfg.weights_fp8 else 32, cfg.max_frames_per_call)
+        step = min(32, cfg.max_frames_per_call)
         for i in range(0, x.shape[0], step):
             xi = x[i:i + step].contiguous()
             if xi.dtype == torch.uint8 and xi.shape[-1] == 3:
@@ -305,7 +305,7 @@ class Videollama2MistralForCausalLM:
         t, P, Cw = x.shape
         pooled = torch.empty(t, Cw, dtype=torch.float32, device=self.device)
         check(nat.lib.sm_pool_rows(x.data_ptr(), _DT[x.dtype], t, P, Cw, pooled.data_ptr(), _stream()), "sm_pool_rows")
-        cap = 16 if cfg.weights_fp8 == 2 else 32
+        cap = 32
         logits = [self.stream.push_pooled(pooled[i:i + cap].contiguous())[0] for i in range(0, t, cap)]
         self._tick_logits = torch.cat(logits)
         self.last_gate_logits = self._tick_logits[-1]

@@ -591,7 +591,12 @@ def test_fp8_mfma_mode_prefill_and_teacher_forced_vs_its_oracle():
     s = m.open_stream(max_frames=32, max_seq=128)
     lg, _ = s.push_pooled(pooled.cuda())
     tok = O.connector_scan(pooled, Wc8, TC)
-    assert maxdiff(lg, O.gate_logits_shortcut(tok, Wc8, TG)) < 1e-3           # the gate (<= 16 rows per pass) is the weight-only mode's
+    assert maxdiff(lg, O.gate_logits_shortcut(tok, Wc8, TG)) < 1e-3           # the gate is the weight-only mode's in BOTH fp8 modes (its rows are never quantised) ...
+    s2 = m.open_stream(max_frames=32, max_seq=128)                            # ... at 17..32 rows per pass too (round 5: the fp8 image streamed by the LDS-shared kernel)
+    pooled26 = torch.randn(26, TC.mm_hidden, generator=torch.Generator().manual_seed(5))
+    lg26, _ = s2.push_pooled(pooled26.cuda())
+    assert maxdiff(lg26, O.gate_logits_shortcut(O.connector_scan(pooled26, Wc8, TC), Wc8, TG)) < 1e-3
+    s2.close()
     ids = torch.cat([torch.tensor([1, 7, 9]), -(torch.arange(6) + 1), torch.tensor([11, 12] * 9), torch.tensor([5, 33, 71])]).to(torch.int32)      # 30 rows: one fp8-MFMA chunk
     s.prefill(ids.cuda())
     logits, _ = s.logits()
@@ -927,8 +932,8 @@ def test_pipelined_push_frames_equals_plain(tiny, tiny_tokenizer):
 
 
 def test_fp8_gate_full_size_vs_its_oracle_definition():
-    """BASELINE configs[4] at FULL size: the 872 M-parameter gate with fp8 (e4m3, per-row scale) weights, 28 rows per pass (two
-    16-row fp8 passes), against the oracle run on the dequantised weights -- the mode's own definition: gate logits 1e-3,
+    """BASELINE configs[4] at FULL size: the 872 M-parameter gate with fp8 (e4m3, per-row scale) weights, 28 rows as two 14-row
+    passes and as one 28-row pass, against the oracle run on the dequantised weights -- the mode's own definition: gate logits 1e-3,
     decisions equal outside a 2e-3 margin; and the quantisation itself moves the logits by more than that (it is a different
     model, reported separately by the bench)."""
     ccfg, gcfg = O.ConnCfg(), O.LmCfg.gate()
@@ -945,6 +950,16 @@ def test_fp8_gate_full_size_vs_its_oracle_definition():
     assert maxdiff(s.tokens(), tok) < 1e-4 * max(1.0, tok.abs().max().item())
     ref_bf16 = O.gate_logits_shortcut(tok, Wc, gcfg)
     assert maxdiff(lg, ref_bf16) > 2e-3
+    # round 5: the same 28 rows in ONE weight pass (the 17..32-row weight-streaming kernel reads the fp8 image; row scales on the fp32 sums, the
+    # two-row gate head included) -- the same definition at the same tolerance, in both fp8 modes (the gate is weight-only in both)
+    for mode in (1, 2):
+        m.set_fp8_mode(mode)
+        s1 = m.open_stream(max_frames=32, max_seq=64)
+        lg1 = s1.push_pooled(pooled.cuda().contiguous())[0].cpu()
+        assert maxdiff(lg1, ref) < 1e-3, mode
+        assert maxdiff(lg1, lg) < 1e-3, mode
+        assert maxdiff(s1.tokens(), tok) < 1e-4 * max(1.0, tok.abs().max().item())
+        s1.close()
 
 
 def test_group_batched_decode_equals_solo_decode(tiny):
