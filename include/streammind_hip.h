@@ -68,7 +68,7 @@ int sm_quant_pack_weight_fp8(const void* w_bf16, int N, int K, int ldw, void* ou
  * Linear:  Y[M,N] = epilogue( X[M,K] . W[N,K]^T ).  Replaces every torch F.linear / cuBLAS GEMM+GEMV on
  * the path (SURVEY 2.3 K2,K3,K5-K8,K10,K11).  M <= 32 takes the weight-streaming "skinny" kernels (HBM-bound, MFMA
  * 16x16x32 with the weights as the A operand); larger M the LDS-tiled MFMA GEMM.  fp8 weights stream as fp8 for M <= 32
- * (row scale on the fp32 sums); for more rows the call first expands them to a bf16 scratch image (row scale folded in) and
+ * (16-bit activations: M <= 64; row scale on the fp32 sums); for more rows the call first expands them to a bf16 scratch image (row scale folded in) and
  * runs the bf16 kernels (SM_W_FP8_MFMA: fp8 x fp8 on the matrix pipe instead, activations quantised per row).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct sm_linear_t {
@@ -98,7 +98,7 @@ typedef struct sm_linear_t {
     int vt_n0, vt_S, vt_dh, vt_ld;
     /* weight storage: SM_W_BF16 (packed bf16) or SM_W_FP8 / SM_W_FP8_MFMA (sm_quant_pack_weight_fp8 image + per-row scales).
      * Up to 16 rows both fp8 kinds stream the weights once and expand them in registers (bf16 activations); SM_W_FP8 does
-     * the same up to 32 rows (the LDS-shared weight-streaming kernel; row scale on the fp32 sums).  Above that
+     * the same up to 32 rows, 64 rows of 16-bit activations (the LDS-shared weight-streaming kernel; row scale on the fp32 sums).  Above that
      * SM_W_FP8 expands the image to a bf16 scratch and runs the bf16 GEMM (weight-only fp8: bf16 activations); above 16 rows SM_W_FP8_MFMA
      * quantises every activation row to e4m3 (scale max|x|/448, the weights' rule) and multiplies on the fp8 matrix instruction
      * (v_mfma_scale_f32_16x16x128_f8f6f4, twice the bf16 rate): y = sx[m] sw[n] sum_k qx qw.  Needs K % 128 == 0, else as SM_W_FP8. */

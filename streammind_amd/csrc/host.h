@@ -32,6 +32,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // (one weight pass = at most 32 rows), so no device-side pointer table has to be built or uploaded per call.
 #define SM_MAX_SEG 32
 #define SM_GROUP_DECODE_MAX 512     // active streams of one batched decode step (beyond SM_MAX_SEG: tiled GEMMs over all rows + per-stream kernels in packs)
+int sm_skinny_lds64_on();           // linear.hip: products of 33..64 16-bit rows take the LDS-shared weight-streaming kernel (dual weights allowed there)
 #define SM_BIG_SEG 128              // streams whose per-stream pointers travel in ONE by-value pack (2.5 KB of kernel arguments)
 struct SmSegStates { float* p[SM_MAX_SEG]; };
 int sm_mamba_conv_step_seg(const float* xz, int S, int F, int di, int d_conv, const SmSegStates& st, const float* conv_w,

@@ -1247,10 +1247,13 @@ static int launch_skinny_fp8(const LinArgs& a, bool xf32, bool split, bool dual,
 // dimension are summed by splitk_reduce_kernel (fixed order), which also applies the epilogue.
 // W8: weight-only fp8 (the packed image of pack_fp8_kernel: 16 bytes per lane = two k-steps), expanded to bf16 in registers -- half the weight bytes of
 // the stream; the row scales stay in the epilogue of the slab pass (store4 / the norm pass), as for <= 16 rows.
-template <bool XF32, bool SPLIT, bool DUAL, bool F16 = false, bool W8 = false>
+// MB: 16-row blocks of activations a block holds (2: up to 32 rows; 4: up to 64 rows -- a batched decode step of 33..64 streams; 16-bit x only: the hi / lo
+// pair of 64 fp32 rows would not fit the two LDS buffers).
+template <bool XF32, bool SPLIT, bool DUAL, bool F16 = false, bool W8 = false, int MB = 2>
 __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __restrict__ ws, float* __restrict__ ws2, int ks_per_split) {
     constexpr int KC = 8;                                   // k-steps per staged chunk
-    __shared__ __attribute__((aligned(16))) bf16x8 xs[2][SPLIT ? 2 : 1][KC * 2 * 64];      // [buf][hi/lo][(ks, mb, lane)]
+    static_assert(MB == 2 || (MB == 4 && !SPLIT), "skinny_lds_kernel: 64 rows only without the hi/lo split");
+    __shared__ __attribute__((aligned(16))) bf16x8 xs[2][SPLIT ? 2 : 1][KC * MB * 64];      // [buf][hi/lo][(ks, mb, lane)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int rg = blockIdx.x * 8 + wave;
@@ -1262,20 +1265,22 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     const int KSP = (KS + 1) >> 1;                                 // fp8 image: pairs of k-steps
     const u32x4* wq = (const u32x4*)a.w + (size_t)(wave_on ? rg : 0) * KSP * 64 + lane;
     const u32x4* wq2 = DUAL ? (const u32x4*)a.w2 + (size_t)(wave_on ? rg : 0) * KSP * 64 + lane : nullptr;
-    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}}, acc2[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    f32x4 acc[MB], acc2[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) { acc[mb] = f32x4{0, 0, 0, 0}; acc2[mb] = f32x4{0, 0, 0, 0}; }
 
     // fill item = (ks_local, mb, lane'): 8 consecutive k of row mb*16 + (lane' & 15) -> one 16-byte B fragment (x2 in split mode).
     // Two halves: fill_load issues the (L2-resident) x loads, fill_store converts and writes LDS.  The weight loads of the
     // same chunk are issued BETWEEN the two: VMEM returns in order, so x loads queued behind the HBM weight loads would make
     // the conversion wait for the weights (measured: 7 us per chunk instead of ~3).
-    constexpr int NIT = (KC * 2 * 64) / 512;
+    constexpr int NIT = (KC * MB * 64) / 512;
     f32x4 xa[NIT], xb[NIT];
     bool xok[NIT];
     auto fill_load = [&](int kbase) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int item = tid + it * 512;
-            const int l2 = item & 63, mb = (item >> 6) & 1, ksl = item >> 7;
+            const int l2 = item & 63, mb = (item >> 6) & (MB - 1), ksl = item >> (MB == 4 ? 8 : 7);
             const int m = mb * 16 + (l2 & 15), ks = kbase + ksl;
             xok[it] = m < a.M && ks < ks1;
             xa[it] = f32x4{0, 0, 0, 0}; xb[it] = f32x4{0, 0, 0, 0};
@@ -1331,12 +1336,12 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
                 if (DUAL) w1 = wb[set][u];
             }
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const bf16x8 xh = xs[buf][0][(u * 2 + mb) * 64 + lane];
+            for (int mb = 0; mb < MB; ++mb) {
+                const bf16x8 xh = xs[buf][0][(u * MB + mb) * 64 + lane];
                 acc[mb] = mfma16<F16>(w0, xh, acc[mb]);
                 if (DUAL) acc2[mb] = mfma16<F16>(w1, xh, acc2[mb]);
                 if (SPLIT) {
-                    const bf16x8 xl = xs[buf][SPLIT ? 1 : 0][(u * 2 + mb) * 64 + lane];
+                    const bf16x8 xl = xs[buf][SPLIT ? 1 : 0][(u * MB + mb) * 64 + lane];
                     acc[mb] = mfma16<F16>(w0, xl, acc[mb]);
                     if (DUAL) acc2[mb] = mfma16<F16>(w1, xl, acc2[mb]);
                 }
@@ -1358,7 +1363,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
     if (!wave_on) return;
     // raw partial sums of this K slice: slab [blockIdx.y][m][n]; lane (g, i) owns row m = mb*16 + i, columns rg*16 + g*4 .. +3
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
         const int m = mb * 16 + i, n0 = rg * 16 + g * 4;
         if (m >= a.M || n0 >= a.N) continue;
         const size_t o = ((size_t)blockIdx.y * a.M + m) * a.N + n0;
@@ -1373,6 +1378,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(LinArgs a, float* __res
 }
 
 static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual, hipStream_t st, const PostLn* ln = nullptr, bool* ln_done = nullptr, bool w8 = false) {
+    const bool rows64 = a.M > 32;                            // 33..64 rows of 16-bit activations (the caller checked)
     const int nb = (a.NRG + 7) / 8;
     static int target = -1;
     if (target < 0) { const char* e = getenv("SM_SKINNY_LDS_BLOCKS"); target = e ? atoi(e) : 256; }
@@ -1390,7 +1396,11 @@ static int launch_skinny_lds(const LinArgs& a, bool xf32, bool split, bool dual,
 #define SL(XF, SP, DU) skinny_lds_kernel<XF, SP, DU><<<grid, 512, 0, st>>>(a, ws, ws2, per)
 #define SLH(XF, SP, DU) skinny_lds_kernel<XF, SP, DU, true><<<grid, 512, 0, st>>>(a, ws, ws2, per)
 #define SL8(XF, SP, DU) skinny_lds_kernel<XF, SP, DU, false, true><<<grid, 512, 0, st>>>(a, ws, ws2, per)
-    if (w8) {              // weight-only fp8 (bf16 operands)
+    if (rows64) {
+        if (w8) { if (dual) skinny_lds_kernel<false, false, true, false, true, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<false, false, false, false, true, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+        else if (a.f16) { if (dual) skinny_lds_kernel<false, false, true, true, false, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<false, false, false, true, false, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+        else { if (dual) skinny_lds_kernel<false, false, true, false, false, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); else skinny_lds_kernel<false, false, false, false, false, 4><<<grid, 512, 0, st>>>(a, ws, ws2, per); }
+    } else if (w8) {       // weight-only fp8 (bf16 operands)
         if (xf32) {
             if (split) { if (dual) SL8(true, true, true); else SL8(true, true, false); }
             else       { if (dual) SL8(true, false, true); else SL8(true, false, false); }
@@ -1525,6 +1535,13 @@ int sm_linear_qkv_rope(const sm_linear_t* p, const SmRopeEpi& re, void* stream) 
 
 extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* gamma, const float* beta, float eps, int post_act,
                           float* out_f32, void* out_bf16, int ldo, int op_dtype, void* stream);                        // vecops.hip
+// 1 (default): fp8 weights only -- on bf16 weights the tiled / weight-streaming MFMA kernels are 5-7 % faster at 33..64 rows (same-box A/B: 64 streams 4.94 vs
+// 5.32 ms per decode step), on fp8 weights the alternative is a bf16 expansion per call; 2: bf16 weights too (A/B); 0: off
+int sm_skinny_lds64_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SM_SKINNY_LDS64"); on = e ? atoi(e) : 1; }
+    return on;
+}
 static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done);
 int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);           // vecops.hip
 // fp32 [M][2F] gate | up rows of an SM_ACT_SWIGLU_DUAL call that does not run on the 256 x 256 kernel (per HIP stream, grown on demand; not the
@@ -1631,12 +1648,16 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     const bool w8 = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
     SM_REQUIRE(p->op_dtype == SM_OP_BF16 || p->op_dtype == SM_OP_F16, "sm_linear: op_dtype must be SM_OP_BF16 or SM_OP_F16");
     SM_REQUIRE(!a.f16 || !w8, "sm_linear: fp16 operands exclude fp8 weights");
-    SM_REQUIRE(!a.f16 || p->M <= 32 || (p->x_dtype == SM_X_BF16 && !p->w2 && !p->norm_gamma),
+    SM_REQUIRE(!a.f16 || p->M <= 32 || (p->x_dtype == SM_X_BF16 && (!p->w2 || p->M <= 64) && !p->norm_gamma),
                "sm_linear: above 32 rows fp16 operands run on the tiled GEMM (16-bit x, single weight image, no fused norm)");
     SM_REQUIRE(!p->norm_gamma || (p->M <= 16 && (long)p->M * p->K <= 16384 && p->x_dtype == SM_X_F32 && !p->precise && (p->K & 31) == 0 && (p->ldx & 3) == 0),
                "sm_linear: fused RMSNorm needs M <= 16, M*K <= 16384 (the normalised rows live in LDS), fp32 x (precise = 0), K %% 32 == 0 (M=%d K=%d)", p->M, p->K);
     SM_REQUIRE(!w8 || (p->w_scale && (!p->w2 || p->w2_scale)), "sm_linear: fp8 weights need their row scales");
-    SM_REQUIRE(!p->w2 || p->M <= 32, "sm_linear: dual weights only on the weight-streaming path (M <= 32)");
+    // 33..64 rows of 16-bit activations on fp8 weights: the LDS-shared weight-streaming kernel with four 16-row blocks (a batched decode step of 33..64 streams)
+    const bool w8_any = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
+    const bool lds64 = (sm_skinny_lds64_on() >= 2 || (sm_skinny_lds64_on() == 1 && w8_any)) && p->M > 32 && p->M <= 64 && p->x_dtype == SM_X_BF16 && !p->precise && !p->norm_gamma && ((p->N & 3) == 0 || p->N < 4) && a.KS >= 8 &&
+                       p->remap_in == 0 && !p->vt && (p->ldx % 8) == 0 && p->act != SM_ACT_SWIGLU_DUAL;
+    SM_REQUIRE(!p->w2 || p->M <= 32 || lds64, "sm_linear: dual weights only on the weight-streaming path (M <= 32; 16-bit rows up to 64)");
     SM_REQUIRE(p->x_rep > 1 || p->ldx >= a.KS * 32, "sm_linear: ldx=%d must cover K padded to 32 (%d)", p->ldx, a.KS * 32);
     SM_REQUIRE(!p->vt || (p->vt_dh > 0 && p->vt_S > 0 && (p->N - p->vt_n0) % p->vt_dh == 0), "sm_linear: bad vt args");
     hipStream_t st = (hipStream_t)stream;
@@ -1652,7 +1673,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     // (N < 4 -- the gate head's two rows -- too: every slab store of such a product takes the element path, and the bf16 expansion it would fall back to
     //  rounds q * s to bf16: 4e-3 on the gate logits where the streamed image gives 3e-5)
     const bool w8_lds = w8 && w8_lds_on && p->M > 16 && p->M <= 32 && !p->norm_gamma && ((p->N & 3) == 0 || p->N < 4) && a.KS >= 8 && p->remap_in == 0 && !p->vt;
-    if (w8 && p->M > 16 && !w8_lds) {
+    if (w8 && p->M > 16 && !w8_lds && !lds64) {
         // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
         // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes
         const void *d0 = nullptr, *d1 = nullptr;
@@ -1663,7 +1684,7 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         if (p->w2) a.w2 = (const bf16x8*)d1;
         a.wscale = a.wscale2 = nullptr;
     }
-    const bool w8k = w8 && (p->M <= 16 || w8_lds);            // fp8 kernels in use
+    const bool w8k = w8 && (p->M <= 16 || w8_lds || lds64);   // fp8 kernels in use
     if (p->M <= 32) {
         SM_REQUIRE(!xf32 || (p->ldx % 4 == 0), "sm_linear: fp32 x needs ldx %% 4 == 0");
         SM_REQUIRE(xf32 || (p->ldx % 8 == 0), "sm_linear: bf16 x needs ldx %% 8 == 0");
@@ -1738,6 +1759,13 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         if (a.KS >= 32) return launch_skinny<8>(a, xf32, split, dual, st);
         if (a.KS >= 8) return launch_skinny<4>(a, xf32, split, dual, st);
         return launch_skinny<1>(a, xf32, split, dual, st);
+    }
+    if (lds64) {
+        SmProfScope prof(SM_PROF_SKINNY, st);
+        static int ln_fuse64 = -1;
+        if (ln_fuse64 < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse64 = e ? atoi(e) : 1; }
+        const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
+        return launch_skinny_lds(a, false, false, p->w2 != nullptr, st, (ln_fuse64 && p->post_ln_gamma && p->out_f32) ? &ln : nullptr, ln_done, w8);
     }
     SM_REQUIRE(!xf32, "sm_linear: the tiled GEMM takes bf16 activations (M=%d > 32)", p->M);
 

@@ -1359,9 +1359,9 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     // up to SM_MAX_SEG streams: weight-streaming kernels (one row per stream); beyond that, up to SM_GROUP_DECODE_MAX: the same step with the
     // linears on the tiled MFMA GEMM (M = streams) -- still ONE pass over the weights per step -- and the per-stream kernels (token gather,
     // RoPE + KV append, attention, arg-max: per-stream pointers travel by value, SM_MAX_SEG at a time) in chunks
-    // (fp8 weights: the weight-streaming kernels read the fp8 image up to 32 rows; beyond that a product would expand it to bf16 per call)
-    SM_REQUIRE(S <= (c.weights_fp8 == 2 ? 16 : c.weights_fp8 ? SM_MAX_SEG : SM_GROUP_DECODE_MAX), "sm_group_llm_decode: %d active streams exceed one weight pass (%d)", S,
-               c.weights_fp8 == 2 ? 16 : c.weights_fp8 ? SM_MAX_SEG : SM_GROUP_DECODE_MAX);
+    // (fp8 weights: the weight-streaming kernels read the fp8 image up to 64 rows; beyond that a product would expand it to bf16 per call)
+    const int s_cap = c.weights_fp8 == 2 ? 16 : c.weights_fp8 ? (sm_skinny_lds64_on() ? 64 : SM_MAX_SEG) : SM_GROUP_DECODE_MAX;
+    SM_REQUIRE(S <= s_cap, "sm_group_llm_decode: %d active streams exceed one weight pass (%d)", S, s_cap);
     const int ld = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, dh = ld / H, qn = H * dh, kn = KV * dh, V = c.llm_vocab;
     int S_max = act[0]->max_seq;
     for (sm_stream* s : act) {
@@ -1427,7 +1427,7 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
                 if ((rc = sm_linear(&a, stream))) return rc; }
-            if (S <= SM_MAX_SEG) {
+            if (S <= SM_MAX_SEG || (S <= 64 && (sm_skinny_lds64_on() >= 2 || (sm_skinny_lds64_on() == 1 && c.weights_fp8)))) {
                 const Slot& gu = *w.gu;
                 sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
                 a.N = c.llm_mlp;

@@ -470,15 +470,15 @@ def test_skinny_linear_fused_rmsnorm(nat, M, N, K, dual):
         assert relerr(y8, y8u.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("M,N,K,dual", [(20, 512, 1056, False), (28, 1024, 512, True), (32, 4096, 4096, False), (17, 2048, 14336, True), (48, 384, 1024, False),
+@pytest.mark.parametrize("M,N,K,dual", [(20, 512, 1056, False), (28, 1024, 512, True), (32, 4096, 4096, False), (17, 2048, 14336, True), (48, 384, 1024, False), (64, 1024, 4096, True), (40, 4096, 512, False),
                                         (300, 768, 4096, False)])
 def test_linear_fp8_weights_more_than_16_rows(nat, M, N, K, dual):
-    """fp8 weights with M > 16 rows.  17..32 rows (a batched decode step of up to 32 streams, the connector / gate pass): the LDS-shared weight-streaming
+    """fp8 weights with M > 16 rows.  17..64 rows (a batched decode step of up to 64 streams, the connector / gate pass): the LDS-shared weight-streaming
     kernel reads the fp8 image itself and the row scale is applied to the fp32 sums, as for <= 16 rows -- the mode's own definition (q * s in fp32)
     to 1e-5 relative.  More rows (prefill chunks, teacher-forced evaluation): the packed fp8 image is expanded to a bf16 scratch image with the row
     scale folded in (bf16(q*s), RNE) and the bf16 kernels run on it -- that definition exactly (1e-5), and within the extra 2^-9-per-weight
     rounding of q*s in fp32 (4e-3 relative)."""
-    streamed = M <= 32                                         # the fp8 image is what the kernel reads
+    streamed = M <= 64                                         # the fp8 image is what the kernel reads (33..64 rows: four 16-row blocks per weight load)
     w = O.bf16_round(rnd((N, K), 1, K ** -0.5))
     x = O.bf16_round(rnd((M, K), 2))
     wq, sc = nat.pack_weight_fp8(w.cuda().bfloat16())

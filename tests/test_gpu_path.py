@@ -1160,14 +1160,15 @@ def test_two_tower_lanes_equal_two_calls_and_the_stream_path():
     assert torch.equal(a.tokens(0, 50), b.tokens(0, 50))
 
 
-@pytest.mark.parametrize("fp8,S", [(False, 16), (True, 16), (True, 28)])
+@pytest.mark.parametrize("fp8,S", [(False, 16), (True, 16), (True, 28), (True, 48)])
 def test_group_decode_full_width_16_streams_one_launch_attention(fp8, S):
     """Mistral-7B widths (head_dim 128, 32 / 8 heads), one layer: 16 streams with contexts of 390..690 tokens decoded together --
     S x KV = 128 blocks, so the batched step takes the ONE-LAUNCH decode attention (in-block merge) at contexts where a single
     stream takes the key-split + merge pair, and its q/k/v rows go through the per-stream RoPE / KV append.  Every stream's ids and
     last logits against its own solo decode.  fp8: the same on fp8 weights -- solo steps run the fused RMSNorm / RoPE fp8 kernels
     on one row, the batched step the 16-row fp8 weight-streaming kernels behind separate norm and RoPE launches; 28 streams on fp8 weights: the
-    17..32-row kernel that reads the fp8 image and shares the rows through LDS (round 5: an fp8 group was capped at 16 streams)."""
+    17..32-row kernel that reads the fp8 image and shares the rows through LDS (round 5: an fp8 group was capped at 16 streams); 48 streams: its
+    four-row-block form (33..64 rows), RoPE / attention through the 128-stream pointer packs."""
     lcfg = O.LmCfg(hidden=4096, layers=1, heads=32, kv_heads=8, mlp=14336, vocab=2048, eps=1e-5, rope_theta=1e6)
     Wl = O.make_lm_weights(lcfg, 78)
     vcfg = O.VitCfg(image_size=28, patch=14, hidden=1024, heads=16, mlp=64, layers=2)
@@ -1175,7 +1176,7 @@ def test_group_decode_full_width_16_streams_one_launch_attention(fp8, S):
     m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 1), conn_gate_weights(ccfg, gcfg, 2), lcfg, Wl, weights_fp8=fp8)
     g = torch.Generator().manual_seed(12)
     n_new = 5
-    lens = [390 + (20 if S == 16 else 11) * t for t in range(S)]
+    lens = [390 + (20 if S == 16 else 11 if S == 28 else 7) * t for t in range(S)]
     ctxs = [torch.randint(3, lcfg.vocab, (n,), generator=g, dtype=torch.int32).cuda() for n in lens]
     streams = [m.open_stream(max_frames=8, max_seq=768) for _ in range(S)]
     solo_ids, solo_first, solo_last, first_tok = [], [], [], []
