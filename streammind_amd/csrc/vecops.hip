@@ -210,7 +210,9 @@ extern "C" int sm_norm_ex(const float* x, int M, int D, int ldx, const float* ga
     const int f16 = op_dtype == SM_OP_F16;
     SM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0, "sm_norm: D, ldx, ldo must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
-    if (M <= 64 && D <= 8192) {
+    static int block_max_m = -1;       // SM_NORM_BLOCK_MAXM: largest M that takes one BLOCK per row (above it: one wave per row)
+    if (block_max_m < 0) { const char* e = getenv("SM_NORM_BLOCK_MAXM"); block_max_m = e ? atoi(e) : 64; }
+    if (M <= block_max_m && D <= 8192) {
         if (beta) norm_row_block_kernel<true><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
         else norm_row_block_kernel<false><<<M, 256, 0, st>>>(x, D, ldx, gamma, beta, eps, post_act, out_f32, (bf16_t*)out_bf16, ldo, f16);
         SM_LAUNCH_CHECK();
