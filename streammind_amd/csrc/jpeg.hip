@@ -1090,6 +1090,8 @@ extern "C" int sm_jpeg_entropy_decode_sync(const uint8_t* bytes, size_t bytes_to
                                            const sm_jpeg_info_t* info, int n_frames, int16_t* coefs, uint16_t* qt, int32_t* status, void* stream) {
     SM_REQUIRE(bytes && bytes_total > 0 && offsets && scans && info && coefs && qt && status && n_frames >= 1, "sm_jpeg_entropy_decode_sync: null arg / no frames");
     SM_REQUIRE(max_file_bytes > 0 && max_file_bytes <= bytes_total, "sm_jpeg_entropy_decode_sync: max_file_bytes %zu outside (0, bytes_total]", max_file_bytes);
+    SM_REQUIRE(bytes_total < ((size_t)1 << 31) && max_file_bytes < ((size_t)1 << 28), "sm_jpeg_entropy_decode_sync: %zu bytes per batch / %zu per file (offsets are 32-bit, bit positions 31-bit)",
+               bytes_total, max_file_bytes);
     SM_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && info->coef_count > 0 && (((size_t)info->coef_count * 2) % 16) == 0 && ((uintptr_t)coefs & 15) == 0,
                "sm_jpeg_entropy_decode_sync: bad info / unaligned coefficient image");
     hipStream_t st = (hipStream_t)stream;
