@@ -443,13 +443,19 @@ __global__ __launch_bounds__(1024) void jpeg_rst_index_kernel(const uint8_t* __r
 // data 0xFF, in place of the raw bytes' own range of a second buffer (the clean image is never longer than the raw one); 64 bytes per step, ranks by ballot.
 // lens[f][iv] = clean length.  The decode lanes then read a plain bit stream: no per-byte marker / stuffing checks in their loop.
 __global__ __launch_bounds__(256) void jpeg_unstuff_kernel(const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ offsets, const sm_jpeg_scan_t* __restrict__ scans,
-                                                           const uint32_t* __restrict__ starts, uint8_t* __restrict__ clean, uint32_t* __restrict__ lens) {
+                                                           const uint32_t* __restrict__ starts, uint8_t* __restrict__ clean, uint32_t* __restrict__ lens,
+                                                           const int32_t* __restrict__ status) {
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int iv = blockIdx.x * 4 + (threadIdx.x >> 6);
     const sm_jpeg_scan_t& sc = scans[f];
     if (iv >= sc.n_intervals || iv >= JH_MAX_INT) return;
+    // a frame whose markers do not number its intervals (a stream cut short, a wrong RSTn) has starts[] entries nobody wrote: nothing of it is read
+    // (found by tools/jpeg_fuzz.py: a 720p file cut at two thirds faulted here on a stale offset)
+    if (status[f] != 0) { if (lane == 0) lens[(size_t)f * JH_MAX_INT + iv] = 0; return; }
     const uint32_t* st = starts + (size_t)f * JH_MAX_INT;
-    const uint32_t lo = st[iv], hi = iv + 1 < sc.n_intervals ? st[iv + 1] - 2 : sc.scan_len;       // (the RSTn marker itself is not data)
+    uint32_t lo = st[iv], hi = iv + 1 < sc.n_intervals ? st[iv + 1] - 2 : sc.scan_len;       // (the RSTn marker itself is not data)
+    hi = hi <= sc.scan_len ? hi : sc.scan_len;
+    lo = lo <= hi ? lo : hi;
     const uint8_t* src = bytes + offsets[f] + sc.scan_offset;
     uint8_t* dst = clean + offsets[f] + sc.scan_offset + lo;
     uint32_t out = 0;
@@ -788,14 +794,16 @@ __device__ __forceinline__ bool js_step(JsDec& d, const TAB* tab, int nb0, int n
 }
 
 // One record per subsequence, ONE 64-bit word (written and read whole, so a record is always a true statement "decoding this subsequence from ENTRY leaves
-// EXIT after NBLK completed blocks"):  bits 0-14 exit state, 15-23 blocks completed, 24-38 entry state; a state = bit offset past the subsequence's first bit
+// EXIT after NBLK completed blocks"):  bits 0-14 exit state, 15-24 blocks completed, 25-39 entry state; a state = bit offset past the subsequence's first bit
 // (0..30: a symbol is at most 31 bits) | block inside the MCU << 5 | next zig-zag index << 8.  All ones = no record yet.
 // The frame is decoded when the records CHAIN: record[0] enters at (0, 0, 0) and record[s] enters where record[s - 1] exits.
 #define JS_CHAIN 64                                             // subsequences a lane follows downstream in one round
 __device__ __forceinline__ uint32_t js_exit(uint64_t r) { return (uint32_t)r & 0x7FFFu; }
-__device__ __forceinline__ uint32_t js_nblk(uint64_t r) { return (uint32_t)(r >> 15) & 0x1FFu; }
-__device__ __forceinline__ uint32_t js_entry(uint64_t r) { return (uint32_t)(r >> 24) & 0x7FFFu; }
-__device__ __forceinline__ uint64_t js_pack(uint32_t entry, uint32_t exit, uint32_t nb) { return (uint64_t)exit | ((uint64_t)nb << 15) | ((uint64_t)entry << 24); }
+// (blocks completed: a block is at least 2 bits -- tables built for a flat image give the DC difference 0 and the end-of-block ONE bit each --, so up to
+//  ~530 blocks end inside 1024 + 30 bits: ten bits; nine were one too few for exactly such images)
+__device__ __forceinline__ uint32_t js_nblk(uint64_t r) { return (uint32_t)(r >> 15) & 0x3FFu; }
+__device__ __forceinline__ uint32_t js_entry(uint64_t r) { return (uint32_t)(r >> 25) & 0x7FFFu; }
+__device__ __forceinline__ uint64_t js_pack(uint32_t entry, uint32_t exit, uint32_t nb) { return (uint64_t)exit | ((uint64_t)(nb & 0x3FFu) << 15) | ((uint64_t)entry << 25); }
 __device__ __forceinline__ uint64_t js_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void js_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1071,7 +1079,7 @@ extern "C" int sm_jpeg_entropy_decode(const uint8_t* bytes, size_t bytes_total, 
     SM_LAUNCH_CHECK();
     // the interval count of a frame is in its scan struct (device); the grids cover the largest possible count for this geometry: one interval per MCU
     const int max_iv = info->mcus_x * info->mcus_y < JH_MAX_INT ? info->mcus_x * info->mcus_y : JH_MAX_INT;
-    jpeg_unstuff_kernel<<<dim3(cdiv(max_iv, 4), n_frames), 256, 0, st>>>(bytes, offsets, scans, ws.starts, ws.clean, ws.lens);
+    jpeg_unstuff_kernel<<<dim3(cdiv(max_iv, 4), n_frames), 256, 0, st>>>(bytes, offsets, scans, ws.starts, ws.clean, ws.lens, status);
     SM_LAUNCH_CHECK();
     JhGeom g;
     memset(&g, 0, sizeof(g));

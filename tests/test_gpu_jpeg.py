@@ -2,6 +2,7 @@
 libjpeg-turbo and against the oracle BYTE FOR BYTE, batches, and a Motion-JPEG AVI read straight into HBM."""
 import ctypes as C
 import io
+import os
 
 import numpy as np
 import pytest
@@ -176,6 +177,21 @@ def test_gpu_entropy_decode_without_restart_markers(dec, case):
     _coefficients_equal_the_host_decoders(dec, b, gray)
 
 
+def test_gpu_entropy_decode_of_two_bit_blocks_and_random_files(dec):
+    """Flat content with tables built for the image (optimize): the DC difference 0 and the end-of-block take ONE bit each, so 512 blocks end inside one
+    1024-bit subsequence (the record's block count needs ten bits: nine sent exactly these files to the host, tools/jpeg_fuzz.py); then 150 random files
+    (size, quality, chroma layout, optimised tables, restart intervals, four kinds of content) against PIL, every byte."""
+    for w, h, ss in ((720, 700, 0), (1280, 720, 2), (225, 269, 1)):
+        b = U.encode(np.full((h, w, 3), (40, 90, 200), dtype=np.uint8), quality=86, subsampling=ss, optimize=True)
+        assert np.array_equal(dec.decode([b], entropy="gpu")[0].cpu().numpy(), U.pil_decode(b)), (w, h, ss)
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "jpeg_fuzz.py"), "150", "7"], capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert r.returncode == 0 and res["mismatches_or_errors"] == 0 and res["decoded_on_gpu"] + res["refused_with_reason_then_host"] + len(res["not_chained_in_16_rounds_then_host"]) == 150, (res, r.stderr[-400:])
+
+
 def test_gpu_entropy_decode_sync_batches_and_broken_streams(dec):
     """28 ordinary 720p frames of different qualities (file lengths 60..300 KB) in ONE call; a second call with other frames reuses the workspaces; a stream
     cut short is reported (status 4: fewer blocks than the frame has), a stream whose middle is overwritten is reported or decodes to SOMETHING without
@@ -222,6 +238,13 @@ def test_gpu_entropy_decode_batch_fallback_and_corruption(dec):
     assert dec.gpu_entropy_frames == before and np.array_equal(both[1], U.pil_decode(plain))
     with pytest.raises(Exception, match="mixes frames with and without"):
         dec.decode(mixed, entropy="gpu")
+    # a restart-interval stream cut short: fewer markers than intervals -- reported, and nothing of the frame's (unwritten) interval index is read
+    # (tools/jpeg_fuzz.py found a memory fault here: the unstuffing kernel walked from a stale offset)
+    cut = frames[2][:len(frames[2]) * 2 // 3] + b"\xff\xd9"
+    for _ in range(3):
+        with pytest.raises(Exception):
+            dec.decode([cut], entropy="gpu")
+    assert np.array_equal(dec.decode([frames[2]], entropy="gpu")[0].cpu().numpy(), got[2])
     bad = bytearray(frames[1])
     k = bad.index(b"\xff\xd1")              # RST1 -> RST3: the numbering check of the index kernel
     bad[k + 1] = 0xD3
