@@ -616,3 +616,16 @@ def test_rope_kv_append_rows_and_tiles(n, pos0):
     assert torch.equal(vtc[:, :, pos0:pos0 + n].cpu(), want_v)
     assert bool((kc[:pos0] == 7).all()) and bool((kc[pos0 + n:] == 7).all())
     assert bool((vtc[:, :, :pos0] == 7).all()) and bool((vtc[:, :, pos0 + n:] == 7).all())
+
+
+def test_linear_random_shapes_and_options_against_fp64():
+    """tools/linear_fuzz.py, 400 cases: rows around every dispatch boundary of sm_linear, N 2..6144, K 32..14336, bf16 / fp32 (plain, hi/lo) / fp16 activations,
+    bf16 / fp16 / fp8 weights, bias, activation, residual, 16-bit copy, dual weights, the SwiGLU-dual image, post-LayerNorm / RMSNorm -- every output against an
+    fp64 product of the same rounded operands (fp32 outputs 3e-5 of the largest value, 16-bit outputs 2^-7); combinations the operator documents as
+    unsupported must be refused with their message, not computed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "linear_fuzz.py"), "400", "11"], capture_output=True, text=True, timeout=900)
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.returncode == 0 and res["mismatches"] == 0 and res["cases"] == 400, (res, r.stderr[-400:])
+    assert all(k.startswith("refused: sm_linear failed (-1): sm_linear:") for k in res["refusals"]), res["refusals"]
