@@ -629,3 +629,14 @@ def test_linear_random_shapes_and_options_against_fp64():
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert r.returncode == 0 and res["mismatches"] == 0 and res["cases"] == 400, (res, r.stderr[-400:])
     assert all(k.startswith("refused: sm_linear failed (-1): sm_linear:") for k in res["refusals"]), res["refusals"]
+
+
+def test_attention_random_shapes_against_fp32_softmax():
+    """tools/attn_fuzz.py, 400 cases: the ViT kernel (batch, 1..600 tokens, heads, head_dim 64 / 128), the causal prefill kernel (1..2048 new queries behind
+    0..3000 cached keys, GQA ratios 1..8, sliding windows, paired query tiles) and single-token decode (one-launch and key-split forms, windows) against
+    fp32 softmax attention of the same bf16 operands: 8e-3 of the largest value, every output finite."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_fuzz.py"), "400", "13"], capture_output=True, text=True, timeout=900)
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert r.returncode == 0 and res["mismatches"] == 0 and res["cases"] + sum(res["refused_with_reason"].values()) == 400, (res, r.stderr[-400:])
