@@ -546,6 +546,24 @@ def test_ingest_frames_bit_exact(nat, H, W, pad):
     assert torch.equal(got.cpu(), want)
 
 
+def test_ingest_frames_random_sizes_bit_exact(nat):
+    """the same on 60 random source sizes (8..1400 a side, both pad modes, aspect ratios up to 1:12): every byte against the oracle's PIL restatement
+    (pinned to the reference's process_video by golden g10, tests/test_oracle_golden.py)."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        H, W = int(rng.integers(8, 1401)), int(rng.integers(8, 1401))
+        if case % 7 == 0:
+            H, W = (int(rng.integers(8, 120)), int(rng.integers(600, 1401))) if case % 2 else (int(rng.integers(600, 1401)), int(rng.integers(8, 120)))
+        pad = bool(rng.integers(0, 2))
+        n = int(rng.integers(1, 3))
+        frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        if case % 3 == 0:                                       # smooth content: the rounding of near-constant sums
+            frames = (frames // 32 + np.linspace(0, 220, W, dtype=np.float32)[None, None, :, None]).astype(np.uint8)
+        got = nat.ingest_frames(torch.from_numpy(frames).cuda(), pad_square=pad, image_size=336)
+        want = O.ingest_frames(list(frames), "pad" if pad else None, 336)
+        assert torch.equal(got.cpu(), want), (case, H, W, pad, int((got.cpu() != want).sum()))
+
+
 def test_torch_library_ops_call_the_native_kernels(nat):
     """torch.ops.streammind_hip.* are the same kernels as the ctypes path (bit-identical outputs), incl. the handle-taking ops."""
     import streammind_amd.torch_ops  # noqa: F401
