@@ -658,3 +658,36 @@ def test_attention_random_shapes_against_fp32_softmax():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_fuzz.py"), "400", "13"], capture_output=True, text=True, timeout=900)
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert r.returncode == 0 and res["mismatches"] == 0 and res["cases"] + sum(res["refused_with_reason"].values()) == 400, (res, r.stderr[-400:])
+
+
+def test_norm_random_shapes_against_fp64():
+    """sm_norm_ex on 150 random shapes: 1..3000 rows, widths 4..8192 (the block-per-row form up to 64 rows, the fixed 1024 / 4096 one-wave-per-row forms, the
+    general one), row strides beyond the width, LayerNorm / RMSNorm, every activation behind it, fp32 and 16-bit outputs -- against fp64."""
+    from streammind_amd._lib import load, check
+    lib = load()
+    rng = np.random.default_rng(77)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    acts = {0: lambda t: t, 1: lambda t: t * torch.sigmoid(1.702 * t), 2: lambda t: torch.nn.functional.leaky_relu(t, 0.01), 3: torch.nn.functional.softplus,
+            4: torch.nn.functional.silu, 5: torch.nn.functional.gelu}
+    for case in range(150):
+        M = int(rng.choice([1, 2, 5, 16, 28, 63, 64, 65, 100, 257, 577, 1000, 3000]))
+        D = int(rng.choice([4, 8, 64, 100, 128, 256, 1000, 1024, 2048, 4096, 4100, 8192]))
+        ldx = D + 4 * int(rng.integers(0, 3))
+        ln = bool(rng.integers(0, 2))
+        act = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
+        x = torch.randn(M, ldx, generator=g, device="cuda") * 3 + 0.5
+        gamma, beta = torch.randn(D, generator=g, device="cuda").abs() + 0.3, torch.randn(D, generator=g, device="cuda") * 0.2
+        o32 = torch.empty(M, D, device="cuda")
+        o16 = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+        check(lib.sm_norm_ex(x.data_ptr(), M, D, ldx, gamma.data_ptr(), beta.data_ptr() if ln else None, 1e-5, act, o32.data_ptr(), o16.data_ptr(), D, 0,
+                             torch.cuda.current_stream().cuda_stream))
+        xd = x[:, :D].double()
+        if ln:
+            mu = xd.mean(1, keepdim=True)
+            ref = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+        else:
+            ref = xd / torch.sqrt((xd ** 2).mean(1, keepdim=True) + 1e-5) * gamma.double()
+        ref = acts[act](ref)
+        sc = float(ref.abs().max().clamp_min(1e-6))
+        assert float((o32.double() - ref).abs().max()) / sc < 2e-5, (case, M, D, ldx, ln, act)
+        assert float((o16.double() - ref).abs().max()) / sc < 2.0 ** -7, (case, M, D, ldx, ln, act)
