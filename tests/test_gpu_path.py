@@ -571,6 +571,35 @@ def test_fp8_weights_mode_gate_and_llm(gold):
             break
 
 
+@pytest.mark.parametrize("fp8", [0, 1, 2])
+def test_random_chunking_of_a_frame_stream_in_every_weight_mode(fp8):
+    """90 frames pushed in random chunks of 1..50 frames (one tower batch per call, the connector + gate pass in parts of at most 32 rows -- with fp8 weights
+    too since round 5) against the same frames pushed one by one: gate logits within 1e-3 (the row count changes the kernels and their summation order, not
+    the arithmetic), decisions equal outside a 2e-3 margin, the stored tokens within 1e-4; and both against the oracle's scan on the dequantised weights."""
+    Wv, Wc = O.make_vit_weights(TV, 41), conn_gate_weights(TC, TG, 86)
+    m = build_native(TV, TC, TG, Wv, Wc, max_frames_per_call=50, weights_fp8=fp8)
+    frames = O.synthetic_frames(90, TV.image_size, seed=321, scene_len=4).cuda()
+    one = m.open_stream(max_frames=128, max_seq=64)
+    lg1 = torch.cat([one.push_frames(frames[i:i + 1])[0] for i in range(90)])
+    rng = np.random.default_rng(5 + fp8)
+    for trial in range(3):
+        s = m.open_stream(max_frames=128, max_seq=64)
+        out, i = [], 0
+        while i < 90:
+            n = min(int(rng.choice([1, 2, 7, 16, 17, 28, 32, 33, 50])), 90 - i)
+            out.append(s.push_frames(frames[i:i + n])[0])
+            i += n
+        lg = torch.cat(out)
+        assert maxdiff(lg, lg1) < 1e-3, (fp8, trial)
+        assert maxdiff(s.tokens(0, 90), one.tokens(0, 90)) < 1e-4 * max(1.0, float(one.tokens(0, 90).abs().max()))
+        d0, d1 = (lg[:, 1] > lg[:, 0]), (lg1[:, 1] > lg1[:, 0])
+        assert bool(((d0 == d1) | ((lg1[:, 1] - lg1[:, 0]).abs() < 2e-3)).all())
+        s.close()
+    Wc8 = Wc if not fp8 else {k: (O.fp8_quantize_rows(v)[0] if (k.startswith("cls_net.") and v.dim() == 2 and "embed_tokens" not in k) else v) for k, v in Wc.items()}
+    ref = O.gate_logits_shortcut(one.tokens(0, 90).cpu(), Wc8, TG)
+    assert maxdiff(lg1, ref) < 1e-3
+
+
 def test_fp8_mfma_mode_prefill_and_teacher_forced_vs_its_oracle():
     """weights_fp8 = 2 (BASELINE configs[4], "CDNA4 fp8 MFMA"): the LLM products of calls with more than 16 rows -- a prefill chunk,
     a teacher-forced forward -- run fp8 x fp8 on the matrix pipe with per-row e4m3 activations; decode steps (one row) keep the
