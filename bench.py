@@ -1535,8 +1535,9 @@ def main():
                     fp8_leg["group_decode_16_streams"] = {"error": repr(e)[:200]}
                 try:      # 32 streams on the weight-only fp8 image (mode 1: the 17..32-row weight-streaming kernel reads fp8 and shares the rows through LDS)
                     m8.set_fp8_mode(1)
-                    g8 = group_decode_leg(m8, cfg8, sizes=(32,))
+                    g8 = group_decode_leg(m8, cfg8, sizes=(32, 64))
                     fp8_leg["group_decode_32_streams_weight_only"] = {"tokens_per_s": g8["tokens_per_s"][0], "ms_per_step": g8["ms_per_step"][0]}
+                    fp8_leg["group_decode_64_streams_weight_only"] = {"tokens_per_s": g8["tokens_per_s"][1], "ms_per_step": g8["ms_per_step"][1]}
                 except Exception as e:
                     fp8_leg["group_decode_32_streams_weight_only"] = {"error": repr(e)[:200]}
                 finally:

@@ -1672,7 +1672,11 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     if (w8_lds_on < 0) { const char* e = getenv("SM_FP8_LDS"); w8_lds_on = e ? atoi(e) : 1; }
     // (N < 4 -- the gate head's two rows -- too: every slab store of such a product takes the element path, and the bf16 expansion it would fall back to
     //  rounds q * s to bf16: 4e-3 on the gate logits where the streamed image gives 3e-5)
-    const bool w8_lds = w8 && w8_lds_on && p->M > 16 && p->M <= 32 && !p->norm_gamma && ((p->N & 3) == 0 || p->N < 4) && a.KS >= 8 && p->remap_in == 0 && !p->vt;
+    static int lds_min_m8 = -1;                   // (the same threshold as the bf16 dispatch below: SM_SKINNY_LDS_MINM)
+    if (lds_min_m8 < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m8 = e ? atoi(e) : 10; }
+    // (10..16 rows on fp8 weights: only with fp32 activations -- the connector / gate pass 568 -> 460 us at 16 rows; with 16-bit activations, a 16-stream decode step,
+    //  the <= 16-row fp8 kernels are faster: 2.97 vs 3.17 ms)
+    const bool w8_lds = w8 && w8_lds_on && (p->M > 16 || (p->M >= lds_min_m8 && p->x_dtype == SM_X_F32)) && p->M <= 32 && !p->norm_gamma && ((p->N & 3) == 0 || p->N < 4) && a.KS >= 8 && p->remap_in == 0 && !p->vt;
     if (w8 && p->M > 16 && !w8_lds && !lds64) {
         // the fp8 kernels are weight-streaming only (one MFMA column block): more rows expand the weights to a bf16 scratch
         // image (row scale folded in) and take the bf16 kernels -- 1.5x the weight bytes once per call instead of M/16 passes
@@ -1739,7 +1743,9 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             }
         }
         static int lds_min_m = -1;                    // SM_SKINNY_LDS_MINM: smallest M sent to the LDS-shared kernel (tuning)
-        if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 17; }
+        // 10 (round 5; was 17): same-box scan of the connector + gate pass -- 10 / 12 / 14 / 16 rows 521 / 557 / 586 / 625 us on the <= 16-row kernels against
+        // 502 / 513 / 511 / 518 through this one (8 rows and fewer: no difference); a 16-stream decode step 4.08 -> 3.84 ms, 12 streams equal
+        if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 10; }
         {
             static int use_lds = -1;
             if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
