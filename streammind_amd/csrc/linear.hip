@@ -1745,11 +1745,14 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         static int lds_min_m = -1;                    // SM_SKINNY_LDS_MINM: smallest M sent to the LDS-shared kernel (tuning)
         // 10 (round 5; was 17): same-box scan of the connector + gate pass -- 10 / 12 / 14 / 16 rows 521 / 557 / 586 / 625 us on the <= 16-row kernels against
         // 502 / 513 / 511 / 518 through this one (8 rows and fewer: no difference); a 16-stream decode step 4.08 -> 3.84 ms, 12 streams equal
-        if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 10; }
+        //   With 16-bit activations (a batched decode step) the crossover sits higher: 10 / 12 streams 3.77 / 3.79 ms through this kernel against ~3.62 / 3.77 on
+        //   the <= 16-row kernels, 16 streams 3.85 against 4.08 -- from 13 rows there (SM_SKINNY_LDS_MINM sets both).
+        static int lds_min_m16 = 13;
+        if (lds_min_m < 0) { const char* e = getenv("SM_SKINNY_LDS_MINM"); lds_min_m = e ? atoi(e) : 10; if (e) lds_min_m16 = lds_min_m; }
         {
             static int use_lds = -1;
             if (use_lds < 0) { const char* e = getenv("SM_SKINNY_LDS"); use_lds = e ? atoi(e) : 1; }
-            if (use_lds && p->M >= lds_min_m && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt) {
+            if (use_lds && p->M >= (xf32 ? lds_min_m : lds_min_m16) && (p->N & 3) == 0 && a.KS >= 8 && p->remap_in == 0 && !p->vt) {
                 static int ln_fuse_rows = -1;
                 if (ln_fuse_rows < 0) { const char* e = getenv("SM_POST_LN_FUSE"); ln_fuse_rows = e ? atoi(e) : 1; }
                 const PostLn ln = {p->post_ln_gamma, p->post_ln_beta, p->post_ln_eps, (bf16_t*)p->post_ln_out, p->post_ln_ldo, p->post_ln_out_f32, p->post_ln_act};
