@@ -1396,10 +1396,15 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         // RMSNorms ride behind the products that finish their rows (sm_linear_t.post_ln_*): with 17..32 active streams o_proj and down_proj
         // run as K-slice slabs and the slab sum + residual + the NEXT norm are one launch; otherwise the call ends with the norm launch
         // that used to be issued here.  Only the first layer's input norm is a launch of its own.
-        if (c.llm_layers > 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
+        // 2..3 active streams: the RMSNorms ride INSIDE the products that consume them, as in a stream's own decode loop (sm_linear_t.norm_gamma: the
+        // normalised rows live in LDS, M x K <= 16384; every block normalises all rows, so the saving ends where that work outgrows two launches --
+        // same box: 2 / 3 / 4 streams 3.03 / 3.16 / 3.27 ms per step against 3.17 / 3.20 / 3.23 with the norm launches)
+        const bool fuse_norm = S <= 3 && (long)S * ld <= 16384 && (ld & 31) == 0 && !g_no_fused_norm;
+        if (!fuse_norm && c.llm_layers > 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
         for (int l = 0; l < c.llm_layers; ++l) {
             const sm_model::LayerW& w = m->R.llm[l];
-            {   sm_linear_t a = lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
+            {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, S, ld) : lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
+                if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
                 a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
                 if ((rc = sm_linear(&a, stream))) return rc; }
             bool rope_done = false, attn_done = false;
@@ -1427,11 +1432,12 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             }
             {   sm_linear_t a = lin(m, *w.o, g->d_ctxb.p, SM_X_BF16, S, qn);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
-                a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
+                if (!fuse_norm) { a.post_ln_gamma = w.ln2_w; a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld; }
                 if ((rc = sm_linear(&a, stream))) return rc; }
             if (S <= SM_MAX_SEG || (S <= 64 && (sm_skinny_lds64_on() >= 2 || (sm_skinny_lds64_on() == 1 && c.weights_fp8)))) {
                 const Slot& gu = *w.gu;
-                sm_linear_t a = lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
+                sm_linear_t a = fuse_norm ? lin(m, gu, x, SM_X_F32, S, ld) : lin(m, gu, g->d_xnb.p, SM_X_BF16, S, ld);
+                if (fuse_norm) { a.norm_gamma = w.ln2_w; a.norm_eps = c.llm_eps; }
                 a.N = c.llm_mlp;
                 if (gu.fp8) { a.w2 = (const char*)gu.buf.p + (size_t)(c.llm_mlp / 16) * ((ld / 32 + 1) / 2) * 1024; a.w2_scale = gu.scale.as<float>() + c.llm_mlp; }
                 else a.w2 = gu.buf.as<bf16_t>() + (size_t)(c.llm_mlp / 16) * (ld / 32) * 512;
@@ -1446,13 +1452,16 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             }
             {   sm_linear_t a = lin(m, *w.down, g->d_actb.p, SM_X_BF16, S, c.llm_mlp);
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
-                a.post_ln_gamma = l + 1 < c.llm_layers ? m->R.llm[l + 1].ln1_w : m->R.llm_norm;       // the next layer's input norm / the final norm
-                a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
+                if (!fuse_norm) {
+                    a.post_ln_gamma = l + 1 < c.llm_layers ? m->R.llm[l + 1].ln1_w : m->R.llm_norm;       // the next layer's input norm / the final norm
+                    a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
+                }
                 if ((rc = sm_linear(&a, stream))) return rc; }
         }
         for (sm_stream* s : act) s->kv_len += 1;
-        if (c.llm_layers == 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
-        {   sm_linear_t a = lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
+        if (!fuse_norm && c.llm_layers == 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm_norm, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
+        {   sm_linear_t a = fuse_norm ? lin(m, *m->R.lm_head, x, SM_X_F32, S, ld) : lin(m, *m->R.lm_head, g->d_xnb.p, SM_X_BF16, S, ld);
+            if (fuse_norm) { a.norm_gamma = m->R.llm_norm; a.norm_eps = c.llm_eps; }
             a.out_f32 = g->d_log.as<float>(); a.ldo = V;
             if ((rc = sm_linear(&a, stream))) return rc; }
         for (int ch = 0; ch < NC; ++ch) {
