@@ -1118,7 +1118,7 @@ struct sm_stream_group {
     std::vector<sm_stream*> streams;
     ConnScratch w;
     // batched decode scratch (rows = streams), allocated by the first sm_group_llm_decode
-    DevBuf d_emb, d_xnb, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
+    DevBuf d_emb, d_xnb, d_xn32, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
     bool d_ready = false;
 };
 
@@ -1375,7 +1375,7 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     if (!g->d_ready) {
         const size_t R = SM_GROUP_DECODE_MAX;
 #define A(buf, bytes) if (!rc) rc = g->buf.alloc(bytes)
-        A(d_emb, R * ld * 4); A(d_xnb, R * ld * 2); A(d_qkvf, R * (qn + 2 * kn) * 4); A(d_qb, R * qn * 2); A(d_ctxb, R * qn * 2);
+        A(d_emb, R * ld * 4); A(d_xnb, R * ld * 2); A(d_xn32, (size_t)16 * ld * 4); A(d_qkvf, R * (qn + 2 * kn) * 4); A(d_qb, R * qn * 2); A(d_ctxb, R * qn * 2);
         A(d_actb, R * c.llm_mlp * 2); A(d_log, R * V * 4); A(d_ws, (size_t)SM_MAX_SEG * SM_DECODE_SPLITS * H * (dh + 2) * 4);
 #undef A
         if (rc) return rc;
@@ -1400,14 +1400,29 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         // normalised rows live in LDS, M x K <= 16384; every block normalises all rows, so the saving ends where that work outgrows two launches --
         // same box: 2 / 3 / 4 streams 3.03 / 3.16 / 3.27 ms per step against 3.17 / 3.20 / 3.23 with the norm launches)
         const bool fuse_norm = S <= 3 && (long)S * ld <= 16384 && (ld & 31) == 0 && !g_no_fused_norm;
-        if (!fuse_norm && c.llm_layers > 0 && (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, nullptr, g->d_xnb.p, ld, od, stream))) return rc;
+        // up to 8 active streams: RoPE + KV append ride in the epilogue of the q/k/v product, every row against ITS stream's cache and position (the per-row
+        // form of the kernel a stream's own decode step uses: one launch and the fp32 q/k/v round trip less per layer); its activations are fp32 rows, so the
+        // norm in front of it leaves fp32.  Worth 0.4-1 % on bf16 weights and 2-3 % on fp8 weights at 2..8 streams (same box), nothing at 12.
+        const bool fuse_rope = S <= 8 && dh == 128 && ld >= 1024 && (ld & 31) == 0 && !g_no_fused_rope;
+        if (!fuse_norm && c.llm_layers > 0 &&
+            (rc = sm_norm_ex(x, S, ld, ld, m->R.llm[0].ln1_w, nullptr, c.llm_eps, 0, fuse_rope ? g->d_xn32.as<float>() : nullptr, fuse_rope ? nullptr : g->d_xnb.p, ld, od, stream))) return rc;
         for (int l = 0; l < c.llm_layers; ++l) {
             const sm_model::LayerW& w = m->R.llm[l];
-            {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, S, ld) : lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
-                if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
-                a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
-                if ((rc = sm_linear(&a, stream))) return rc; }
             bool rope_done = false, attn_done = false;
+            {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, S, ld) : fuse_rope ? lin(m, *w.qkv, g->d_xn32.p, SM_X_F32, S, ld) : lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
+                if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
+                if (fuse_rope) {
+                    SmRopeEpi re;
+                    re.cos_tab = m->rope_cos.as<float>(); re.sin_tab = m->rope_sin.as<float>(); re.q = g->d_qb.p;
+                    re.H = H; re.KV = KV; re.S_max = S_max;
+                    for (int t = 0; t < S; ++t) { re.seg.kc[t] = act[t]->kc[l].p; re.seg.vtc[t] = act[t]->vtc[l].p; re.seg.pos[t] = act[t]->kv_len; }
+                    if ((rc = sm_linear_qkv_rope(&a, re, stream))) return rc;
+                    rope_done = true;
+                } else {
+                    a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
+                    if ((rc = sm_linear(&a, stream))) return rc;
+                }
+            }
             if (NC > 1) {           // SM_BIG_SEG streams per RoPE + append launch and per attention launch (pointer packs by value): 1 pack up to 128 streams, 4 at 512
                 rope_done = attn_done = true;
                 for (int b0 = 0; b0 < S; b0 += SM_BIG_SEG) {
@@ -1454,7 +1469,9 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                 a.residual = x; a.ldr = ld; a.out_f32 = x; a.ldo = ld;
                 if (!fuse_norm) {
                     a.post_ln_gamma = l + 1 < c.llm_layers ? m->R.llm[l + 1].ln1_w : m->R.llm_norm;       // the next layer's input norm / the final norm
-                    a.post_ln_eps = c.llm_eps; a.post_ln_out = g->d_xnb.p; a.post_ln_ldo = ld;
+                    a.post_ln_eps = c.llm_eps; a.post_ln_ldo = ld;
+                    if (fuse_rope && l + 1 < c.llm_layers) a.post_ln_out_f32 = g->d_xn32.as<float>();     // (the fused q/k/v + RoPE product reads fp32 rows)
+                    else a.post_ln_out = g->d_xnb.p;
                 }
                 if ((rc = sm_linear(&a, stream))) return rc; }
         }
