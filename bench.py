@@ -893,6 +893,102 @@ def cpu_baseline(n_frames: int = 28) -> dict:
     return out
 
 
+def pick_schedule(local: int, piped: bool, rank: int = 0, cands=(56, 28), frames_per_round=224, rounds=2) -> dict:
+    """Untimed A/B of the tower schedules on this box: `frames_per_round` frames pushed as calls of 56 (two concurrent 28-frame lanes) or of 28
+    (one lane), the connector + gate pass pipelined or not as the run will be.  Its own small model (tower + connector + gate, no LLM) and
+    stream, closed before the run's model exists.  -> {"frames_per_s": {"56": .., "28": ..}, "chosen_frames_per_call": ..}"""
+    from streammind_amd.native import NativeModel, PathConfig
+    cfg = PathConfig(llm_layers=0, max_frames_per_call=max(cands))
+    m = NativeModel(cfg, f"cuda:{local}")
+    random_weights_into(m, cfg, seed=1234)
+    m.finalize()
+    fr = synthetic_frames_gpu(frames_per_round, 336, 4321, rank)
+    st = m.open_stream(max_frames=frames_per_round * (rounds + 1) * len(cands) + 256, max_seq=64)
+    best = {}
+
+    def run(nb):
+        call = st.push_frames_pipelined if piped else st.push_frames
+        for off in range(0, frames_per_round - nb + 1, nb):
+            call(fr[off:off + nb])
+        st.join()
+        torch.cuda.synchronize()
+    for nb in cands:                      # warm both (lazy per-HIP-stream workspaces, lane streams)
+        run(nb)
+    for _ in range(rounds):
+        for nb in cands:
+            t0 = time.perf_counter()
+            run(nb)
+            r = (frames_per_round // nb * nb) / (time.perf_counter() - t0)
+            best[nb] = max(best.get(nb, 0.0), r)
+    st.close(); m.close()
+    torch.cuda.empty_cache()
+    chosen = max(cands, key=lambda nb: best[nb])
+    return {"frames_per_s": {str(nb): round(best[nb], 1) for nb in cands}, "chosen_frames_per_call": chosen, "frames_per_round": frames_per_round, "rounds": rounds,
+            "note": "untimed, before the warm-up: the same frames as calls of 56 (two concurrent tower lanes of 28) and of 28 (one lane), best of two interleaved rounds; "
+                    "the faster one is the schedule `value` is then timed on"}
+
+
+def stress_graph_leg(m8, lib, frames, nb: int, n_frames: int) -> dict:
+    """BASELINE configs[4] as it names it: the per-frame gate step CAPTURED in a hipGraph and REPLAYED over the stress stream.  One call of
+    sm_stream_push_frames(nb frames) -- tower + connector + fp8-weight gate, ~190 launches at nb = 1 -- is captured once on a side stream; every
+    replay first copies the next nb frames into the captured input buffer (a device copy on the same stream: what a decoder's ring hands over) and
+    the gate logits out of the captured output.  The Mamba state lives on the device and advances with every replay, so this IS a stream (only the
+    host's frame counter stays at its captured value: replays overwrite one token-store row, which a silent stream never reads back).  Checked in
+    the run: the logits of every replayed frame equal, bit for bit, those of the same frames pushed eagerly from the same reset state."""
+    from streammind_amd import _lib
+    st_e = m8.open_stream(max_frames=n_frames + 4 * nb + 64, max_seq=64)
+    st_g = m8.open_stream(max_frames=4 * nb + 64, max_seq=64)
+    n_calls = n_frames // nb
+    lg = torch.empty(nb, 2, device="cuda"); dc = torch.empty(nb, dtype=torch.int32, device="cuda")
+    fr = torch.empty_like(frames[:nb]).contiguous()
+    hist_e = torch.empty(n_calls, nb, 2, device="cuda"); hist_g = torch.empty(n_calls, nb, 2, device="cuda")
+    side = torch.cuda.Stream()
+
+    def push(st):
+        _lib.check(lib.sm_stream_push_frames(st.h, fr.data_ptr(), nb, lg.data_ptr(), dc.data_ptr(), torch.cuda.current_stream().cuda_stream), "sm_stream_push_frames")
+
+    def eager_pass():
+        _lib.check(lib.sm_stream_reset(st_e.h, torch.cuda.current_stream().cuda_stream), "sm_stream_reset")
+        for i in range(n_calls):
+            fr.copy_(frames[(i * nb) % (frames.shape[0] - nb + 1):][:nb])
+            push(st_e)
+            hist_e[i].copy_(lg)
+    with torch.cuda.stream(side):
+        fr.copy_(frames[:nb])
+        push(st_g); push(st_e)                                   # warm-up on the capture stream (lazy per-stream workspaces)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            push(st_g)
+        torch.cuda.synchronize()
+        eager_pass()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eager_pass()
+        torch.cuda.synchronize()
+        d_e = time.perf_counter() - t0
+
+        def graph_pass():
+            _lib.check(lib.sm_stream_reset(st_g.h, torch.cuda.current_stream().cuda_stream), "sm_stream_reset")
+            for i in range(n_calls):
+                fr.copy_(frames[(i * nb) % (frames.shape[0] - nb + 1):][:nb])
+                g.replay()
+                hist_g[i].copy_(lg)
+        graph_pass()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graph_pass()
+        torch.cuda.synchronize()
+        d_g = time.perf_counter() - t0
+    same = bool(torch.equal(hist_e, hist_g))
+    st_e.close(); st_g.close()
+    n = n_calls * nb
+    return {"frames_per_call": nb, "frames": n, "captured_graph": {"seconds": round(d_g, 4), "frames_per_s": round(n / d_g, 1), "ms_per_call": round(d_g / n_calls * 1e3, 4),
+                                                                  "realtime_factor_at_60fps": round(n / d_g / 60.0, 2)},
+            "eager": {"seconds": round(d_e, 4), "frames_per_s": round(n / d_e, 1), "ms_per_call": round(d_e / n_calls * 1e3, 4)},
+            "graph_over_eager_time": round(d_g / d_e, 4), "gate_logits_bit_identical_to_eager": same}
+
+
 class _PlumbingStream:
     """SM_BENCH_PLUMBING=1 (test hook, tests/test_dist_cpu.py): stands in for the native stream so that the N > 1 CONTROL FLOW of
     this file -- rendezvous, barriers, the gated-token exchange, the max-over-ranks reduction, rank 0's line -- can run under gloo
@@ -921,9 +1017,11 @@ def main():
     ap.add_argument("--steps", type=int, default=32, help="timed steps.  The timed region is always about ONE pass over the 1800-frame (60 s x 30 fps) "
                     "stream of BASELINE configs[1]: a step is round(1800 / (steps x batch)) >= 1 calls of `--batch` frames (32 steps x 56 frames: one call)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=56, help="frames per step.  > 28: the tower runs as two concurrent half batches (two lanes, "
-                                                           "sm_vit_encode); a 28-frame lane is 28 x 577 tokens = 63.1 tiles of 256 rows, so every ViT "
-                                                           "GEMM is a whole number of 256-CU rounds.  --batch 28 --no-pipeline = the round-1 configuration")
+    ap.add_argument("--batch", type=int, default=0, help="frames per call.  > 28: the tower runs as two concurrent half batches (two lanes, "
+                                                          "sm_vit_encode); a 28-frame lane is 28 x 577 tokens = 63.1 tiles of 256 rows, so every ViT "
+                                                          "GEMM is a whole number of 256-CU rounds.  --batch 28 --no-pipeline = the round-1 configuration.  "
+                                                          "Default 0 = pick between 56 (two lanes) and 28 (one lane) by a short untimed A/B on THIS box before the "
+                                                          "warm-up (config.schedule_pick); a step is 56 frames either way")
     ap.add_argument("--vit-fp16", action="store_true", help="vision-tower operands in IEEE fp16 (the reference demo's precision, "
                                                             "model/builder.py:54) instead of BASELINE configs[1]'s bf16")
     ap.add_argument("--no-pipeline", action="store_true", help="issue each timed step with the plain sm_stream_push_frames instead of "
@@ -972,8 +1070,25 @@ def main():
     from streammind_amd import _lib
     from streammind_amd.native import NativeModel, PathConfig
     lib = _lib.load()                 # raises when the HIP library is missing: there is no other compute path
-    B = a.batch
     a.pipeline = not a.no_pipeline
+    sched_pick = None
+    if a.batch <= 0:
+        # The tower schedule is picked by measurement, not by a constant (one pipelined lane of 28 frames was 2.7 % faster than
+        # two lanes of 28 on the builder's box, 3 % slower on others).  Both candidates run the SAME 56 frames per step over the same stream; untimed,
+        # before the warm-up; two interleaved rounds, best of each.
+        a.batch = 56
+        if not plumbing:
+            try:
+                sched_pick = pick_schedule(local, a.pipeline, rank)
+                a.batch = sched_pick["chosen_frames_per_call"]
+            except Exception as e:      # noqa: BLE001 -- the pick must never take the run down: the round-2..5 default stands
+                sched_pick = {"error": repr(e)[:200], "chosen_frames_per_call": 56}
+        if dist is not None and not plumbing:
+            # every rank of a node must run the same schedule (the exchange ticks once per step): rank 0's pick wins
+            pick_t = torch.tensor([a.batch], device=cdev, dtype=torch.int32)
+            dist.broadcast(pick_t, src=0)
+            a.batch = int(pick_t.item())
+    B = a.batch
     lanes = 2 if (B >= int(os.environ.get("SM_VIT_LANE_MIN", "29")) and os.environ.get("SM_VIT_LANES", "2") != "1") else 1
     LB = (B + 1) // 2 if lanes == 2 else B            # frames per tower lane: the batch of the single-lane legs and of the roofline segment
     concurrent = lanes == 2 or a.pipeline             # kernels of independent work share the chip during the timed steps
@@ -1549,8 +1664,14 @@ def main():
                                "activations; calls with more rows (prefill, teacher-forced) run fp8 x fp8 MFMA on per-token-quantised activations (weights_fp8 = 2)")
             fp8_leg["stress_60fps"] = {"frames": n60, "seconds": round(d60, 3), "frames_per_s": round(n60 / d60, 1),
                                        "realtime_factor_at_60fps": round(n60 / d60 / 60.0, 1),
-                                       "note": "BASELINE configs[4]: 60 fps x 60 s synthetic stream, full CLIP tower (bf16) + connector + fp8-weight gate; "
-                                               "hipGraph capture of the step measured and not used (profiles/r02_graph_ab.json: replay 0.3-1 % slower)"}
+                                       "note": "BASELINE configs[4]: 60 fps x 60 s synthetic stream, full CLIP tower (bf16) + connector + fp8-weight gate, eager calls of "
+                                               f"{B} frames; `captured_per_frame_step` / `captured_28_frame_step` are the configuration AS NAMED (hipGraph-captured gate step, "
+                                               "replayed; eager stays the product default: the replay is no faster)"}
+            for key, nb_, nfr in (("captured_per_frame_step", 1, 600), ("captured_28_frame_step", 28, 3584)):
+                try:       # (600 one-frame replays = 10 s of the 60 fps stream: bounded, ~1.4 s of GPU time each way)
+                    fp8_leg["stress_60fps"][key] = stress_graph_leg(m8, lib, frames, nb_, nfr)
+                except Exception as e:
+                    fp8_leg["stress_60fps"][key] = {"error": repr(e)[:300]}
             s8.close(); m8.close()
         except Exception as e:          # the optional leg must never take the headline down
             fp8_leg = {"error": repr(e)[:300]}
@@ -1567,7 +1688,7 @@ def main():
                                    f"{a.steps} steps x {cps} call(s) x {B} frames = {frames_timed} frames), {B} frames per call" + (f" (two concurrent tower lanes of {LB})" if lanes == 2 else "") +
                                    (", connector + gate pass of step i under the tower of step i+1" if a.pipeline else "") +
                                    ", one stream per GPU, random-init weights of the true shapes",
-                       "frames_per_step": B * cps, "frames_per_call": B, "calls_per_step": cps, "frames_timed_per_gpu": frames_timed, "stream_frames": n_pool, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
+                       "frames_per_step": B * cps, "frames_per_call": B, "calls_per_step": cps, "frames_timed_per_gpu": frames_timed, "stream_frames": n_pool, "tower_lanes": lanes, "frames_per_lane": LB, "streams_per_gpu": 1, "pipelined_gate_pass": bool(a.pipeline), "schedule_pick": sched_pick, "parallelism": f"replicas x{world} (stream-sharded" + (", gated-token all-gather on fire ticks)" if world > 1 else ", no collective)")},
             "frames_per_s_per_gpu": round(total_frames / dt / world, 2),
             # flat copies of the figures the legs below hold (a parser that keeps only top-level scalars still sees them)
             "fp16_tower_frames_per_s": ((fp16_tower_leg or {}).get("headline_schedule") or {}).get("frames_per_s", (fp16_tower_leg or {}).get("frames_per_s")),

@@ -375,6 +375,10 @@ int sm_llm_forward_logits(sm_stream* s, const int32_t* ids_dev, int n, float* lo
  * rows; class-weighted mean for the gate, builder.py:345-349).  Either output may be NULL.                   */
 int sm_cross_entropy(const float* logits, int n, int V, int ld, const int32_t* labels, int ignore_index, float* nll,
                      int32_t* argmax, void* stream);
+/* f1 "similarity" frame sampling (videollama2_arch.py:603-611: the top fraction of a clip's frame tokens by cosine similarity to the
+ * LAST one): out[t] = cos(x[t], ref) for the T rows of x fp32 [T][ld >= D]; torch.nn.functional.cosine_similarity's arithmetic
+ * (each norm clamped at 1e-8).  The caller ranks the T numbers.                                              */
+int sm_cosine_rows(const float* x, int T, int D, int ld, const float* ref, float* out, void* stream);
 /* a12 decode: n_steps greedy steps continuing from the last prefill/decode; out_ids_dev[n_steps] int32 device.
  * Step j emits the token predicted after the previous one, feeds it back, appends its KV.             */
 int sm_llm_decode(sm_stream* s, int n_steps, int32_t* out_ids_dev, void* stream);

@@ -125,6 +125,7 @@ SIGNATURES = {
     "sm_llm_prefill": (i32, [vp, vp, i32, vp]),
     "sm_llm_forward_logits": (i32, [vp, vp, i32, vp, vp]),
     "sm_cross_entropy": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),
+    "sm_cosine_rows": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sm_llm_decode": (i32, [vp, i32, vp, vp]),
     "sm_stream_set_next_token": (i32, [vp, vp, vp]),
     "sm_stream_logits": (vp, [vp]),

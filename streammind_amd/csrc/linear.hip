@@ -1603,8 +1603,8 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
     if (p->act == SM_ACT_SWIGLU_DUAL) {
         const int F = p->N >> 1;
         SM_REQUIRE(p->M > 16 && p->x_dtype == SM_X_BF16 && p->out_bf16 && !p->out_f32 && !p->residual && !p->vt && !p->w2 && p->remap_in == 0 && !p->post_ln_gamma &&
-                   !p->norm_gamma && (p->N & 255) == 0 && p->ldo_bf16 >= F,
-                   "sm_linear: SM_ACT_SWIGLU_DUAL needs M > 16, 16-bit x, one [gate | up] weight image with N %% 256 == 0 and a 16-bit output [M][ldo_bf16 >= N / 2] only");
+                   !p->norm_gamma && (p->N & 1) == 0 && p->ldo_bf16 >= F,
+                   "sm_linear: SM_ACT_SWIGLU_DUAL needs M > 16, 16-bit x, one [gate | up] weight image (N even) and a 16-bit output [M][ldo_bf16 >= N / 2] only");
         static int dual_fuse = -1;                    // SM_SWIGLU_FUSE=0: always the product + the SwiGLU pass (A/B)
         if (dual_fuse < 0) { const char* e = getenv("SM_SWIGLU_FUSE"); dual_fuse = e ? atoi(e) : 1; }
         const int bn = gemm_tile_choice(p);
@@ -1612,7 +1612,9 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         const bool fp8_mfma = p->w_dtype == SM_W_FP8_MFMA && p->M > 16 && (p->K & 127) == 0 && (p->ldx & 7) == 0;
         int ksl_ = 0;
         const bool fused = dual_fuse && !fp8_mfma && (!w8 || p->w_scale) &&
-                           (((bn == 256 || bn == 257) && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0) || wstream_slabs(p, &ksl_) == 1);
+                           (((bn == 256 || bn == 257) && (p->N & 255) == 0 && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0) || wstream_slabs(p, &ksl_) == 1);
+        // (N %% 256 == 0 -- whole tiles of 128 gate + 128 up rows -- is the 256 x 256 kernel's requirement only; the weight-streaming kernel takes N %% 32 == 0
+        //  and the product + SwiGLU pass below any even N: a model with llm_mlp %% 128 == 64 prefills through it)
         if (!fused) {
             SM_REQUIRE(p->ldo_bf16 == F, "sm_linear: SM_ACT_SWIGLU_DUAL outside the 256 x 256 kernel writes a dense [M][N / 2] output (ldo_bf16=%d)", p->ldo_bf16);
             float* ws = nullptr;

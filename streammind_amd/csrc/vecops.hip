@@ -979,6 +979,38 @@ extern "C" int sm_cross_entropy(const float* logits, int n, int V, int ld, const
     return SM_OK;
 }
 
+// cosine similarity of every row of x [T][D] (fp32, row stride ld) with one reference row: one wave per row, 16-byte loads, fp32 sums.
+// torch.nn.functional.cosine_similarity's arithmetic: x . r / (max(|x|, eps) * max(|r|, eps)), eps = 1e-8
+// (videollama2_arch.py:603-611 ranks the frame tokens of a clip by it: "similarity" sampling)
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ x, int T, int D, int ld, const float* __restrict__ ref,
+                                                          float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= T) return;
+    const float* xr = x + (size_t)row * ld;
+    float dot = 0.f, xx = 0.f, rr = 0.f;
+    const bool vec = ((ld | D) & 3) == 0 && (((uintptr_t)x | (uintptr_t)ref) & 15) == 0;
+    if (vec) {
+        for (int k = lane * 4; k < D; k += 256) {
+            const f32x4 a = *(const f32x4*)(xr + k), b = *(const f32x4*)(ref + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dot = __builtin_fmaf(a[j], b[j], dot); xx = __builtin_fmaf(a[j], a[j], xx); rr = __builtin_fmaf(b[j], b[j], rr); }
+        }
+    } else {
+        for (int k = lane; k < D; k += 64) {
+            const float a = xr[k], b = ref[k];
+            dot = __builtin_fmaf(a, b, dot); xx = __builtin_fmaf(a, a, xx); rr = __builtin_fmaf(b, b, rr);
+        }
+    }
+    dot = wave_sum(dot); xx = wave_sum(xx); rr = wave_sum(rr);
+    if (lane == 0) out[row] = dot / (fmaxf(sqrtf(xx), 1e-8f) * fmaxf(sqrtf(rr), 1e-8f));
+}
+extern "C" int sm_cosine_rows(const float* x, int T, int D, int ld, const float* ref, float* out, void* stream) {
+    SM_REQUIRE(x && ref && out && T > 0 && D > 0 && ld >= D, "sm_cosine_rows: bad args");
+    cosine_rows_kernel<<<cdiv(T, 4), 256, 0, (hipStream_t)stream>>>(x, T, D, ld, ref, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
 // one block per row: greedy token of row t into stream t's own pending-token word
 __global__ __launch_bounds__(1024) void argmax_rows_seg_kernel(const float* __restrict__ lg, int V, int ld, SmTokPtrs out) {
     __shared__ float bv[16];

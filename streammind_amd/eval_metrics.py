@@ -18,17 +18,35 @@ def llm_turn_metrics(logits: torch.Tensor, labels: torch.Tensor, eos_id: int = 2
     label is not IGNORE_INDEX.  -> per-video means as the script accumulates them:
     lm_ppl (mean over turns of exp(CE)), lm_correctness (mean token accuracy), lm_correct_tokens, lm_tokens, pred_ids."""
     lab = labels.reshape(-1).to("cpu")
-    lg = logits.float().to("cpu")
     turns = (lab == eos_id).nonzero(as_tuple=True)[0].tolist()
     start = [-1] + turns[:-1]
     ppls, corr, ncorr, ntok, preds = [], [], [], [], []
+    if logits.is_cuda:
+        # logits still in HBM (what `model(..., llm_eval=True)` returns): the per-row NLL and arg-max of EVERY position in one library call
+        # (sm_cross_entropy on the labels shifted by one); what is left per turn is a mean over a few dozen numbers
+        from . import native as _native
+        S = lab.numel()
+        shifted = torch.full((S,), IGNORE_INDEX, dtype=torch.int32)
+        shifted[:-1] = lab[1:].to(torch.int32)
+        lg2 = logits.reshape(S, -1)
+        nll_d, am_d = _native.cross_entropy(lg2 if lg2.dtype == torch.float32 and lg2.stride(1) == 1 else lg2.float().contiguous(), shifted)
+        nll, am = nll_d.cpu(), am_d.cpu().long()
+    else:
+        lg = logits.float()
     for a, b in zip(start, turns):
-        tl, tg = lg[a + 1:b + 1][:-1], lab[a + 1:b + 1][1:]
+        tg = lab[a + 1:b + 1][1:]
         keep = tg != IGNORE_INDEX
-        tl, tg = tl[keep], tg[keep]
-        ppls.append(torch.nn.functional.cross_entropy(tl, tg).exp())
-        ok = (tl.argmax(dim=-1) == tg).sum()
-        preds.append(tl.argmax(dim=-1).tolist())
+        tg = tg[keep]
+        if logits.is_cuda:
+            rows = torch.arange(a + 1, b)[keep]                      # position t of the turn is scored against label t + 1
+            ppls.append(nll[rows].mean().exp())
+            pred = am[rows]
+        else:                                                        # host tensors (the CPU tests of this arithmetic, golden g16)
+            tl = lg[a + 1:b + 1][:-1][keep]
+            ppls.append(torch.nn.functional.cross_entropy(tl, tg).exp())
+            pred = tl.argmax(dim=-1)
+        ok = (pred == tg).sum()
+        preds.append(pred.tolist())
         ncorr.append(ok); ntok.append(tg.numel()); corr.append(ok / tg.numel())
     n = max(len(turns), 1)
     return {"lm_ppl": float(sum(ppls) / n), "lm_correctness": float(sum(corr) / n),

@@ -213,7 +213,8 @@ def exponential_sampling_indices(n: int, percentage: float = 0.6) -> List[int]:
 
 def similarity_sampling_indices(tokens: torch.Tensor, percentage: float = 0.6) -> List[int]:
     """videollama2_arch.py:603-611: the top `percentage` frames by cosine similarity to the last one, in time order."""
-    sim = torch.nn.functional.cosine_similarity(tokens, tokens[-1].unsqueeze(0), dim=1)
+    # the T similarities are a library call (sm_cosine_rows); ranking T numbers is host bookkeeping
+    sim = _native.cosine_rows(tokens.float().contiguous(), tokens[-1])
     order = torch.argsort(sim, descending=True)
     return sorted(order[:max(int(percentage * len(order)), 1)].tolist())
 

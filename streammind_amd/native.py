@@ -422,6 +422,18 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     return nll, am
 
 
+def cosine_rows(x: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """cos(x[t], ref) for every row of fp32 x [T, D] (sm_cosine_rows; torch.nn.functional.cosine_similarity's arithmetic) -> fp32 [T]"""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    ref = ref.to(device=x.device, dtype=torch.float32).contiguous().reshape(-1)
+    T, D = x.shape
+    assert ref.numel() == D
+    out = torch.empty(T, dtype=torch.float32, device=x.device)
+    check(lib.sm_cosine_rows(x.data_ptr(), T, D, x.stride(0), ref.data_ptr(), out.data_ptr(), _stream()), "sm_cosine_rows")
+    return out
+
+
 def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, act: int = 0, residual: Optional[torch.Tensor] = None,
            out_dtype: torch.dtype = torch.float32, precise: bool = False, w_scale: Optional[torch.Tensor] = None,

@@ -36,3 +36,34 @@ def test_bench_two_ranks_one_device_gloo():
     assert ex["rows_received"] == frames_per_step * (1 + 9 + 2 + 9)
     assert d["end_to_end"]["allgather_gated_tokens"] == {"calls": 2, "rows": 2 * 4 * c["frames_per_call"]}
     assert d["decode"]["tokens_per_s_all_gpus"] > d["decode"]["tokens_per_s"] > 0
+
+
+@pytest.mark.parametrize("exchange", ["peer", "rccl"])
+def test_bench_one_rank_forced_dist_nccl(exchange):
+    """the code of BASELINE configs[3] that no 1-GPU box otherwise executes -- `init_process_group("nccl")` (RCCL), the
+    collectives of the timed loop on a real device communicator, the peer-write exchange's self-test (`sm_comm_*`: hipIpc mailbox exported and
+    mapped by the one rank there is) and, with SM_BENCH_EXCHANGE=rccl, the torch.distributed all-gather form -- run with ONE real rank through
+    bench.py's own hook (SM_BENCH_FORCE_DIST=1, bench.py main()).  A box whose RCCL or IPC path is broken fails here, not on the first 8-GPU run."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SM_BENCH_FORCE_DIST="1", SM_BENCH_EXCHANGE=exchange, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "1", "--batch", "28", "--stream-frames", "280",
+           "--no-aux", "--no-fp8", "--no-cpu-baseline", "--no-decode", "--no-prof"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["per_rank_frames_per_s"] and len(d["per_rank_frames_per_s"]) == 1
+    ex = d["gated_token_exchange"]
+    fps_ = d["config"]["frames_per_step"]
+    # steps 0..9 (warm-up included): the one rank fires on steps 0 and 9 -> two payload ticks carrying every frame token since the previous fire
+    assert ex["ticks"] == 10 and ex["payload_collectives"] == 2 and ex["rows_received"] == fps_ * (1 + 9), ex
+    if exchange == "rccl":
+        assert ex["implementation"].startswith("torch.distributed all-gather (nccl)") and ex["fallback_reason"] is None, ex
+    else:
+        # the library's own exchange must prove itself on one rank (self-test tick), else the reason is in the line and the RCCL form took over
+        assert ex["implementation"].startswith("peer_write") or (ex["fallback_reason"] and ex["implementation"].startswith("torch.distributed")), ex
+        assert ex["ranks"][0]["peer_write_self_test"] is not None
+    assert ex["ranks"][0]["device"] and ex["ranks"][0]["exchange"] == ex["implementation"]

@@ -184,6 +184,34 @@ def test_llm_sliding_window_prefill_and_decode_beyond_the_window():
     assert outs["full"][1] != got or maxdiff(lgN, outs["full"][2]) > 1e-2      # ... and so does the windowed decode
 
 
+def test_llm_mlp_width_not_a_multiple_of_128_prefills_beyond_32_rows():
+    """round-5 advisor: SM_ACT_SWIGLU_DUAL demanded N % 256 == 0 (llm_mlp % 128 == 0) BEFORE choosing between the fused 256 x 256 kernel and
+    the product + SwiGLU pass, so a decoder with llm_mlp % 128 == 64 (sm_model_create asks for % 64) failed with SM_EINVAL on every prefill
+    of more than 32 rows.  A tiny decoder with mlp = 320: a 150-token prefill (> 32 rows: the gate | up product of a chunk) and 20 greedy
+    steps against the oracle in its mixed-precision mode."""
+    from tests.util_models import build_native, conn_gate_weights
+    import dataclasses
+    TL320 = dataclasses.replace(TL, mlp=320)
+    Wv, Wc, Wl = O.make_vit_weights(TV, 1), conn_gate_weights(TC, TG, 2), O.make_lm_weights(TL320, 3)
+    emb = torch.randn(150, TL.hidden, generator=torch.Generator().manual_seed(6)) * 0.5
+    ids = (-torch.arange(1, emb.shape[0] + 1, dtype=torch.int32)).cuda()
+    m = build_native(TV, TC, TG, Wv, Wc, TL320, Wl)
+    s = m.open_stream(max_frames=256, max_seq=256)
+    _load_tokens(s, emb)
+    s.prefill(ids)
+    lg0, _ = s.logits()
+    got = s.decode(20).cpu().tolist()
+    s.close(); m.close()
+    ref_ids, trace = O.greedy_generate(emb, Wl, TL320, 20, eos_token_id=None, prec=O.MIXED, return_logits=True)
+    assert maxdiff(lg0, trace[0]) < 3e-2
+    for j, (a, b) in enumerate(zip(got, ref_ids)):
+        margin = float(torch.topk(trace[j], 2).values.diff().abs())
+        if margin > 2 * 3e-2:
+            assert a == b, (j, a, b, margin)
+        if a != b:
+            break
+
+
 def _load_tokens(stream, emb):
     stream.write_tokens(0, emb.float().cuda().contiguous())
 
@@ -678,8 +706,12 @@ def test_teacher_forced_forward_vs_reference_golden(tiny, gold, tiny_tokenizer, 
     assert maxdiff(out.logits[0], torch.from_numpy(g[f"logits_{sample_type}"])) < 3e-2
     assert abs(float(out.loss) - float(g[f"loss_{sample_type}"])) < 2e-2
     if sample_type == "all":
+        assert out.logits.is_cuda                      # ... so the per-row NLL / arg-max below is sm_cross_entropy, not a torch op
         r = M.llm_turn_metrics(out.logits[0], lab)
         assert abs(r["lm_ppl"] - float(g["lm_ppl"])) < 0.03 * float(g["lm_ppl"])
+        rc = M.llm_turn_metrics(out.logits[0].cpu(), lab)            # the host form of the same arithmetic (golden g16 pins it on CPU)
+        assert abs(r["lm_ppl"] - rc["lm_ppl"]) < 1e-4 * rc["lm_ppl"] and r["pred_ids"] == rc["pred_ids"]
+        assert (r["lm_correctness"], r["lm_correct_tokens"], r["lm_tokens"]) == (rc["lm_correctness"], rc["lm_correct_tokens"], rc["lm_tokens"])
         # the forward leaves a reusable KV prefix: decoding continues from the teacher-forced context
         assert model.stream.kv_len == len(lab[0])
         assert model.stream.decode(2).shape == (2,)
@@ -725,6 +757,20 @@ def test_cross_entropy_op():
     ref = torch.nn.functional.cross_entropy(lg, lab, ignore_index=-100, reduction="none")
     assert maxdiff(nll, ref) < 2e-5
     assert am.cpu().tolist() == lg.argmax(dim=-1).tolist() and int(am[5]) == 17
+
+
+def test_cosine_rows_op():
+    """sm_cosine_rows (the "similarity" frame sampling's ranking key, videollama2_arch.py:603-611) against torch: aligned rows, a strided view,
+    an odd width (scalar path), a zero row (norm clamped at 1e-8 -> 0)."""
+    from streammind_amd import native
+    g = torch.Generator().manual_seed(11)
+    for T, D, ld in ((37, 4096, 4096), (5, 1024, 1536), (9, 203, 203)):
+        x = torch.randn(T, ld, generator=g)
+        x[T // 2] = 0.0
+        xv = x.cuda()[:, :D]
+        got = native.cosine_rows(xv, xv[-1])
+        ref = torch.nn.functional.cosine_similarity(x[:, :D], x[-1, :D].unsqueeze(0), dim=1)
+        assert maxdiff(got, ref) < 2e-6 and float(got[T // 2]) == 0.0 and abs(float(got[-1]) - 1.0) < 1e-6
 
 
 def test_full_width_teacher_forced_logits_match_prefill_and_oracle():

@@ -314,3 +314,38 @@ def test_loader_rejects_configs_the_kernels_do_not_implement():
         path_config_from_checkpoint(dict(lm, head_dim=128), vis)
     with pytest.raises(ValueError, match="select feature"):
         path_config_from_checkpoint(dict(lm, mm_vision_select_feature="cls_patch"), vis)
+
+
+def test_video_test_stream_demo_main_loop(tmp_path, monkeypatch):
+    """eval/video_test_stream_demo.py:147-182 (`run_inference_time_metric`): ONE video, the fixed instruction, every sampled frame handed
+    to `infer` alone with the carried prompt, and the reference's printed line (mm:ss from frame_id // 25, as upstream) for every frame the
+    gate fired on.  `infer` is a stub here (the tick itself is pinned by golden g6 on the GPU); what is checked is the loop: which frames
+    are fed (read_video_stream at cur_fps, last frame excluded), the argument set of each tick, prompt carry-over, the line format."""
+    import types
+    from streammind_amd.eval import video_test_stream_demo as demo
+    frames = np.zeros((200, 8, 8, 3), np.uint8)
+    frames[:, 0, 0, 0] = np.arange(200) % 256
+    np.savez(tmp_path / "v.npz", frames=frames, fps=np.float64(30.0))
+    calls = []
+
+    def fake_infer(model, video, instruct, tokenizer, do_sample=False, version="mistral_instruct", score_video=None, prompt=None, **kw):
+        calls.append(dict(first=int(video[0]), instruct=instruct, do_sample=do_sample, version=version, score_video=score_video, prompt=prompt, kw=kw))
+        fired = len(calls) % 3 == 0
+        return ("reply %d" % len(calls) if fired else None), (prompt or "P") + ("+" if fired else "")
+
+    monkeypatch.setattr(demo, "infer", fake_infer)
+    processor = lambda imgs, num_frames: [int(np.asarray(imgs[0])[0, 0, 0])]
+    args = types.SimpleNamespace(model=("M", processor, "T", "llama_2"), video_path=str(tmp_path / "v.npz"), cur_fps=2, model_path=None, model_base=None, model_name=None)
+    lines = []
+    out = demo.run_inference_time_metric(args, on_reply=lines.append)
+    want_ids = list(range(0, 199, 15))                       # 30 fps source at 2 fps: every 15th frame, the LAST frame (199) never sampled
+    assert [c["first"] for c in calls] == want_ids
+    assert all(c["instruct"] == demo.INSTRUCT and c["do_sample"] is False and c["version"] == "llama_2" and c["score_video"] is True and c["kw"] == {} for c in calls)
+    assert calls[0]["prompt"] is None and calls[1]["prompt"] == "P" and calls[3]["prompt"] == "P+"      # the prompt is carried and grows on a fire
+    fired = [want_ids[i] for i in range(len(want_ids)) if (i + 1) % 3 == 0]
+    assert [f for f, _ in out] == fired and lines == [l for _, l in out]
+    f = fired[-1]
+    assert out[-1][1] == "The content of the video until {}:{}  is: reply {}:".format(f // 25 // 60, f // 25 % 60, want_ids.index(f) + 1)
+    # the reference's filter (:163) with its never-advanced cur_min / cur_sec = -1 passes every frame; advanced, it skips the past
+    assert demo._frame_passes(0, -1, -1) and demo._frame_passes(1799, -1, -1)
+    assert not demo._frame_passes(30 * 59, 0, 59) and demo._frame_passes(30 * 60, 0, 59) and demo._frame_passes(30 * 30, 0, 29) and not demo._frame_passes(30 * 29, 0, 29)
