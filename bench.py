@@ -928,6 +928,34 @@ def pick_schedule(local: int, piped: bool, rank: int = 0, cands=(56, 28), frames
                     "the faster one is the schedule `value` is then timed on"}
 
 
+def ln_fold_ab(model_, frames, nb: int, n_pool: int, rounds: int = 2, calls: int = 12) -> dict:
+    """Same-box, same-process A/B of the tower's LayerNorm folding (sm_set_vit_ln_fold; sm_linear_t.fold_*): `calls` pipelined calls of nb frames with the
+    fold off / on, interleaved `rounds` times, best of each.  -> frames/s off / on."""
+    from streammind_amd import native
+    st = model_.open_stream(max_frames=nb * (calls + 4) + 64, max_seq=64)
+    best = {0: 0.0, 1: 0.0}
+    try:
+        for mode in (0, 1):               # warm both
+            native.set_vit_ln_fold(mode)
+            st.reset(); st.push_frames_pipelined(frames[:nb]); st.join()
+        torch.cuda.synchronize()
+        for _ in range(rounds):
+            for mode in (0, 1):
+                native.set_vit_ln_fold(mode)
+                st.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(calls):
+                    st.push_frames_pipelined(frames[(i * nb) % (n_pool - nb + 1):][:nb])
+                st.join()
+                torch.cuda.synchronize()
+                best[mode] = max(best[mode], calls * nb / (time.perf_counter() - t0))
+    finally:
+        native.set_vit_ln_fold(-2)
+        st.close()
+    return {"frames_per_call": nb, "off_frames_per_s": round(best[0], 1), "on_frames_per_s": round(best[1], 1), "on_over_off": round(best[1] / best[0], 4)}
+
+
 def stress_graph_leg(m8, lib, frames, nb: int, n_frames: int) -> dict:
     """BASELINE configs[4] as it names it: the per-frame gate step CAPTURED in a hipGraph and REPLAYED over the stress stream.  One call of
     sm_stream_push_frames(nb frames) -- tower + connector + fp8-weight gate, ~190 launches at nb = 1 -- is captured once on a side stream; every
@@ -1378,6 +1406,7 @@ def main():
             torch.cuda.synchronize()
             dh16 = (time.perf_counter() - t1) / n16
             fp16_tower_leg["headline_schedule"] = {"frames_per_s": round(B / dh16, 1), "frames_per_step": B, "ms_per_step": round(dh16 * 1e3, 3)}
+            fp16_tower_leg["ln_fold_ab"] = ln_fold_ab(m16, frames, LB, n_pool)
             s16.close(); m16.close()
         except Exception as e:
             fp16_tower_leg = {"error": repr(e)[:200]}
@@ -1437,6 +1466,13 @@ def main():
                 pipe_leg["two_lanes_pipelined"] = ladder(B, True)
             pipe_leg["note"] = "identical results in every row (tests/test_gpu_path.py); single_lane_plain is the round-1 bench configuration"
             sp.close()
+            try:
+                pipe_leg["ln_fold_ab_bf16"] = ln_fold_ab(model, frames, LB, n_pool)
+                pipe_leg["ln_fold_ab_bf16"]["note"] = ("the tower's LayerNorms folded into the neighbouring products (sm_linear_t.fold_*), single lane, pipelined gate pass.  OFF by default for bf16 "
+                                                       "operands (the folded bf16 tower sits 1.2e-3 from its matching-precision oracle, the unfolded one 8.8e-4: tests/test_gpu_path.py), ON by default "
+                                                       "for the fp16 tower (fp16_tower.ln_fold_ab; 2.4e-4 from its oracle, 1.7e-4 from fp32); `value` is measured with the defaults")
+            except Exception as e:
+                pipe_leg["ln_fold_ab_bf16"] = {"error": repr(e)[:200]}
         except Exception as e:
             pipe_leg = {"error": repr(e)[:200]}
     two_leg = None

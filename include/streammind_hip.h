@@ -135,6 +135,23 @@ typedef struct sm_linear_t {
      * x_rep > 1: column k of the [M][K] operand is read from x[m][(k / (x_rep * x_rep_dh)) * x_rep_dh + k % x_rep_dh] -- x holds
      * K / x_rep columns.  Weight-streaming path only (M <= 32, fp32 x); x_rep and x_rep_dh powers of two, x_rep_dh >= 8. */
     int x_rep, x_rep_dh;
+    /* LayerNorm FOLDED into the two products around it (round 6; the ViT at >= 21 frames per lane, where every product runs on the
+     * 256 x 256 tile kernels and the LayerNorm would otherwise be a launch of its own: 100 MB each, 46 per tower pass):
+     *   LN(x) W^T + b  =  rstd[m] * ( (x * gamma) W^T  -  mu[m] * (W gamma) )  +  (W beta + b)
+     * PRODUCER (fold_stats_out != NULL; a post-LN call: out_f32, post_ln_gamma, post_ln_out, N % 256 == 0): instead of the LayerNorm the call
+     *   writes post_ln_out[m][n] = 16-bit(out_f32[m][n] * post_ln_gamma[n]) -- ONE rounding of the activation, as the LayerNorm's output has --
+     *   and fold_stats_out[(m * (N / 256) + t) * 2 + {0, 1}] = (sum, sum of squares) of row m over the 256 columns of column tile t (fp32).
+     * CONSUMER (fold_stats_in != NULL; 16-bit output only, N % 256 == 0, act none / quick_gelu): x holds those raw scaled rows of width K,
+     *   fold_stats_in their K / 256 partial sums per row; mu / rstd come from them (tiles summed in order, E[x^2] - mu^2, + fold_eps), `bias`
+     *   is ignored and the epilogue is  rstd * (acc - mu * fold_g[n]) + fold_c[n]  with fold_g = W gamma, fold_c = W beta + b (fp32 [N], the
+     *   caller's, made once: sm_model_finalize does it for the tower).
+     * Both sides exist on the 256 x 256 tile kernels only (>= 192 tiles, or tile_hint SM_TILE_256): anything else is SM_EINVAL, never a
+     * silently LayerNorm-less product. */
+    float* fold_stats_out;
+    const float* fold_stats_in;
+    const float* fold_g;
+    const float* fold_c;
+    float fold_eps;
 } sm_linear_t;
 int sm_linear(const sm_linear_t* args, void* stream);
 
@@ -332,6 +349,10 @@ int sm_model_missing(sm_model* m, char* buf, size_t buflen);
  * frames/s, results bit-identical to separate calls of the lanes.  SM_VIT_LANES=1 in the environment keeps one lane.   */
 int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void* feats_bf16_opt,
                   float* pixel_values_opt, void* stream);
+/* LayerNorm folding of the tower (sm_linear_t.fold_*; lanes of >= 21 frames, where every product runs on the 256 x 256 tile kernels): process-wide switch.
+ * -1 = the default -- the fp16 tower (vit_fp16) folds, the bf16 tower does not (its folded form sits 1.2e-3 from the matching-precision oracle, beyond the
+ * 1e-3 asserted for the benchmarked dtype) --, 0 = never, 1 = both, -2 = back to the SM_VIT_LN_FOLD environment variable / the default. */
+int sm_set_vit_ln_fold(int mode);
 /* the same from normalised pixel_values [B][3][H][W] (what the reference's callers hand to CLIPVisionTower.forward) */
 int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int dtype, int B, float* pooled, void* feats_bf16_opt,
                          void* stream);
@@ -362,6 +383,12 @@ int sm_stream_num_frames(sm_stream* s);
 const float* sm_stream_tokens(sm_stream* s);             /* device fp32 [num_frames][d_model]          */
 int sm_stream_kv_len(sm_stream* s);
 int sm_stream_set_kv_len(sm_stream* s, int n);            /* truncate the KV cache (prefix reuse)       */
+/* tokens the stream's K / V cache holds room for RIGHT NOW.  The cache starts at min(max_seq, SM_KV_INITIAL_CAP = 512) tokens and is grown
+ * (doubled, up to max_seq: reallocated and copied on the call's HIP stream) by the prefill / decode call that needs more -- a stream opened for
+ * a 4096-token context costs 64 MB of cache until it fills it, so hundreds of open streams fit beside the model in 288 GB.  The prefill chunk
+ * buffers are the MODEL's (one set per HIP stream a decoder call is issued on), not the stream's.  A call that has to grow the cache cannot be
+ * captured into a hipGraph (it allocates): run the step eagerly once at that context first. */
+int sm_stream_kv_capacity(sm_stream* s);
 /* a10+a12 prefill: n new positions; ids[i] >= 0 text token, ids[i] < 0 -> frame token (-ids[i]-1).
  * Appends to the KV cache at kv_len, leaves the greedy next token in the stream (device).           */
 int sm_llm_prefill(sm_stream* s, const int32_t* ids_dev, int n, void* stream);

@@ -132,9 +132,32 @@ class Prec:
         return x
 
 
+    # ViT LayerNorm folding (the HIP tower at >= 21 frames per lane, csrc/gemm256.hip; sm_linear_t.fold_* in include/streammind_hip.h): the LayerNorm
+    # in front of fc1 (every layer) and of q/k/v (layers >= 1) is not a pass of its own.  The GEMM that PRODUCES the residual stream x (out-proj / fc2)
+    # also writes ht = 16-bit(x * gamma) and per-row sums of x and x^2 over each 256-column tile; the GEMM that CONSUMES the LayerNorm multiplies the raw
+    # ht and applies y = rstd * (ht @ W^T - mu * (W @ gamma)) + (W @ beta + b) on its accumulators -- LayerNorm(x) @ W^T + b exactly (the reference's
+    # clip_encoder.py:41-53 arithmetic), up to WHERE the one 16-bit rounding of the activation happens (x * gamma instead of the normalised value).
+    ln_fold = False
+
+    def ln_linear(self, x: Tensor, lnw: Tensor, lnb: Tensor, w: Tensor, b: Tensor, eps: float, tile: int = 256) -> Tensor:
+        """linear(LayerNorm(x), w, b) the way the folded HIP path computes it (see ln_fold)"""
+        D = x.shape[-1]
+        parts = x.split(tile, dim=-1)
+        s1 = sum(p.sum(-1, keepdim=True) for p in parts)                  # per-tile partial sums, then the tiles in order
+        s2 = sum((p * p).sum(-1, keepdim=True) for p in parts)
+        mu = s1 / D
+        rstd = torch.rsqrt(s2 / D + eps - mu * mu)
+        ht = self.act(x * lnw)
+        return rstd * (ht @ w.t() - mu * (w @ lnw)) + (w @ lnb + b)
+
+
 FP32 = Prec("fp32")
 MIXED = Prec("mixed")
 MIXED_F16 = Prec("mixed", torch.float16)      # the ViT's optional fp16-operand mode (the reference demo's precision)
+MIXED_FOLD = Prec("mixed")                    # bf16 roundings of the tower with its LayerNorms folded into the neighbouring products (>= 21 frames per lane)
+MIXED_FOLD.ln_fold = True
+MIXED_F16_FOLD = Prec("mixed", torch.float16)
+MIXED_F16_FOLD.ln_fold = True
 MIXED_FP8ACT = Prec("mixed")                  # bf16 roundings + fp8 activation rows for products of >= 17 rows (BASELINE configs[4])
 MIXED_FP8ACT.fp8_act_rows = 17
 
@@ -371,10 +394,14 @@ def vit_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg: VitCfg, prec: Prec =
     p = f"{prefix}encoder.layers.{i}."
     B, S, D = x.shape
     H, dh = cfg.heads, cfg.head_dim
-    h = prec.act(layer_norm(x, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.eps))
-    q = prec.act(linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]))
-    k = prec.act(linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"]))
-    v = prec.act(linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]))
+    if prec.ln_fold and i >= 1:              # layer 0's LayerNorm follows the pre-LayerNorm kernel: a pass of its own
+        q, k, v = (prec.act(prec.ln_linear(x, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], W[p + f"self_attn.{n}_proj.weight"],
+                                           W[p + f"self_attn.{n}_proj.bias"], cfg.eps)) for n in "qkv")
+    else:
+        h = prec.act(layer_norm(x, W[p + "layer_norm1.weight"], W[p + "layer_norm1.bias"], cfg.eps))
+        q = prec.act(linear(h, W[p + "self_attn.q_proj.weight"], W[p + "self_attn.q_proj.bias"]))
+        k = prec.act(linear(h, W[p + "self_attn.k_proj.weight"], W[p + "self_attn.k_proj.bias"]))
+        v = prec.act(linear(h, W[p + "self_attn.v_proj.weight"], W[p + "self_attn.v_proj.bias"]))
     q = q.reshape(B, S, H, dh).transpose(1, 2)
     k = k.reshape(B, S, H, dh).transpose(1, 2)
     v = v.reshape(B, S, H, dh).transpose(1, 2)
@@ -389,8 +416,12 @@ def vit_layer(x: Tensor, W: Dict[str, Tensor], i: int, cfg: VitCfg, prec: Prec =
         ctx = torch.softmax(s, dim=-1) @ v
     ctx = prec.act(ctx.transpose(1, 2).reshape(B, S, D))
     x = x + linear(ctx, W[p + "self_attn.out_proj.weight"], W[p + "self_attn.out_proj.bias"])
-    h = prec.act(layer_norm(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.eps))
-    h = prec.act(quick_gelu(linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])))
+    if prec.ln_fold:
+        h = prec.act(quick_gelu(prec.ln_linear(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], W[p + "mlp.fc1.weight"],
+                                               W[p + "mlp.fc1.bias"], cfg.eps)))
+    else:
+        h = prec.act(layer_norm(x, W[p + "layer_norm2.weight"], W[p + "layer_norm2.bias"], cfg.eps))
+        h = prec.act(quick_gelu(linear(h, W[p + "mlp.fc1.weight"], W[p + "mlp.fc1.bias"])))
     return x + linear(h, W[p + "mlp.fc2.weight"], W[p + "mlp.fc2.bias"])
 
 

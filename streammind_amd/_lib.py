@@ -34,6 +34,7 @@ class sm_linear_t(C.Structure):
         ("norm_gamma", vp), ("norm_eps", f32), ("tile_hint", i32), ("op_dtype", i32),
         ("post_ln_gamma", vp), ("post_ln_beta", vp), ("post_ln_eps", f32), ("post_ln_out", vp), ("post_ln_ldo", i32),
         ("post_ln_out_f32", vp), ("post_ln_act", i32), ("x_rep", i32), ("x_rep_dh", i32),
+        ("fold_stats_out", vp), ("fold_stats_in", vp), ("fold_g", vp), ("fold_c", vp), ("fold_eps", f32),
     ]
 
 
@@ -122,6 +123,8 @@ SIGNATURES = {
     "sm_stream_tokens": (vp, [vp]),
     "sm_stream_kv_len": (i32, [vp]),
     "sm_stream_set_kv_len": (i32, [vp, i32]),
+    "sm_stream_kv_capacity": (i32, [vp]),
+    "sm_set_vit_ln_fold": (i32, [i32]),
     "sm_llm_prefill": (i32, [vp, vp, i32, vp]),
     "sm_llm_forward_logits": (i32, [vp, vp, i32, vp, vp]),
     "sm_cross_entropy": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),

@@ -80,7 +80,82 @@ __device__ __forceinline__ void half_rows_epilogue(const char* __restrict__ smem
     }
 }
 
-template <int ACT, int WN, bool F16>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves; F16: fp16 operands / outputs
+// sum over the 32 lanes of a half wave on the VALU: two quad permutes, the two row mirrors, one v_permlane16_swap (fixed order: deterministic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v = dpp_add<0xB1>(v);          // quad_perm [1, 0, 3, 2]
+    v = dpp_add<0x4E>(v);          // quad_perm [2, 3, 0, 1]
+    v = dpp_add<0x141>(v);         // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v = dpp_add<0x140>(v);         // row_mirror: the two halves of a 16-lane row
+    return xor16_sum(v);           // rows 0 <-> 1 (2 <-> 3)
+}
+
+// The fp32 + residual epilogue of the 256 x 256 tile as the PRODUCER of a folded LayerNorm (sm_linear_t.fold_stats_out; 512 threads, 128 staged rows
+// of 256 fp32 columns).  32 lanes own one row, 16 rows per pass, 8 passes per half tile.  Lane t holds the row's 16-byte chunks t and t + 32, so every
+// load / store INSTRUCTION covers contiguous memory (512 B of one row per half wave): the first form of this epilogue gave a lane 8 consecutive columns
+// -- two 16-byte fp32 stores per lane at a 32-byte stride, i.e. half-filled 64-byte segments twice over -- and cost +12 us per launch, what write-through
+// stores do with partial segments.  The 16-bit copy needs 8 consecutive columns per 16-byte store: lane pairs (t, t ^ 1) swap one packed chunk on the VALU
+// (quad permute), after which even lanes hold columns 8t' .. 8t' + 7 of the row's first half and odd lanes of its second half -- one store instruction, 512
+// contiguous bytes per row.  The row's sum / sum of squares over the tile's 256 columns is reduced on the VALU and written by lane 0.
+template <bool F16>
+__device__ __forceinline__ void half_rows_epilogue_fold(const char* __restrict__ smem, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
+                                                        float* __restrict__ out_f32, int ldo, bf16_t* __restrict__ out_ht, int ldh, const float* __restrict__ og,
+                                                        float* __restrict__ ostats, int ntiles, int tile_n, int m0, int M, int tid) {
+    const int t = tid & 31, rsub = tid >> 5;
+    const int n0 = tile_n * 256 + t * 4, n1 = n0 + 128;             // the lane's two chunks: columns n0 .. n0 + 3 and n1 .. n1 + 3
+    f32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    if (bias) { b0 = *(const f32x4*)(bias + n0); b1 = *(const f32x4*)(bias + n1); }
+    const f32x4 g0 = *(const f32x4*)(og + n0), g1 = *(const f32x4*)(og + n1);
+    const bool odd = t & 1;
+    // after the pair swap: even lane t -> columns 4t .. 4t + 7 (chunks t, t + 1); odd lane t -> columns 128 + 4(t - 1) .. + 7 (chunks t + 31, t + 32)
+    const int nh = tile_n * 256 + (odd ? 128 + (t - 1) * 4 : t * 4);
+#pragma unroll
+    for (int p0 = 0; p0 < 8; p0 += 2) {         // two rows (32 bytes of fp32 + 32 of residual per lane and row) in flight: the other half tile's accumulators are still live
+        f32x4 v0[2], v1[2], r0[2], r1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ml = (p0 + u) * 16 + rsub;
+            v0[u] = *(const f32x4*)(smem + ml * 1024 + ((t ^ (ml & 31)) * 16));
+            v1[u] = *(const f32x4*)(smem + ml * 1024 + (((t + 32) ^ (ml & 31)) * 16));
+            r0[u] = r1[u] = f32x4{0, 0, 0, 0};
+            if (residual && m0 + ml < M) {
+                r0[u] = *(const f32x4*)(residual + (size_t)(m0 + ml) * ldr + n0);
+                r1[u] = *(const f32x4*)(residual + (size_t)(m0 + ml) * ldr + n1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = m0 + (p0 + u) * 16 + rsub;
+            f32x4 o0, o1;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o0[j] = (v0[u][j] + b0[j]) + r0[u][j]; o1[j] = (v1[u][j] + b1[j]) + r1[u][j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += o0[j]; s2 = __builtin_fmaf(o0[j], o0[j], s2); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1 += o1[j]; s2 = __builtin_fmaf(o1[j], o1[j], s2); }
+            s1 = half_wave_sum(s1);
+            s2 = half_wave_sum(s2);
+            // 16-bit(o * gamma): chunk t in (lo0, lo1), chunk t + 32 in (hi0, hi1); the even lane hands its second chunk to the odd lane and takes the odd lane's first
+            const uint32_t lo0 = pack16<F16>(o0[0] * g0[0], o0[1] * g0[1]), lo1 = pack16<F16>(o0[2] * g0[2], o0[3] * g0[3]);
+            const uint32_t hi0 = pack16<F16>(o1[0] * g1[0], o1[1] * g1[1]), hi1 = pack16<F16>(o1[2] * g1[2], o1[3] * g1[3]);
+            const uint32_t x0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? lo0 : hi0), 0xB1, 0xf, 0xf, true);       // quad_perm [1, 0, 3, 2]: the pair partner's word
+            const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? lo1 : hi1), 0xB1, 0xf, 0xf, true);
+            const u32x4 hv = odd ? u32x4{x0, x1, hi0, hi1} : u32x4{lo0, lo1, x0, x1};
+            if (m < M) {
+                store16_wt(out_f32 + (size_t)m * ldo + n0, __builtin_bit_cast(u32x4, o0));
+                store16_wt(out_f32 + (size_t)m * ldo + n1, __builtin_bit_cast(u32x4, o1));
+                store16_wt(out_ht + (size_t)m * ldh + nh, hv);
+                if (t == 0) *(f32x2*)(ostats + ((size_t)m * ntiles + tile_n) * 2) = f32x2{s1, s2};
+            }
+        }
+    }
+}
+
+template <int ACT, int WN, bool F16, bool PFOLD = false>   // WN = wave columns along n: tile is 256(m) x 128*WN(n), 4*WN waves; F16: fp16 operands / outputs; PFOLD: producer of a folded LayerNorm (its own instantiation: inlined beside the plain epilogue it cost that kernel 192 bytes of scratch)
 __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int tiles_m, int tiles_n, int cb) {
     constexpr int BN = 128 * WN;
     constexpr int NW = 4 * WN;                       // waves
@@ -481,11 +556,21 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                 return;
             }
 #endif
+            // LayerNorm folding, consumer side (sm_linear_t.fold_stats_in): (-mu * rstd, rstd) of the lane's rows from the producer's partial sums
+            f32x2 fst[NMB];
+#pragma unroll
+            for (int mb = 0; mb < NMB; ++mb) fst[mb] = f32x2{0.f, 1.f};
+            const bool fold = a.fold_istats != nullptr;
+            if (fold) {
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb) fst[mb] = fold_row_stats(a, tile_m * G2_BM + wm * 64 + mb * MBS + lane_m);
+            }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int nl = wn * 128 + p * PS + lane_n;
-                f32x4 b4 = {0, 0, 0, 0};
-                if (a.bias) b4 = *(const f32x4*)(a.bias + tile_n * BN + nl);
+                f32x4 b4 = {0, 0, 0, 0}, g4 = {0, 0, 0, 0};
+                if (fold) { b4 = *(const f32x4*)(a.fold_ic + tile_n * BN + nl); g4 = *(const f32x4*)(a.fold_ig + tile_n * BN + nl); }
+                else if (a.bias) b4 = *(const f32x4*)(a.bias + tile_n * BN + nl);
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb) {
                     const int ml = wm * 64 + mb * MBS + lane_m;
@@ -493,7 +578,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                     float o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float t = av[j] + b4[j];
+                        float t = __builtin_fmaf(av[j], fst[mb][1], __builtin_fmaf(fst[mb][0], g4[j], b4[j]));      // fold off: av * 1 + (0 * 0 + b)
                         if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
                         o[j] = t;
                     }
@@ -557,6 +642,9 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
                     }
                 }
             }
+        } else if (PFOLD) {             // (the launcher guarantees the fast path's conditions: whole column tiles, aligned rows)
+            if constexpr (PFOLD)
+                half_rows_epilogue_fold<F16>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, a.fold_og, a.fold_ostats, tiles_n, tile_n, m0, a.M, tid);
         } else if (fast) {
             half_rows_epilogue<ACT, CPR, RPP, F16>(smem, a.bias, a.residual, a.ldr, a.out_f32, a.ldo, a.out_bf16, a.ldo_bf16, m0,
                                               tile_n * BN, a.M, tid);
@@ -590,7 +678,7 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 // The arithmetic is that of gemm256_kernel (same fragment order, same accumulation order): results are bit-identical.
 // Every barrier is a raw s_barrier: __syncthreads() is an LDS fence, which hipcc turns into s_waitcnt vmcnt(0) while LDS-DMA is in
 // flight -- exactly the wait this kernel exists to avoid.
-template <int ACT, bool F16>
+template <int ACT, bool F16, bool FOLD = false>      // FOLD: consumer of a folded LayerNorm (a.fold_istats / fold_ig / fold_ic: sm_linear_t.fold_*)
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m, int tiles_n, int cb) {
     constexpr int BN = 256;
     constexpr int STAGE = 32768, WINDOW = 4 * STAGE;
@@ -656,6 +744,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
     stage(cur, 1, 1);
     stage(cur, 2, 2);
     stage(cur, 3, 3);
+    // LayerNorm folding: (-mu * rstd, rstd) of this lane's four rows of the CURRENT tile travel through the k-loop in 8 registers; the next tile's are
+    // fetched at the START of this tile's register phase (their flight hides behind its arithmetic) and finalised behind the wait that phase ends with.
+    // Fetching them where they are used cost 2.3 us per tile in situ (q|k|v 87 -> 94 us, fc1 125 -> 135 us): the partial sums were written by the kernel
+    // before this one, from other XCDs -- every first touch is a miss, and the whole register phase waits for it.
+    // A lane's four rows (mf * 16 + i) are also the rows of the three other lane groups of its wave: lane (g, i) fetches and finalises ROW g * 16 + i only
+    // and the four groups swap results (8 ds_bpermute) -- 8 registers in flight instead of 32 (with 32 the epilogue spilled a Tile register across the
+    // tile loop, and the reload's compiler-inserted vmcnt(0) at the head of the next tile waited for the epilogue's stores).
+    f32x2 fst[4];
+    if constexpr (FOLD) {
+        const f32x2 own = fold_row_stats(a, cur.tile_m * G2_BM + wm * 64 + g * 16 + i);
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) fst[mf] = f32x2{__shfl(own[0], mf * 16 + i, 64), __shfl(own[1], mf * 16 + i, 64)};
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -742,6 +843,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         constexpr bool DUAL = ACT == SM_ACT_SWIGLU_DUAL;      // SwiGLU-dual: fragments 2f / 2f + 1 are gate / up of the same 16 columns -> 4 output fragments per wave
         constexpr int NPK = DUAL ? 4 : 8, OBN = DUAL ? 128 : 256;
         uint32_t pk[NPK][4][2];
+        f32x4 fraw[2];                 // FOLD: the next tile's partial row sums of this lane's share (one row)
+        f32x2 fst_next[4];
         if constexpr (DUAL) {
             const int F = a.N >> 1;
 #pragma unroll
@@ -759,17 +862,52 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
                 }
             }
         } else {
+        // LayerNorm folding: the NEXT tile's partial sums (plain loads, issued behind the next tile's fourth stage like the bias loads: hipcc counts its own
+        // loads only, so its waits cover the older DMA as well -- over-waiting, never early); consumed together with the column vectors below
+        if constexpr (FOLD) {
+            int mrow = nxt.tile_m * G2_BM + wm * 64 + g_e * 16 + i_e;          // this lane's share: the row of ITS lane group (see the prologue)
+            if (mrow >= a.M) mrow = a.M - 1;
+            const f32x4* sp = (const f32x4*)(a.fold_istats + (size_t)mrow * 8);
+            fraw[0] = sp[0]; fraw[1] = sp[1];
+        }
+        // (FOLD) all 16 column vectors are fetched up front and PINNED as landed (the empty asm reads them, so hipcc waits for ALL its loads there): hipcc sinks the arithmetic of the later window passes
+        // between the passes (good: it runs under the stores' flight), and with the loads left where they are used its counted waits -- it does not see
+        // the asm stores in the queue -- waited for every earlier pass's write-through stores to complete: +2 us per tile, in isolation and in situ
+        f32x4 fgv[8], fcv[8];
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int nf = 0; nf < 8; ++nf) {
+                const int nl = wn * 128 + nf * 16 + g_e * 4;
+                fcv[nf] = *(const f32x4*)(a.fold_ic + cur.tile_n * BN + nl);
+                fgv[nf] = *(const f32x4*)(a.fold_ig + cur.tile_n * BN + nl);
+            }
+            asm volatile("" : "+v"(fgv[0]), "+v"(fgv[1]), "+v"(fgv[2]), "+v"(fgv[3]), "+v"(fgv[4]), "+v"(fgv[5]), "+v"(fgv[6]), "+v"(fgv[7]),
+                              "+v"(fcv[0]), "+v"(fcv[1]), "+v"(fcv[2]), "+v"(fcv[3]), "+v"(fcv[4]), "+v"(fcv[5]), "+v"(fcv[6]), "+v"(fcv[7]));
+            // the next tile's (-mu * rstd, rstd), finalised at once (fold_row_stats' arithmetic; the 32 raw registers are free again before the tile's own arithmetic starts)
+            {
+                const f32x4 u = fraw[0], v = fraw[1];
+                const float s1 = ((u[0] + u[2]) + v[0]) + v[2], s2 = ((u[1] + u[3]) + v[1]) + v[3];
+                const float mu = s1 * a.fold_invd;
+                const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(s2, a.fold_invd, a.fold_eps) - mu * mu);
+                const float o0 = -mu * rstd;
+#pragma unroll
+                for (int mf = 0; mf < 4; ++mf) fst_next[mf] = f32x2{__shfl(o0, mf * 16 + i_e, 64), __shfl(rstd, mf * 16 + i_e, 64)};
+            }
+        }
 #pragma unroll
         for (int nf = 0; nf < 8; ++nf) {
             const int nl = wn * 128 + nf * 16 + g_e * 4;
-            f32x4 b4 = {0, 0, 0, 0};
-            if (a.bias) b4 = *(const f32x4*)(a.bias + cur.tile_n * BN + nl);
+            f32x4 b4 = {0, 0, 0, 0}, g4 = {0, 0, 0, 0};
+            if constexpr (FOLD) { b4 = fcv[nf]; g4 = fgv[nf]; }
+            else if (a.bias) b4 = *(const f32x4*)(a.bias + cur.tile_n * BN + nl);
 #pragma unroll
             for (int mf = 0; mf < 4; ++mf) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = acc[nf][mf][j] + b4[j];
+                    float t;
+                    if constexpr (FOLD) t = __builtin_fmaf(acc[nf][mf][j], fst[mf][1], __builtin_fmaf(fst[mf][0], g4[j], b4[j]));
+                    else t = acc[nf][mf][j] + b4[j];
                     if (ACT == SM_ACT_QUICK_GELU) t = t * sigmoidf_(1.702f * t);
                     o[j] = t;
                 }
@@ -780,6 +918,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) fst[mf] = fst_next[mf];          // (the register phase above was the last reader of this tile's)
+        }
         // ---- window passes: pass qn moves columns [32 qn, 32 qn + 32) of both 128-column halves (fragments 2 qn, 2 qn + 1 of
         // every wave).  Window row = 128 B (8 chunks of 16 B: 4 of the wn = 0 half, 4 of the wn = 1 half), chunk index XOR
         // ((row >> 1) & 7): the 16 lanes of a ds_write_b64 group meet 16 distinct (row parity, chunk) bank groups.
@@ -836,6 +978,7 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<-1, WN, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        if constexpr (WN == 2) SM_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<0, WN, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const dim3 grid(tiles_m * tiles_n, S);              // S > 1 (WN == 2, one-tile kernel only): split-K slabs, see the kernel
@@ -864,15 +1007,20 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
                 SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<0, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
                 SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<1, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
                 SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<SM_ACT_SWIGLU_DUAL, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+                SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<0, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
+                SM_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<1, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768));
                 attr_p = true;
             }
         }
         const bool bf16_only = a.out_bf16 && !a.out_f32 && !a.residual && !a.vt && a.remap_in == 0 && (a.ldo_bf16 & 7) == 0 &&
                                ((uintptr_t)a.out_bf16 & 15) == 0 && (a.N % BN) == 0 && (act == SM_ACT_NONE || act == SM_ACT_QUICK_GELU || dual);
-        if (persist && allow_persistent && bf16_only && n_cu >= 8 && (n_cu & 7) == 0 && (nblk & 7) == 0 && nblk > n_cu && (a.KS & 3) == 0 && a.KS >= 8 &&
+        if (persist && allow_persistent && bf16_only && (!a.fold_istats || a.fold_itiles == 4) && n_cu >= 8 && (n_cu & 7) == 0 && (nblk & 7) == 0 && nblk > n_cu && (a.KS & 3) == 0 && a.KS >= 8 &&
             (cb == 0 || (nblk >> 3) % tiles_n == 0)) {
             const dim3 pgrid(n_cu);
-            if (act == SM_ACT_NONE) gemm256p_kernel<0, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            if (a.fold_istats && !dual) {
+                if (act == SM_ACT_NONE) gemm256p_kernel<0, F16, true><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+                else gemm256p_kernel<1, F16, true><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
+            } else if (act == SM_ACT_NONE) gemm256p_kernel<0, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
             else if (dual) gemm256p_kernel<SM_ACT_SWIGLU_DUAL, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
             else gemm256p_kernel<1, F16><<<pgrid, 512, 5 * 32768, st>>>(a, tiles_m, tiles_n, cb);
             SM_LAUNCH_CHECK();
@@ -885,6 +1033,15 @@ static int launch_wn(const LinArgs& a, int act, hipStream_t st, bool allow_persi
             SM_LAUNCH_CHECK();
             return SM_OK;
         }
+    }
+    if (a.fold_ostats) {
+        // producer of a folded LayerNorm: the one-tile kernel's fp32 epilogue in its own instantiation (sm_linear checked the rest)
+        if constexpr (WN == 2) {
+            if (act != SM_ACT_NONE || S > 1 || (a.N % BN) || a.vt || a.remap_in || !a.out_f32 || !a.out_bf16 || !a.fold_og) return SM_EINVAL;
+            gemm256_kernel<0, WN, F16, true><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
+            SM_LAUNCH_CHECK();
+            return SM_OK;
+        } else return SM_EINVAL;
     }
     if (act == SM_ACT_NONE) gemm256_kernel<0, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);
     else if (act == SM_ACT_QUICK_GELU) gemm256_kernel<1, WN, F16><<<grid, 256 * WN, LDS, st>>>(a, tiles_m, tiles_n, cb);

@@ -1490,6 +1490,13 @@ static void fill_args(const sm_linear_t* p, LinArgs& a) {
     a.f16 = p->op_dtype == SM_OP_F16;
     a.xr_sh = a.xr_dh_sh = 0;
     if (p->x_rep > 1) { while ((1 << a.xr_sh) < p->x_rep) ++a.xr_sh; while ((1 << a.xr_dh_sh) < p->x_rep_dh) ++a.xr_dh_sh; }
+    // LayerNorm folding (sm_linear validates the call): the producer's 16-bit copy travels in the out_bf16 slot
+    a.fold_og = nullptr; a.fold_ostats = p->fold_stats_out;
+    if (p->fold_stats_out) { a.fold_og = p->post_ln_gamma; a.out_bf16 = (bf16_t*)p->post_ln_out; a.ldo_bf16 = p->post_ln_ldo; }
+    a.fold_istats = p->fold_stats_in; a.fold_ig = p->fold_g; a.fold_ic = p->fold_c;
+    a.fold_itiles = p->fold_stats_in ? p->K / 256 : 0;
+    a.fold_invd = p->fold_stats_in ? 1.0f / (float)p->K : 0.f;
+    a.fold_eps = p->fold_eps;
 }
 
 // the decode step's q/k/v product with RoPE + KV append in the epilogue (SmRopeEpi, host.h): 16-bit or fp8 weights, head_dim
@@ -1631,6 +1638,23 @@ extern "C" int sm_linear(const sm_linear_t* p, void* stream) {
         SM_REQUIRE((p->post_ln_out || p->post_ln_out_f32) && p->out_f32 && !p->out_bf16 && p->remap_in == 0 && !p->vt && !p->w2 && p->post_ln_ldo >= p->N && (p->post_ln_ldo & 3) == 0,
                    "sm_linear: post-norm needs gamma, an output [M][post_ln_ldo >= N, %% 4 == 0] (16-bit and / or fp32), an fp32 product output (out_bf16 is not written by the fused "
                    "slab-sum + norm passes: leave it NULL) and plain rows");
+    if (p->fold_stats_out || p->fold_stats_in) {
+        // LayerNorm folding (sm_linear_t.fold_*): both sides live in the 256 x 256 tile kernels' epilogues
+        const int bn = gemm_tile_choice(p);
+        const bool w8f = p->w_dtype == SM_W_FP8 || p->w_dtype == SM_W_FP8_MFMA;
+        SM_REQUIRE(!(p->fold_stats_out && p->fold_stats_in), "sm_linear: a call is the producer OR the consumer of a folded LayerNorm");
+        SM_REQUIRE((bn == 256 || bn == 257) && p->M > 128 && (p->N & 255) == 0 && !w8f && p->x_dtype == SM_X_BF16 && !p->vt && p->remap_in == 0 && !p->w2 && !p->norm_gamma &&
+                   p->x_rep <= 1, "sm_linear: LayerNorm folding needs the 256 x 256 tile kernel (>= 192 tiles or tile_hint SM_TILE_256, N %% 256 == 0, plain 16-bit operands; M=%d N=%d)", p->M, p->N);
+        if (p->fold_stats_out)
+            SM_REQUIRE(p->post_ln_gamma && p->post_ln_out && !p->post_ln_out_f32 && p->post_ln_act == SM_ACT_NONE && p->out_f32 && !p->out_bf16 && p->act == SM_ACT_NONE &&
+                       (p->ldo & 3) == 0 && (p->post_ln_ldo & 7) == 0 && (!p->residual || (p->ldr & 3) == 0) &&
+                       (((uintptr_t)p->out_f32 | (uintptr_t)p->post_ln_out | (uintptr_t)p->residual | (uintptr_t)p->post_ln_gamma | (uintptr_t)p->bias) & 15) == 0 && ((uintptr_t)p->fold_stats_out & 7) == 0,
+                       "sm_linear: the producer of a folded LayerNorm is an fp32 (+ residual) product with post_ln_gamma / post_ln_out (16-byte aligned rows)");
+        else
+            SM_REQUIRE(p->fold_g && p->fold_c && (p->K & 255) == 0 && p->out_bf16 && !p->out_f32 && !p->residual && !p->post_ln_gamma && (p->ldo_bf16 & 7) == 0 && ((uintptr_t)p->out_bf16 & 15) == 0 &&
+                       (((uintptr_t)p->fold_g | (uintptr_t)p->fold_c | (uintptr_t)p->fold_stats_in) & 15) == 0 && (p->act == SM_ACT_NONE || p->act == SM_ACT_QUICK_GELU),
+                       "sm_linear: the consumer of a folded LayerNorm is a 16-bit-output product (K %% 256 == 0, act none / quick_gelu) with fold_g / fold_c");
+    }
     if (p->x_rep > 1)
         SM_REQUIRE(p->M <= 32 && p->x_dtype == SM_X_F32 && p->w_dtype == SM_W_BF16 && !p->norm_gamma && (p->x_rep & (p->x_rep - 1)) == 0 && p->x_rep_dh >= 8 &&
                    (p->x_rep_dh & (p->x_rep_dh - 1)) == 0 && p->K % (p->x_rep * p->x_rep_dh) == 0 && p->ldx >= p->K / p->x_rep,
@@ -1844,8 +1868,10 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         }
         if (bn) {
             SmProfScope prof(SM_PROF_GEMM, st, ((long long)p->N << 32) | (unsigned)p->K);
+            if (p->fold_stats_out) *ln_done = true;          // the folded LayerNorm's producer: no norm launch behind it (the consumer applies mu / rstd)
             return launch_gemm256(a, p->act, bn, st);
         }
+        SM_REQUIRE(!p->fold_stats_out && !p->fold_stats_in, "sm_linear: internal: LayerNorm folding outside the 256 x 256 kernel");
     }
     SM_REQUIRE((a.KS & 1) == 0, "sm_linear: the 128x128 GEMM needs K padded to a multiple of 64 (K=%d)", p->K);
     int tiles_m = cdiv(p->M, GEMM_BM), tiles_n = cdiv(p->N, GEMM_BN);

@@ -26,7 +26,38 @@ struct LinArgs {
     float neps;
     int f16;                    // 16-bit operands AND 16-bit outputs are IEEE fp16 instead of bf16 (tiled GEMM path only)
     int xr_sh, xr_dh_sh;        // repeated column groups of x (sm_linear_t.x_rep): log2(x_rep) (0 = off), log2(x_rep_dh)
+    // LayerNorm folding (sm_linear_t.fold_*; 256 x 256 tile kernels only).  Producer (fp32 + residual outputs): out_bf16 holds 16-bit(o * fold_og[n])
+    // and fold_ostats[(m * (N / 256) + tile_n) * 2 + {0, 1}] the row's (sum, sum of squares) over the tile's 256 columns.  Consumer (16-bit outputs):
+    // the accumulators S of the raw scaled rows become rstd[m] * (S - mu[m] * fold_ig[n]) + fold_ic[n], mu / rstd from row m's fold_itiles partial sums.
+    const float* fold_og;
+    float* fold_ostats;
+    const float* fold_istats;
+    const float* fold_ig;
+    const float* fold_ic;
+    int fold_itiles;
+    float fold_invd, fold_eps;
 };
+
+// (-mu * rstd, rstd) of row m from the partial sums the producing GEMM left: tiles in order (deterministic), E[x^2] - mu^2
+static __device__ __forceinline__ f32x2 fold_row_stats(const LinArgs& a, int m) {
+    if (m >= a.M) m = a.M - 1;
+    float s1, s2;
+    if (a.fold_itiles == 4) {                    // the tower's width (1024): one row's partials are 32 contiguous bytes
+        const f32x4* p = (const f32x4*)(a.fold_istats + (size_t)m * 8);
+        const f32x4 u = p[0], v = p[1];
+        s1 = ((u[0] + u[2]) + v[0]) + v[2];
+        s2 = ((u[1] + u[3]) + v[1]) + v[3];
+    } else {
+        s1 = s2 = 0.f;
+        for (int t = 0; t < a.fold_itiles; ++t) {
+            const f32x2 v = *(const f32x2*)(a.fold_istats + ((size_t)m * a.fold_itiles + t) * 2);
+            s1 += v[0]; s2 += v[1];
+        }
+    }
+    const float mu = s1 * a.fold_invd;
+    const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(s2, a.fold_invd, a.fold_eps) - mu * mu);
+    return f32x2{-mu * rstd, rstd};
+}
 
 // column of the stored x row that operand column k reads (k a multiple of 8: a fragment's 8 columns stay inside one group)
 static __device__ __forceinline__ int xcol(const LinArgs& a, int k) {

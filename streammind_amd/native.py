@@ -209,6 +209,11 @@ class NativeStream:
     def set_kv_len(self, n: int) -> None:
         check(self.lib.sm_stream_set_kv_len(self.h, n), "sm_stream_set_kv_len")
 
+    @property
+    def kv_capacity(self) -> int:
+        """tokens the K / V cache holds room for right now (grows with the context up to max_seq: sm_stream_kv_capacity)"""
+        return self.lib.sm_stream_kv_capacity(self.h)
+
     def push_pooled(self, pooled: torch.Tensor):
         assert pooled.dtype == torch.float32 and pooled.is_cuda and pooled.is_contiguous()
         M = pooled.shape[0]
@@ -422,6 +427,11 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int 
     return nll, am
 
 
+def set_vit_ln_fold(mode: int) -> None:
+    """tower LayerNorm folding, process-wide (sm_set_vit_ln_fold): -1 default (fp16 tower folds, bf16 does not), 0 off, 1 on for both, -2 back to SM_VIT_LN_FOLD"""
+    check(_lib.load().sm_set_vit_ln_fold(int(mode)), "sm_set_vit_ln_fold")
+
+
 def cosine_rows(x: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
     """cos(x[t], ref) for every row of fp32 x [T, D] (sm_cosine_rows; torch.nn.functional.cosine_similarity's arithmetic) -> fp32 [T]"""
     lib = _lib.load()
@@ -441,8 +451,11 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
            norm_eps: float = 0.0, tile_hint: int = 0, remap: Optional[Tuple[int, int, int]] = None,
            out: Optional[torch.Tensor] = None, fp8_mfma: bool = False, out16: Optional[torch.Tensor] = None,
            post_ln: Optional[Tuple[torch.Tensor, Optional[torch.Tensor], float, torch.Tensor]] = None, post_ln_act: int = 0,
-           x_rep: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+           x_rep: Optional[Tuple[int, int]] = None, fold_out: Optional[torch.Tensor] = None,
+           fold_in: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
     """Operator-level entry used by the parity tests: y = epilogue(x @ W^T); norm_gamma: RMSNorm of x fused in front.
+    LayerNorm folding (sm_linear_t.fold_*): fold_out = stats [M, N / 256, 2] fp32 turns a post_ln call into the PRODUCER (post_ln's `out` receives
+    16-bit(y * gamma), stats the per-tile row sums); fold_in = (stats [M, K / 256, 2], g [N], c [N], eps) makes the call the CONSUMER of such rows.
     post_ln = (gamma, beta | None, eps, out [M, N]): LayerNorm (beta given) / RMSNorm of the finished fp32 rows into `out` (16-bit or fp32) from
     the same call (sm_linear_t.post_ln_*), post_ln_act applied to the normalised value; x_rep = (rep, dh): x holds K / rep columns and column
     group j of width dh is read rep times (the gate's repeat_kv in front of o_proj).
@@ -495,6 +508,13 @@ def linear(x: torch.Tensor, wp: torch.Tensor, N: int, K: int, *, w2p: Optional[t
         else:
             assert ln_out.dtype == (torch.float16 if a_f16 else torch.bfloat16)
             a.post_ln_out = ln_out.data_ptr()
+    if fold_out is not None:
+        assert post_ln is not None and fold_out.dtype == torch.float32 and fold_out.is_contiguous() and fold_out.numel() == M * (N // 256) * 2
+        a.fold_stats_out = fold_out.data_ptr()
+    if fold_in is not None:
+        st_, g_, c_, eps_ = fold_in
+        assert st_.dtype == torch.float32 and st_.is_contiguous() and st_.numel() == M * (K // 256) * 2 and g_.numel() == N and c_.numel() == N
+        a.fold_stats_in, a.fold_g, a.fold_c, a.fold_eps = st_.data_ptr(), g_.data_ptr(), c_.data_ptr(), float(eps_)
     check(lib.sm_linear(C.byref(a), _stream()), "sm_linear")
     return out
 

@@ -345,3 +345,70 @@ def test_round5_kernels_repeat_bit_for_bit(nat):
         first = fn().clone()
         for it in range(40):
             assert torch.equal(fn(), first), (name, it)
+
+
+@pytest.mark.parametrize("M,f16,persistent", [(VIT_M, False, True), (VIT_M, True, True), (24 * 577, False, False), (VIT_M + 77, False, False)],
+                         ids=["28f_bf16_persistent", "28f_fp16_persistent", "24f_bf16_one_tile", "ragged_rows"])
+def test_layernorm_folded_into_the_256_tile_products(nat, M, f16, persistent):
+    """LayerNorm folding (sm_linear_t.fold_*, round 6): the PRODUCER -- out-proj's shape, fp32 + in-place residual -- leaves the fp32 rows, 16-bit(x * gamma)
+    and the per-256-column-tile row sums; the CONSUMER -- fc1's shape (quick_gelu) and q|k|v's (none) -- multiplies the raw rows and applies mean / 1/std on
+    its accumulators.  Against fp64 on the host: the producer's three outputs each to their own bar (fp32 rows 1e-5, the 16-bit copy one rounding of the
+    GPU's own fp32 row, the sums 1e-5 of their magnitude), and the consumer against LayerNorm-then-linear in fp64 of the rows the GPU left (so only the fold's
+    own arithmetic is measured: bf16 output, 5e-3 as every 16-bit-output product here; fp16 5e-4).  Row means are pushed away from zero (+0.7) so that the
+    mu * (W gamma) term matters.  28 frames run the persistent consumer, 24 frames (55 row tiles: not whole XCD bands) the one-tile kernel's epilogue."""
+    D, F, eps = 1024, 4096, 1e-5
+    dt = torch.float16 if f16 else torch.bfloat16
+    rd = (lambda t: t.half().float()) if f16 else O.bf16_round
+    wo, ctx = rd(rnd((D, D), 21, D ** -0.5)), rd(rnd((M, D), 22))
+    bo, x0 = rnd((D,), 23, 0.1), rnd((M, D), 24) + 0.7
+    gam, bet = 1.0 + 0.2 * rnd((D,), 25), 0.1 * rnd((D,), 26)
+    x = x0.cuda().clone()
+    ht = torch.empty(M, D, dtype=dt, device="cuda")
+    stats = torch.full((M, D // 256, 2), float("nan"), device="cuda")
+    nat.linear(ctx.cuda().to(dt), nat.pack_weight(wo.cuda().to(dt)), D, D, bias=bo.cuda(), residual=x, out=x,
+               post_ln=(gam.cuda(), bet.cuda(), eps, ht), fold_out=stats)
+    torch.cuda.synchronize()
+    want_x = ref_linear(ctx, wo, bo, 0, x0)
+    assert relerr(x, want_x) < 1e-5
+    xg = x.cpu()                                                        # what the consumer's LayerNorm sees
+    assert torch.equal(ht.cpu(), (xg * gam).to(dt))                     # ONE rounding of the GPU's own fp32 row times gamma
+    s_ref = torch.stack([xg.double().reshape(M, D // 256, 256).sum(-1), (xg.double() ** 2).reshape(M, D // 256, 256).sum(-1)], dim=-1)
+    assert ((stats.cpu().double() - s_ref).abs() / s_ref.abs().clamp_min(1.0)).max().item() < 1e-5
+    # consumers
+    for N, act, seed in ((F, 1, 31), (3 * D, 0, 32)):
+        w = rd(rnd((N, D), seed, D ** -0.5))
+        b = rnd((N,), seed + 10, 0.1)
+        g_vec = (w.double() @ gam.double()).float().cuda()
+        c_vec = (w.double() @ bet.double() + b.double()).float().cuda()
+        got = nat.linear(ht, nat.pack_weight(w.cuda().to(dt)), N, D, act=act, out_dtype=dt, fold_in=(stats, g_vec, c_vec, eps),
+                         tile_hint=0 if persistent else SM_TILE_256_ONE)
+        torch.cuda.synchronize()
+        # fp64 of the SAME operands: rstd * (ht @ W^T - mu * (W gamma)) + (W beta + b), mu / rstd from the fp32 rows
+        mu = xg.double().mean(-1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(xg.double().var(-1, unbiased=False, keepdim=True) + eps)
+        want = torch.empty(M, N, dtype=torch.float64)
+        wt = w.double().t().contiguous()
+        for i in range(0, M, 2048):
+            t = rstd[i:i + 2048] * (ht[i:i + 2048].cpu().double() @ wt - mu[i:i + 2048] * g_vec.cpu().double()) + c_vec.cpu().double()
+            want[i:i + 2048] = O.quick_gelu(t) if act == 1 else t
+        assert relerr(got, want) < (5e-4 if f16 else 5e-3)
+        # ... and the fold IS the LayerNorm: the same product from LayerNorm(x) in fp64 differs only by where the one 16-bit rounding sits
+        ln = (xg.double() - mu) * rstd * gam.double() + bet.double()
+        plain = ref_linear(ln.float(), w, b, act, None)
+        assert relerr(want, plain) < (2e-3 if f16 else 1.5e-2)
+
+
+def test_layernorm_fold_refuses_what_the_256_tile_cannot_do(nat):
+    """both sides are SM_EINVAL outside the 256 x 256 tile kernels -- never a silently LayerNorm-less product"""
+    from streammind_amd._lib import StreamMindHipError
+    M, D = 577, 1024
+    w = nat.pack_weight(O.bf16_round(rnd((D, D), 1, D ** -0.5)).cuda().bfloat16())
+    xin = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(M, D, device="cuda")
+    ht = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(M, 4, 2, device="cuda")
+    one = torch.ones(D, device="cuda")
+    with pytest.raises(StreamMindHipError):       # one frame: 12 tiles, the 128 x 128 / split-K path
+        nat.linear(xin, w, D, D, residual=x, out=x, post_ln=(one, one, 1e-5, ht), fold_out=stats)
+    with pytest.raises(StreamMindHipError):
+        nat.linear(xin, w, D, D, out_dtype=torch.bfloat16, fold_in=(stats, one, one, 1e-5))

@@ -53,6 +53,23 @@ dual)         # SwiGLU-dual epilogue + split-K slabs on the 256 tile: operator t
 graph)        timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab.json
   FP8=1 timeout 900 python tools/graph_ab.py 2>/dev/null > $O/graph_ab_fp8.json; grep -E '"what"|eager_us"|graph_us"|over_eager' $O/graph_ab_fp8.json
   timeout 900 python -m pytest tests/test_gpu_graph.py -q 2>&1 | tail -3 ;;
+fold)         # round 6: LayerNorm folded into the 256 x 256 products (SM_VIT_LN_FOLD): operator tests, full-size parity probe (bf16 / fp16 tower), same-box A/B of the bench
+  timeout 900 python -m pytest tests/test_gpu_gemm256.py -q -x -k "layernorm" 2>&1 | tail -6 | tee $O/pytest_fold_ops.txt
+  (timeout 900 python tools/fullsize_parity_probe.py; VIT_FP16=1 timeout 900 python tools/fullsize_parity_probe.py; SM_VIT_LN_FOLD=0 timeout 900 python tools/fullsize_parity_probe.py) 2>&1 | grep -v Warning | tee $O/fold_parity_probe.txt
+  for L in 1 0 1 0; do
+    SM_VIT_LN_FOLD=$L timeout 600 python bench.py $BENCH_FAST --batch 56 2>/dev/null | line "two-lanes SM_VIT_LN_FOLD=$L"
+    SM_VIT_LN_FOLD=$L timeout 600 python bench.py $BENCH_FAST --batch 28 2>/dev/null | line "single-lane-pipelined SM_VIT_LN_FOLD=$L"
+  done | tee $O/fold_ab.txt ;;
+foldab)       # the A/B alone, bench lines kept (roofline.by_shape: which product pays for the fold in situ)
+  for L in 1 0 1 0; do
+    SM_VIT_LN_FOLD=$L timeout 600 python bench.py $BENCH_FAST ${EXTRA:-} --batch 56 2>/dev/null | grep '^{"metric"' > $O/bench_two_lanes_fold$L.json; line "two-lanes ${EXTRA:-} SM_VIT_LN_FOLD=$L" < $O/bench_two_lanes_fold$L.json
+    SM_VIT_LN_FOLD=$L timeout 600 python bench.py $BENCH_FAST ${EXTRA:-} --batch 28 2>/dev/null | grep '^{"metric"' > $O/bench_single_lane_fold$L.json; line "single-lane-pipelined ${EXTRA:-} SM_VIT_LN_FOLD=$L" < $O/bench_single_lane_fold$L.json
+    python -c "
+import json
+for f in ('two_lanes', 'single_lane'):
+    d = json.load(open('$O/bench_%s_fold$L.json' % f))['roofline']['by_shape']
+    print('   by_shape', f, {k: v['avg_launch_us'] for k, v in d.items()})"
+  done | tee $O/fold_ab${EXTRA:+_fp16}.txt ;;
 bench)        timeout 900 python bench.py 2>/dev/null | grep '^{"metric"' > $O/bench_default.json; cut -c1-600 $O/bench_default.json ;;
 *) echo "unknown step $STEP" ;;
 esac
