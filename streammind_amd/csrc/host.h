@@ -49,7 +49,9 @@ int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* 
 template <int N> struct SmDecodeSegT { void* kc[N]; void* vtc[N]; int pos[N]; };
 typedef SmDecodeSegT<SM_MAX_SEG> SmDecodeSeg;
 typedef SmDecodeSegT<SM_BIG_SEG> SmDecodeSegBig;      // every stream of a large batched decode step in ONE launch (2.5 KB of kernel arguments)
-struct SmTokPtrs { int32_t* p[SM_MAX_SEG]; };
+template <int N> struct SmTokPtrsT { int32_t* p[N]; };
+typedef SmTokPtrsT<SM_MAX_SEG> SmTokPtrs;
+typedef SmTokPtrsT<SM_BIG_SEG> SmTokPtrsBig;             // the token words of up to SM_BIG_SEG streams in one launch (1 KB of kernel arguments)
 // epilogue of the decode-step q/k/v product with RoPE + KV append fused in (linear.hip sm_linear_qkv_rope): row i of the
 // activations is stream i's token at seg.pos[i]; q goes out rotated as bf16 [M][H*dh], k rotated into seg.kc[i], v transposed
 // into seg.vtc[i] -- the arithmetic of rope_kv_kernel on the fp32 accumulators, without the fp32 round trip and its launch
@@ -79,6 +81,10 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
                         int f16, void* stream);
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);
+// the same two per-stream kernels of a batched decode step for up to SM_BIG_SEG streams per launch (round 6: at 512 streams the token gather and the arg-max were
+// 16 launches of 32 rows each, 0.39 ms of a 16.4 ms step)
+int sm_embed_tokens_seg_big(const SmTokPtrsBig& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrsBig& out_rows, int col, int f16, void* stream);
+int sm_argmax_rows_seg_big(const float* logits, int S, int V, int ld, const SmTokPtrsBig& out, void* stream);
 
 // Optional in-library kernel timing (bench.py's roofline leg): when a class bit is enabled, every launch of that
 // class is bracketed by HIP events recorded ON THE LAUNCH STREAM; sm_prof_read() synchronises and sums.

@@ -1544,6 +1544,14 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     auto cn = [&](int ch) { return S - c0(ch) < SM_MAX_SEG ? S - c0(ch) : SM_MAX_SEG; };
     for (int j = 0; j < n_steps; ++j) {
         // emit the pending token of every stream (out_ids[stream][j], rows of inactive streams untouched) and feed it back
+        if (NC > 1) {               // packs of SM_BIG_SEG streams per launch
+            for (int b0 = 0; b0 < S; b0 += SM_BIG_SEG) {
+                const int bn = S - b0 < SM_BIG_SEG ? S - b0 : SM_BIG_SEG;
+                SmTokPtrsBig tok, rows;
+                for (int t = 0; t < bn; ++t) { tok.p[t] = act[b0 + t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[b0 + t] * n_steps; }
+                if ((rc = sm_embed_tokens_seg_big(tok, bn, m->R.embed->buf.p, ld, x + (size_t)b0 * ld, rows, j, f16, stream))) return rc;
+            }
+        } else
         for (int ch = 0; ch < NC; ++ch) {
             SmTokPtrs tok, rows;
             for (int t = 0; t < cn(ch); ++t) { tok.p[t] = act[c0(ch) + t]->next_tok.as<int32_t>(); rows.p[t] = out_ids + (size_t)idx[c0(ch) + t] * n_steps; }
@@ -1637,6 +1645,14 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
             if (fuse_norm) { a.norm_gamma = m->R.llm_norm; a.norm_eps = c.llm_eps; }
             a.out_f32 = g->d_log.as<float>(); a.ldo = V;
             if ((rc = sm_linear(&a, stream))) return rc; }
+        if (NC > 1) {
+            for (int b0 = 0; b0 < S; b0 += SM_BIG_SEG) {
+                const int bn = S - b0 < SM_BIG_SEG ? S - b0 : SM_BIG_SEG;
+                SmTokPtrsBig tok;
+                for (int t = 0; t < bn; ++t) tok.p[t] = act[b0 + t]->next_tok.as<int32_t>();
+                if ((rc = sm_argmax_rows_seg_big(g->d_log.as<float>() + (size_t)b0 * V, bn, V, V, tok, stream))) return rc;
+            }
+        } else
         for (int ch = 0; ch < NC; ++ch) {
             SmTokPtrs tok;
             for (int t = 0; t < cn(ch); ++t) tok.p[t] = act[c0(ch) + t]->next_tok.as<int32_t>();

@@ -5,7 +5,7 @@
 
 thread_local char g_sm_err[512] = {0};
 extern "C" const char* sm_last_error(void) { return g_sm_err; }
-extern "C" int sm_abi_version(void) { return 3; }
+extern "C" int sm_abi_version(void) { return 4; }       // 4: sm_linear_t grew by the fold_* fields (round 6)
 
 // ------------------------------------------------------------------------------------------------ profiling hooks
 #include <vector>
@@ -872,8 +872,9 @@ int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, co
 }
 
 // row t: emit stream t's pending token (out_rows.p[t][col]) and gather its embedding
-__global__ void embed_tokens_seg_kernel(SmTokPtrs tok, const bf16_t* __restrict__ table, int D, float* __restrict__ out,
-                                        SmTokPtrs out_rows, int col, int f16) {
+template <typename PACK>
+__global__ void embed_tokens_seg_kernel(PACK tok, const bf16_t* __restrict__ table, int D, float* __restrict__ out,
+                                        PACK out_rows, int col, int f16) {
     const int t = blockIdx.x;
     const int id = *tok.p[t];
     if (threadIdx.x == 0) out_rows.p[t][col] = id;
@@ -882,7 +883,14 @@ __global__ void embed_tokens_seg_kernel(SmTokPtrs tok, const bf16_t* __restrict_
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table, int D, float* out, const SmTokPtrs& out_rows, int col,
                         int f16, void* stream) {
     SM_REQUIRE(table && out && S > 0 && S <= SM_MAX_SEG, "sm_embed_tokens_seg: bad args");
-    embed_tokens_seg_kernel<<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col, f16);
+    embed_tokens_seg_kernel<SmTokPtrs><<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col, f16);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+int sm_embed_tokens_seg_big(const SmTokPtrsBig& tok, int S, const void* table, int D, float* out, const SmTokPtrsBig& out_rows, int col,
+                            int f16, void* stream) {
+    SM_REQUIRE(table && out && S > 0 && S <= SM_BIG_SEG, "sm_embed_tokens_seg_big: bad args");
+    embed_tokens_seg_kernel<SmTokPtrsBig><<<S, 256, 0, (hipStream_t)stream>>>(tok, (const bf16_t*)table, D, out, out_rows, col, f16);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
@@ -1012,7 +1020,8 @@ extern "C" int sm_cosine_rows(const float* x, int T, int D, int ld, const float*
 }
 
 // one block per row: greedy token of row t into stream t's own pending-token word
-__global__ __launch_bounds__(1024) void argmax_rows_seg_kernel(const float* __restrict__ lg, int V, int ld, SmTokPtrs out) {
+template <typename PACK>
+__global__ __launch_bounds__(1024) void argmax_rows_seg_kernel(const float* __restrict__ lg, int V, int ld, PACK out) {
     __shared__ float bv[16];
     __shared__ int bi[16];
     const float* row = lg + (size_t)blockIdx.x * ld;
@@ -1039,7 +1048,13 @@ __global__ __launch_bounds__(1024) void argmax_rows_seg_kernel(const float* __re
 }
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream) {
     SM_REQUIRE(logits && S > 0 && S <= SM_MAX_SEG && V > 0, "sm_argmax_rows_seg: bad args");
-    argmax_rows_seg_kernel<<<S, 1024, 0, (hipStream_t)stream>>>(logits, V, ld, out);
+    argmax_rows_seg_kernel<SmTokPtrs><<<S, 1024, 0, (hipStream_t)stream>>>(logits, V, ld, out);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+int sm_argmax_rows_seg_big(const float* logits, int S, int V, int ld, const SmTokPtrsBig& out, void* stream) {
+    SM_REQUIRE(logits && S > 0 && S <= SM_BIG_SEG && V > 0, "sm_argmax_rows_seg_big: bad args");
+    argmax_rows_seg_kernel<SmTokPtrsBig><<<S, 1024, 0, (hipStream_t)stream>>>(logits, V, ld, out);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

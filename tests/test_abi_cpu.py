@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/streammind_hip.h but not exported"
     assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
-    assert lib.sm_abi_version() == 3
+    assert lib.sm_abi_version() == 4
     assert lib.sm_packed_elems(40, 70) == 3 * 3 * 512
 
 

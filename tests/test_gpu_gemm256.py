@@ -412,3 +412,20 @@ def test_layernorm_fold_refuses_what_the_256_tile_cannot_do(nat):
         nat.linear(xin, w, D, D, residual=x, out=x, post_ln=(one, one, 1e-5, ht), fold_out=stats)
     with pytest.raises(StreamMindHipError):
         nat.linear(xin, w, D, D, out_dtype=torch.bfloat16, fold_in=(stats, one, one, 1e-5))
+
+
+@pytest.mark.parametrize("frames,N,act", [(8, 4096, 1), (16, 4096, 1), (9, 3072, 0), (12, 4096, 1)], ids=["8f_fc1", "16f_fc1", "9f_qkv", "12f_fc1"])
+def test_whole_rounds_plus_remainder_row_split(nat, frames, N, act):
+    """round 6: a 16-bit-output product whose 256 x 256 tile count is a little over whole rounds of the chip's CUs (fc1 at 8 frames: 304
+    tiles on 256 CUs) is cut by ROWS into the whole rounds and a remainder that runs on the 128 x 128 kernel (linear.hip rowsplit_rows).  Whatever the cut,
+    every row is the same product: against fp64 at the 16-bit-output bar, over the whole output (the seam rows included), bias + quick_gelu riding along."""
+    M, K = frames * 577, 1024
+    w = O.bf16_round(rnd((N, K), 41, K ** -0.5))
+    x = O.bf16_round(rnd((M, K), 42))
+    bias = rnd((N,), 43, 0.1)
+    got = nat.linear(x.cuda().bfloat16(), nat.pack_weight(w.cuda().bfloat16()), N, K, bias=bias.cuda(), act=act, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    want = ref_linear(x, w, bias, act, None)
+    assert relerr(got, want) < 5e-3
+    seam = 4096 if frames <= 12 else 8192
+    assert relerr(got[seam - 4:seam + 4], want[seam - 4:seam + 4]) < 5e-3
