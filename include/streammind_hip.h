@@ -511,7 +511,7 @@ int sm_jpeg_entropy_decode(const uint8_t* bytes_dev, size_t bytes_total, const u
 /* The same for frames WITHOUT restart markers (restart == 0 in every frame's scan): the one serial Huffman stream of a frame is cut into subsequences of
  * 1024 bits, one GPU lane each.  A lane decodes its subsequence from a guessed decoder state and keeps a record (entry state, exit state, blocks completed);
  * in every round the lanes whose record does not enter where their predecessor's exits decode again from there and follow the stream downstream until they
- * reach an exit state already on record (a prefix code synchronises).  When the records chain (at most 32 rounds, usually 2-4) a prefix sum numbers the
+ * reach an exit state already on record (a prefix code synchronises).  When the records chain (at most 16 rounds -- JS_ROUNDS in csrc/jpeg.hip; usually 1-2, status 5 beyond) a prefix sum numbers the
  * blocks, a last pass writes the coefficients and a scan turns the DC differences into values.  max_file_bytes: the longest file of the batch (bounds the
  * lanes per frame).  status as above, plus 5 = the records did not chain (the caller decodes that batch on the host). */
 int sm_jpeg_entropy_decode_sync(const uint8_t* bytes_dev, size_t bytes_total, size_t max_file_bytes, const uint32_t* offsets_dev, const sm_jpeg_scan_t* scans_dev,

@@ -81,6 +81,8 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
                         int f16, void* stream);
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);
+// linear.hip: grow the per-HIP-stream split-K slabs / unfused-SwiGLU rows to at least these sizes NOW (set-up time), so that no request allocates
+int sm_linear_reserve(hipStream_t st, size_t slab_bytes, size_t dual_bytes);
 // the same two per-stream kernels of a batched decode step for up to SM_BIG_SEG streams per launch (round 6: at 512 streams the token gather and the arg-max were
 // 16 launches of 32 rows each, 0.39 ms of a 16.4 ms step)
 int sm_embed_tokens_seg_big(const SmTokPtrsBig& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrsBig& out_rows, int col, int f16, void* stream);

@@ -1110,11 +1110,12 @@ __global__ __launch_bounds__(1024) void splitk_reduce_norm_rows_kernel(LinArgs a
     // bias / residual / row scales as 16-byte loads (c is a multiple of 4; the residual row needs ldr % 4 == 0, which every caller of this pass
     // guarantees -- checked here so that an odd stride still takes the element loads): at 2048 rows (prefill chunks) the four element loads per
     // operand made this pass 39 us for 151 MB
-    const bool vec = (a.ldr & 3) == 0;
+    // (round-5 advisor: the BASE pointers too -- a caller's sliced bias / scale / residual with 4-byte alignment takes the element loads, not a misaligned-address fault)
+    const bool vec = (a.ldr & 3) == 0 && ((((uintptr_t)a.residual) | ((uintptr_t)a.bias) | ((uintptr_t)a.wscale)) & 15) == 0;
     f32x4 r4 = {0, 0, 0, 0}, b4 = {0, 0, 0, 0}, s4 = {1.f, 1.f, 1.f, 1.f};
     if (a.residual && vec) r4 = *(const f32x4*)(a.residual + (size_t)m * a.ldr + c);
-    if (a.bias) b4 = *(const f32x4*)(a.bias + c);
-    if (a.wscale) s4 = *(const f32x4*)(a.wscale + c);
+    if (a.bias) { if (vec) b4 = *(const f32x4*)(a.bias + c); else b4 = f32x4{a.bias[c], a.bias[c + 1], a.bias[c + 2], a.bias[c + 3]}; }
+    if (a.wscale) { if (vec) s4 = *(const f32x4*)(a.wscale + c); else s4 = f32x4{a.wscale[c], a.wscale[c + 1], a.wscale[c + 2], a.wscale[c + 3]}; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float t = acc[e];
@@ -1174,6 +1175,16 @@ int splitk_workspace(hipStream_t st, size_t bytes, float** out) {
     }
     *out = e.first;
     return SM_OK;
+}
+static int dual_workspace(hipStream_t st, size_t bytes, float** out);
+// Reserve the per-HIP-stream scratch of the tiled products up front (round-5 advisor: the split-K slabs and the unfused SwiGLU rows were grown on demand -- a
+// hipStreamSynchronize + hipFree + hipMalloc in the middle of a request, illegal under stream capture and able to run out of memory there instead of at
+// set-up).  The model calls this when it creates the LLM workspaces of a HIP stream, with the worst case of a prefill chunk; later calls never grow below that.
+int sm_linear_reserve(hipStream_t st, size_t slab_bytes, size_t dual_bytes) {
+    float* p = nullptr;
+    int rc = slab_bytes ? splitk_workspace(st, slab_bytes, &p) : SM_OK;
+    if (!rc && dual_bytes) rc = dual_workspace(st, dual_bytes, &p);
+    return rc;
 }
 int launch_splitk_reduce(const LinArgs& a, const float* ws, int S, int ldw, hipStream_t st) {
     const size_t nthr = (size_t)a.M * ((a.N + 3) / 4);

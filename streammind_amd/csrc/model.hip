@@ -185,6 +185,10 @@ struct sm_model {
             if ((rc = w->ctxb.alloc(ch * qn * 2))) return rc;
             if ((rc = w->actb.alloc(ch * c.llm_mlp * 2))) return rc;
             if ((rc = w->attn_ws.alloc((size_t)32 * c.llm_heads * (dh + 2) * 4))) return rc;       // SM_DECODE_SPLITS (= 32) partial softmaxes per head
+            // the products' own scratch on this HIP stream, worst case of a chunk, reserved now (never grown inside a request): up to 4 K slabs of
+            // [chunk][hidden] fp32 (o_proj / down_proj of a 1024..2048-row chunk) and the [rows][2 mlp] fp32 gate | up rows of a SwiGLU product that
+            // does not run fused (<= 256 rows outside the weight-streaming kernel; SM_SWIGLU_FUSE=0 grows it on demand)
+            if ((rc = sm_linear_reserve((hipStream_t)stream, (size_t)4 * ch * ld * 4, (size_t)256 * 2 * c.llm_mlp * 4))) return rc;
             e = std::move(w);
         }
         *out = e.get();

@@ -15,6 +15,7 @@ import argparse
 import asyncio
 import base64
 import json
+import contextlib
 import threading
 import time
 import uuid
@@ -186,9 +187,13 @@ class ModelWorker:
         import queue
         q, cancelled, DONE = queue.Queue(), threading.Event(), object()
 
+        dev = getattr(self.model, "device", None)
+
         def run():
             try:
-                with self._lock, torch.inference_mode():
+                # a fresh thread starts on device 0 with device 0's current stream: pin it to the model's device (round-5 advisor; `--device cuda:N`)
+                ctx = torch.cuda.device(dev) if (dev is not None and torch.cuda.is_available() and getattr(dev, "type", "cuda") == "cuda") else contextlib.nullcontext()
+                with ctx, self._lock, torch.inference_mode():
                     body(q.put, cancelled.is_set)
                 q.put(DONE)
             except BaseException as e:                      # delivered in-band to the consumer
