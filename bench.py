@@ -1561,7 +1561,7 @@ def main():
             # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot be collected by the process
             # being profiled): the newest committed summary is quoted and its source named
             traffic = traffic_src = None
-            for rnd in ("r05", "r04", "r03", "r02", "r01"):
+            for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
                 tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic.json")
                 if os.path.exists(tf):
                     traffic, traffic_src = json.load(open(tf)).get("hbm_bytes_per_launch"), f"profiles/{rnd}_gemm_traffic.json (rocprofv3 --pmc, separate run)"
@@ -1571,7 +1571,7 @@ def main():
             ktrace = None
             try:
                 import csv as _csv
-                for rnd in ("r05", "r04", "r03", "r02"):
+                for rnd in ("r06", "r05", "r04", "r03", "r02"):
                     kf = os.path.join(ROOT, "profiles", f"{rnd}_bench_steps_kernel_stats.csv")
                     if os.path.exists(kf):
                         rows = [r for r in _csv.DictReader(open(kf)) if r["Name"].startswith(("void gemm256_kernel", "void gemm256p_kernel"))]

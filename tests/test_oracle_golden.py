@@ -38,6 +38,36 @@ def test_g2_vit_tiny(gold):
     close(g["out"], O.vit_features(pix, W, cfg, O.MIXED), 3e-2)
 
 
+def test_ln_fold_mode_of_the_oracle_is_the_references_tower(gold):
+    """round 6: the oracle's LayerNorm-fold modes (O.MIXED_FOLD / O.MIXED_F16_FOLD; what the HIP tower computes at >= 21 frames per lane with the fold on:
+    rstd * ((x * gamma) W^T - mu * (W gamma)) + (W beta + b), sums per 256-column tile) restate the SAME tower.  In fp32 the fold is the reference's own
+    output (golden g2, minted from the imported reference) to 3e-5 -- pure algebra plus fp32 summation order --, and its 16-bit modes stay as near the
+    reference as the unfolded 16-bit modes do.  Width 256 so that the statistics really come from ONE tile of 256, and a second model of width 512 (two tiles)."""
+    g = gold("g2_vit_tiny")
+    im, p, h, nh, mlp, L = [int(v) for v in g["cfg"]]
+    cfg = O.VitCfg(image_size=im, patch=p, hidden=h, heads=nh, mlp=mlp, layers=L)
+    W = O.make_vit_weights(cfg, int(g["seed_w"]))
+    pix = torch.randn(3, 3, im, im, generator=torch.Generator().manual_seed(int(g["seed_x"])))
+    fold32 = O.Prec("fp32"); fold32.ln_fold = True
+    close(g["out"], O.vit_features(pix, W, cfg, fold32), 3e-5)                 # the reference's own output
+    close(g["out"], O.vit_features(pix, W, cfg, O.MIXED_FOLD), 3e-2)
+    close(g["out"], O.vit_features(pix, W, cfg, O.MIXED_F16_FOLD), 4e-3)
+    for hidden in (256, 512):
+        c2 = O.VitCfg(image_size=56, patch=14, hidden=hidden, heads=4, mlp=2 * hidden, layers=4)
+        W2 = O.make_vit_weights(c2, 7)
+        for k in list(W2):                                                     # non-trivial LayerNorm parameters and row means
+            if "layer_norm" in k and k.endswith("weight"):
+                W2[k] = W2[k] * (1.0 + 0.3 * torch.randn(W2[k].shape, generator=torch.Generator().manual_seed(len(k))))
+            if "layer_norm" in k and k.endswith("bias"):
+                W2[k] = W2[k] + 0.2 * torch.randn(W2[k].shape, generator=torch.Generator().manual_seed(len(k) + 1))
+        px = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(9)) + 0.5
+        a = O.vit_features(px, W2, c2, O.FP32)
+        assert (a - O.vit_features(px, W2, c2, fold32)).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+        d_fold = (a - O.vit_features(px, W2, c2, O.MIXED_FOLD)).abs().max().item()
+        d_plain = (a - O.vit_features(px, W2, c2, O.MIXED)).abs().max().item()
+        assert d_fold < 2.0 * d_plain + 1e-3                                   # the same class of 16-bit error, not a worse one
+
+
 def test_g2_vit_fullwidth(gold):
     g = gold("g2_vit_fullwidth")
     cfg = O.VitCfg(layers=int(g["layers"]))
