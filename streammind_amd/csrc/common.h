@@ -24,6 +24,20 @@ __device__ __forceinline__ void store16_wt(void* p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// The same store for an output that is STREAMED -- written once, read once by the next kernel -- and large enough to push the residual stream out of the
+// 256 MB Infinity Cache: fc1's activation of a 28-frame lane is 132 MB, written between out-proj's update of the 66 MB fp32 residual and fc2's read-modify-write
+// of it.  With `nt` (no allocation on the way through) the residual is still there when fc2's epilogue asks: measured in situ, same box, per launch
+// (profiles/r06_nt_store_ab.txt): fc2 123.4 -> 113.5 us (its residual read comes from the cache: 126 -> 113 us is also what fc2 costs in isolation, where the
+// residual never leaves it), fc1 116.5 -> 121.7 us (the stores go out to HBM instead of being absorbed); frames/s +0.5-1 % with two lanes, -0.3..+0.9 % single
+// lane depending on the box.  The q|k|v output the same way loses (+9.5 us on q|k|v, out-proj unchanged: its residual was resident anyway); plain `nt` (no sc1) and
+// `sc0 sc1 nt` measure like `sc1 nt` on fc2 and worse / equal on fc1.  SM_STREAM_STORE_MODS picks the bits for A/B builds (tools/build_variant.sh, tools/nt_store_ab.sh).
+#ifndef SM_STREAM_STORE_MODS
+#define SM_STREAM_STORE_MODS "sc1 nt"
+#endif
+__device__ __forceinline__ void store16_stream(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off " SM_STREAM_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // round-to-nearest-even fp32 -> bf16 bits (hardware v_cvt_pk_bf16_f32; NaN stays NaN); matches torch .to(bfloat16)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }

@@ -600,7 +600,10 @@ __global__ __launch_bounds__(256 * WN, 2) void gemm256_kernel(LinArgs a, int til
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int m = tile_m * G2_BM + (p0 + u) * 16 + (tid >> 5);
-                    if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8, v[u]);
+                    if (m < a.M) {
+                        if constexpr (ACT == SM_ACT_QUICK_GELU) store16_stream(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8, v[u]);
+                        else store16_wt(ob + (size_t)m * a.ldo_bf16 + tile_n * BN + chunk * 8, v[u]);
+                    }
                 }
             }
             TL(4);
@@ -949,7 +952,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(LinArgs a, int tiles_m
                 const u32x4 v = *(const u32x4*)(win + row * 128 + ((c ^ ((row >> 1) & 7)) * 16));
                 const int m = cur.tile_m * G2_BM + row;
                 const int n = cur.tile_n * OBN + (c >> 2) * (OBN / 2) + qn * 32 + (c & 3) * 8;
-                if (m < a.M) store16_wt(ob + (size_t)m * a.ldo_bf16 + n, v);
+                if (m < a.M) {
+                    if constexpr (ACT == SM_ACT_QUICK_GELU) store16_stream(ob + (size_t)m * a.ldo_bf16 + n, v);
+                    else store16_wt(ob + (size_t)m * a.ldo_bf16 + n, v);
+                }
             }
             if (qn < NPK / 2 - 1) {                                           // the window is free again (the reads were consumed by the stores)
                 asm volatile("" ::: "memory");

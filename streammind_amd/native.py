@@ -2,6 +2,7 @@
 computation is a libstreammind_hip.so call.  No numerical work happens in this file."""
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -535,6 +536,7 @@ class JpegDecoder:
         self.host_decode_s = 0.0     # accumulated wall time of the host (entropy) stage
         self.frames = 0
         self.gpu_entropy_frames = 0  # frames whose entropy-coded segment was decoded on the GPU
+        self.crosscheck_batches = 0  # SM_JPEG_CROSSCHECK=1: batches cross-checked so far (the checked frame rotates through the batch)
         self.keep_sync_rounds = False  # diagnostic: after a self-synchronising decode, last_sync_rounds = rounds until each frame's states settled (a stream sync)
         self.last_sync_rounds = None
 
@@ -606,6 +608,15 @@ class JpegDecoder:
         if entropy != "host":
             rgb = self._decode_gpu_entropy(jpegs, inf)
             if rgb is not None:
+                if os.environ.get("SM_JPEG_CROSSCHECK") == "1":
+                    # soak mode (round-5 advisor): a wrong-but-status-0 device decode would not fall back by itself -- with this set, ONE frame of every batch is
+                    # decoded again by the host Huffman path and compared byte for byte; a difference raises instead of travelling on
+                    k = self.crosscheck_batches % n
+                    self.crosscheck_batches += 1
+                    ref = self.decode([jpegs[k]], entropy="host")[0]
+                    if not torch.equal(ref, rgb[k]):
+                        raise _lib.StreamMindHipError(f"SM_JPEG_CROSSCHECK: frame {k} of a {n}-frame batch decodes differently on the device and on the host")
+                    self.frames -= 1                    # (the cross-check frame is not a delivered frame)
                 self.frames += n
                 return rgb
             if entropy == "gpu":

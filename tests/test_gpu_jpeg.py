@@ -252,3 +252,26 @@ def test_gpu_entropy_decode_batch_fallback_and_corruption(dec):
     bad[k + 1] = 0xD3
     with pytest.raises(Exception):
         dec.decode([bytes(bad)], entropy="gpu")
+
+
+def test_crosscheck_soak_mode(dec, monkeypatch):
+    """SM_JPEG_CROSSCHECK=1 (round-5 advisor): with the entropy decode on the device by default, one frame of every batch is decoded again by the host
+    Huffman path and compared byte for byte -- a silent device-side mis-decode would raise instead of travelling on.  Clean files pass and the checked frame
+    rotates through the batch; a tampered device result is caught."""
+    files = [U.encode(U.test_image(96, 72, 30 + i), quality=80, subsampling=2) for i in range(3)]
+    monkeypatch.setenv("SM_JPEG_CROSSCHECK", "1")
+    b0 = dec.crosscheck_batches
+    a = dec.decode(files)
+    b = dec.decode(files)
+    assert torch.equal(a, b) and dec.crosscheck_batches == b0 + 2
+    orig = dec._decode_gpu_entropy
+
+    def tampered(jpegs, inf):
+        out = orig(jpegs, inf)
+        if out is not None:
+            out = out.clone(); out[:, 0, 0, 0] ^= 1
+        return out
+    monkeypatch.setattr(dec, "_decode_gpu_entropy", tampered)
+    from streammind_amd._lib import StreamMindHipError
+    with pytest.raises(StreamMindHipError):
+        dec.decode(files)

@@ -1311,13 +1311,15 @@ def test_group_decode_full_width_16_streams_one_launch_attention(fp8, S):
     assert same >= S - 2, (same, out, solo_ids)
 
 
-def test_full_size_two_lanes_of_28_frames_equal_two_calls():
+@pytest.mark.parametrize("vit_fp16", [False, True], ids=["bf16", "fp16_folded"])
+def test_full_size_two_lanes_of_28_frames_equal_two_calls(vit_fp16):
     """The bench's step: 56 FULL-SIZE frames in one call = two concurrent 28-frame tower lanes (256x256 GEMMs, split-K reduces,
     attention and norms of two batches in flight on two HIP streams of one model).  Pooled features must be bit-identical to two
     separate 28-frame calls, repeatedly (any cross-lane sharing of scratch would show as a difference), and the pipelined push
-    must give the plain push's logits."""
+    must give the plain push's logits.  fp16_folded (round 6): the fp16 tower, whose lanes fold their LayerNorms into the neighbouring products --
+    each lane has its own row-sum buffer; a shared one would show here."""
     vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
-    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 101), conn_gate_weights(ccfg, gcfg, 102), max_frames_per_call=56)
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 101), conn_gate_weights(ccfg, gcfg, 102), max_frames_per_call=56, vit_fp16=vit_fp16)
     frames = O.synthetic_frames(56, 336, seed=91, scene_len=4).cuda()
     ref = torch.cat([m.vit_encode(frames[:28]), m.vit_encode(frames[28:])])
     for _ in range(4):
