@@ -387,7 +387,9 @@ int sm_stream_set_kv_len(sm_stream* s, int n);            /* truncate the KV cac
  * (doubled, up to max_seq: reallocated and copied on the call's HIP stream) by the prefill / decode call that needs more -- a stream opened for
  * a 4096-token context costs 64 MB of cache until it fills it, so hundreds of open streams fit beside the model in 288 GB.  The prefill chunk
  * buffers are the MODEL's (one set per HIP stream a decoder call is issued on), not the stream's.  A call that has to grow the cache cannot be
- * captured into a hipGraph (it allocates): run the step eagerly once at that context first. */
+ * captured into a hipGraph (it allocates): run the step eagerly once at that context first; and a graph captured BEFORE a growth holds the old
+ * buffers' addresses -- re-capture after sm_stream_kv_capacity changes (a captured step bakes the host-side position as well, so it was never valid
+ * beyond the context it was captured at). */
 int sm_stream_kv_capacity(sm_stream* s);
 /* a10+a12 prefill: n new positions; ids[i] >= 0 text token, ids[i] < 0 -> frame token (-ids[i]-1).
  * Appends to the KV cache at kv_len, leaves the greedy next token in the stream (device).           */

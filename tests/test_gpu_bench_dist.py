@@ -48,8 +48,9 @@ def test_bench_one_rank_forced_dist_nccl(exchange):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SM_BENCH_FORCE_DIST="1", SM_BENCH_EXCHANGE=exchange, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "1", "--batch", "28", "--stream-frames", "280",
-           "--no-aux", "--no-fp8", "--no-cpu-baseline", "--no-decode", "--no-prof"]
+    # (the "peer" case leaves --batch at its default: the in-run schedule pick and its broadcast of rank 0's choice run on the nccl communicator too)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "9", "--warmup", "1"] + (["--batch", "28"] if exchange == "rccl" else []) + [
+           "--stream-frames", "280", "--no-aux", "--no-fp8", "--no-cpu-baseline", "--no-decode", "--no-prof"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -67,3 +68,5 @@ def test_bench_one_rank_forced_dist_nccl(exchange):
         assert ex["implementation"].startswith("peer_write") or (ex["fallback_reason"] and ex["implementation"].startswith("torch.distributed")), ex
         assert ex["ranks"][0]["peer_write_self_test"] is not None
     assert ex["ranks"][0]["device"] and ex["ranks"][0]["exchange"] == ex["implementation"]
+    if exchange == "peer":
+        assert d["config"]["schedule_pick"]["chosen_frames_per_call"] == d["config"]["frames_per_call"] in (28, 56)
