@@ -773,11 +773,14 @@ struct DecAttnPT {
     SEG seg;
 };
 typedef DecAttnPT<SmDecodeSeg> DecAttnP;
-template <bool F16, class P = DecAttnP>
-__global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
+// NW waves per block (8, or 4 for the batched step: round 6).  The kernel needs 213 registers, i.e. two waves per SIMD: an 8-wave block owns its CU, so its phases
+// -- q, one K / V round trip to HBM, softmax + PV, the merge through LDS -- run strictly one after the other per CU (11.5 us per block at 336 keys, 3.8 TB/s over a
+// 512-stream step).  Two 4-wave blocks per CU at the same registers overlap one block's round trip with the other's arithmetic and merge.
+template <bool F16, class P = DecAttnP, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(P p) {
     constexpr int DH = 128;
-    __shared__ float osh[8][16][DH + 4];
-    __shared__ float msh[8][16], lsh[8][16];
+    __shared__ float osh[NW][16][DH + 4];
+    __shared__ float msh[NW][16], lsh[NW][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int b = blockIdx.x, kvh = blockIdx.y;
@@ -801,13 +804,13 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
     float m_run = -INFINITY, l_run = 0.f;
     const int NB = (nk + 31) >> 5;
     const int k_lo = p.window > 0 ? max(0, nk - p.window) : 0;          // first visible key
-    for (int blk0 = (k_lo >> 5) + wave; blk0 < NB; blk0 += 16) {
-        const bool two = blk0 + 8 < NB;
+    for (int blk0 = (k_lo >> 5) + wave; blk0 < NB; blk0 += 2 * NW) {
+        const bool two = blk0 + NW < NB;
         bf16x8 kf[2][2][4], vf[2][8];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
-            const int key0 = (blk0 + 8 * u) * 32;
+            const int key0 = (blk0 + NW * u) * 32;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 int key = key0 + (i >> 2) * 8 + a * 4 + (i & 3);
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u == 1 && !two) break;
-            const int key0 = (blk0 + 8 * u) * 32;
+            const int key0 = (blk0 + NW * u) * 32;
             f32x4 sc[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -883,14 +886,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
         if (g == 0) { msh[wave][i] = m_run; lsh[wave][i] = l_run; }
     }
     __syncthreads();
-    for (int idx = tid; idx < rep * DH; idx += 512) {
+    for (int idx = tid; idx < rep * DH; idx += NW * 64) {
         const int qi = idx >> 7, d = idx & (DH - 1);
         float M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) M = fmaxf(M, msh[w][qi]);
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, msh[w][qi]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float mw = msh[w][qi];
             const float wt = mw == -INFINITY ? 0.f : exp2f((mw - M) * p.c);
             num += wt * osh[w][qi][d];
@@ -903,6 +906,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(P p) {
 // ONE CU per (stream, KV group): measured at Mistral-7B shapes it equals the launch pair at 328 keys for a single stream and
 // loses beyond ~512 (1024 keys: 301 vs 322 tokens/s) -- but with 16+ streams its S x KV blocks fill the chip by themselves and
 // it wins (32 streams at 328 keys: 7026 vs 6674 tokens/s aggregate).
+// waves per block of the one-launch kernel in a BATCHED step (SM_DECODE_ATTN_NW = 8 | 4; see the kernel)
+static int decode_attn_group_waves() {
+    static int nw = -1;
+    // same box, interleaved twice (profiles/r06_decode_attn_nw_ab.txt), ms per batched step with 8 / 4 waves: 64 streams 4.84 / 4.79, 128: 6.29 / 6.18, 256: 10.19 / 9.98,
+    // 512: 16.54 / 16.09 (+1.2 .. +2.8 % tokens/s); 32 streams equal (the small pack keeps 8 waves below 512 blocks)
+    if (nw < 0) { const char* e = getenv("SM_DECODE_ATTN_NW"); nw = e ? atoi(e) : 4; if (nw != 4) nw = 8; }
+    return nw;
+}
 static bool decode_attn_fused_ok(int nk, int dh, int S, int KV) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("SM_DECODE_ATTN_FUSED"); on = e ? atoi(e) : 1; }
@@ -991,7 +1002,10 @@ int sm_llm_decode_attention_seg_big(const void* q, const SmDecodeSegBig& seg, in
     d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
     d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
     SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
-    if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegBig>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+    if (decode_attn_group_waves() == 4) {
+        if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegBig>, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+        else decode_attn_kernel<false, DecAttnPT<SmDecodeSegBig>, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+    } else if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegBig>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
     else decode_attn_kernel<false, DecAttnPT<SmDecodeSegBig>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
     SM_LAUNCH_CHECK();
     return SM_OK;
@@ -1017,7 +1031,10 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
         d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
         d.nk = nk; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = seg; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
         SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
-        if (f16) decode_attn_kernel<true><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+        if (decode_attn_group_waves() == 4 && S * KV >= 512) {
+            if (f16) decode_attn_kernel<true, DecAttnP, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+            else decode_attn_kernel<false, DecAttnP, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+        } else if (f16) decode_attn_kernel<true><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
         else decode_attn_kernel<false><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
         SM_LAUNCH_CHECK();
         return SM_OK;
