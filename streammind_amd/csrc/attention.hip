@@ -786,7 +786,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(P p) {
     const int b = blockIdx.x, kvh = blockIdx.y;
     const int rep = p.H / p.KV;
     const bool segm = p.nseg > 0;
-    const int nk = segm ? p.seg.pos[b] + 1 : p.nk;
+    const int nk = segm ? seg_pos(p.seg, b) + 1 : p.nk;
     const bf16_t* kc = (segm ? (const bf16_t*)p.seg.kc[b] : p.k) + kvh * DH;
     const bf16_t* vt = (segm ? (const bf16_t*)p.seg.vtc[b] : p.vt) + (size_t)kvh * DH * p.S_max;
     const long k_rs = (long)p.KV * DH;
@@ -1014,6 +1014,23 @@ int sm_llm_decode_attention_seg_big(const void* q, const SmDecodeSegBig& seg, in
 // single-token decode attention of S streams in ONE launch pair: stream t's query row block q[t] (H heads) against ITS cache
 // [0, pos[t]]; the key range is cut into the same number of splits for every stream (sized for the longest context; a split
 // that lies beyond a shorter stream's cache contributes weight 0 to the merge)
+int sm_llm_decode_attention_seg_tab(const void* q, const SmDecodeSegTab& tab, int S, int nk_max, int H, int KV, int dh, int S_max, void* ctx, int f16, void* stream, int window) {
+    SM_REQUIRE(q && ctx && S > 0 && S_max % 64 == 0 && H % KV == 0 && H / KV <= 16 && tab.kc && tab.vtc && tab.pos0 && nk_max >= 1 && nk_max <= S_max,
+               "sm_llm_decode_attention_seg_tab: bad args");
+    const int nk_eff = window > 0 && nk_max > window + 63 ? window + 63 : nk_max;
+    if (!decode_attn_fused_ok(nk_eff, dh, S, KV)) return 1;
+    DecAttnPT<SmDecodeSegTab> d;
+    d.q = (const bf16_t*)q; d.ctx = (bf16_t*)ctx; d.k = nullptr; d.vt = nullptr;
+    d.nk = nk_max; d.H = H; d.KV = KV; d.S_max = S_max; d.nseg = S; d.seg = tab; d.window = window; d.c = (1.0f / sqrtf((float)dh)) * 1.4426950408889634f;
+    SmProfScope prof(SM_PROF_ATTN, (hipStream_t)stream);
+    if (decode_attn_group_waves() == 4) {
+        if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegTab>, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+        else decode_attn_kernel<false, DecAttnPT<SmDecodeSegTab>, 4><<<dim3(S, KV), 256, 0, (hipStream_t)stream>>>(d);
+    } else if (f16) decode_attn_kernel<true, DecAttnPT<SmDecodeSegTab>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+    else decode_attn_kernel<false, DecAttnPT<SmDecodeSegTab>><<<dim3(S, KV), 512, 0, (hipStream_t)stream>>>(d);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
 int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, int H, int KV, int dh, int S_max, float* workspace,
                                 int splits_max, void* ctx, int f16, void* stream, int window) {
     SM_REQUIRE(q && ctx && workspace && S > 0 && S <= SM_MAX_SEG, "sm_llm_decode_attention_seg: bad args");

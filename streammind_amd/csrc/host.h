@@ -47,6 +47,12 @@ int sm_unpack_rows_f32(const void* wp, int N, int K, int f16, float* out, void* 
 
 // batched single-token decode over S streams (one row per stream): per-stream KV caches and positions, by value
 template <int N> struct SmDecodeSegT { void* kc[N]; void* vtc[N]; int pos[N]; };
+// The same per-stream pointers as a TABLE in device memory (round 6): any number of streams in ONE launch.  kc / vtc point at this layer's row of the table
+// the batched decode call uploaded once (the pointers do not change during a call: the caches were brought to their common capacity before it), pos0 at the
+// streams' positions when the call started; `step` = decode steps since.
+struct SmDecodeSegTab { void* const* kc; void* const* vtc; const int* pos0; int step; };
+template <class SEG> static __device__ __forceinline__ int seg_pos(const SEG& s, int b) { return s.pos[b]; }
+template <> __device__ __forceinline__ int seg_pos<SmDecodeSegTab>(const SmDecodeSegTab& s, int b) { return s.pos0[b] + s.step; }
 typedef SmDecodeSegT<SM_MAX_SEG> SmDecodeSeg;
 typedef SmDecodeSegT<SM_BIG_SEG> SmDecodeSegBig;      // every stream of a large batched decode step in ONE launch (2.5 KB of kernel arguments)
 template <int N> struct SmTokPtrsT { int32_t* p[N]; };
@@ -74,6 +80,12 @@ int sm_llm_decode_attention_seg_big(const void* q_bf16, const SmDecodeSegBig& se
                                     void* stream, int window = 0);
 int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
                               const SmDecodeSegBig& seg, int S_max, int f16, void* stream);                       // vecops.hip
+// ... and for any number of streams through the device-side table (nk_max = the longest context incl. the new token, the caller's own bookkeeping);
+// the attention returns 1 like the _big form when the contexts are too long for the one-launch kernel
+int sm_llm_decode_attention_seg_tab(const void* q_bf16, const SmDecodeSegTab& tab, int S, int nk_max, int H, int KV, int dh, int S_max, void* ctx_bf16, int f16,
+                                    void* stream, int window);                                                       // attention.hip
+int sm_rope_kv_append_seg_tab(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q_bf16,
+                              const SmDecodeSegTab& tab, int S_max, int f16, void* stream, int nslab = 0, size_t slab_stride = 0);   // vecops.hip (nslab > 0: qkv = unsummed split-K slabs)
 int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max,
                         void* ctx, int f16, void* stream, int window = 0);
 int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vtcache, int pos, int H, int KV, int dh, int S_max,
@@ -81,6 +93,12 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
 int sm_embed_tokens_seg(const SmTokPtrs& tok, int S, const void* table_bf16, int D, float* out, const SmTokPtrs& out_rows, int col,
                         int f16, void* stream);
 int sm_argmax_rows_seg(const float* logits, int S, int V, int ld, const SmTokPtrs& out, void* stream);
+// linear.hip: sm_linear that may leave its split-K slabs UNSUMMED for the next kernel to sum on load (round 6: the batched decode's q|k|v product at 33..128
+// streams is 5 K slabs + a reduce launch + the RoPE launch that reads the sums -- the RoPE kernel sums the slabs itself).  Only a plain product (no bias,
+// activation, residual, 16-bit output) on the 128 x 128 split-K path leaves slabs: out->S = their count (raw fp32 [S][M][N], stride M * N floats, valid until the
+// next tiled product on this HIP stream); out->S == 0: the call wrote p->out_f32 as sm_linear would.
+struct SmSlabOut { const float* ws; int S; size_t stride; };
+int sm_linear_leave_slabs(const sm_linear_t* p, SmSlabOut* out, void* stream);
 // linear.hip: grow the per-HIP-stream split-K slabs / unfused-SwiGLU rows to at least these sizes NOW (set-up time), so that no request allocates
 int sm_linear_reserve(hipStream_t st, size_t slab_bytes, size_t dual_bytes);
 // the same two per-stream kernels of a batched decode step for up to SM_BIG_SEG streams per launch (round 6: at 512 streams the token gather and the arg-max were

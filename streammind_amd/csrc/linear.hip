@@ -1561,6 +1561,15 @@ int sm_skinny_lds64_on() {
     return on;
 }
 static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done);
+static thread_local SmSlabOut* g_leave_slabs = nullptr;          // set by sm_linear_leave_slabs (host.h) around one sm_linear call
+int sm_linear_leave_slabs(const sm_linear_t* p, SmSlabOut* out, void* stream) {
+    SM_REQUIRE(p && out, "sm_linear_leave_slabs: null args");
+    out->ws = nullptr; out->S = 0; out->stride = 0;
+    g_leave_slabs = out;
+    const int rc = sm_linear(p, stream);
+    g_leave_slabs = nullptr;
+    return rc;
+}
 int sm_swiglu_ex(const float* gu, int M, int F, void* out, int f16, void* stream);           // vecops.hip
 // fp32 [M][2F] gate | up rows of an SM_ACT_SWIGLU_DUAL call that does not run on the 256 x 256 kernel (per HIP stream, grown on demand; not the
 // split-K slabs: the product itself may use those)
@@ -2016,6 +2025,10 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             splitk_reduce_norm_rows_kernel<<<p->M, p->N / 4, 0, st>>>(a, ws, S, ln);
             SM_LAUNCH_CHECK();
             *ln_done = true;
+            return SM_OK;
+        }
+        if (g_leave_slabs && !p->bias && !p->residual && p->act == SM_ACT_NONE && !a.wscale && !p->out_bf16 && !p->vt && p->remap_in == 0 && !p->post_ln_gamma) {
+            g_leave_slabs->ws = ws; g_leave_slabs->S = S; g_leave_slabs->stride = (size_t)p->M * p->N;        // the caller's next kernel sums them on load
             return SM_OK;
         }
         const size_t nthr = (size_t)p->M * ((p->N + 3) / 4);

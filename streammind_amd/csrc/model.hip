@@ -1263,6 +1263,7 @@ struct sm_stream_group {
     ConnScratch w;
     // batched decode scratch (rows = streams), allocated by the first sm_group_llm_decode
     DevBuf d_emb, d_xnb, d_xn32, d_qkvf, d_qb, d_ctxb, d_actb, d_log, d_ws;
+    DevBuf d_tab;                // > SM_MAX_SEG streams: [layers][S] K pointers, [layers][S] V^T pointers, [S] start positions (SmDecodeSegTab), uploaded once per call
     bool d_ready = false;
 };
 
@@ -1544,6 +1545,27 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
     float* x = g->d_emb.as<float>();
     const int f16 = c.llm_fp16 ? 1 : 0, od = f16 ? SM_OP_F16 : SM_OP_BF16;
     const int NC = cdiv(S, SM_MAX_SEG);                       // chunks of the per-stream kernels
+    // > SM_MAX_SEG streams: the per-stream cache pointers of every layer and the start positions go to the device ONCE per call (SmDecodeSegTab; 256 KB at 512
+    // streams x 32 layers), so that RoPE + append and the attention of ALL streams are one launch each per layer -- they were one launch per 128 streams
+    // (pointer packs by value: 4 + 4 launches per layer at 512 streams).  SM_DECODE_TAB=0: the packs (A/B)
+    static const bool tab_env = [] { const char* e = getenv("SM_DECODE_TAB"); return !e || atoi(e) != 0; }();
+    const bool use_tab = tab_env && NC > 1;
+    void* const* tab_kc = nullptr; void* const* tab_vtc = nullptr; const int* tab_pos0 = nullptr;
+    int kv_max0 = 0;
+    if (use_tab) {
+        const size_t np = (size_t)c.llm_layers * S;
+        std::vector<void*> hp(2 * np);
+        std::vector<int> hpos(S);
+        for (int l = 0; l < c.llm_layers; ++l)
+            for (int t = 0; t < S; ++t) { hp[(size_t)l * S + t] = act[t]->kc[l].p; hp[np + (size_t)l * S + t] = act[t]->vtc[l].p; }
+        for (int t = 0; t < S; ++t) { hpos[t] = act[t]->kv_len; if (act[t]->kv_len > kv_max0) kv_max0 = act[t]->kv_len; }
+        const size_t bytes = 2 * np * sizeof(void*) + (size_t)S * sizeof(int);
+        if (g->d_tab.bytes < bytes) { SM_HIP(hipStreamSynchronize((hipStream_t)stream)); if ((rc = g->d_tab.alloc(bytes))) return rc; }
+        SM_HIP(hipMemcpyAsync(g->d_tab.p, hp.data(), 2 * np * sizeof(void*), hipMemcpyHostToDevice, (hipStream_t)stream));
+        SM_HIP(hipMemcpyAsync((char*)g->d_tab.p + 2 * np * sizeof(void*), hpos.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+        SM_HIP(hipStreamSynchronize((hipStream_t)stream));            // the host vectors go out of scope; once per call, not per step
+        tab_kc = (void* const*)g->d_tab.p; tab_vtc = tab_kc + np; tab_pos0 = (const int*)((char*)g->d_tab.p + 2 * np * sizeof(void*));
+    }
     auto c0 = [&](int ch) { return ch * SM_MAX_SEG; };
     auto cn = [&](int ch) { return S - c0(ch) < SM_MAX_SEG ? S - c0(ch) : SM_MAX_SEG; };
     for (int j = 0; j < n_steps; ++j) {
@@ -1577,6 +1599,7 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
         for (int l = 0; l < c.llm_layers; ++l) {
             const sm_model::LayerW& w = m->R.llm[l];
             bool rope_done = false, attn_done = false;
+            SmSlabOut qkv_slabs = {nullptr, 0, 0};
             {   sm_linear_t a = fuse_norm ? lin(m, *w.qkv, x, SM_X_F32, S, ld) : fuse_rope ? lin(m, *w.qkv, g->d_xn32.p, SM_X_F32, S, ld) : lin(m, *w.qkv, g->d_xnb.p, SM_X_BF16, S, ld);
                 if (fuse_norm) { a.norm_gamma = w.ln1_w; a.norm_eps = c.llm_eps; }
                 if (fuse_rope) {
@@ -1588,10 +1611,20 @@ extern "C" int sm_group_llm_decode(sm_stream_group* g, const int32_t* active_hos
                     rope_done = true;
                 } else {
                     a.out_f32 = g->d_qkvf.as<float>(); a.ldo = qn + 2 * kn;
-                    if ((rc = sm_linear(&a, stream))) return rc;
+                    // with the table path the RoPE kernel can sum the product's split-K slabs itself (33..128 streams: five slabs; one launch less per layer)
+                    if (use_tab) { if ((rc = sm_linear_leave_slabs(&a, &qkv_slabs, stream))) return rc; }
+                    else if ((rc = sm_linear(&a, stream))) return rc;
                 }
             }
-            if (NC > 1) {           // SM_BIG_SEG streams per RoPE + append launch and per attention launch (pointer packs by value): 1 pack up to 128 streams, 4 at 512
+            if (NC > 1 && use_tab) {           // every stream in ONE RoPE + append launch and ONE attention launch (device-side pointer table)
+                SmDecodeSegTab tab = {tab_kc + (size_t)l * S, tab_vtc + (size_t)l * S, tab_pos0, j};
+                const float* qsrc = qkv_slabs.S > 0 ? qkv_slabs.ws : g->d_qkvf.as<float>();
+                if ((rc = sm_rope_kv_append_seg_tab(qsrc, S, H, KV, dh, m->rope_cos.as<float>(), m->rope_sin.as<float>(), g->d_qb.p, tab, S_max, f16, stream, qkv_slabs.S, qkv_slabs.stride))) return rc;
+                rope_done = true;
+                rc = sm_llm_decode_attention_seg_tab(g->d_qb.p, tab, S, kv_max0 + j + 1, H, KV, dh, S_max, g->d_ctxb.p, f16, stream, c.llm_sliding_window);
+                if (rc < 0) return rc;
+                attn_done = rc == 0;                 // 1: contexts too long for the one-launch kernel -> the chunks below (RoPE + append are done)
+            } else if (NC > 1) {           // SM_BIG_SEG streams per RoPE + append launch and per attention launch (pointer packs by value): 1 pack up to 128 streams, 4 at 512
                 rope_done = attn_done = true;
                 for (int b0 = 0; b0 < S; b0 += SM_BIG_SEG) {
                     const int bn = S - b0 < SM_BIG_SEG ? S - b0 : SM_BIG_SEG;

@@ -835,13 +835,18 @@ extern "C" int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int K
 template <class SEG>
 __global__ __launch_bounds__(64) void rope_kv_seg_kernel(const float* __restrict__ qkv, int H, int KV, int dh,
                                                          const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-                                                         bf16_t* __restrict__ q, SEG seg, int S_max, int f16) {
+                                                         bf16_t* __restrict__ q, SEG seg, int S_max, int f16, int nslab = 0, size_t sstride = 0) {
     const int t = blockIdx.x, hd = blockIdx.y;
-    const int pos = seg.pos[t];
+    const int pos = seg_pos(seg, t);
     bf16_t* __restrict__ kc = (bf16_t*)seg.kc[t];
     bf16_t* __restrict__ vtc = (bf16_t*)seg.vtc[t];
     const int half = dh >> 1;
-    const float* x = qkv + (size_t)t * (H + 2 * KV) * dh + (size_t)hd * dh;
+    const float* x0 = qkv + (size_t)t * (H + 2 * KV) * dh + (size_t)hd * dh;
+    // nslab > 0: qkv holds the q|k|v product's UNSUMMED split-K slabs ([nslab][rows][(H + 2 KV) dh], sm_linear_leave_slabs): summed here in slab order, the
+    // arithmetic of the reduce launch this replaces
+    struct Row { const float* p; int n; size_t st;
+                 __device__ float operator[](int i) const { if (n <= 0) return p[i]; float v = 0.f; for (int s_ = 0; s_ < n; ++s_) v += p[(size_t)s_ * st + i]; return v; } };
+    const Row x = {x0, nslab, sstride};
     if (hd < H + KV) {
         for (int j = threadIdx.x; j < half; j += 64) {
             const float c = cos_tab[(size_t)pos * half + j], s = sin_tab[(size_t)pos * half + j];
@@ -867,6 +872,14 @@ int sm_rope_kv_append_seg_big(const float* qkv, int S, int H, int KV, int dh, co
                               const SmDecodeSegBig& seg, int S_max, int f16, void* stream) {
     SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && S <= SM_BIG_SEG, "sm_rope_kv_append_seg_big: bad args");
     rope_kv_seg_kernel<SmDecodeSegBig><<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, seg, S_max, f16);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+
+int sm_rope_kv_append_seg_tab(const float* qkv, int S, int H, int KV, int dh, const float* cos_tab, const float* sin_tab, void* q,
+                              const SmDecodeSegTab& tab, int S_max, int f16, void* stream, int nslab, size_t slab_stride) {
+    SM_REQUIRE(qkv && q && cos_tab && sin_tab && S > 0 && tab.kc && tab.vtc && tab.pos0 && nslab >= 0 && nslab <= 64, "sm_rope_kv_append_seg_tab: bad args");
+    rope_kv_seg_kernel<SmDecodeSegTab><<<dim3(S, H + 2 * KV), 64, 0, (hipStream_t)stream>>>(qkv, H, KV, dh, cos_tab, sin_tab, (bf16_t*)q, tab, S_max, f16, nslab, slab_stride);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
