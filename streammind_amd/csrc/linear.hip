@@ -2017,7 +2017,11 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
             *ln_done = true;
             return SM_OK;
         }
-        if (p->post_ln_gamma && ln_fuse && p->M <= 256 && (p->N & 255) == 0 && p->N <= 4096 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) &&
+        static int ln_rows_max = -1;                 // SM_POST_LN_ROWS_MAX (default 1024; 256 = the round-5 rule, A/B)
+        if (ln_rows_max < 0) { const char* e = getenv("SM_POST_LN_ROWS_MAX"); ln_rows_max = e ? atoi(e) : 1024; }
+        // (round 6: up to 1024 rows -- a 512-stream decode step sums o_proj / down_proj's two slabs and norms the rows in ONE pass instead of a slab-sum launch
+        //  + a norm launch: 11.7 + 10.5 us per product at 512 rows)
+        if (p->post_ln_gamma && ln_fuse && p->M <= ln_rows_max && (p->N & 255) == 0 && p->N <= 4096 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) &&
             p->remap_in == 0 && !a.wscale) {
             // few rows (a batched decode step of 33..128 streams): the row-block pass of the weight-streaming path -- slab sum, epilogue and the
             // LayerNorm / RMSNorm of the finished row in one launch (the slabs have the same [S][M][N] layout)

@@ -30,7 +30,7 @@ lnxtl)        # (needs the same patch) phase timeline of the fused LayerNorm epi
 gdtrace)      # kernel trace of the grouped decode step at $GD streams (default 128) -> per-kernel us per step
   rm -rf /tmp/prof_gd; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gd -- python tools/group_decode_bench.py ${GD:-128} > $O/gd_profiled.log 2>&1
   cp "$(find /tmp/prof_gd -name '*kernel_stats.csv' | head -1)" $O/group_decode${GD:-128}_kernel_stats.csv; tail -1 $O/gd_profiled.log
-  python tools/trace_window.py /tmp/prof_gd embed_tokens_seg_kernel $(( (${GD:-128} + 31) / 32 )) > $O/group_decode${GD:-128}_step_timeline.txt; python - $O/group_decode${GD:-128}_step_timeline.txt <<'PY'
+  python tools/trace_window.py /tmp/prof_gd embed_tokens_seg_kernel $(( ${GD:-128} <= 32 ? 1 : (${GD:-128} + 127) / 128 )) > $O/group_decode${GD:-128}_step_timeline.txt; python - $O/group_decode${GD:-128}_step_timeline.txt <<'PY'
 import sys, collections, re
 d = collections.defaultdict(lambda: [0.0, 0])
 for ln in open(sys.argv[1]):
