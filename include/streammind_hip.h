@@ -245,6 +245,10 @@ int sm_rope_kv_append(const float* qkv, int n, int pos0, int H, int KV, int dh, 
 /* causal GQA attention of n new queries (positions pos0..) against the cache [0, pos0+n): ctx bf16 [n][H*dh] */
 int sm_llm_attention(const void* q_bf16, const void* kcache, const void* vtcache, int n, int pos0, int H,
                      int KV, int dh, int S_max, void* ctx_bf16, void* stream);
+/* Which kernel runs the causal prefill at head_dim 128 (process-wide; results are bit-identical either way): 1 = the round-6 prefill kernel (one 128-query
+ * tile per block, longest tiles first, K / V^T tiles by LDS-DMA, fragment reads a batch ahead of the MFMAs), 0 = the general tile kernel, -1 = back to the
+ * SM_ATTN_PREFILL environment variable / the default (1).  For A/B runs and the equality test. */
+int sm_set_prefill_attention_kernel(int on);
 /* single-token decode attention (flash-decoding: keys split over up to splits_max blocks per KV group, then merged);
  * q bf16 [H*dh] at position pos, cache as above; workspace fp32 [splits_max * H * (dh + 2)]                */
 int sm_llm_attention_window(const void* q, const void* kcache, const void* vtcache, int n, int pos0, int H, int KV, int dh, int S_max, int window,

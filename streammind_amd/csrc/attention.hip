@@ -10,6 +10,7 @@
 //   PV MFMA wants in its B operand: no transpose, no LDS round trip, no cross-lane traffic for P.
 //   V is consumed as V^T ([d][keys]); the producers (QKV GEMM epilogue / KV-append kernel) write it that way.
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include "common.h"
 #include "host.h"
@@ -32,6 +33,7 @@ struct AttnP {
     float* part_o;                           // [splits][H][nq][DH] fp32
     float* part_ml;                          // [splits][H][nq][2]  (running max in scaled-log2 domain source units, l)
     int nqt, nbatch;                         // tiled mode: query tiles per (batch, head), batch count
+    int lpt;                                 // causal prefill, one query tile per block: heaviest tiles of ALL heads first, the query heads of one KV group on one XCD (round 6)
     int pair;                                // causal prefill: a block runs query tiles t and nqt - 1 - t one after the other (nqt even): every block walks nqt + 1 key-tile units
                                              // instead of 1 .. nqt (the whole grid is resident at once, so the launch lasted as long as its heaviest tile)
     // batched decode (GROUPQ, blockIdx.x = stream): per-stream caches and key counts; nseg == 0: single stream (k / vt / nk above)
@@ -64,8 +66,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
     } else {
         const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
         const int nqt_g = (CAUSAL && p.pair) ? p.nqt >> 1 : p.nqt;
-        const int grp = (j / nqt_g) * 8 + xcd;
+        int grp = (j / nqt_g) * 8 + xcd;
         qtile0 = j % nqt_g;
+        if (CAUSAL && p.lpt) {
+            // longest first: tile t walks 2 (t + 1) key tiles, so the dispatch order is t = nqt - 1 of every head, then nqt - 2, ... (two blocks per CU, the light
+            // tiles fill the tail); XCD x takes heads x G/8 .. (x + 1) G/8 - 1: with grouped-query attention the heads that stream the same K / V share an L2
+            const int g8 = (p.H * p.nbatch) >> 3;
+            qtile0 = p.nqt - 1 - j / g8;
+            grp = xcd * g8 + j % g8;
+        }
         if (grp >= p.H * p.nbatch) return;
         h = grp % p.H; b = grp / p.H;
     }
@@ -250,7 +259,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
                 s[1][kb][f] = a1;
             }
         // ---- mask + online softmax (lane-local query = lane & 15)
-        if (CAUSAL || kt0 + 64 > nk || kt0 < dec_lo) {
+        // (causal: only the tiles that reach past the wave's FIRST query position -- the diagonal ones -- or start before its LAST query's window hold a
+        // masked score; below the diagonal the ~130 compare / select instructions per tile are skipped, wave-uniformly)
+        const bool diag = CAUSAL && (kt0 + 63 > p.pos0 + q0 || (p.window > 0 && kt0 < p.pos0 + q0 + 32 - p.window));
+        if (diag || kt0 + 64 > nk || kt0 < dec_lo) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int qpos = p.pos0 + q0 + qb * 16 + i;
@@ -352,6 +364,267 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnP p) {
         }
     }
   }     // pass
+}
+
+// ------------------------------------------------------------------------------------------------ LLM causal prefill, head_dim 128 (round 6)
+// The causal tile kernel above spends its key tile like this at Mistral-7B's shape (2048 new tokens, 32 heads over 8 K / V heads of 128; rocprofv3 counters,
+// profiles/r06_attn_causal_pmc.txt): matrix pipe busy 20-25 % of the launch, VALU 25-30 %, and the ISA shows why -- with K / V staged through 32 + 16 registers
+// next to 64 accumulators hipcc has no room to hoist fragment reads, so both products run as `ds_read_b128 x2; s_waitcnt lgkmcnt(0); v_mfma x2`, one exposed
+// LDS round trip per pair of MFMAs (32 per tile), and the paired-tile grid (256 blocks of 4 waves) leaves ONE wave per SIMD to hide it.  This kernel keeps the
+// arithmetic of attn_kernel<128, false, false, true> instruction for instruction (same fragment order, same softmax: outputs are bit-identical, tested) and changes
+// the schedule around it:
+//   * K and V^T tiles go global -> LDS by DMA (global_load_lds, 16 B per lane; the K row permutation and both chunk swizzles sit on the per-lane SOURCE
+//     address, the LDS image of a DMA being lane-linear): no staging registers, no ds_write, four 64-bit adds of address arithmetic per tile;
+//   * the fragments of a 32-key block are read as a BATCH of eight ds_read_b128 into one of two register sets, always one batch ahead of the MFMAs that
+//     consume the other set (K block 0, K block 1 | QK 0 | V^T block 0 | QK 1 | V^T block 1 | softmax | PV 0 | PV 1; sched_barriers pin the phases);
+//   * one query tile per block, the LONGEST tiles of all heads first (tile t walks 2 (t + 1) key tiles; the light ones fill the tail), two blocks per CU, and the
+//     four query heads of a K / V group on one XCD (they stream the same cache rows through the same L2);
+//   * the causal compare / select runs only on tiles that reach past the wave's first query (the diagonal), wave-uniformly.
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(AttnP p) {
+    constexpr int DH = 128, KROW = 256, TILE_BYTES = 32768, DF = 8, KSQ = 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    int h, qtile;
+    {
+        const int L = blockIdx.x, G = p.H;
+        if ((G & 7) == 0) { const int xcd = L & 7, j = L >> 3, g8 = G >> 3; qtile = p.nqt - 1 - j / g8; h = xcd * g8 + j % g8; }
+        else { qtile = p.nqt - 1 - L / G; h = L % G; }
+    }
+    const int kvh = h / (p.H / p.KV);
+    const int q0 = qtile * 128 + wave * 32;
+    const int nk = p.nk;
+
+    bf16x8 qf[2][KSQ];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        int qr = q0 + qb * 16 + i;
+        if (qr >= p.nq) qr = p.nq - 1;
+        const bf16_t* src = p.q + (long)qr * p.q_rs + h * DH + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) qf[qb][ks] = *(const bf16x8*)(src + ks * 32);
+    }
+    f32x4 o[2][DF];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) o[qb][df] = f32x4{0, 0, 0, 0};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    f32x4 lsum[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+    bf16x8 ones;
+    {
+        const uint32_t one2 = pack16<F16>(1.0f, 1.0f);
+        ones = __builtin_bit_cast(bf16x8, u32x4{one2, one2, one2, one2});
+    }
+    const bool active = q0 < p.nq;
+
+    int k_end = min(nk, p.pos0 + min(qtile * 128 + 127, p.nq - 1) + 1), k_begin = 0;
+    if (p.window > 0) k_begin = max(0, p.pos0 + qtile * 128 - p.window + 1) & ~63;
+
+    // per-lane DMA sources: wave w brings the 1-KiB pieces 4 w .. 4 w + 3 of the K tile (4 permuted key rows of 256 B each) and of the V^T tile (8 dims x 64 keys)
+    const bf16_t* ksrc[4];
+    const bf16_t* vsrc[4];
+    int krow[4];
+    {
+        const bf16_t* kbase = p.k + kvh * DH;
+        const bf16_t* vbase = p.vt + kvh * p.vt_hs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int P = wave * 4 + j;
+            const int R = P * 4 + (lane >> 4), slot = lane & 15, r5 = R & 31;
+            const int key = (R & 32) | (((r5 >> 2) & 3) << 3) | (((r5 >> 4) & 1) << 2) | (r5 & 3);      // LDS row R holds key inv(R)
+            krow[j] = key;
+            ksrc[j] = kbase + (long)(k_begin + key) * p.k_rs + ((slot ^ (R & 15)) * 8);
+            const int d = P * 8 + (lane >> 3), s8 = lane & 7;
+            vsrc[j] = vbase + (long)d * p.vt_ld + k_begin + ((s8 ^ (d & 7)) * 8);
+        }
+    }
+    const long kadv = 64 * p.k_rs;
+    auto issue = [&](int kt0, int bufi) {
+        char* Kl = lds + bufi * TILE_BYTES;
+        char* Vl = Kl + 16384;
+        const bool clamp = kt0 + 64 > nk;                 // the tile runs past the cache's last row: keys >= nk re-read row nk - 1 (masked later)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16_t* ks = ksrc[j];
+            if (clamp) ks -= (long)max(kt0 + krow[j] - (nk - 1), 0) * p.k_rs;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)ks, (lds_ptr_a)(Kl + (wave * 4 + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_a)vsrc[j], (lds_ptr_a)(Vl + (wave * 4 + j) * 1024), 16, 0, 0);
+            ksrc[j] += kadv;
+            vsrc[j] += 64;
+        }
+    };
+    if (k_begin < k_end) issue(k_begin, 0);
+    int buf = 0;
+    for (int kt0 = k_begin; kt0 < k_end; kt0 += 64) {
+        const char* Kl = lds + buf * TILE_BYTES;
+        const char* Vl = Kl + 16384;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                  // every wave's pieces of this tile have landed; everyone is done with the other buffer
+        if (kt0 + 64 < k_end) issue(kt0 + 64, buf ^ 1);
+        buf ^= 1;
+        if (!active) continue;
+        const bool half = kt0 + 32 >= k_end;          // the tile's second 32-key block lies past the last visible key
+        bf16x8 fa[8], fb[8];
+        // ---- batch 1, 2: the K fragments of both key blocks
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) {
+                const int rho = f * 16 + i;
+                fa[f * 4 + ks] = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & 15)) * 16));
+            }
+        __builtin_amdgcn_sched_barrier(0);        // (keeps the two batches apart: QK 0 then waits for the first eight reads only)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)               // (read even when the block is skipped: a branch here makes hipcc wait for ALL sixteen reads before the first MFMA)
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) {
+                const int rho = 32 + f * 16 + i;
+                fb[f * 4 + ks] = *(const bf16x8*)(Kl + rho * KROW + (((ks * 4 + g) ^ (rho & 15)) * 16));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 s[2][2][2];
+        // ---- S^T = K . Q^T, key block 0
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) {
+                a0 = mfma16<F16>(fa[f * 4 + ks], qf[0][ks], a0);
+                a1 = mfma16<F16>(fa[f * 4 + ks], qf[1][ks], a1);
+            }
+            s[0][0][f] = a0;
+            s[1][0][f] = a1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- batch 3: the V^T fragments of key block 0 (into the registers QK 0 has just released)
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int d = df * 16 + i;
+            fa[df] = *(const bf16x8*)(Vl + d * 128 + ((g ^ (d & 7)) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!half) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) {
+                    a0 = mfma16<F16>(fb[f * 4 + ks], qf[0][ks], a0);
+                    a1 = mfma16<F16>(fb[f * 4 + ks], qf[1][ks], a1);
+                }
+                s[0][1][f] = a0;
+                s[1][1][f] = a1;
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                s[0][1][f] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                s[1][1][f] = s[0][1][f];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- batch 4: the V^T fragments of key block 1
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            const int d = df * 16 + i;
+            fb[df] = *(const bf16x8*)(Vl + d * 128 + (((4 + g) ^ (d & 7)) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- mask (diagonal tiles, the window's edge, the tile past nk) + online softmax (lane-local query = lane & 15)
+        const bool diag = kt0 + 63 > p.pos0 + q0 || (p.window > 0 && kt0 < p.pos0 + q0 + 32 - p.window);
+        if (diag || kt0 + 64 > nk) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qpos = p.pos0 + q0 + qb * 16 + i;
+                const int lim = min(nk - 1, qpos);                                  // last visible key of this lane's query
+                const int lo = p.window > 0 ? qpos - p.window + 1 : 0;              // first visible key
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt0 + kb * 32 + g * 8 + f * 4 + r;
+                            s[qb][kb][f][r] = (key > lim || key < lo) ? -INFINITY : s[qb][kb][f][r];
+                        }
+            }
+        }
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kb][f][r]);
+            mx = xor32_max(xor16_max(mx));
+            const float m_new = fmaxf(m_run[qb], mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;                 // a fully masked row keeps m_new = -inf: guard the subtraction
+            const float mc = m_use * p.c;
+            const bool moved = m_new != m_run[qb];
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m_run[qb], p.c, -mc));
+            m_run[qb] = m_new;
+            const f32x2 c2 = {p.c, p.c}, mc2 = {-mc, -mc};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                u32x4 pv;
+                if (kb == 1 && half) {
+                    pf[qb][1] = __builtin_bit_cast(bf16x8, u32x4{0, 0, 0, 0});
+                    continue;
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 t = f32x2{s[qb][kb][f][r], s[qb][kb][f][r + 1]} * c2 + mc2;
+                        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        pv[f * 2 + (r >> 1)] = pack16<F16>(e[0], e[1]);
+                    }
+                pf[qb][kb] = __builtin_bit_cast(bf16x8, pv);
+            }
+            if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+                for (int df = 0; df < DF; ++df) o[qb][df] *= alpha;
+                lsum[qb] *= alpha;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T . P^T
+        lsum[0] = mfma16<F16>(ones, pf[0][0], lsum[0]);
+        lsum[1] = mfma16<F16>(ones, pf[1][0], lsum[1]);
+#pragma unroll
+        for (int df = 0; df < DF; ++df) {
+            o[0][df] = mfma16<F16>(fa[df], pf[0][0], o[0][df]);
+            o[1][df] = mfma16<F16>(fa[df], pf[1][0], o[1][df]);
+        }
+        if (!half) {
+            lsum[0] = mfma16<F16>(ones, pf[0][1], lsum[0]);
+            lsum[1] = mfma16<F16>(ones, pf[1][1], lsum[1]);
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                o[0][df] = mfma16<F16>(fb[df], pf[0][1], o[0][df]);
+                o[1][df] = mfma16<F16>(fb[df], pf[1][1], o[1][df]);
+            }
+        }
+    }
+    // ---- normalise and store: lane (g, q = i) holds d = df*16 + g*4 + 0..3
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float inv = 1.0f / lsum[qb][0];
+        const int qr = q0 + qb * 16 + i;
+        if (qr < p.nq) {
+            bf16_t* dst = p.o + (long)qr * p.o_rs + h * DH + g * 4;
+#pragma unroll
+            for (int df = 0; df < DF; ++df) {
+                const f32x4 v = o[qb][df] * inv;
+                *(u32x2*)(dst + df * 16) = u32x2{pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3])};
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ ViT fast path
@@ -675,13 +948,23 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(const float* __restric
     }
 }
 
+// SM_ATTN_PREFILL=0: the causal prefill through attn_kernel (paired tiles / SM_ATTN_PAIR) instead of prefill_attn_kernel (A/B, and the bit-identity test)
+static std::atomic<int> g_prefill_kernel{-1};
+static bool prefill_kernel_on() {
+    int v = g_prefill_kernel.load(std::memory_order_relaxed);
+    if (v < 0) { const char* e = getenv("SM_ATTN_PREFILL"); v = e ? atoi(e) : 1; g_prefill_kernel.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+extern "C" int sm_set_prefill_attention_kernel(int on) { g_prefill_kernel.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); return SM_OK; }
 static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false) {
     p.nqt = cdiv(p.nq, 128); p.nbatch = B;
     if (p.v && dh == 64) p.nqt = cdiv(p.nq, VIT_ATTN_WAVES * 32);
     // causal prefill with an even number (>= 4) of query tiles: tiles t and nqt - 1 - t share a block (SM_ATTN_PAIR=0: off, A/B)
     static int pair_on = -1;
     if (pair_on < 0) { const char* e = getenv("SM_ATTN_PAIR"); pair_on = e ? atoi(e) : 1; }
-    p.pair = (pair_on && p.causal && !p.v && !p.split_len && p.nqt >= 4 && (p.nqt & 1) == 0) ? 1 : 0;
+    p.pair = (pair_on == 1 && p.causal && !p.v && !p.split_len && p.nqt >= 4 && (p.nqt & 1) == 0) ? 1 : 0;
+    // SM_ATTN_PAIR=2: one tile per block, longest tiles first (see the kernel)
+    p.lpt = (pair_on == 2 && p.causal && !p.v && !p.split_len && p.nqt >= 4 && ((p.H * B) & 7) == 0) ? 1 : 0;
     dim3 grid(cdiv(p.H * B, 8) * 8 * (p.pair ? p.nqt >> 1 : p.nqt));
     SmProfScope prof(SM_PROF_ATTN, st);
     SM_REQUIRE(dh == 64 || dh == 128, "attention: head_dim %d not supported (64 or 128)", dh);
@@ -691,6 +974,11 @@ static int launch_attn(AttnP& p, int B, int dh, hipStream_t st, bool f16 = false
         if (dh == 64 && f16) vit_attn_kernel<true><<<grid, VIT_ATTN_WAVES * 64, 0, st>>>(p);
         else if (dh == 64) vit_attn_kernel<false><<<grid, VIT_ATTN_WAVES * 64, 0, st>>>(p);
         else attn_kernel<128, false, true><<<grid, 256, 0, st>>>(p);
+    } else if (p.causal && dh == 128 && B == 1 && !p.split_len && prefill_kernel_on()) {
+        // the prefill kernel (round 6): one 128-query tile per block, longest first
+        const dim3 g2(p.H * p.nqt);
+        if (f16) prefill_attn_kernel<true><<<g2, 256, 0, st>>>(p);
+        else prefill_attn_kernel<false><<<g2, 256, 0, st>>>(p);
     } else if (p.causal) {
         if (f16) {
             if (dh == 64) attn_kernel<64, false, false, true, true><<<grid, 256, 0, st>>>(p);
@@ -710,7 +998,7 @@ extern "C" int sm_vit_attention(const void* qkv, const void* vt, void* ctx, int 
     SM_REQUIRE(qkv && ctx && B > 0 && S > 0, "sm_vit_attention: bad args");
     SM_REQUIRE(!vt || (vt_ld % 64 == 0 && vt_ld >= cdiv(S, 64) * 64), "sm_vit_attention: vt_ld must be a multiple of 64 covering S");
     AttnP p;
-    p.pair = 0;
+    p.pair = 0; p.lpt = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     const long ld = 3L * H * dh;
     p.q = (const bf16_t*)qkv; p.q_bs = (long)S * ld; p.q_rs = ld;
@@ -730,7 +1018,7 @@ int sm_llm_attention_ex(const void* q, const void* kcache, const void* vtcache, 
     SM_REQUIRE(q && kcache && vtcache && ctx && n > 0 && pos0 >= 0, "sm_llm_attention: bad args");
     SM_REQUIRE(S_max % 64 == 0 && pos0 + n <= S_max && H % KV == 0, "sm_llm_attention: S_max %% 64, pos0+n <= S_max, H %% KV");
     AttnP p;
-    p.pair = 0;
+    p.pair = 0; p.lpt = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = (long)H * dh;
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
@@ -947,7 +1235,7 @@ int sm_llm_decode_attention_ex(const void* q, const void* kcache, const void* vt
     const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
     splits = cdiv(nk_eff, split_len);
     AttnP p;
-    p.pair = 0;
+    p.pair = 0; p.lpt = 0;
     p.nseg = 0; p.part_bs = 0; p.ml_bs = 0; p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = 0; p.q_rs = dh;                 // "query row" r of group h <-> head h*rep + r
     p.k = (const bf16_t*)kcache; p.k_bs = 0; p.k_rs = (long)KV * dh;
@@ -1061,7 +1349,7 @@ int sm_llm_decode_attention_seg(const void* q, const SmDecodeSeg& seg, int S, in
     const int split_len = cdiv(cdiv(nk_eff, splits), 64) * 64;
     splits = cdiv(nk_eff, split_len);
     AttnP p;
-    p.pair = 0;
+    p.pair = 0; p.lpt = 0;
     p.window = window;
     p.q = (const bf16_t*)q; p.q_bs = (long)H * dh; p.q_rs = dh;
     p.k = nullptr; p.k_bs = 0; p.k_rs = (long)KV * dh;

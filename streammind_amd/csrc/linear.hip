@@ -1902,10 +1902,14 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
         static int sk256 = -1;
         if (sk256 < 0) { const char* e = getenv("SM_GEMM256_SPLITK"); sk256 = e ? atoi(e) : 1; }
         const int t256 = cdiv(p->M, 256) * cdiv(p->N, 256);
-        if (sk256 && bn == 0 && hint == 0 && p->M >= 768 && t256 >= 64 && t256 <= 128 && p->N >= 2048 && (p->N & 255) == 0 && p->K >= 4096 && p->out_f32 && !p->out_bf16 && !p->vt &&
+        static int sk_minrows = 768, sk_mint = 64, sk_smax = 4;                 // SM_GEMM256_SPLITK_MINROWS / _MINTILES / _SMAX: the rule's thresholds (A/B)
+        static bool sk_env = false;
+        if (!sk_env) { const char* e = getenv("SM_GEMM256_SPLITK_MINROWS"); if (e) sk_minrows = atoi(e); e = getenv("SM_GEMM256_SPLITK_MINTILES"); if (e) sk_mint = atoi(e);
+                       e = getenv("SM_GEMM256_SPLITK_SMAX"); if (e) sk_smax = atoi(e); sk_env = true; }
+        if (sk256 && bn == 0 && hint == 0 && p->M >= sk_minrows && t256 >= sk_mint && t256 <= 128 && p->N >= 2048 && (p->N & 255) == 0 && p->K >= 4096 && p->out_f32 && !p->out_bf16 && !p->vt &&
             p->remap_in == 0 && (p->ldo & 3) == 0 && (!p->residual || (p->ldr & 3) == 0) && !a.wscale) {
             int S = 256 / t256;
-            if (S > 4) S = 4;
+            if (S > sk_smax) S = sk_smax;
             while (S > 1 && a.KS % S) --S;
             if (S >= 2) {
                 float* ws = nullptr;
@@ -1920,6 +1924,10 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
                     splitk_reduce_norm_rows_kernel<<<p->M, p->N / 4, 0, st>>>(a, ws, S, ln);
                     SM_LAUNCH_CHECK();
                     *ln_done = true;
+                    return SM_OK;
+                }
+                if (g_leave_slabs && !p->bias && !p->residual && p->act == SM_ACT_NONE && !p->post_ln_gamma) {
+                    g_leave_slabs->ws = ws; g_leave_slabs->S = S; g_leave_slabs->stride = (size_t)p->M * p->N;        // the caller's next kernel sums them on load
                     return SM_OK;
                 }
                 return launch_splitk_reduce(a, ws, S, p->N, st);

@@ -433,6 +433,11 @@ def set_vit_ln_fold(mode: int) -> None:
     check(_lib.load().sm_set_vit_ln_fold(int(mode)), "sm_set_vit_ln_fold")
 
 
+def set_prefill_attention_kernel(on: int) -> None:
+    """which kernel runs the causal prefill at head_dim 128 (sm_set_prefill_attention_kernel): 1 the prefill kernel, 0 the general tile kernel, -1 environment / default"""
+    check(_lib.load().sm_set_prefill_attention_kernel(int(on)), "sm_set_prefill_attention_kernel")
+
+
 def cosine_rows(x: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
     """cos(x[t], ref) for every row of fp32 x [T, D] (sm_cosine_rows; torch.nn.functional.cosine_similarity's arithmetic) -> fp32 [T]"""
     lib = _lib.load()

@@ -379,6 +379,45 @@ def test_prefill_attention_sliding_window(nat, n, pos0, W, H, KV, dh):
     assert relerr(ctx, ref) < 8e-3
 
 
+@pytest.mark.parametrize("n,pos0,W,H,KV", [(2048, 0, 0, 32, 8), (1000, 0, 0, 32, 8), (257, 4000, 4096, 32, 8), (300, 100, 64, 8, 2), (130, 7, 0, 4, 4), (64, 0, 0, 6, 3),
+                                           (1, 50, 0, 8, 2), (513, 1535, 0, 32, 8), (700, 0, 200, 12, 4)])
+def test_prefill_attention_kernel_equals_the_tile_kernel_bit_for_bit(nat, n, pos0, W, H, KV):
+    """round 6: the dedicated causal prefill kernel (head_dim 128: one query tile per block, longest first, K / V^T by LDS-DMA, batched fragment reads) keeps the
+    general tile kernel's arithmetic -- same outputs bit for bit on full tiles, ragged tails, a cache offset, windows, head counts that are not a multiple of 8
+    -- and both sit within 8e-3 of fp32 softmax attention on the same bf16 operands."""
+    from streammind_amd._lib import load, check
+    from streammind_amd import native
+    lib = load()
+    dh = 128
+    S_max = ((pos0 + n + 63) // 64) * 64
+    g = torch.Generator().manual_seed(n + pos0 + W)
+    q = O.bf16_round(torch.randn(n, H, dh, generator=g))
+    k = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    v = O.bf16_round(torch.randn(S_max, KV, dh, generator=g))
+    qg, kg = q.reshape(n, H * dh).cuda().bfloat16(), k.cuda().bfloat16()
+    vt = v.permute(1, 2, 0).contiguous().cuda().bfloat16()
+    out = []
+    try:
+        for on in (1, 0):
+            native.set_prefill_attention_kernel(on)
+            ctx = torch.full((n, H * dh), float("nan"), device="cuda", dtype=torch.bfloat16)
+            check(lib.sm_llm_attention_window(qg.data_ptr(), kg.data_ptr(), vt.data_ptr(), n, pos0, H, KV, dh, S_max, W, ctx.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            out.append(ctx)
+    finally:
+        native.set_prefill_attention_kernel(-1)
+    assert torch.equal(out[0], out[1])
+    S = pos0 + n
+    rep = H // KV
+    kk, vv = k[:S].repeat_interleave(rep, dim=1), v[:S].repeat_interleave(rep, dim=1)
+    s_ = torch.einsum("qhd,khd->hqk", q, kk) * dh ** -0.5
+    pos = torch.arange(pos0, pos0 + n)
+    mask = torch.arange(S)[None, :] > pos[:, None]
+    if W > 0:
+        mask = mask | (torch.arange(S)[None, :] <= pos[:, None] - W)
+    ref = torch.einsum("hqk,khd->qhd", torch.softmax(s_.masked_fill(mask[None], float("-inf")), -1), vv).reshape(n, H * dh)
+    assert relerr(out[0], ref) < 8e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (3, 48, 96), (8, 4096, 4096), (1, 4096, 14336), (16, 288, 8192), (2, 2, 4096)])
 @pytest.mark.parametrize("mode", ["f32_precise", "bf16"])
 def test_skinny_linear_fp8_weights(nat, M, N, K, mode):
