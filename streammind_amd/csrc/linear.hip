@@ -796,7 +796,12 @@ __global__ __launch_bounds__(WV * 64, WV == 4 ? 2 : 1) void gemm_kernel(LinArgs 
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    // (a.n_band, round 6: with fewer row tiles than column tiles -- a decode step of 129..512 streams, a short prefill chunk -- W is the big operand and every XCD that holds a
+    // different row tile of the same columns fetched it again: 4 x 117 MB for down_proj at 512 rows, which is what that launch took at HBM speed.  m fastest inside the band puts
+    // the row tiles of one W tile side by side on one XCD)
+    int tile_m, tile_n;
+    if (a.n_band) { tile_n = bid / tiles_m; tile_m = bid - tile_n * tiles_m; }
+    else { tile_m = bid / tiles_n; tile_n = bid - tile_m * tiles_n; }
 
     // split-K (prefill-sized M, few tiles): blockIdx.y owns k-tiles [kt0, KT) of the K loop and writes its raw fp32 partial tile
     // to the workspace slab a.out_f32 + blockIdx.y * M * ldo (the launcher redirected the outputs; splitk_reduce_kernel sums the
@@ -1483,6 +1488,7 @@ static int launch_skinny_norm(const LinArgs& a, bool dual, bool fp8, hipStream_t
 }
 
 static void fill_args(const sm_linear_t* p, LinArgs& a) {
+    a.n_band = 0;
     a.w = (const bf16x8*)p->w;
     a.w2 = (const bf16x8*)p->w2;
     a.N = p->N; a.K = p->K;
@@ -1967,6 +1973,11 @@ static int linear_impl(const sm_linear_t* p, void* stream, bool* ln_done) {
     if (force_s < 0) { const char* e = getenv("SM_SPLITK"); force_s = e ? atoi(e) : 0; }
     if (use_w8 < 0) { const char* e = getenv("SM_GEMM_W8"); use_w8 = e ? atoi(e) : 2; }   // 0: 4-wave blocks, 1: 8 waves when blocks <= 256, 2: always
     const int tiles = tiles_m * tiles_n, KTall = a.KS >> 1;
+    {   // tile order of the 128 x 128 kernel (SM_GEMM128_NBAND = 0 | 1 forces, default: by shape)
+        static int nband = -2;
+        if (nband == -2) { const char* e = getenv("SM_GEMM128_NBAND"); nband = e ? atoi(e) : -1; }
+        a.n_band = nband >= 0 ? nband : (tiles_m > 1 && tiles_m < tiles_n ? 1 : 0);
+    }
     int S = tiles <= 128 ? 256 / tiles : 1;
     // up to 128 rows (a batched decode step of 33..128 streams: one row tile, the product is a weight stream) more slabs pay: every CU should
     // pull weights, and a slab of 128 rows is 2 MB (SM_SPLITK_SMALLM_MAX, default 8; 4 = the rule of the larger shapes)

@@ -36,6 +36,8 @@ struct LinArgs {
     const float* fold_ic;
     int fold_itiles;
     float fold_invd, fold_eps;
+    int n_band;           // 128 x 128 kernel's tile order: 0 = an XCD's band of tile ids walks n fastest (whole ROW tiles per XCD: X stays in its L2), 1 = m fastest (whole COLUMNS of
+                          // tiles per XCD: the row tiles that multiply the same W tile share an L2 -- the weight-heavy shapes, fewer row tiles than column tiles)
 };
 
 // (-mu * rstd, rstd) of row m from the partial sums the producing GEMM left: tiles in order (deterministic), E[x^2] - mu^2
