@@ -179,7 +179,7 @@ def prefill_leg(model, cfg, lib, n=2048, reps=3, prof=True):
         out = {"tokens": n, "tokens_per_s": round(n / dt, 1), "ms": round(dt * 1e3, 3),
                "roofline": {"bound": "mfma", "achieved": round((lin_fl + att_fl) / dt / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round((lin_fl + att_fl) / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "flops": lin_fl + att_fl,
-                            "note": "every launch of the prefill (GEMMs, causal attention, RoPE + KV append, slab sums + RMSNorms); see profiles/r05_prefill2048_breakdown.txt"}}
+                            "note": "every launch of the prefill (GEMMs, causal attention, RoPE + KV append, slab sums + RMSNorms); see profiles/r06_prefill2048_breakdown.txt"}}
         if prof:
             def run():
                 st.set_kv_len(0); st.prefill(ids)

@@ -39,4 +39,10 @@ rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pd 
 for F in 1 4 7 8 14 16; do timeout 300 python tools/tick_bench.py $F 100 2>&1 | tail -1; done > $O/tick_latency.txt; cat $O/tick_latency.txt
 for R in 1 28; do timeout 300 python tools/pass_bench.py $R 200 2>&1 | tail -1; done > $O/pass_bench.txt; cat $O/pass_bench.txt
 timeout 300 python tools/fold_bench.py 28 2>&1 | grep -v Warning > $O/fold_bench.txt; cat $O/fold_bench.txt
+# LLM side: per-kernel time of a 2048-token and of a 328-token prefill, the step timeline of a 128- and a 512-stream batched decode, the prefill attention in isolation
+for N in 1976 256; do rm -rf /tmp/prof_pf; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_pf -- python tools/decode_bench.py 8 4096 $N > /dev/null 2>&1
+  python tools/prefill_breakdown.py /tmp/prof_pf > $O/prefill$((N + 72))_breakdown.txt; head -8 $O/prefill$((N + 72))_breakdown.txt; done
+for GD in 128 512; do rm -rf /tmp/prof_gd; timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_gd -- python tools/group_decode_bench.py $GD > /dev/null 2>&1
+  python tools/trace_window.py /tmp/prof_gd embed_tokens_seg_kernel $(( (GD + 127) / 128 )) > $O/group_decode${GD}_step_timeline.txt; head -12 $O/group_decode${GD}_step_timeline.txt | cut -c1-150; done
+for shape in "2048 0" "512 0" "2048 2048" "300 0"; do for P in 1 0; do SM_ATTN_PREFILL=$P timeout 120 python tools/attn_causal_bench.py $shape 2>/dev/null; done; done > $O/attn_causal_bench.txt; cat $O/attn_causal_bench.txt
 head -8 $O/bench_steps_kernel_stats.csv | cut -c1-150; head -6 $O/bench_steps_fp16_fold_kernel_stats.csv | cut -c1-150
