@@ -41,6 +41,22 @@ bench.random_weights_into(model, cfg, seed=3)
 model.finalize()
 frames = bench.synthetic_frames_gpu(28, 336, 5, 0)
 ref_vit = model.vit_encode(frames).clone()
+# round 6: the folded tower (fp16 operands: LayerNorm statistics written by one product's epilogue, prefetched a tile ahead by the next product's persistent loop) and the
+# causal prefill kernel (K / V^T tiles by LDS-DMA, one barrier per key tile, fragment batches pinned by sched_barriers)
+cfg16 = PathConfig(llm_layers=0, max_frames_per_call=28, vit_fp16=True)
+model16 = NativeModel(cfg16)
+bench.random_weights_into(model16, cfg16, seed=3)
+model16.finalize()
+ref_vit16 = model16.vit_encode(frames).clone()
+PN, PH, PKV, PD = 2048, 32, 8, 128
+pq = (torch.randn(PN, PH * PD, device="cuda") * 0.5).bfloat16()
+pk = (torch.randn(PN, PKV * PD, device="cuda") * 0.5).bfloat16()
+pvt = (torch.randn(PKV, PD, PN, device="cuda") * 0.5).bfloat16()
+pctx = torch.empty(PN, PH * PD, device="cuda", dtype=torch.bfloat16)
+def run_prefill_attn():
+    _lib.check(lib.sm_llm_attention(pq.data_ptr(), pk.data_ptr(), pvt.data_ptr(), PN, 0, PH, PKV, PD, PN, pctx.data_ptr(), st))
+    return pctx
+ref_pattn = run_prefill_attn().clone()
 t0, it, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     for c, ref in zip(cases, refs):
@@ -50,7 +66,11 @@ while time.time() - t0 < budget:
         bad += 1; print("attention mismatch, iteration", it, flush=True)
     if it % 4 == 0 and not torch.equal(model.vit_encode(frames), ref_vit):
         bad += 1; print("ViT mismatch, iteration", it, flush=True)
+    if it % 4 == 2 and not torch.equal(model16.vit_encode(frames), ref_vit16):
+        bad += 1; print("folded fp16 ViT mismatch, iteration", it, flush=True)
+    if not torch.equal(run_prefill_attn(), ref_pattn):
+        bad += 1; print("prefill attention mismatch, iteration", it, flush=True)
     it += 1
 torch.cuda.synchronize()
-print(f"race screen: {it} iterations x ({len(cases)} GEMMs + attention) + {it // 4 + 1} ViT batches, {bad} mismatches")
+print(f"race screen: {it} iterations x ({len(cases)} GEMMs + ViT attention + causal prefill attention) + {it // 4 + 1} ViT batches (bf16) + {(it + 1) // 4} (fp16, LayerNorms folded), {bad} mismatches")
 sys.exit(1 if bad else 0)
