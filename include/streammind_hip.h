@@ -357,6 +357,10 @@ int sm_vit_encode(sm_model* m, const uint8_t* frames, int B, float* pooled, void
  * -1 = the default -- the fp16 tower (vit_fp16) folds, the bf16 tower does not (its folded form sits 1.2e-3 from the matching-precision oracle, beyond the
  * 1e-3 asserted for the benchmarked dtype) --, 0 = never, 1 = both, -2 = back to the SM_VIT_LN_FOLD environment variable / the default. */
 int sm_set_vit_ln_fold(int mode);
+/* Frame lanes of a call with few frames (process-wide).  -1 = the default rule: a call whose out-proj / fc2 would be a little more than one or two whole rounds of
+ * 128 x 128 tiles on this chip (8..10 and 15..20 frames of 577 tokens on 256 CUs) runs as TWO half batches on two HIP streams -- 4-9 % less time per call, results those
+ * of the two half calls --, 1 = never, 2..8 = that many lanes for calls of up to SM_VIT_SMALL_MAX (8) frames, -2 = back to SM_VIT_SMALL_LANES / the default. */
+int sm_set_vit_frame_lanes(int mode);
 /* the same from normalised pixel_values [B][3][H][W] (what the reference's callers hand to CLIPVisionTower.forward) */
 int sm_vit_encode_pixels(sm_model* m, const void* pixel_values, int dtype, int B, float* pooled, void* feats_bf16_opt,
                          void* stream);

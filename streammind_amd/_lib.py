@@ -125,6 +125,7 @@ SIGNATURES = {
     "sm_stream_set_kv_len": (i32, [vp, i32]),
     "sm_stream_kv_capacity": (i32, [vp]),
     "sm_set_vit_ln_fold": (i32, [i32]),
+    "sm_set_vit_frame_lanes": (i32, [i32]),
     "sm_set_prefill_attention_kernel": (i32, [i32]),
     "sm_llm_prefill": (i32, [vp, vp, i32, vp]),
     "sm_llm_forward_logits": (i32, [vp, vp, i32, vp, vp]),

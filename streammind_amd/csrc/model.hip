@@ -636,12 +636,34 @@ static int vit_lane_count(int B) {
 // lanes 9.9 vs 5.56 -- and with one HOST THREAD per lane (tools/lanes_threads_probe.py: the issue cost taken out) 4 frames still take
 // 3.52 ms: the chip retires ~one dependent launch per 4.7 us ACROSS all queues (740 launches of four concurrent one-frame chains in
 // 3.5 ms), so side-by-side launch chains do not buy latency here; only fewer launches do.
-static int vit_small_lanes(int B) {
-    static int max_l = -1, max_b = 8;
-    if (max_l < 0) {
-        const char* e = getenv("SM_VIT_SMALL_LANES"); max_l = e ? atoi(e) : 1;
-        const char* mb = getenv("SM_VIT_SMALL_MAX"); if (mb) max_b = atoi(mb);
+// ROUND 6 -- TWO frame lanes where one lane sits between whole rounds of the 128 x 128 tiles (the 7 -> 8 and 14 -> 16 frame steps of the per-call latency; kernel traces in
+// profiles/r06_tick_cliff_kernels.txt).  Out-proj and fc2 are rows / 128 x 8 tiles: up to 256 of them run one per CU on the ring kernel (7 frames, 30 us), 296 (8 frames) go
+// to the two-stage kernel with two blocks on 40 of the CUs and take as long as those 40 do (46 us); 512 is two blocks everywhere, 584 (16 frames) a second round of 72.
+// Two half batches on two HIP streams put the same tiles on the chip as two launches of half the size whose tails fill each other: measured per frame count, same box, twice
+// (profiles/r06_small_lanes_scan.txt), 8 / 9 / 10 frames 5.47 / 5.78 / 6.22 -> 5.05 / 5.43 / 5.77 ms, 15 .. 20 frames -4 / -8 / -9 / -5 / -5 / -2 %, and a loss of 1-8 % everywhere
+// else (4 .. 7, 11, 12, 14, 21 .. 28 frames) -- hence a rule in tiles, not a switch.  Results are those of the two half calls (tested).
+static std::atomic<int> g_vit_frame_lanes{-2};          // sm_set_vit_frame_lanes: -2 = read SM_VIT_SMALL_LANES (default -1)
+extern "C" int sm_set_vit_frame_lanes(int mode) {
+    SM_REQUIRE(mode >= -2 && mode <= 8 && mode != 0, "sm_set_vit_frame_lanes: -2 (environment / default), -1 (the tile rule), 1 (never), 2..8 (that many lanes up to SM_VIT_SMALL_MAX frames)");
+    g_vit_frame_lanes.store(mode, std::memory_order_relaxed);
+    return SM_OK;
+}
+static int vit_small_lanes(int B, int S, int D) {
+    static int max_b = -1;
+    int max_l = g_vit_frame_lanes.load(std::memory_order_relaxed);
+    if (max_l == -2) {
+        const char* e = getenv("SM_VIT_SMALL_LANES"); max_l = e ? atoi(e) : -1;          // -1: the tile rule below; 1: never; n >= 2: n lanes up to SM_VIT_SMALL_MAX frames (the round-4 experiment)
         if (max_l > 8) max_l = 8;
+        if (max_l == 0 || max_l < -1) max_l = 1;
+        g_vit_frame_lanes.store(max_l, std::memory_order_relaxed);
+    }
+    if (max_b < 0) { const char* mb = getenv("SM_VIT_SMALL_MAX"); max_b = mb ? atoi(mb) : 8; }
+    if (max_l < 0) {
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; hipDeviceProp_t prop; n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256; }
+        const long t = (long)cdiv(B * S, 128) * cdiv(D, 128);            // 128 x 128 tiles of the N = vit_hidden products (out-proj, fc2) of ONE lane: rows / 128 x 8 for ViT-L
+        const bool between = (t > n_cu && 2 * t <= 3 * n_cu) || (t > 2 * n_cu && 8 * t <= 23 * n_cu);       // (256, 384] and (512, 736] tiles on 256 CUs
+        return B >= 2 && between ? 2 : 1;
     }
     if (B < 2 || B > max_b || max_l < 2) return 1;
     return B < max_l ? B : max_l;
@@ -652,7 +674,7 @@ static int vit_encode_lanes(sm_model* m, int B, float* pooled, void* feats, void
     sm_model::VitWs* ws;
     int rc = m->vit_workspace(stream, &ws);
     if (rc) return rc;
-    if (const int sl = vit_small_lanes(B); sl > 1) {
+    if (const int sl = vit_small_lanes(B, m->S, c.vit_hidden); sl > 1) {
         sm_model::Lane* L;
         if ((rc = m->lane_of(stream, &L, sl - 1))) return rc;
         VitLaneArgs args[8];

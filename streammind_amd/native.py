@@ -433,6 +433,11 @@ def set_vit_ln_fold(mode: int) -> None:
     check(_lib.load().sm_set_vit_ln_fold(int(mode)), "sm_set_vit_ln_fold")
 
 
+def set_vit_frame_lanes(mode: int) -> None:
+    """frame lanes of small calls, process-wide (sm_set_vit_frame_lanes): -1 the tile rule (8..10 / 15..20 full-size frames run as two concurrent halves), 1 never, 2..8 forced, -2 environment / default"""
+    check(_lib.load().sm_set_vit_frame_lanes(int(mode)), "sm_set_vit_frame_lanes")
+
+
 def set_prefill_attention_kernel(on: int) -> None:
     """which kernel runs the causal prefill at head_dim 128 (sm_set_prefill_attention_kernel): 1 the prefill kernel, 0 the general tile kernel, -1 environment / default"""
     check(_lib.load().sm_set_prefill_attention_kernel(int(on)), "sm_set_prefill_attention_kernel")

@@ -1708,6 +1708,32 @@ def test_fp16_checkpoint_weights_gate_logits_need_fp16_storage():
     assert diffs[False] > 2 * diffs[True], diffs
 
 
+@pytest.mark.parametrize("B", [8, 9, 16, 19])
+def test_full_size_two_frame_lanes_between_whole_rounds_equal_two_calls(B):
+    """round 6: a call of 8..10 or 15..20 FULL-SIZE frames runs as two half batches on two HIP streams (one lane's out-proj / fc2 would sit between whole rounds of
+    128 x 128 tiles: model.hip vit_small_lanes) -- pooled features bit-identical to the two half calls (4 + 4, 4 + 5, 8 + 8, 9 + 10 frames, each as ONE lane),
+    repeatedly, and the stream path's gate logits are those of the half pushes."""
+    vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
+    m = build_native(vcfg, ccfg, gcfg, O.make_vit_weights(vcfg, 101), conn_gate_weights(ccfg, gcfg, 102), max_frames_per_call=20)
+    from streammind_amd import native
+    frames = O.synthetic_frames(B, 336, seed=93, scene_len=3).cuda()
+    h = B // 2
+    a, b = m.open_stream(max_frames=64, max_seq=64), m.open_stream(max_frames=64, max_seq=64)
+    try:
+        native.set_vit_frame_lanes(1)                 # the halves as plain single-lane calls (9 or 10 frames alone would be split again)
+        ref = torch.cat([m.vit_encode(frames[:h]), m.vit_encode(frames[h:])])
+        whole_one_lane = m.vit_encode(frames)
+        lg_a = torch.cat([a.push_frames(frames[:h])[0], a.push_frames(frames[h:])[0]])
+    finally:
+        native.set_vit_frame_lanes(-2)
+    for _ in range(4):
+        assert torch.equal(m.vit_encode(frames), ref)
+    assert (whole_one_lane - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()        # one lane of B frames: the same tower through other tile shapes / slab counts
+    lg_b, _ = b.push_frames(frames)
+    # (the connector + gate pass of B rows and of the two halves are different launches of the weight-streaming kernels: same pooled features in, fp32 sums in another order)
+    assert (lg_a - lg_b).abs().max().item() < 1e-4
+
+
 def test_full_size_three_lanes_84_frames():
     """84 FULL-SIZE frames in one call: three lanes of 28 (two concurrent, the third alone) -- bit-identical to three 28-frame calls."""
     vcfg, ccfg, gcfg = O.VitCfg(), O.ConnCfg(), O.LmCfg.gate()
