@@ -254,9 +254,10 @@ def teacher_forced_leg(model, stream, cfg, n_text=128, n_frames=384):
             "linear_tflops": round(flops / dt / 1e12, 1), "loss_random_weights": round(loss, 4)}
 
 
-def latency_leg(model, frames, sizes=(1, 2, 4, 8), reps=25):
+def latency_leg(model, frames, sizes=(1, 2, 4, 7, 8, 14, 16), reps=25):
     """Per-call latency of the perception path at small frame counts (the reference's own streaming loop pushes ONE frame per
-    call, eval/video_score_stream_demo.py:266-299): ms per push_frames call and the frames/s that gives."""
+    call, eval/video_score_stream_demo.py:266-299): ms per push_frames call and the frames/s that gives.  7 / 8 and 14 / 16 frames sit on either side of a whole round of
+    128 x 128 tiles for out-proj / fc2 (8 and 16 run as two concurrent frame lanes since round 6: sm_set_vit_frame_lanes)."""
     sizes = tuple(b for b in sizes if b <= frames.shape[0])
     s = model.open_stream(max_frames=sum(sizes) * (reps + 3) + 8, max_seq=64)
     out = {"frames_per_call": list(sizes), "ms_per_call": [], "frames_per_s": []}
