@@ -36,7 +36,7 @@ rm -rf /tmp/pm16; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRB
 python tools/pmc_mfma_summary.py /tmp/pm16 $O/mfma_util_fp16_fold.json
 # decode (bf16 / fp8), per-call latency, the pass
 rm -rf /tmp/pd; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pd -- python tools/decode_bench.py 64 1024 > /dev/null 2>&1; cp "$(find /tmp/pd -name '*kernel_stats.csv' | head -1)" $O/decode_kernel_stats.csv
-for F in 1 4 7 8 14 16; do timeout 300 python tools/tick_bench.py $F 100 2>&1 | tail -1; done > $O/tick_latency.txt; cat $O/tick_latency.txt
+for F in 1 4 7 8 10 14 16 17 20; do timeout 300 python tools/tick_bench.py $F 100 2>&1 | tail -1; done > $O/tick_latency.txt; cat $O/tick_latency.txt
 for R in 1 28; do timeout 300 python tools/pass_bench.py $R 200 2>&1 | tail -1; done > $O/pass_bench.txt; cat $O/pass_bench.txt
 timeout 300 python tools/fold_bench.py 28 2>&1 | grep -v Warning > $O/fold_bench.txt; cat $O/fold_bench.txt
 # LLM side: per-kernel time of a 2048-token and of a 328-token prefill, the step timeline of a 128- and a 512-stream batched decode, the prefill attention in isolation
