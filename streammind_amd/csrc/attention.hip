@@ -752,6 +752,14 @@ __global__ __launch_bounds__(VIT_ATTN_WAVES * 64, 8 / VIT_ATTN_WAVES) void vit_a
             vsrc[j] += vadv;
         }
     };
+    // per-lane part of the V^T transpose-read addresses: key = kb*32 + g*8 + u*4 + (i >> 2) reads row `key` at 32-byte block df ^ h(key), and h(key) = bit 1 | bit 3 << 1 of the
+    // key depends on the lane only ((i >> 3) & 1, g & 1) -- four offsets for the whole kernel instead of sixteen address computations per tile (the compiler does not see through the XOR)
+    int vlane[4];
+    {
+        const int hk = ((i >> 3) & 1) | ((g & 1) << 1);
+#pragma unroll
+        for (int df = 0; df < 4; ++df) vlane[df] = (g * 8 + (i >> 2)) * 128 + ((df ^ hk) * 32) + (i & 3) * 8;
+    }
     // one key tile; PART: the (last) tile that runs past nk -- only it carries the key mask and the half-tile skip
     int buf = 0;
     auto tile = [&](int kt0, auto part) {
@@ -886,12 +894,8 @@ __global__ __launch_bounds__(VIT_ATTN_WAVES * 64, 8 / VIT_ATTN_WAVES) void vit_a
             for (int df = 0; df < 4; ++df) {
                 union { bf16x8 v; s16x4 hlf[2]; } vf;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int key = kb * 32 + g * 8 + u * 4 + (i >> 2);
-                    const int hk = ((key >> 1) & 1) | (((key >> 3) & 1) << 1);
-                    vf.hlf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(Vl + key * 128 + ((df ^ hk) * 32) + (i & 3) * 8));
-                }
+                for (int u = 0; u < 2; ++u)       // key = kb*32 + g*8 + u*4 + (i >> 2): the lane's part of the address is vlane[df] (hoisted), kb and u are immediates
+                    vf.hlf[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + vlane[df] + kb * 4096 + u * 512));
                 o[0][df] = mfma16<F16>(vf.v, pf[0][kb], o[0][df]);
                 o[1][df] = mfma16<F16>(vf.v, pf[1][kb], o[1][df]);
             }
